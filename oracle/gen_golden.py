@@ -1,0 +1,390 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (it needs /root/reference, which is read-only,
+hence PYTHONDONTWRITEBYTECODE):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+The fixtures are data (seeded inputs + the outputs the reference produced for
+them on CPU, torch 2.10, fp32).  No reference source or bytecode is copied.
+The GPU box never runs this script; tests read the committed .npz files.
+
+Fixture list:
+  svgd_phi.npz        rbf()/phi for seeded P, G            (svgd.py:14-32, 86-89)
+  svgd_traj_*.npz     5-step SVGDOptimizer trajectories     (svgd.py:65-105; Q1-Q5)
+  swag_schedule.npz   update-gate counter traces            (swag.py:91-97)
+  swag_stats.npz      moments / deviation columns / samples (swag.py:98-114, 53-58)
+  bbb.npz             GaussianParameter draw, KL, one BBBOptimizer trajectory
+  ivon.npz            iVON trajectories with recorded noise (ivorn.py:41-115)
+  ensemble.npz        DeepEnsemble.predict sample split     (ensemble.py:37-40)
+"""
+import math
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REF = os.environ.get("BDE_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import src.algos.util as ref_util
+import src.algos.svgd as ref_svgd
+import src.algos.swag as ref_swag
+import src.algos.bbb as ref_bbb
+import src.algos.bbb_layers as ref_bbb_layers
+import src.algos.ivorn as ref_ivon
+import src.algos.ensemble as ref_ens
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(1)  # reproducible reduction order
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def flat(ts):
+    return torch.cat([t.detach().reshape(-1) for t in ts])
+
+
+# ------------------------------------------------------------------ SVGD phi
+def gen_svgd_phi():
+    out = {}
+    cases = []
+    g = torch.Generator().manual_seed(1234)
+    idx = 0
+    for (m, d) in [(5, 751), (8, 751), (8, 2050), (3, 10), (16, 300), (2, 64), (1, 33)]:
+        for l2, shared in ((0.0, False), (0.01, True)):
+            if True:
+                if shared:
+                    # particles share a "backbone" and differ only in the last 10 % ("head")
+                    theta0 = torch.randn(d, generator=g) * 0.05
+                    p = theta0.repeat(m, 1)
+                    head = max(1, d // 10)
+                    p[:, -head:] += (torch.rand(m, head, generator=g) * 2 - 1) / math.sqrt(2048)
+                else:
+                    p = torch.randn(m, d, generator=g) * 0.05
+                grad = torch.randn(m, d, generator=g) * 0.01
+                n = 129809
+                scale = 1.0 if idx % 3 else 0.5
+                gv = grad.clone()
+                gv += l2 / 2 * p
+                kernel, grad_kernel = ref_svgd.rbf(p)
+                phi = torch.matmul(kernel, -gv) + scale * grad_kernel / n
+                d2 = torch.cdist(p, p, p=2) ** 2
+                h = torch.sqrt(0.5 * torch.quantile(d2, 0.5) / np.log(m + 1)) + 1e-8
+                out[f"P_{idx}"] = npy(p)
+                out[f"G_{idx}"] = npy(grad)
+                out[f"K_{idx}"] = npy(kernel)
+                out[f"gradK_{idx}"] = npy(grad_kernel)
+                out[f"phi_{idx}"] = npy(phi)
+                out[f"h_{idx}"] = npy(h)
+                # fp64 evaluation of the same formula: the tolerance anchor
+                p64, g64 = p.double(), grad.double()
+                gv64 = g64 + l2 / 2 * p64
+                k64, gk64 = ref_svgd.rbf(p64)
+                out[f"phi64_{idx}"] = npy(torch.matmul(k64, -gv64) + scale * gk64 / n)
+                out[f"K64_{idx}"] = npy(k64)
+                cases.append([m, d, l2, scale, n, int(shared)])
+                idx += 1
+    out["cases"] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "svgd_phi.npz"), **out)
+
+
+# ------------------------------------------------------------------ SVGD trajectories
+def make_mlp():
+    return nn.Sequential(nn.Linear(13, 50), nn.ReLU(), nn.Linear(50, 1))
+
+
+def gen_svgd_traj(name, make_opt, m, l2_reg, scale, steps=5):
+    torch.manual_seed(7)
+    model = make_mlp()
+    x = torch.randn(64, 13)
+    y = torch.randn(64, 1)
+    base = make_opt(model.parameters())
+    opt = ref_svgd.SVGDOptimizer(model.parameters(), lambda: ref_util.reset_model_params(model), base,
+                                 particle_count=m, dataset_size=64, l2_reg=l2_reg, kernel_grad_scale=scale)
+    params = list(model.parameters())
+    init = torch.stack([flat([opt.state[p][f"particle_{i}"] for p in params]) for i in range(m)])
+    traj, losses = [], []
+    for t in range(steps):
+        xb, yb = x[(t % 4) * 16:(t % 4 + 1) * 16], y[(t % 4) * 16:(t % 4 + 1) * 16]
+        loss = opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+        losses.append(float(loss))
+        traj.append(torch.stack([flat([opt.state[p][f"particle_{i}"] for p in params]) for i in range(m)]))
+    st = base.state[params[0]]
+    step_count = float(st["step"]) if "step" in st else -1.0
+    # which particle the model's params alias after step(): the last one (svgd.py:96)
+    np.savez_compressed(os.path.join(OUT, f"svgd_traj_{name}.npz"), x=npy(x), y=npy(y), init=npy(init),
+                        traj=npy(torch.stack(traj)), losses=np.array(losses, dtype=np.float64),
+                        base_step_count=np.array(step_count), m=np.array(m), l2_reg=np.array(l2_reg),
+                        scale=np.array(scale), model_after=npy(flat(params)))
+
+
+# ------------------------------------------------------------------ SWAG
+def gen_swag_schedule():
+    out = {}
+    cfgs = [(5, 1, 2, 3), (4, 0, 1, 3), (7, 2, 3.7, 5), (3, 0, 5, 4), (6, 3, 4, 6)]
+    for ci, (steps_per_epoch, start_epoch, interval, epochs) in enumerate(cfgs):
+        p = nn.Parameter(torch.zeros(3))
+        base = torch.optim.SGD([p], lr=1.0)
+        opt = ref_swag.SwagOptimizer([p], base, update_interval=interval, start_epoch=start_epoch, deviation_samples=4)
+        trace = []
+        for e in range(epochs):
+            for b in range(steps_per_epoch):
+                opt.step(lambda: p.sum(), lambda l: l.backward())
+                trace.append([e, b, opt.state["__epoch"], opt.state["__steps_since_swag_start"], opt.state["__updates"]])
+            opt.complete_epoch()
+        out[f"trace_{ci}"] = np.array(trace, dtype=np.int64)
+    out["cfgs"] = np.array(cfgs, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "swag_schedule.npz"), **out)
+
+
+def gen_swag_stats():
+    out = {}
+    k = 5
+    ci = 0
+    cases = []
+    for total_updates in (3, k, k + 7):
+        for mode in ("tag", "real"):
+            torch.manual_seed(11 + ci)
+            p1 = nn.Parameter(torch.zeros(7) if mode == "tag" else torch.randn(7) * 0.05)
+            p2 = nn.Parameter(torch.zeros(2, 3) if mode == "tag" else torch.randn(2, 3) * 0.05)
+            c1 = torch.ones(7) if mode == "tag" else torch.randn(7)
+            c2 = torch.ones(2, 3) if mode == "tag" else torch.randn(2, 3)
+            lr = 1.0 if mode == "tag" else 0.1
+            base = torch.optim.SGD([p1, p2], lr=lr)
+            interval = 2
+            opt = ref_swag.SwagOptimizer([p1, p2], base, update_interval=interval, start_epoch=0, deviation_samples=k)
+            theta0 = flat([p1, p2])
+            thetas = []
+            for t in range(total_updates * interval):
+                opt.step(lambda: (p1 * c1).sum() + (p2 * c2).sum(), lambda l: l.backward())
+                thetas.append(flat([p1, p2]))
+            assert opt.state["__updates"] == total_updates
+            out[f"theta0_{ci}"] = npy(theta0)
+            out[f"thetas_{ci}"] = npy(torch.stack(thetas))          # theta after every step
+            out[f"mean_{ci}"] = npy(opt.state["__mean"])
+            out[f"sq_{ci}"] = npy(opt.state["__sq_weights"])
+            out[f"dev_{ci}"] = npy(opt.state["__deviations"])       # [D, K], newest column last
+            # samples with recorded noise (eps_W first, then eps_D; swag.py:57)
+            d = theta0.numel()
+            samples, eps_ws, eps_ds = [], [], []
+            for s in range(3):
+                torch.manual_seed(100 + s)
+                opt.sample_parameters()
+                samples.append(flat([p1, p2]))
+                torch.manual_seed(100 + s)
+                eps_ws.append(torch.empty(k).normal_())
+                eps_ds.append(torch.empty(d).normal_())
+            out[f"samples_{ci}"] = npy(torch.stack(samples))
+            out[f"eps_w_{ci}"] = npy(torch.stack(eps_ws))
+            out[f"eps_d_{ci}"] = npy(torch.stack(eps_ds))
+            # a step() after sampling restores the pre-sampling weights first (swag.py:38,76-82)
+            opt.step(lambda: (p1 * c1).sum() + (p2 * c2).sum(), lambda l: l.backward())
+            out[f"theta_after_restore_step_{ci}"] = npy(flat([p1, p2]))
+            out[f"c_{ci}"] = npy(flat([c1, c2]))
+            cases.append([total_updates, 1 if mode == "tag" else 0, lr, interval, k])
+            ci += 1
+    out["cases"] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "swag_stats.npz"), **out)
+
+
+# ------------------------------------------------------------------ noise recording
+class NoiseTape:
+    """Replaces the reference's normal_like() so the draws can be replayed."""
+
+    def __init__(self, seed):
+        self.gen = torch.Generator().manual_seed(seed)
+        self.tape = []
+
+    def __call__(self, tensor):
+        eps = torch.empty(tensor.shape, dtype=tensor.dtype).normal_(0, 1, generator=self.gen)
+        self.tape.append(eps.clone())
+        return eps
+
+
+# ------------------------------------------------------------------ BBB
+class RefSampledLinear(nn.Module):
+    """A weight-sampling linear layer over the REFERENCE's GaussianParameter
+    (exercises util.py:170-171 sample() the way rank1.py:51-52 does)."""
+
+    def __init__(self, i, o):
+        super().__init__()
+        self.weight = ref_util.GaussianParameter((o, i))
+        self.bias = ref_util.GaussianParameter((o,))
+        self.weight.blundell_init()
+        self.bias.blundell_init()
+
+    def forward(self, x):
+        return F.linear(x, self.weight.sample(), self.bias.sample())
+
+
+def gen_bbb():
+    out = {}
+    torch.manual_seed(3)
+    # (a) draw + KL + grads on a raw GaussianParameter
+    gp = ref_util.GaussianParameter((257,))
+    gp.blundell_init()
+    with torch.no_grad():
+        gp.rho.copy_(torch.randn(257) * 1.5 - 2.0)
+    tape = NoiseTape(5)
+    old = ref_util.normal_like
+    ref_util.normal_like = tape
+    try:
+        w = gp.sample()
+        gout = torch.randn(257)
+        (w * gout).sum().backward()
+    finally:
+        ref_util.normal_like = old
+    out["a_mean"], out["a_rho"], out["a_eps"] = npy(gp.mean), npy(gp.rho), npy(tape.tape[0])
+    out["a_sample"], out["a_gout"] = npy(w), npy(gout)
+    out["a_gmean"], out["a_grho"] = npy(gp.mean.grad), npy(gp.rho.grad)
+    for si, sigma in enumerate((0.1, 1.0, 10.0)):
+        for mi, mu in enumerate((0.0, 0.3)):
+            gp.mean.grad = None
+            gp.rho.grad = None
+            prior = ref_bbb.GaussianPrior(mu, sigma)
+            kl = gp.kl_divergence(prior)
+            kl.backward()
+            out[f"a_kl_{si}_{mi}"] = npy(kl)
+            out[f"a_kl_gmean_{si}_{mi}"] = npy(gp.mean.grad)
+            out[f"a_kl_grho_{si}_{mi}"] = npy(gp.rho.grad)
+    out["a_priors"] = np.array([[mu, sigma] for sigma in (0.1, 1.0, 10.0) for mu in (0.0, 0.3)])
+
+    # (b) BBBOptimizer trajectory, UCI-housing-shaped MLP (BASELINE config #1):
+    #     the reference's own BBBLinear (local reparameterisation), Adam base.
+    for tag, layer_kind in (("b", "bbblinear"), ("c", "sampled")):
+        torch.manual_seed(21)
+        prior = ref_bbb.GaussianPrior(0, 1.0)
+        if layer_kind == "bbblinear":
+            model = nn.Sequential(ref_bbb_layers.BBBLinear(13, 50, prior, prior), nn.ReLU(),
+                                  ref_bbb_layers.BBBLinear(50, 1, prior, prior))
+        else:
+            model = nn.Sequential(RefSampledLinear(13, 50), nn.ReLU(), RefSampledLinear(50, 1))
+        # one plain parameter too, so the l2_scale branch (bbb.py:75-76) is exercised
+        extra = nn.Parameter(torch.randn(4) * 0.1)
+        x = torch.randn(48, 13)
+        y = torch.randn(48, 1)
+        params = list(model.parameters()) + [extra]
+        base = torch.optim.Adam(params, lr=1e-2)
+        opt = ref_bbb.BBBOptimizer(params, base, prior, dataset_size=48, mc_samples=2, kl_rescaling=0.5,
+                                   components=1, l2_scale=0.3)
+        tape = NoiseTape(9)
+        old_u, old_l = ref_util.normal_like, ref_bbb_layers.normal_like
+        ref_util.normal_like = tape
+        ref_bbb_layers.normal_like = tape
+        names = [n for n, _ in model.named_parameters()] + ["extra"]
+        init = {n: npy(p) for n, p in zip(names, params)}
+        losses, trajs = [], []
+        try:
+            for t in range(3):
+                xb, yb = x[(t % 3) * 16:(t % 3 + 1) * 16], y[(t % 3) * 16:(t % 3 + 1) * 16]
+                loss = opt.step(lambda: F.mse_loss(model(xb), yb) + extra.sum() * 0.01, lambda l: l.backward())
+                losses.append(float(loss))
+                trajs.append(flat(params))
+        finally:
+            ref_util.normal_like, ref_bbb_layers.normal_like = old_u, old_l
+        out[f"{tag}_x"], out[f"{tag}_y"] = npy(x), npy(y)
+        for n in names:
+            out[f"{tag}_init/{n}"] = init[n]
+        out[f"{tag}_names"] = np.array(names)
+        out[f"{tag}_losses"] = np.array(losses, dtype=np.float64)
+        out[f"{tag}_traj"] = npy(torch.stack(trajs))
+        out[f"{tag}_n_eps"] = np.array(len(tape.tape))
+        for i, e in enumerate(tape.tape):
+            out[f"{tag}_eps_{i}"] = npy(e)
+    np.savez_compressed(os.path.join(OUT, "bbb.npz"), **out)
+
+
+# ------------------------------------------------------------------ iVON
+def gen_ivon():
+    out = {}
+    cases = []
+    for ci, (aug, mc, damping, temp) in enumerate([(1.0, 2, 1e-3, 1.0), (10.0, 2, 1e-3, 1.0), (2.0, 3, 0.0, 0.7)]):
+        torch.manual_seed(31 + ci)
+        model = make_mlp()
+        x = torch.randn(48, 13)
+        y = torch.randn(48, 1)
+        params = list(model.parameters())
+        opt = ref_ivon.iVONOptimizer(params, lr=1e-2, prior_prec=50.0, dataset_size=48, damping=damping,
+                                     tempering=temp, augmentation=aug, mc_samples=mc)
+        tape = NoiseTape(17 + ci)
+        old = ref_ivon.normal_like
+        ref_ivon.normal_like = tape
+        init = flat(params)
+        means, moms, precs, losses, after, accg, dsum = [], [], [], [], [], [], []
+        try:
+            for t in range(3):
+                xb, yb = x[(t % 3) * 16:(t % 3 + 1) * 16], y[(t % 3) * 16:(t % 3 + 1) * 16]
+                loss = opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+                losses.append(float(loss))
+                means.append(flat([opt.state[p]["mean"] for p in params]))
+                moms.append(flat([opt.state[p]["momentum"] for p in params]))
+                precs.append(flat([opt.state[p]["precision"] for p in params]))
+                after.append(flat(params))       # params stay at the last noisy sample (Q13)
+                accg.append(flat([opt.state[p]["acc_grad"] for p in params]))   # sum of the mc gradients
+                dsum.append(flat([opt.state[p]["delta"] for p in params]))      # sum of the mc noise draws
+            # one extra sample_parameters() as eval would call it (ivorn.py:102-115)
+            opt.sample_parameters()
+            out[f"eval_sample_{ci}"] = npy(flat(params))
+        finally:
+            ref_ivon.normal_like = old
+        n_t = len(params)
+        # tape holds one eps per tensor per draw; regroup into flat [n_draws, D]
+        draws = [flat(tape.tape[i:i + n_t]) for i in range(0, len(tape.tape), n_t)]
+        out[f"x_{ci}"], out[f"y_{ci}"], out[f"init_{ci}"] = npy(x), npy(y), npy(init)
+        out[f"eps_{ci}"] = npy(torch.stack(draws))           # [3*mc + 1, D]
+        out[f"means_{ci}"] = npy(torch.stack(means))
+        out[f"moms_{ci}"] = npy(torch.stack(moms))
+        out[f"precs_{ci}"] = npy(torch.stack(precs))
+        out[f"after_{ci}"] = npy(torch.stack(after))
+        out[f"acc_grad_{ci}"] = npy(torch.stack(accg))
+        out[f"delta_sum_{ci}"] = npy(torch.stack(dsum))
+        out[f"losses_{ci}"] = np.array(losses, dtype=np.float64)
+        cases.append([aug, mc, damping, temp])
+    out["cases"] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "ivon.npz"), **out)
+
+
+# ------------------------------------------------------------------ ensemble split
+class _CountingOpt:
+    def __init__(self):
+        self.n = 0
+
+    def sample_parameters(self):
+        self.n += 1
+
+
+def gen_ensemble():
+    rows = []
+    for samples, members in [(10, 5), (30, 5), (50, 3), (7, 4), (150, 5), (3, 5), (1, 1)]:
+        pairs = [(nn.Linear(1, 1), _CountingOpt()) for _ in range(members)]
+        ens = ref_ens.DeepEnsemble(pairs)
+        outp = ens.predict(lambda m: torch.zeros(1), samples)
+        counts = [o.n for _, o in pairs]
+        rows.append([samples, members, outp.shape[0]] + counts + [-1] * (5 - members))
+    np.savez_compressed(os.path.join(OUT, "ensemble.npz"), rows=np.array(rows, dtype=np.int64))
+
+
+if __name__ == "__main__":
+    gen_svgd_phi()
+    gen_svgd_traj("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4),
+                  m=5, l2_reg=0.01, scale=1.0)
+    gen_svgd_traj("adam", lambda ps: torch.optim.Adam(ps, lr=1e-3), m=8, l2_reg=0.0, scale=1.0)
+    gen_svgd_traj("adam_wd", lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2), m=3, l2_reg=1e-5, scale=0.5)
+    gen_swag_schedule()
+    gen_swag_stats()
+    gen_bbb()
+    gen_ivon()
+    gen_ensemble()
+    print("golden fixtures written to", os.path.normpath(OUT))
+    for f in sorted(os.listdir(OUT)):
+        print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} B")
