@@ -1,0 +1,127 @@
+// Shared device/host helpers for libbde_hip (gfx950 / CDNA4 only).
+//
+// Everything on this path is an HBM-bound stream over flat fp32 parameter
+// buffers, so the helpers are about: 16-byte coalesced accesses, enough
+// workgroups to fill 256 CUs with grid-stride loops, deterministic two-stage
+// reductions (wave shuffles -> LDS -> fixed-order fp64 finish), and a
+// counter-based RNG whose output does not depend on the launch geometry.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "../../include/bde_hip.h"
+
+namespace bde {
+
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kCUs = 256;            // MI355X
+constexpr int kBlock = 256;          // 4 waves per workgroup for streaming kernels
+constexpr int kMaxStreamBlocks = kCUs * 8;   // 8 workgroups of 256 per CU = 32 waves/CU
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+static inline int to_err(hipError_t e) { return e == hipSuccess ? 0 : -static_cast<int>(e); }
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Grid for a grid-stride streaming kernel over `n_items` per-thread work items.
+static inline int stream_grid(int64_t n_items, int block = kBlock, int max_blocks = kMaxStreamBlocks) {
+  int64_t g = (n_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return static_cast<int>(g);
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, f32x4 v) {
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+// Streaming store: the line is not re-read by this kernel.
+__device__ __forceinline__ void st4_nt(float* __restrict__ p, f32x4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+}
+__device__ __forceinline__ f32x4 ld4_nt(const float* __restrict__ p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
+
+// ---- reductions ---------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// Sum over the workgroup; result valid in thread 0.  `smem` >= blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* smem) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  v = wave_sum(v);
+  if (lane == 0) smem[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += smem[i];
+  }
+  __syncthreads();
+  return r;
+}
+
+// ---- Philox4x32-10 + Box-Muller ----------------------------------------
+// Counter layout: (lo32(idx), hi32(idx), lo32(stream), hi32(stream) ^ domain),
+// key = seed.  `idx` is the float4 group index of the element, so the normal
+// attached to element e of stream s is a pure function of (seed, s, e).
+struct Philox {
+  static constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  __device__ __forceinline__ static uint4 round10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+      const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+      c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+      k.x += W0;
+      k.y += W1;
+    }
+    return c;
+  }
+};
+
+enum : uint32_t { kDomainDiag = 0x0u, kDomainLowRank = 0x80000000u };
+
+// Four standard normals for float4 group `idx4` of stream `stream_id`.
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t stream_id, uint64_t idx4, uint32_t domain) {
+  const uint4 c = make_uint4(static_cast<uint32_t>(idx4), static_cast<uint32_t>(idx4 >> 32),
+                             static_cast<uint32_t>(stream_id), static_cast<uint32_t>(stream_id >> 32) ^ domain);
+  const uint2 k = make_uint2(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+  const uint4 r = Philox::round10(c, k);
+  // u in (0, 1]: (x + 1) * 2^-32 would round to 1.0f for large x only, never 0.
+  const float u0 = (static_cast<float>(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u1 = static_cast<float>(r.y >> 8) * (1.0f / 16777216.0f);
+  const float u2 = (static_cast<float>(r.z >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u3 = static_cast<float>(r.w >> 8) * (1.0f / 16777216.0f);
+  const float r0 = __builtin_sqrtf(-2.0f * __logf(u0));
+  const float r1 = __builtin_sqrtf(-2.0f * __logf(u2));
+  // v_sin_f32 / v_cos_f32 take their argument in revolutions
+  f32x4 z;
+  z.x = r0 * __builtin_amdgcn_cosf(u1);
+  z.y = r0 * __builtin_amdgcn_sinf(u1);
+  z.z = r1 * __builtin_amdgcn_cosf(u3);
+  z.w = r1 * __builtin_amdgcn_sinf(u3);
+  return z;
+}
+
+// torch.nn.functional.softplus(x) with beta=1, threshold=20 (util.py:183).
+__device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace bde

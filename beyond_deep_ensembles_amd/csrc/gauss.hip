@@ -1,0 +1,288 @@
+// Mean-field Gaussian parameters (Bayes by Backprop): reparameterised draw,
+// its backward, and the closed-form KL with fused analytic gradients.
+//
+// Reference: src/algos/util.py:151-186 (GaussianParameter, normal_like) and
+// src/algos/bbb.py:18-21,71-80 (GaussianPrior.kl_divergence, the KL/L2
+// collection loop of BBBOptimizer.step).  The reference runs ~4 ATen launches
+// per tensor per draw plus an autograd graph, and ~8 launches + a reduction
+// per tensor for the KL (again in backward).  Here mean/rho of all Gaussian
+// parameters live in two flat buffers and each operation is one streaming
+// pass: draw 12 B/param (8 with Philox noise), draw-backward 24 B/param (RMW)
+// or 16 (overwrite), KL value + both gradients 16 B/param (overwrite) or 24
+// (accumulate).  All HBM-bound.
+#include "bde_common.hpp"
+
+namespace bde {
+
+constexpr int kReduceMaxBlocks = 1024;
+constexpr int kReduceHeader = 2;   // doubles: [0] = #partials
+
+// ------------------------------------------------------------------ draw --
+template <bool RNG>
+__global__ __launch_bounds__(kBlock) void gauss_draw_fwd_kernel(const float* __restrict__ mean,
+                                                               const float* __restrict__ rho,
+                                                               const float* __restrict__ eps, uint64_t seed,
+                                                               uint64_t stream_id, float* __restrict__ w,
+                                                               float* __restrict__ eps_out, int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 m = ld4(mean + 4 * i), r = ld4(rho + 4 * i);
+    const f32x4 e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag) : ld4(eps + 4 * i);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = m[j] + e[j] * softplus(r[j]);   // util.py:171: mean + eps * std
+    st4(w + 4 * i, o);
+    if (RNG && eps_out) st4(eps_out + 4 * i, e);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t k = (n4 << 2) + threadIdx.x;
+    if (k < n) {
+      float e;
+      if (RNG) {
+        const f32x4 z = philox_normal4(seed, stream_id, static_cast<uint64_t>(n4), kDomainDiag);
+        e = z[threadIdx.x & 3];
+        if (eps_out) eps_out[k] = e;
+      } else {
+        e = eps[k];
+      }
+      w[k] = mean[k] + e * softplus(rho[k]);
+    }
+  }
+}
+
+template <bool RNG, bool ACC>
+__global__ __launch_bounds__(kBlock) void gauss_draw_bwd_kernel(const float* __restrict__ g,
+                                                               const float* __restrict__ rho,
+                                                               const float* __restrict__ eps, uint64_t seed,
+                                                               uint64_t stream_id, float* __restrict__ gmean,
+                                                               float* __restrict__ grho, int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 go = ld4(g + 4 * i), r = ld4(rho + 4 * i);
+    const f32x4 e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag) : ld4(eps + 4 * i);
+    f32x4 gm = go, gr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gr[j] = (go[j] * e[j]) * sigmoidf(r[j]);   // d softplus = sigmoid
+    if (ACC) {
+      gm = gm + ld4(gmean + 4 * i);
+      gr = gr + ld4(grho + 4 * i);
+    }
+    st4(gmean + 4 * i, gm);
+    st4(grho + 4 * i, gr);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t k = (n4 << 2) + threadIdx.x;
+    if (k < n) {
+      float e;
+      if (RNG) {
+        const f32x4 z = philox_normal4(seed, stream_id, static_cast<uint64_t>(n4), kDomainDiag);
+        e = z[threadIdx.x & 3];
+      } else {
+        e = eps[k];
+      }
+      const float gm = g[k], gr = (g[k] * e) * sigmoidf(rho[k]);
+      gmean[k] = ACC ? gmean[k] + gm : gm;
+      grho[k] = ACC ? grho[k] + gr : gr;
+    }
+  }
+}
+
+// -------------------------------------------------------------------- KL --
+// Per element (bbb.py:20): 0.5 * (2 ln(sp/s) - 1 + (s/sp)^2 + ((mp - m)/sp)^2).
+__device__ __forceinline__ float kl_elem(float m, float r, float pmu, float psig, float c, bool want_grad, float& gm,
+                                        float& gr) {
+  const float s = softplus(r);
+  const float a = s / psig;
+  const float b = (pmu - m) / psig;
+  const float kl = 0.5f * (2.0f * logf(psig / s) - 1.0f + a * a + b * b);
+  if (want_grad) {
+    gm = c * ((m - pmu) / (psig * psig));
+    gr = c * ((-1.0f / s + s / (psig * psig)) * sigmoidf(r));
+  }
+  return kl;
+}
+
+template <bool GRAD, bool ACC>
+__global__ __launch_bounds__(kBlock) void gauss_kl_kernel(const float* __restrict__ mean, const float* __restrict__ rho,
+                                                         float pmu, float psig, float grad_scale,
+                                                         const float* __restrict__ grad_scale_dev,
+                                                         float* __restrict__ gmean, float* __restrict__ grho,
+                                                         double* __restrict__ partials, int64_t n) {
+  __shared__ double smem[kBlock / 64];
+  const float c = grad_scale * (grad_scale_dev ? grad_scale_dev[0] : 1.0f);
+  const int64_t n4 = n >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  float local = 0.f;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 m = ld4(mean + 4 * i), r = ld4(rho + 4 * i);
+    f32x4 gm, gr;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f, b = 0.f;
+      part += kl_elem(m[j], r[j], pmu, psig, c, GRAD, a, b);
+      gm[j] = a;
+      gr[j] = b;
+    }
+    local += part;
+    if (GRAD) {
+      if (ACC) {
+        gm = gm + ld4(gmean + 4 * i);
+        gr = gr + ld4(grho + 4 * i);
+      }
+      st4(gmean + 4 * i, gm);
+      st4(grho + 4 * i, gr);
+    }
+  }
+  double acc = static_cast<double>(local);
+  if (blockIdx.x == 0) {
+    const int64_t k = (n4 << 2) + threadIdx.x;
+    if (k < n) {
+      float gm, gr;
+      acc += static_cast<double>(kl_elem(mean[k], rho[k], pmu, psig, c, GRAD, gm, gr));
+      if (GRAD) {
+        gmean[k] = ACC ? gmean[k] + gm : gm;
+        grho[k] = ACC ? grho[k] + gr : gr;
+      }
+    }
+  }
+  const double tot = block_sum(acc, smem);
+  if (threadIdx.x == 0) {
+    partials[kReduceHeader + blockIdx.x] = tot;
+    if (blockIdx.x == 0) partials[0] = static_cast<double>(gridDim.x);
+  }
+}
+
+template <bool GRAD, bool ACC>
+__global__ __launch_bounds__(kBlock) void l2_kernel(const float* __restrict__ p, float l2_scale, float grad_scale,
+                                                   const float* __restrict__ grad_scale_dev, float* __restrict__ g,
+                                                   double* __restrict__ partials, int64_t n) {
+  __shared__ double smem[kBlock / 64];
+  const float c = grad_scale * (grad_scale_dev ? grad_scale_dev[0] : 1.0f) * l2_scale;
+  const int64_t n4 = n >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  float local = 0.f;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = ld4(p + 4 * i);
+    local += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    if (GRAD) {
+      f32x4 o = c * v;
+      if (ACC) o = o + ld4(g + 4 * i);
+      st4(g + 4 * i, o);
+    }
+  }
+  double acc = static_cast<double>(local);
+  if (blockIdx.x == 0) {
+    const int64_t k = (n4 << 2) + threadIdx.x;
+    if (k < n) {
+      acc += static_cast<double>(p[k] * p[k]);
+      if (GRAD) g[k] = ACC ? g[k] + c * p[k] : c * p[k];
+    }
+  }
+  const double tot = block_sum(acc, smem);
+  if (threadIdx.x == 0) {
+    partials[kReduceHeader + blockIdx.x] = tot;
+    if (blockIdx.x == 0) partials[0] = static_cast<double>(gridDim.x);
+  }
+}
+
+// Fixed-order finish: one workgroup, fp64.  out[0] = factor * sum.
+__global__ __launch_bounds__(kBlock) void reduce_finish_kernel(const double* __restrict__ partials, float factor,
+                                                              float* __restrict__ out) {
+  __shared__ double smem[kBlock];
+  const int nb = static_cast<int>(partials[0]);
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nb; b += kBlock) s += partials[kReduceHeader + b];
+  smem[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) smem[threadIdx.x] += smem[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = static_cast<float>(static_cast<double>(factor) * smem[0]);
+}
+
+}  // namespace bde
+
+using namespace bde;
+
+extern "C" size_t bde_reduce_ws_bytes(void) { return sizeof(double) * (kReduceHeader + kReduceMaxBlocks); }
+
+extern "C" int bde_gauss_draw_fwd(const float* mean, const float* rho, const float* eps, uint64_t seed,
+                                  uint64_t stream_id, float* w, float* eps_out, int64_t n, void* stream) {
+  if (!mean || !rho || !w || n <= 0) return BDE_ERR_INVALID;
+  if (!aligned16(mean) || !aligned16(rho) || !aligned16(w) || (eps && !aligned16(eps)) ||
+      (eps_out && !aligned16(eps_out)))
+    return BDE_ERR_INVALID;
+  const int grid = stream_grid((n + 3) / 4);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (eps)
+    hipLaunchKernelGGL(gauss_draw_fwd_kernel<false>, dim3(grid), dim3(kBlock), 0, s, mean, rho, eps, seed, stream_id, w,
+                       eps_out, n);
+  else
+    hipLaunchKernelGGL(gauss_draw_fwd_kernel<true>, dim3(grid), dim3(kBlock), 0, s, mean, rho, eps, seed, stream_id, w,
+                       eps_out, n);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_gauss_draw_bwd(const float* g, const float* rho, const float* eps, uint64_t seed,
+                                  uint64_t stream_id, float* gmean, float* grho, int accumulate, int64_t n,
+                                  void* stream) {
+  if (!g || !rho || !gmean || !grho || n <= 0) return BDE_ERR_INVALID;
+  if (!aligned16(g) || !aligned16(rho) || !aligned16(gmean) || !aligned16(grho) || (eps && !aligned16(eps)))
+    return BDE_ERR_INVALID;
+  const int grid = stream_grid((n + 3) / 4);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define BDE_LAUNCH(R, A)                                                                                         \
+  hipLaunchKernelGGL((gauss_draw_bwd_kernel<R, A>), dim3(grid), dim3(kBlock), 0, s, g, rho, eps, seed, stream_id, \
+                     gmean, grho, n)
+  if (eps) {
+    if (accumulate) BDE_LAUNCH(false, true); else BDE_LAUNCH(false, false);
+  } else {
+    if (accumulate) BDE_LAUNCH(true, true); else BDE_LAUNCH(true, false);
+  }
+#undef BDE_LAUNCH
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_gauss_kl(const float* mean, const float* rho, float prior_mu, float prior_sigma, float grad_scale,
+                            const float* grad_scale_dev, float* gmean, float* grho, int accumulate, float* kl_out,
+                            void* ws, int64_t n, void* stream) {
+  if (!mean || !rho || !ws || n <= 0 || !(prior_sigma > 0.f)) return BDE_ERR_INVALID;
+  if ((gmean == nullptr) != (grho == nullptr)) return BDE_ERR_INVALID;
+  if (!aligned16(mean) || !aligned16(rho) || (gmean && (!aligned16(gmean) || !aligned16(grho)))) return BDE_ERR_INVALID;
+  const int grid = stream_grid((n + 3) / 4, kBlock, kReduceMaxBlocks);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* part = static_cast<double*>(ws);
+#define BDE_LAUNCH(G, A)                                                                                         \
+  hipLaunchKernelGGL((gauss_kl_kernel<G, A>), dim3(grid), dim3(kBlock), 0, s, mean, rho, prior_mu, prior_sigma, \
+                     grad_scale, grad_scale_dev, gmean, grho, part, n)
+  if (!gmean) BDE_LAUNCH(false, false);
+  else if (accumulate) BDE_LAUNCH(true, true);
+  else BDE_LAUNCH(true, false);
+#undef BDE_LAUNCH
+  int rc = to_err(hipGetLastError());
+  if (rc || !kl_out) return rc;
+  hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(kBlock), 0, s, part, 1.0f, kl_out);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_l2(const float* p, float l2_scale, float grad_scale, const float* grad_scale_dev, float* g,
+                      int accumulate, float* val_out, void* ws, int64_t n, void* stream) {
+  if (!p || !ws || n <= 0 || !aligned16(p) || (g && !aligned16(g))) return BDE_ERR_INVALID;
+  const int grid = stream_grid((n + 3) / 4, kBlock, kReduceMaxBlocks);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* part = static_cast<double*>(ws);
+#define BDE_LAUNCH(G, A) \
+  hipLaunchKernelGGL((l2_kernel<G, A>), dim3(grid), dim3(kBlock), 0, s, p, l2_scale, grad_scale, grad_scale_dev, g, part, n)
+  if (!g) BDE_LAUNCH(false, false);
+  else if (accumulate) BDE_LAUNCH(true, true);
+  else BDE_LAUNCH(true, false);
+#undef BDE_LAUNCH
+  int rc = to_err(hipGetLastError());
+  if (rc || !val_out) return rc;
+  hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(kBlock), 0, s, part, 0.5f * l2_scale, val_out);
+  return to_err(hipGetLastError());
+}

@@ -1,0 +1,459 @@
+// SVGD posterior update over M flattened particles.
+//
+// Reference: src/algos/svgd.py:14-32 (rbf) and :83-103 (step's no_grad block).
+// The reference gathers M*n_tensors per-tensor states into two [M, D]
+// matrices, then runs cdist**2 -> quantile -> exp -> rowsum*P - K@P -> K@(-G)
+// as ~10 separate ATen passes.  Here the particles and gradients LIVE in flat
+// [M, ld] buffers and the whole update is
+//
+//   gram    (reads P once,  4*M*D B): mean-centred Gram partials on the f32
+//           MFMA (v_mfma_f32_16x16x4_f32).  Centring matters: in the real
+//           configs the particles share a pretrained backbone, so ||x||^2 >>
+//           d^2 and the plain Gram trick loses 3 digits; centred by the
+//           per-coordinate particle mean (DPP butterfly across the lanes that
+//           hold the M particles) the error is ~1e-7.
+//   kstats  (one workgroup): fixed-order fp64 reduction of the partials ->
+//           d2 -> torch.quantile median -> h -> K -> coefficient matrices.
+//   combine (reads P, G, writes out, 12*M*D B): out = CG@G + CP@P with the
+//           2*M*M coefficients in SGPRs; out may alias G, so -phi lands
+//           directly in the gradient rows the base optimizer consumes.
+//
+// 16*M*D bytes and 6*M*M*D flop per step: ~3 flop/B at M = 8, far below the
+// fp32 ridge (~20 flop/B) -> HBM-bound; the MFMA is used for the Gram
+// contraction because it leaves the VALU free for the centring, not because
+// the kernel is matrix-bound.
+#include "bde_common.hpp"
+
+namespace bde {
+
+constexpr int kGramBlock = 256;            // 4 waves
+constexpr int kGramU = 4;                  // float4 loads in flight per lane per iteration
+constexpr int kWsHeaderFloats = 16;        // [0] = #partial tiles, [1] = padded M (8 or 16)
+constexpr int kGramMaxBlocks = 2048;
+
+using f32x4acc = __attribute__((ext_vector_type(4))) float;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the 8 (PACK 2) or 16 (PACK 1) consecutive lanes that hold one
+// coordinate of all particles; every lane of the group gets the sum.
+template <int PACK>
+__device__ __forceinline__ float group_sum(float x) {
+  float s = x + dpp_mov<0xB1>(x);      // quad_perm [1,0,3,2]
+  s += dpp_mov<0x4E>(s);               // quad_perm [2,3,0,1]
+  s += dpp_mov<0x141>(s);              // row_half_mirror: 8 lanes
+  if (PACK == 1) s += dpp_mov<0x140>(s);   // row_mirror: 16 lanes
+  return s;
+}
+
+// PACK = 2: M <= 8, the 16 tile rows are (particle, d-chunk 0/1); PACK = 1: M <= 16.
+template <int PACK>
+__global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __restrict__ P, int M, int64_t D,
+                                                              int64_t ld, float* __restrict__ ws) {
+  constexpr int W4 = (PACK == 2) ? 8 : 4;           // float4 columns one wave-load covers
+  constexpr int MP = (PACK == 2) ? 8 : 16;          // padded particle count
+  __shared__ float tile[kGramBlock / 64][16][17];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int prow = (PACK == 2) ? (r16 & 7) : r16;
+  const int c4 = (PACK == 2) ? ((r16 >> 3) * 4 + kq) : kq;
+  const bool valid = prow < M;
+  const float inv_m = 1.0f / static_cast<float>(M);
+  const float* rowp = P + static_cast<int64_t>(valid ? prow : 0) * ld;
+
+  const int64_t n4 = (D + 3) >> 2;                   // float4 columns (last may be partial)
+  const int64_t tile4 = static_cast<int64_t>(kGramU) * W4;
+  const int64_t n_tiles = (n4 + tile4 - 1) / tile4;
+  const int64_t waves_total = static_cast<int64_t>(gridDim.x) * (kGramBlock / 64);
+
+  f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * (kGramBlock / 64) + wave; t < n_tiles; t += waves_total) {
+    const int64_t base4 = t * tile4 + c4;
+    f32x4 v[kGramU];
+    if ((t + 1) * tile4 * 4 <= D) {                  // wave-uniform: every column full
+#pragma unroll
+      for (int u = 0; u < kGramU; ++u) v[u] = valid ? ld4(rowp + 4 * (base4 + u * W4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int u = 0; u < kGramU; ++u) {
+        const int64_t col = base4 + u * W4;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (valid && col < n4) {
+          x = ld4(rowp + 4 * col);                   // in bounds: ld >= roundup4(D)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (4 * col + j >= D) x[j] = 0.f;        // select, never multiply (padding may be NaN)
+        }
+        v[u] = x;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kGramU; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = v[u][j];
+        const float s = group_sum<PACK>(x);
+        const float q = valid ? (x - s * inv_m) : 0.f;
+        if ((j & 1) == 0)
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q, q, acc0, 0, 0, 0);
+        else
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q, q, acc1, 0, 0, 0);
+      }
+    }
+  }
+
+  // C[i][j]: lane holds column j = lane & 15, rows i = 4 * (lane >> 4) + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][r16] = acc0[r] + acc1[r];
+  __syncthreads();
+  if (threadIdx.x < MP * MP) {
+    const int pi = threadIdx.x / MP, pj = threadIdx.x % MP;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < kGramBlock / 64; ++w) {
+      s += tile[w][pi][pj];
+      if (PACK == 2) s += tile[w][pi + 8][pj + 8];
+    }
+    ws[kWsHeaderFloats + static_cast<int64_t>(blockIdx.x) * (MP * MP) + threadIdx.x] = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ws[0] = static_cast<float>(gridDim.x);
+    ws[1] = static_cast<float>(MP);
+  }
+}
+
+// ---------------------------------------------------------------- kstats --
+constexpr int kStatsBlock = 1024;
+
+__global__ __launch_bounds__(kStatsBlock) void svgd_kstats_kernel(const float* __restrict__ ws, int M, float l2_reg,
+                                                                 float kernel_grad_scale, float dataset_size,
+                                                                 float sign, float h_override, float log_m1, int mode,
+                                                                 float* __restrict__ kstat) {
+  __shared__ double red[kStatsBlock];
+  __shared__ double gmat[256];
+  __shared__ float d2f[256];
+  __shared__ float sorted[256];
+  __shared__ float kmat[256];
+  __shared__ float rowsum[16];
+  __shared__ float hs[2];
+
+  const int nb = static_cast<int>(ws[0]);
+  const int MP = static_cast<int>(ws[1]);
+  const int mp2 = MP * MP;
+  const float* part = ws + kWsHeaderFloats;
+  const int tid = threadIdx.x;
+
+  // fixed-order fp64 reduction of the per-workgroup partial Gram tiles
+  const int nslices = kStatsBlock / mp2;
+  {
+    const int e = tid % mp2, slice = tid / mp2;
+    double s = 0.0;
+    for (int b = slice; b < nb; b += nslices) s += static_cast<double>(part[static_cast<int64_t>(b) * mp2 + e]);
+    red[tid] = s;
+  }
+  __syncthreads();
+  if (tid < mp2) {
+    double s = 0.0;
+    for (int sl = 0; sl < nslices; ++sl) s += red[sl * mp2 + tid];
+    gmat[tid] = s;
+  }
+  __syncthreads();
+
+  const int n = M * M;
+  if (tid < n) {
+    const int i = tid / M, j = tid % M;
+    double d = gmat[i * MP + i] + gmat[j * MP + j] - 2.0 * gmat[i * MP + j];   // svgd.py:15
+    if (d < 0.0 || i == j) d = 0.0;
+    d2f[tid] = static_cast<float>(d);
+  }
+  __syncthreads();
+  // rank sort of the M*M distances (diagonal zeros included, svgd.py:18)
+  if (tid < n) {
+    const float v = d2f[tid];
+    int rank = 0;
+    for (int u = 0; u < n; ++u) {
+      const float o = d2f[u];
+      rank += (o < v || (o == v && u < tid)) ? 1 : 0;
+    }
+    sorted[rank] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // torch.quantile(d2, 0.5), 'linear' interpolation, fp32 like the reference
+    const float pos = 0.5f * static_cast<float>(n - 1);
+    const float lo = floorf(pos);
+    const float wgt = pos - lo;
+    const float a = sorted[static_cast<int>(lo)], b = sorted[static_cast<int>(ceilf(pos))];
+    const float med = (fabsf(wgt) < 0.5f) ? a + wgt * (b - a) : b - (b - a) * (1.0f - wgt);   // at::lerp
+    float h = __builtin_sqrtf((0.5f * med) / log_m1) + 1e-8f;                                 // svgd.py:18
+    if (h_override > 0.f) h = h_override;
+    hs[0] = h;
+    hs[1] = med;
+  }
+  __syncthreads();
+  const float h = hs[0];
+  if (tid < n) kmat[tid] = expf(-d2f[tid] / (2.0f * (h * h)));   // svgd.py:21
+  __syncthreads();
+  if (tid < M) {
+    float s = 0.f;
+    for (int j = 0; j < M; ++j) s += kmat[tid * M + j];
+    rowsum[tid] = s;
+  }
+  __syncthreads();
+
+  const int oK = 0, oD2 = n, oRow = 2 * n, oMisc = 2 * n + M, oCG = oMisc + 4, oCP = oCG + n;
+  const double h2 = static_cast<double>(h) * static_cast<double>(h);
+  const double s_rep = static_cast<double>(kernel_grad_scale) / (static_cast<double>(dataset_size) * h2);
+  if (tid < n) {
+    const int i = tid / M, j = tid % M;
+    const double kij = kmat[tid];
+    const double rep = ((i == j) ? static_cast<double>(rowsum[i]) : 0.0) - kij;   // rowsum_i [i==j] - K_ij
+    double cg, cp;
+    if (mode == 0) {
+      // phi_i = sum_j -K_ij (G_j + l2/2 P_j) + s_rep * (rowsum_i P_i - K_ij P_j)   (svgd.py:86-89)
+      cg = static_cast<double>(sign) * (-kij);
+      cp = static_cast<double>(sign) * (-kij * (0.5 * static_cast<double>(l2_reg)) + s_rep * rep);
+    } else {
+      cg = 0.0;
+      cp = rep / h2;                                                              // svgd.py:23,31
+    }
+    kstat[oK + tid] = kmat[tid];
+    kstat[oD2 + tid] = d2f[tid];
+    kstat[oCG + j * M + i] = static_cast<float>(cg);
+    kstat[oCP + j * M + i] = static_cast<float>(cp);
+  }
+  if (tid < M) kstat[oRow + tid] = rowsum[tid];
+  if (tid == 0) {
+    kstat[oMisc + 0] = h;
+    kstat[oMisc + 1] = hs[1];
+    kstat[oMisc + 2] = static_cast<float>(s_rep);
+    kstat[oMisc + 3] = static_cast<float>(M);
+  }
+}
+
+// --------------------------------------------------------------- combine --
+template <int M, bool HAS_G>
+__global__ __launch_bounds__(kBlock) void svgd_combine_kernel(const float* __restrict__ P, const float* G, float* out,
+                                                             int64_t D, int64_t ld, const float* __restrict__ cgT,
+                                                             const float* __restrict__ cpT) {
+  const int64_t n4 = D >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i4 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i4 < n4; i4 += stride) {
+    f32x4 acc[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const f32x4 p = ld4(P + j * ld + 4 * i4);
+      if (HAS_G) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(G + j * ld + 4 * i4);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          const float a = cgT[j * M + i];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_fmaf(a, g[c], acc[i][c]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        const float b = cpT[j * M + i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_fmaf(b, p[c], acc[i][c]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) *reinterpret_cast<f32x4*>(out + i * ld + 4 * i4) = acc[i];
+  }
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < D) {
+      float acc[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const float p = P[j * ld + e];
+        const float g = HAS_G ? G[j * ld + e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          if (HAS_G) acc[i] = __builtin_fmaf(cgT[j * M + i], g, acc[i]);
+          acc[i] = __builtin_fmaf(cpT[j * M + i], p, acc[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i) out[i * ld + e] = acc[i];
+    }
+  }
+}
+
+template <int M>
+static int launch_combine(const float* P, const float* G, float* out, int64_t D, int64_t ld, const float* kstat,
+                          hipStream_t s) {
+  const int n = M * M;
+  const float* cg = kstat + 2 * n + M + 4;
+  const float* cp = cg + n;
+  const int grid = stream_grid((D + 3) / 4);
+  if (G)
+    hipLaunchKernelGGL((svgd_combine_kernel<M, true>), dim3(grid), dim3(kBlock), 0, s, P, G, out, D, ld, cg, cp);
+  else
+    hipLaunchKernelGGL((svgd_combine_kernel<M, false>), dim3(grid), dim3(kBlock), 0, s, P, G, out, D, ld, cg, cp);
+  return to_err(hipGetLastError());
+}
+
+// ------------------------------------------- fused shared-state optimizers --
+// One thread owns a float4 column of all M particles and walks the particles
+// in order, carrying the SHARED optimizer state in registers.
+struct AdamSteps {
+  float step_size[BDE_MAX_PARTICLES];     // lr / (1 - beta1^t)
+  float bc2_sqrt[BDE_MAX_PARTICLES];      // sqrt(1 - beta2^t)
+};
+
+__global__ __launch_bounds__(kBlock) void svgd_apply_sgd_kernel(float* __restrict__ P, const float* __restrict__ grad,
+                                                               float* __restrict__ buf, int M, int64_t D, int64_t ld,
+                                                               float lr, float momentum, float omd, float wd,
+                                                               int nesterov, int first) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < D; e += stride) {
+    float b = (momentum != 0.f && !first) ? buf[e] : 0.f;
+    for (int i = 0; i < M; ++i) {
+      float p = P[i * ld + e];
+      float g = grad[i * ld + e];
+      if (wd != 0.f) g = __builtin_fmaf(wd, p, g);
+      if (momentum != 0.f) {
+        if (first && i == 0) b = g;
+        else b = momentum * b + omd * g;
+        g = nesterov ? __builtin_fmaf(momentum, b, g) : b;
+      }
+      P[i * ld + e] = p - lr * g;
+    }
+    if (momentum != 0.f) buf[e] = b;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void svgd_apply_adam_kernel(float* __restrict__ P, const float* __restrict__ grad,
+                                                                float* __restrict__ exp_avg,
+                                                                float* __restrict__ exp_avg_sq, int M, int64_t D,
+                                                                int64_t ld, float beta1, float beta2, float omb1,
+                                                                float omb2, float eps, float wd, AdamSteps st) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < D; e += stride) {
+    float m = exp_avg[e], v = exp_avg_sq[e];
+    for (int i = 0; i < M; ++i) {
+      float p = P[i * ld + e];
+      float g = grad[i * ld + e];
+      if (wd != 0.f) g = __builtin_fmaf(wd, p, g);
+      m = m + (g - m) * omb1;                       // exp_avg.lerp_(grad, 1 - beta1)
+      v = __builtin_fmaf(omb2 * g, g, beta2 * v);   // mul_(beta2).addcmul_(g, g, value=1-beta2)
+      const float denom = __builtin_sqrtf(v) / st.bc2_sqrt[i] + eps;
+      P[i * ld + e] = p - st.step_size[i] * (m / denom);
+    }
+    exp_avg[e] = m;
+    exp_avg_sq[e] = v;
+  }
+}
+
+}  // namespace bde
+
+using namespace bde;
+
+extern "C" size_t bde_svgd_ws_bytes(int M) {
+  if (M < 1 || M > BDE_MAX_PARTICLES) return 0;
+  const size_t mp = (M <= 8) ? 8 : 16;
+  return sizeof(float) * (kWsHeaderFloats + static_cast<size_t>(kGramMaxBlocks) * mp * mp);
+}
+
+extern "C" size_t bde_svgd_kstat_floats(int M) {
+  if (M < 1 || M > BDE_MAX_PARTICLES) return 0;
+  return static_cast<size_t>(4 * M * M + M + 4);
+}
+
+static bool svgd_args_ok(const float* P, int M, int64_t D, int64_t ld) {
+  return P && M >= 1 && M <= BDE_MAX_PARTICLES && D >= 1 && ld >= D && (ld & 3) == 0 && aligned16(P);
+}
+
+extern "C" int bde_svgd_gram(const float* P, int M, int64_t D, int64_t ld, void* ws, void* stream) {
+  if (!svgd_args_ok(P, M, D, ld) || !ws || !aligned16(ws)) return BDE_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n4 = (D + 3) / 4;
+  if (M <= 8) {
+    const int64_t tiles = (n4 + kGramU * 8 - 1) / (kGramU * 8);
+    const int grid = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, kGramMaxBlocks));
+    hipLaunchKernelGGL(svgd_gram_kernel<2>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, static_cast<float*>(ws));
+  } else {
+    const int64_t tiles = (n4 + kGramU * 4 - 1) / (kGramU * 4);
+    const int grid = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, kGramMaxBlocks));
+    hipLaunchKernelGGL(svgd_gram_kernel<1>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, static_cast<float*>(ws));
+  }
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_svgd_kstats(const void* ws, int M, float l2_reg, float kernel_grad_scale, float dataset_size,
+                               float sign, float h_override, int mode, float* kstat, void* stream) {
+  if (!ws || !kstat || M < 1 || M > BDE_MAX_PARTICLES || (mode != 0 && mode != 1)) return BDE_ERR_INVALID;
+  const float log_m1 = static_cast<float>(std::log(static_cast<double>(M) + 1.0));   // np.log(M + 1), svgd.py:18
+  hipLaunchKernelGGL(svgd_kstats_kernel, dim3(1), dim3(kStatsBlock), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(ws), M, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, log_m1,
+                     mode, kstat);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_svgd_combine(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
+                                const float* kstat, void* stream) {
+  if (!svgd_args_ok(P, M, D, ld) || !out || !kstat || !aligned16(out) || (G && !aligned16(G)) || out == P)
+    return BDE_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (M) {
+#define BDE_CASE(m) \
+  case m:           \
+    return launch_combine<m>(P, G, out, D, ld, kstat, s);
+    BDE_CASE(1) BDE_CASE(2) BDE_CASE(3) BDE_CASE(4) BDE_CASE(5) BDE_CASE(6) BDE_CASE(7) BDE_CASE(8)
+    BDE_CASE(9) BDE_CASE(10) BDE_CASE(11) BDE_CASE(12) BDE_CASE(13) BDE_CASE(14) BDE_CASE(15) BDE_CASE(16)
+#undef BDE_CASE
+  }
+  return BDE_ERR_INVALID;
+}
+
+extern "C" int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld, float l2_reg,
+                             float kernel_grad_scale, float dataset_size, float sign, void* ws, float* kstat,
+                             void* stream) {
+  if (!G) return BDE_ERR_INVALID;
+  int rc = bde_svgd_gram(P, M, D, ld, ws, stream);
+  if (rc) return rc;
+  rc = bde_svgd_kstats(ws, M, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, kstat, stream);
+  if (rc) return rc;
+  return bde_svgd_combine(P, G, out, M, D, ld, kstat, stream);
+}
+
+extern "C" int bde_svgd_apply_sgd(float* P, const float* grad, float* momentum_buf, int M, int64_t D, int64_t ld,
+                                  double lr, double momentum, double dampening, double weight_decay, int nesterov,
+                                  int first, void* stream) {
+  if (!svgd_args_ok(P, M, D, ld) || !grad || (momentum != 0.0 && !momentum_buf)) return BDE_ERR_INVALID;
+  const int grid = stream_grid(D);
+  hipLaunchKernelGGL(svgd_apply_sgd_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), P, grad,
+                     momentum_buf, M, D, ld, static_cast<float>(lr), static_cast<float>(momentum),
+                     static_cast<float>(1.0 - dampening), static_cast<float>(weight_decay), nesterov, first);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_svgd_apply_adam(float* P, const float* grad, float* exp_avg, float* exp_avg_sq, int M, int64_t D,
+                                   int64_t ld, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                   int64_t step0, void* stream) {
+  if (!svgd_args_ok(P, M, D, ld) || !grad || !exp_avg || !exp_avg_sq || step0 < 0) return BDE_ERR_INVALID;
+  AdamSteps st;
+  for (int i = 0; i < BDE_MAX_PARTICLES; ++i) {
+    const double t = static_cast<double>(step0 + i + 1);
+    st.step_size[i] = static_cast<float>(lr / (1.0 - std::pow(beta1, t)));
+    st.bc2_sqrt[i] = static_cast<float>(std::sqrt(1.0 - std::pow(beta2, t)));
+  }
+  const int grid = stream_grid(D);
+  hipLaunchKernelGGL(svgd_apply_adam_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), P, grad,
+                     exp_avg, exp_avg_sq, M, D, ld, static_cast<float>(beta1), static_cast<float>(beta2),
+                     static_cast<float>(1.0 - beta1), static_cast<float>(1.0 - beta2), static_cast<float>(eps),
+                     static_cast<float>(weight_decay), st);
+  return to_err(hipGetLastError());
+}

@@ -1,0 +1,164 @@
+"""Tensor-level wrappers over the C ABI (include/bde_hip.h).
+
+``HipOps`` is the only kernel backend the product has.  Each method checks its
+tensors (CUDA, fp32, contiguous last dim), passes raw device pointers and the
+CURRENT torch stream to libbde_hip.so and raises on a non-zero return code.
+The optimizer shells call kernels only through an object with this interface;
+tests may inject a checker object with the same methods (see tests/), the
+product never does.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+class BdeKernelError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor], name: str = "tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BdeKernelError(f"{name}: expected a CUDA (HIP) tensor, got device {t.device}; "
+                             "beyond_deep_ensembles_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise BdeKernelError(f"{name}: expected float32, got {t.dtype}")
+    if t.dim() > 0 and t.stride(-1) != 1:
+        raise BdeKernelError(f"{name}: last dimension must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise BdeKernelError(f"{what} failed with code {rc}" + (" (invalid argument)" if rc == -1 else " (hipError)"))
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.dim() == 2 else t.shape[-1]
+
+
+def pad4(n: int, mult: int = 64) -> int:
+    """Leading dimension used for flat rows: a multiple of 64 floats (256 B)."""
+    return (n + mult - 1) // mult * mult
+
+
+class HipOps:
+    """Kernel backend over libbde_hip.so."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # ------------------------------------------------------------ SVGD --
+    def svgd_ws(self, m: int, device) -> torch.Tensor:
+        n = self.lib.bde_svgd_ws_bytes(m)
+        if n == 0:
+            raise BdeKernelError(f"SVGD supports 1 <= particle_count <= 16, got {m}")
+        return torch.empty(n // 4, dtype=torch.float32, device=device)
+
+    def svgd_kstat(self, m: int, device) -> torch.Tensor:
+        return torch.zeros(self.lib.bde_svgd_kstat_floats(m), dtype=torch.float32, device=device)
+
+    def svgd_gram(self, P, d, ws):
+        m = P.shape[0]
+        _check(self.lib.bde_svgd_gram(_ptr(P, "P"), m, d, _ld(P), _ptr(ws), _stream()), "bde_svgd_gram")
+
+    def svgd_kstats(self, ws, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override=0.0, mode=0):
+        _check(self.lib.bde_svgd_kstats(_ptr(ws), m, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, mode,
+                                        _ptr(kstat), _stream()), "bde_svgd_kstats")
+
+    def svgd_combine(self, P, G, out, d, kstat):
+        m = P.shape[0]
+        if G is not None and _ld(G) != _ld(P) or _ld(out) != _ld(P):
+            raise BdeKernelError("P, G, out must share one leading dimension")
+        _check(self.lib.bde_svgd_combine(_ptr(P, "P"), _ptr(G, "G"), _ptr(out, "out"), m, d, _ld(P), _ptr(kstat),
+                                         _stream()), "bde_svgd_combine")
+
+    def svgd_step(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat):
+        """out = sign * phi (svgd.py:86-89); out may alias G."""
+        m = P.shape[0]
+        if _ld(G) != _ld(P) or _ld(out) != _ld(P):
+            raise BdeKernelError("P, G, out must share one leading dimension")
+        _check(self.lib.bde_svgd_step(_ptr(P, "P"), _ptr(G, "G"), _ptr(out, "out"), m, d, _ld(P), l2_reg,
+                                      kernel_grad_scale, dataset_size, sign, _ptr(ws), _ptr(kstat), _stream()),
+               "bde_svgd_step")
+
+    def svgd_apply_sgd(self, P, grad, buf, d, lr, momentum, dampening, weight_decay, nesterov, first):
+        _check(self.lib.bde_svgd_apply_sgd(_ptr(P), _ptr(grad), _ptr(buf), P.shape[0], d, _ld(P), lr, momentum,
+                                           dampening, weight_decay, int(nesterov), int(first), _stream()),
+               "bde_svgd_apply_sgd")
+
+    def svgd_apply_adam(self, P, grad, exp_avg, exp_avg_sq, d, lr, beta1, beta2, eps, weight_decay, step0):
+        _check(self.lib.bde_svgd_apply_adam(_ptr(P), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), P.shape[0], d,
+                                            _ld(P), lr, beta1, beta2, eps, weight_decay, int(step0), _stream()),
+               "bde_svgd_apply_adam")
+
+    # ------------------------------------------------------------ SWAG --
+    def swag_update(self, theta, mean, sq, dev_row, n, d):
+        _check(self.lib.bde_swag_update(_ptr(theta, "theta"), _ptr(mean), _ptr(sq), _ptr(dev_row), int(n), d,
+                                        _stream()), "bde_swag_update")
+
+    def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0):
+        k = dev.shape[0]
+        _check(self.lib.bde_swag_sample(_ptr(mean), _ptr(sq), _ptr(dev), k, _ld(dev), head, _ptr(eps_w), _ptr(eps_d),
+                                        seed, stream_id, _ptr(out), d, _stream()), "bde_swag_sample")
+
+    def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0):
+        k, s = dev.shape[0], out.shape[0]
+        if eps_d is not None and _ld(eps_d) != _ld(out):
+            raise BdeKernelError("eps_d and out must share one leading dimension")
+        _check(self.lib.bde_swag_sample_batched(_ptr(mean), _ptr(sq), _ptr(dev), k, _ld(dev), head, _ptr(eps_w),
+                                                _ptr(eps_d), seed, stream_id0, _ptr(out), _ld(out), s, d, _stream()),
+               "bde_swag_sample_batched")
+
+    def philox_normal(self, seed, stream_id, eps_w=None, eps_d=None, d=None):
+        k = 0 if eps_w is None else eps_w.numel()
+        n = 0 if eps_d is None else (d if d is not None else eps_d.numel())
+        _check(self.lib.bde_philox_normal(seed, stream_id, _ptr(eps_w), k, _ptr(eps_d), n, _stream()),
+               "bde_philox_normal")
+
+    # ----------------------------------------------------------- Gauss --
+    def reduce_ws(self, device) -> torch.Tensor:
+        return torch.empty(self.lib.bde_reduce_ws_bytes() // 4, dtype=torch.float32, device=device)
+
+    def gauss_draw_fwd(self, mean, rho, out, n, eps=None, seed=0, stream_id=0, eps_out=None):
+        _check(self.lib.bde_gauss_draw_fwd(_ptr(mean), _ptr(rho), _ptr(eps), seed, stream_id, _ptr(out), _ptr(eps_out),
+                                           n, _stream()), "bde_gauss_draw_fwd")
+
+    def gauss_draw_bwd(self, g, rho, gmean, grho, n, eps=None, seed=0, stream_id=0, accumulate=False):
+        _check(self.lib.bde_gauss_draw_bwd(_ptr(g), _ptr(rho), _ptr(eps), seed, stream_id, _ptr(gmean), _ptr(grho),
+                                           int(accumulate), n, _stream()), "bde_gauss_draw_bwd")
+
+    def gauss_kl(self, mean, rho, prior_mu, prior_sigma, n, ws, kl_out=None, gmean=None, grho=None, grad_scale=1.0,
+                 grad_scale_dev=None, accumulate=False):
+        _check(self.lib.bde_gauss_kl(_ptr(mean), _ptr(rho), prior_mu, prior_sigma, grad_scale, _ptr(grad_scale_dev),
+                                     _ptr(gmean), _ptr(grho), int(accumulate), _ptr(kl_out), _ptr(ws), n, _stream()),
+               "bde_gauss_kl")
+
+    def l2(self, p, l2_scale, n, ws, val_out=None, g=None, grad_scale=1.0, grad_scale_dev=None, accumulate=False):
+        _check(self.lib.bde_l2(_ptr(p), l2_scale, grad_scale, _ptr(grad_scale_dev), _ptr(g), int(accumulate),
+                               _ptr(val_out), _ptr(ws), n, _stream()), "bde_l2")
+
+    # ------------------------------------------------------------ iVON --
+    def ivon_sample(self, mean, prec, param, delta_sum, n, n_eff, first, eps=None, seed=0, stream_id=0,
+                    deterministic=False):
+        _check(self.lib.bde_ivon_sample(_ptr(mean), _ptr(prec), _ptr(eps), seed, stream_id, n_eff, int(deterministic),
+                                        int(first), _ptr(param), _ptr(delta_sum), n, _stream()), "bde_ivon_sample")
+
+    def ivon_update(self, mean, momentum, prec, delta_sum, acc_grad, n, *, lam, n_eff, mc, beta1, beta2, t, lr,
+                    damping):
+        # Python-double scalar expressions exactly as ivorn.py:72-89 forms them
+        _check(self.lib.bde_ivon_update(_ptr(mean), _ptr(momentum), _ptr(prec), _ptr(delta_sum), _ptr(acc_grad),
+                                        lam, n_eff, mc, beta1, 1 - beta1, 1 - beta2, 0.5 * (1 - beta2) ** 2,
+                                        1 - beta1 ** t, 1 - beta2 ** t, lr, damping, n, _stream()), "bde_ivon_update")

@@ -1,0 +1,217 @@
+/*
+ * bde_hip.h -- C ABI of libbde_hip.so: the MI355X (gfx950) posterior-update
+ * kernels behind BayesianOptimizer.step()/complete_epoch()/sample_parameters().
+ *
+ * The reference (Feuermagier/Beyond_Deep_Ensembles) is pure Python over PyTorch
+ * and has no FFI for this path; its "operator API" is the Python optimizer
+ * surface in src/algos.  Each entry point below replaces the ATen op sequence
+ * at the cited reference lines.  The Python shells in
+ * beyond_deep_ensembles_amd/ bind these symbols with ctypes (INTEGRATION.md
+ * shows the stub a reference maintainer would add).
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes, fp32 data, no torch types;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *     work is only ENQUEUED on it: no allocation, no free, no synchronisation,
+ *     no host<->device copies -- every call is hipGraph-capturable;
+ *   - return 0 on success, a negative hipError_t on a launch failure, or
+ *     BDE_ERR_INVALID (-1) for a rejected argument (nothing is enqueued);
+ *   - every vector pointer must be 16-byte aligned; leading dimensions `ld`
+ *     are in floats and must be multiples of 4 with ld >= D;
+ *   - scratch memory is supplied by the caller (sizes from bde_*_ws_bytes);
+ *   - results are deterministic run to run (two-stage reductions, no float
+ *     atomics).
+ */
+#ifndef BDE_HIP_H
+#define BDE_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDE_ERR_INVALID (-1)
+#define BDE_MAX_PARTICLES 16   /* SVGD: M <= 16 (one 16x16 MFMA tile)        */
+#define BDE_MAX_RANK 256       /* SWAG: deviation_samples K <= 256           */
+#define BDE_MAX_BATCH 32       /* SWAG batched sampling: S <= 32 per call    */
+
+/* Library/ABI version (major*10000 + minor*100 + patch). */
+int bde_version(void);
+/* gfx target the device code was compiled for, e.g. "gfx950". */
+const char* bde_arch(void);
+
+/* ------------------------------------------------------------------ SVGD --
+ * One SVGD posterior update over M flattened particles P [M, ld] with
+ * gradients G [M, ld] (D valid floats per row).
+ *
+ * Replaces src/algos/svgd.py:14-32 (rbf) and :83-89 (stack/cat, prior term,
+ * phi) -- torch.cdist**2, torch.quantile, exp, kernel.sum, two matmuls and
+ * ~6 elementwise passes -- by three launches:
+ *   gram    : mean-centred Gram partials of P on the f32 MFMA (reads P once)
+ *   kstats  : fixed-order fp64 reduction of the partials, d2, median
+ *             bandwidth h (torch.quantile semantics, diagonal included),
+ *             K = exp(-d2/(2h^2)), and the two M x M coefficient matrices
+ *   combine : out = CG @ G + CP @ P in one streaming pass (reads P, G; writes
+ *             out; out may alias G).
+ */
+
+/* Bytes of scratch `ws` needed by the SVGD entry points for M particles. */
+size_t bde_svgd_ws_bytes(int M);
+
+/* Number of floats of the `kstat` result block for M particles.  Layout:
+ *   [0, M*M)        K        row-major kernel matrix      (svgd.py:21)
+ *   [M*M, 2M*M)     d2       squared distances            (svgd.py:15)
+ *   [2M*M, 2M*M+M)  rowsum   sum_j K_ij                   (svgd.py:23)
+ *   next 4 floats   h, median(d2), s = kernel_grad_scale/(dataset_size*h^2), M
+ *   next M*M        CG^T     coefficient of G, stored [j][i]
+ *   next M*M        CP^T     coefficient of P, stored [j][i]
+ */
+size_t bde_svgd_kstat_floats(int M);
+
+/* Stage 1: per-workgroup partial Gram matrices of the mean-centred particles
+ * into ws.  P [M, ld]. */
+int bde_svgd_gram(const float* P, int M, int64_t D, int64_t ld, void* ws, void* stream);
+
+/* Stage 2: reduce the partials, bandwidth, kernel, coefficients -> kstat.
+ * phi = K @ (-(G + l2_reg/2 * P)) + kernel_grad_scale * gradK / dataset_size
+ * (svgd.py:86-89); the coefficients produce `sign * phi` (sign = -1 gives the
+ * gradient the reference hands to the base optimizer, svgd.py:95).
+ * If h_override > 0 it replaces the median bandwidth (rbf's h_override).
+ * mode 0: step coefficients (CG = -sign*K ...); mode 1: rbf coefficients, i.e.
+ * CG = 0 and CP = (diag(rowsum) - K) / h^2 so that combine() yields grad_kernel
+ * (svgd.py:23,31). */
+int bde_svgd_kstats(const void* ws, int M, float l2_reg, float kernel_grad_scale,
+                    float dataset_size, float sign, float h_override, int mode,
+                    float* kstat, void* stream);
+
+/* Stage 3: out[i, :] = sum_j CG[i][j] * G[j, :] + CP[i][j] * P[j, :].
+ * G may be NULL (CG ignored).  out may alias G (not P). */
+int bde_svgd_combine(const float* P, const float* G, float* out, int M, int64_t D,
+                     int64_t ld, const float* kstat, void* stream);
+
+/* All three stages back to back on `stream` (one SVGD posterior update). */
+int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
+                  float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
+                  void* ws, float* kstat, void* stream);
+
+/* Shared-state base-optimizer apply for the M particles, in particle order
+ * (svgd.py:92-103 with ONE torch.optim.SGD / Adam whose state is keyed on the
+ * model's parameters and therefore shared by all particles).
+ * grad [M, ld] is the gradient handed to the optimizer (= -phi), P [M, ld] the
+ * particles (updated in place), state buffers are [D]-sized (ld_state = ld).
+ * sgd: torch.optim.SGD semantics (momentum, dampening, nesterov, weight_decay,
+ * maximize=False); `first` != 0 means the momentum buffer is uninitialised
+ * (torch initialises it with the first gradient it sees).
+ * adam: torch.optim.Adam semantics (amsgrad=False, maximize=False), `step0` is
+ * the shared step counter before this call (it advances by M).
+ * Hyper-parameters are doubles: torch forms step_size = lr / (1 - beta1^t) etc.
+ * in Python double arithmetic before rounding to fp32. */
+int bde_svgd_apply_sgd(float* P, const float* grad, float* momentum_buf, int M, int64_t D, int64_t ld,
+                       double lr, double momentum, double dampening, double weight_decay, int nesterov,
+                       int first, void* stream);
+int bde_svgd_apply_adam(float* P, const float* grad, float* exp_avg, float* exp_avg_sq, int M, int64_t D,
+                        int64_t ld, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        int64_t step0, void* stream);
+
+/* ------------------------------------------------------------------ SWAG --
+ * Statistics live on the device: mean [D], sq [D], and the deviation matrix as
+ * a ring dev [K, ld] (row = one iterate) instead of the reference's CPU
+ * [D, K] matrix that is physically rolled every update (swag.py:103).
+ * Logical column c of the reference (0 = oldest ... K-1 = newest) is physical
+ * row (head + c) mod K, where `head` is the row the NEXT update overwrites.
+ */
+
+/* One moment update, n = the already incremented `__updates` counter
+ * (swag.py:97-104): mean = (n*mean + theta)/(n+1); sq = (n*sq + theta^2)/(n+1);
+ * dev_row[:] = theta - mean_new.  The caller passes dev_row = dev + head*ld and
+ * advances head.  Bit-exact with the reference's fp32 CPU arithmetic. */
+int bde_swag_update(const float* theta, float* mean, float* sq, float* dev_row,
+                    int64_t n, int64_t D, void* stream);
+
+/* One posterior sample (swag.py:57,112-114 + LowRankMultivariateNormal.rsample):
+ *   out = mean + sum_c dev[col c] * eps_w[c] / sqrt(2 (K-1))
+ *              + sqrt(0.5 * (relu(sq - mean^2) + 1e-6)) * eps_d
+ * eps_w [K] is indexed by LOGICAL column.  eps_w / eps_d may be NULL: the
+ * noise then comes from the in-kernel Philox4x32-10 stream (seed, stream_id),
+ * which is independent of the launch geometry. */
+int bde_swag_sample(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
+                    const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id,
+                    float* out, int64_t D, void* stream);
+
+/* S posterior samples in one pass over the statistics: out [S, ld_out].
+ * The deviation-matrix x noise product [D,K]x[K,S] runs on the f32 MFMA.
+ * eps_w [S, K] (logical columns) / eps_d [S, ld_out] may be NULL (Philox
+ * streams stream_id0 + s, identical to S calls of bde_swag_sample). */
+int bde_swag_sample_batched(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
+                            const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id0,
+                            float* out, int64_t ld_out, int S, int64_t D, void* stream);
+
+/* The Philox normals bde_swag_sample would use, written out (for tests and for
+ * callers that want the noise): eps_w [K] and/or eps_d [D] (either may be NULL). */
+int bde_philox_normal(uint64_t seed, uint64_t stream_id, float* eps_w, int K, float* eps_d, int64_t D,
+                      void* stream);
+
+/* ------------------------------------------------- mean-field Gaussian (BBB) --
+ * src/algos/util.py:151-183 (GaussianParameter) and bbb.py:18-21 (KL). */
+
+/* w = mean + softplus(rho) * eps   (util.py:170-171,181-183).
+ * eps == NULL: eps comes from Philox(seed, stream_id) and, if eps_out != NULL,
+ * is also written there. */
+int bde_gauss_draw_fwd(const float* mean, const float* rho, const float* eps, uint64_t seed,
+                       uint64_t stream_id, float* w, float* eps_out, int64_t n, void* stream);
+
+/* Backward of the draw: gmean (+)= g ; grho (+)= g * eps * sigmoid(rho).
+ * accumulate != 0 adds into gmean/grho, else overwrites.  eps == NULL
+ * regenerates the Philox noise of the forward call. */
+int bde_gauss_draw_bwd(const float* g, const float* rho, const float* eps, uint64_t seed,
+                       uint64_t stream_id, float* gmean, float* grho, int accumulate, int64_t n,
+                       void* stream);
+
+/* Bytes of scratch for the reductions of bde_gauss_kl / bde_l2. */
+size_t bde_reduce_ws_bytes(void);
+
+/* Closed-form KL(q || N(prior_mu, prior_sigma^2)) summed over n elements
+ * (bbb.py:18-21) -> kl_out[0] (if kl_out != NULL), fused with its analytic
+ * gradients (if gmean/grho != NULL):
+ *   gmean (+)= c * (mean - prior_mu) / prior_sigma^2
+ *   grho  (+)= c * (-1/sigma + sigma/prior_sigma^2) * sigmoid(rho)
+ * with c = grad_scale * (grad_scale_dev ? *grad_scale_dev : 1) -- the host
+ * part is pi = kl_rescaling/dataset_size (bbb.py:78), the device part an AMP
+ * GradScaler's scale tensor. */
+int bde_gauss_kl(const float* mean, const float* rho, float prior_mu, float prior_sigma,
+                 float grad_scale, const float* grad_scale_dev, float* gmean, float* grho,
+                 int accumulate, float* kl_out, void* ws, int64_t n, void* stream);
+
+/* Plain-parameter L2 term (bbb.py:75-76): val_out[0] = l2_scale/2 * sum p^2,
+ * g (+)= c * l2_scale * p. */
+int bde_l2(const float* p, float l2_scale, float grad_scale, const float* grad_scale_dev, float* g,
+           int accumulate, float* val_out, void* ws, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ iVON --
+ * src/algos/ivorn.py:102-115 (weight-noise draw) and :66-89 (update). */
+
+/* delta = eps / sqrt(n_eff * max(prec, 1e-4)); param = mean + delta;
+ * delta_sum = (first ? delta : delta_sum + delta).  eps == NULL: Philox.
+ * deterministic != 0: delta = 0 (ivorn.py:109-110). */
+int bde_ivon_sample(const float* mean, const float* prec, const float* eps, uint64_t seed, uint64_t stream_id,
+                    float n_eff, int deterministic, int first, float* param, float* delta_sum, int64_t n,
+                    void* stream);
+
+/* The fused natural-gradient update (ivorn.py:76-89), one pass, 32 B/param.
+ * The scalars are the Python-double expressions of the reference, each rounded
+ * to fp32 by the caller exactly where PyTorch rounds them (a Python scalar
+ * meets an fp32 tensor):
+ *   lam = tempering*prior_prec/n_eff (line 74), n_eff = N*augmentation (72),
+ *   mc = mc_samples, omb1 = 1-beta1, omb2 = 1-beta2, c2 = 0.5*(1-beta2)^2,
+ *   bc1 = 1-beta1^t, bc2 = 1-beta2^t (84-85).
+ * mean/momentum/prec are updated in place. */
+int bde_ivon_update(float* mean, float* momentum, float* prec, const float* delta_sum, const float* acc_grad,
+                    float lam, float n_eff, float mc, float beta1, float omb1, float omb2, float c2,
+                    float bc1, float bc2, float lr, float damping, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDE_HIP_H */

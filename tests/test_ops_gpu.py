@@ -1,0 +1,396 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point (called through
+ctypes, beyond_deep_ensembles_amd.ops.HipOps) against the CPU oracle and the
+golden vectors captured from the imported reference.
+
+Tolerances (fp32):
+  * SWAG moment update, iVON update: separately rounded IEEE ops in the
+    reference's order -> compared bit for bit (array_equal).  iVON draw: IEEE
+    exact on the device, but torch's CPU sqrt is 1 ulp off on long vectors, so
+    the draw is checked to 1e-6 of the noise magnitude.
+  * SVGD: the anchor is the fp64 evaluation of the reference formula
+    (tests/golden phi64).  The reference's own fp32 result deviates from it by
+    err_ref; ours must stay within max(2*err_ref, 3e-6 * scale).
+  * SWAG sample / Gaussian draw / KL: 2e-6 relative to the magnitude of the
+    terms (different summation order / device expf, log1pf).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bde_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from beyond_deep_ensembles_amd.ops import HipOps
+    return HipOps()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def flat_rows(x: torch.Tensor, ld=None):
+    """[M, D] CPU tensor -> device buffer [M, ld] (ld multiple of 64), filled with NaN padding."""
+    m, d = x.shape
+    ld = ld or (d + 63) // 64 * 64
+    buf = torch.full((m, ld), float("nan"), dtype=torch.float32, device=DEV)
+    buf[:, :d] = x.to(DEV)
+    return buf
+
+
+def padded(x: torch.Tensor):
+    d = x.numel()
+    buf = torch.full(((d + 63) // 64 * 64,), float("nan"), dtype=torch.float32, device=DEV)
+    buf[:d] = x.to(DEV)
+    return buf
+
+
+# ------------------------------------------------------------------ SVGD --
+def run_svgd(ops, P, G, l2, scale, n, sign=-1.0):
+    m, d = P.shape
+    Pb, Gb = flat_rows(P), flat_rows(G)
+    out = torch.zeros_like(Gb)
+    ws, ks = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV)
+    ops.svgd_step(Pb, Gb, out, d, l2, scale, n, sign, ws, ks)
+    torch.cuda.synchronize()
+    return out[:, :d].cpu(), ks.cpu()
+
+
+def test_svgd_step_golden(ops, golden):
+    g = golden("svgd_phi.npz")
+    for i, (m, d, l2, scale, n, shared) in enumerate(g["cases"]):
+        m, d = int(m), int(d)
+        P, G = T(g[f"P_{i}"]), T(g[f"G_{i}"])
+        out, ks = run_svgd(ops, P, G, float(l2), float(scale), float(n))
+        phi64 = g[f"phi64_{i}"]
+        ref32 = g[f"phi_{i}"].astype(np.float64)
+        err_ref = np.max(np.abs(ref32 - phi64))
+        scale_mag = np.max(np.abs(phi64)) + 1e-30
+        err = np.max(np.abs(-out.numpy().astype(np.float64) - phi64))
+        assert err <= max(2 * err_ref, 3e-6 * scale_mag), (i, m, d, err, err_ref, scale_mag)
+        K = ks[:m * m].reshape(m, m).numpy()
+        errK_ref = np.max(np.abs(g[f"K_{i}"].astype(np.float64) - g[f"K64_{i}"]))
+        assert np.max(np.abs(K - g[f"K64_{i}"])) <= max(2 * errK_ref, 3e-6), (i, m, d)
+        h = float(ks[2 * m * m + m])
+        assert abs(h - float(g[f"h_{i}"])) <= max(2e-6 * h, 1e-12) or shared, (i, h, float(g[f"h_{i}"]))
+
+
+def test_svgd_inplace_and_rbf_mode(ops, golden):
+    g = golden("svgd_phi.npz")
+    i = 2  # (8, 751)
+    m, d, l2, scale, n, _ = g["cases"][i]
+    m, d = int(m), int(d)
+    P, G = T(g[f"P_{i}"]), T(g[f"G_{i}"])
+    ref, _ = run_svgd(ops, P, G, float(l2), float(scale), float(n))
+    Pb, Gb = flat_rows(P), flat_rows(G)
+    ws, ks = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV)
+    ops.svgd_step(Pb, Gb, Gb, d, float(l2), float(scale), float(n), -1.0, ws, ks)   # out aliases G
+    assert torch.equal(Gb[:, :d].cpu(), ref)
+    # rbf(): K and grad_kernel (svgd.py:14-32)
+    out = torch.zeros_like(Pb)
+    ops.svgd_gram(Pb, d, ws)
+    ops.svgd_kstats(ws, m, 0.0, 1.0, 1.0, 1.0, ks, mode=1)
+    ops.svgd_combine(Pb, None, out, d, ks)
+    k64, gk64 = O.svgd_rbf(P.double())
+    gk32 = g[f"gradK_{i}"].astype(np.float64)
+    err_ref = np.max(np.abs(gk32 - gk64.numpy()))
+    err = np.max(np.abs(out[:, :d].cpu().numpy() - gk64.numpy()))
+    assert err <= max(2 * err_ref, 3e-6 * np.max(np.abs(gk64.numpy())))
+
+
+def test_svgd_deterministic_and_ragged_sizes(ops):
+    torch.manual_seed(0)
+    for m, d in [(8, 1), (8, 3), (8, 4), (8, 127), (8, 129), (5, 4097), (16, 1000), (13, 515), (1, 77), (2, 100003)]:
+        P = torch.randn(m, d) * 0.05
+        G = torch.randn(m, d) * 0.01
+        a, _ = run_svgd(ops, P, G, 0.01, 1.0, 5000.0)
+        b, _ = run_svgd(ops, P, G, 0.01, 1.0, 5000.0)
+        assert torch.equal(a, b)
+        phi64 = O.svgd_phi(P.double(), G.double(), 0.01, 1.0, 5000.0).numpy()
+        ref32 = O.svgd_phi(P, G, 0.01, 1.0, 5000.0).numpy().astype(np.float64)
+        err_ref = np.max(np.abs(ref32 - phi64))
+        err = np.max(np.abs(-a.numpy() - phi64))
+        assert err <= max(2 * err_ref, 3e-6 * np.max(np.abs(phi64))), (m, d, err, err_ref)
+
+
+def test_svgd_rejects_bad_arguments(ops):
+    from beyond_deep_ensembles_amd.ops import BdeKernelError
+    P = torch.zeros(17, 64, device=DEV)
+    with pytest.raises(BdeKernelError):
+        ops.svgd_ws(17, DEV)
+    ws, ks = ops.svgd_ws(8, DEV), ops.svgd_kstat(8, DEV)
+    with pytest.raises(BdeKernelError):
+        ops.svgd_gram(P, 64, ws)                      # M > 16
+    with pytest.raises(BdeKernelError):
+        ops.svgd_gram(torch.zeros(8, 64), 64, ws)     # CPU tensor: no CPU path
+    P8 = torch.zeros(8, 64, device=DEV)
+    with pytest.raises(BdeKernelError):
+        ops.svgd_combine(P8, None, P8, 64, ks)        # out must not alias P
+
+
+def test_svgd_fused_optimizers_match_torch_shared_state(ops):
+    """svgd.py:92-103 with ONE optimizer shared by all particles (Q5)."""
+    torch.manual_seed(1)
+    m, d = 5, 1003
+    for kind in ("sgd_nesterov", "sgd_plain", "adam", "adam_wd"):
+        P0 = torch.randn(m, d) * 0.1
+        model_p = torch.nn.Parameter(P0[0].clone())
+        if kind == "sgd_nesterov":
+            opt = torch.optim.SGD([model_p], lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)
+        elif kind == "sgd_plain":
+            opt = torch.optim.SGD([model_p], lr=0.05)
+        elif kind == "adam":
+            opt = torch.optim.Adam([model_p], lr=1e-3)
+        else:
+            opt = torch.optim.Adam([model_p], lr=1e-3, weight_decay=1e-2)
+        rows = [P0[i].clone() for i in range(m)]
+        Pb = flat_rows(P0)
+        Pb[:, d:] = 0
+        buf = torch.zeros(Pb.shape[1], device=DEV)
+        ea, eas = torch.zeros_like(buf), torch.zeros_like(buf)
+        step0 = 0
+        for it in range(3):
+            grads = torch.randn(m, d) * 0.01
+            for i in range(m):
+                model_p.grad = grads[i].clone()
+                model_p.data = rows[i]
+                opt.step()
+            Gb = flat_rows(grads)
+            if kind.startswith("sgd"):
+                pg = opt.param_groups[0]
+                ops.svgd_apply_sgd(Pb, Gb, buf, d, pg["lr"], pg["momentum"], pg["dampening"], pg["weight_decay"],
+                                   pg["nesterov"], first=(it == 0))
+            else:
+                pg = opt.param_groups[0]
+                ops.svgd_apply_adam(Pb, Gb, ea, eas, d, pg["lr"], pg["betas"][0], pg["betas"][1], pg["eps"],
+                                    pg["weight_decay"], step0)
+                step0 += m
+            want = torch.stack(rows)
+            got = Pb[:, :d].cpu()
+            assert torch.allclose(got, want, rtol=2e-6, atol=2e-7), (kind, it, (got - want).abs().max())
+
+
+# ------------------------------------------------------------------ SWAG --
+def test_swag_update_bit_exact(ops):
+    torch.manual_seed(2)
+    for d in (1, 5, 64, 1027, 100003):
+        theta0 = torch.randn(d) * 0.05
+        st = O.swag_init(theta0, 4)
+        mean, sq = padded(st.mean), padded(st.sq_weights)
+        dev = torch.zeros(4, mean.numel(), device=DEV)
+        head = 0
+        for n in range(1, 8):
+            theta = theta0 + torch.randn(d) * 1e-3 * n
+            st.updates = n
+            O.swag_moment_update(st, theta)
+            ops.swag_update(padded(theta), mean, sq, dev[head], n, d)
+            head = (head + 1) % 4
+            assert torch.equal(mean[:d].cpu(), st.mean)
+            assert torch.equal(sq[:d].cpu(), st.sq_weights)
+            # ring -> reference layout: logical column c = physical row (head + c) % K
+            logical = torch.stack([dev[(head + c) % 4, :d].cpu() for c in range(4)], dim=1)
+            assert torch.equal(logical, st.deviations)
+
+
+def test_swag_sample_golden_and_oracle(ops, golden):
+    g = golden("swag_stats.npz")
+    for ci in range(len(g["cases"])):
+        mean, sq, devDK = T(g[f"mean_{ci}"]), T(g[f"sq_{ci}"]), T(g[f"dev_{ci}"])
+        d, k = devDK.shape
+        for head in (0, 2):
+            ring = torch.zeros(k, (d + 63) // 64 * 64, device=DEV)
+            for c in range(k):
+                ring[(head + c) % k, :d] = devDK[:, c].to(DEV)
+            out = torch.zeros((d + 63) // 64 * 64, device=DEV)
+            for s in range(3):
+                ops.swag_sample(padded(mean), padded(sq), ring, head, out, d, eps_w=T(g[f"eps_w_{ci}"][s]).to(DEV),
+                                eps_d=padded(T(g[f"eps_d_{ci}"][s])))
+                want = g[f"samples_{ci}"][s]
+                mag = np.abs(g[f"mean_{ci}"]) + np.abs(want) + 1e-3
+                assert np.max(np.abs(out[:d].cpu().numpy() - want) / mag) < 2e-6
+
+
+def test_swag_sample_large_vs_fp64(ops):
+    torch.manual_seed(3)
+    d, k = 50021, 20
+    theta = torch.randn(d) * 0.05
+    st = O.swag_init(theta, k)
+    for n in range(1, 26):
+        theta = theta + torch.randn(d) * 1e-3
+        st.updates = n
+        O.swag_moment_update(st, theta)
+    eps_w, eps_d = O.swag_draw_noise(k, d)
+    want64 = (st.mean.double() + (st.deviations.double() / math.sqrt(2 * (k - 1))) @ eps_w.double()
+              + (0.5 * (torch.relu(st.sq_weights.double() - st.mean.double() ** 2) + 1e-6)).sqrt() * eps_d.double())
+    ref32 = O.swag_sample(st.mean, st.sq_weights, st.deviations, eps_w, eps_d)
+    ld = (d + 63) // 64 * 64
+    ring = torch.zeros(k, ld, device=DEV)
+    head = 7
+    for c in range(k):
+        ring[(head + c) % k, :d] = st.deviations[:, c].to(DEV)
+    out = torch.zeros(ld, device=DEV)
+    ops.swag_sample(padded(st.mean), padded(st.sq_weights), ring, head, out, d, eps_w=eps_w.to(DEV), eps_d=padded(eps_d))
+    err = (out[:d].cpu().double() - want64).abs().max().item()
+    err_ref = (ref32.double() - want64).abs().max().item()
+    assert err <= max(2 * err_ref, 1e-7), (err, err_ref)
+    # batched == unbatched on the same noise
+    S = 5
+    ew = torch.randn(S, k)
+    ed = torch.randn(S, d)
+    edb = torch.zeros(S, ld, device=DEV)
+    edb[:, :d] = ed.to(DEV)
+    outb = torch.zeros(S, ld, device=DEV)
+    ops.swag_sample_batched(padded(st.mean), padded(st.sq_weights), ring, head, outb, d, eps_w=ew.to(DEV), eps_d=edb)
+    for s in range(S):
+        ops.swag_sample(padded(st.mean), padded(st.sq_weights), ring, head, out, d, eps_w=ew[s].to(DEV), eps_d=edb[s])
+        assert torch.allclose(outb[s, :d], out[:d], rtol=1e-6, atol=1e-7), s
+
+
+def test_philox_streams(ops):
+    d, k = 1 << 20, 20
+    ld = d
+    a = torch.zeros(d, device=DEV)
+    b = torch.zeros(d, device=DEV)
+    w = torch.zeros(k, device=DEV)
+    ops.philox_normal(1234, 0, eps_w=w, eps_d=a)
+    ops.philox_normal(1234, 1, eps_d=b)
+    assert torch.isfinite(a).all() and torch.isfinite(w).all()
+    assert abs(a.mean().item()) < 5e-3 and abs(a.var().item() - 1.0) < 5e-3
+    assert abs((a * a * a).mean().item()) < 2e-2                       # skewness ~ 0
+    assert abs((a ** 4).mean().item() - 3.0) < 5e-2                    # kurtosis ~ 3
+    assert abs((a * b).mean().item()) < 5e-3                           # streams uncorrelated
+    assert abs((a[1:] * a[:-1]).mean().item()) < 5e-3                  # neighbours uncorrelated
+    c = torch.zeros(d, device=DEV)
+    ops.philox_normal(1234, 0, eps_d=c)
+    assert torch.equal(a, c)                                           # pure function of (seed, stream, index)
+    # the sampling kernel's in-kernel noise IS this stream: RNG mode == supplied-noise mode, bit for bit
+    dd, kk = 10007, 6
+    ldd = (dd + 63) // 64 * 64
+    mean, sq = torch.randn(ldd, device=DEV) * 0.05, torch.rand(ldd, device=DEV)
+    ring = torch.randn(kk, ldd, device=DEV) * 1e-3
+    o1, o2 = torch.zeros(ldd, device=DEV), torch.zeros(ldd, device=DEV)
+    ew, ed = torch.zeros(kk, device=DEV), torch.zeros(ldd, device=DEV)
+    ops.philox_normal(99, 5, eps_w=ew, eps_d=ed, d=dd)
+    ops.swag_sample(mean, sq, ring, 3, o1, dd, seed=99, stream_id=5)
+    ops.swag_sample(mean, sq, ring, 3, o2, dd, eps_w=ew, eps_d=ed)
+    assert torch.equal(o1[:dd], o2[:dd])
+    # batched RNG mode == S unbatched calls with stream ids stream0 + s
+    S = 4
+    ob = torch.zeros(S, ldd, device=DEV)
+    ops.swag_sample_batched(mean, sq, ring, 3, ob, dd, seed=99, stream_id0=5)
+    for s in range(S):
+        ops.swag_sample(mean, sq, ring, 3, o1, dd, seed=99, stream_id=5 + s)
+        assert torch.allclose(ob[s, :dd], o1[:dd], rtol=1e-6, atol=1e-7)
+
+
+# ----------------------------------------------------------------- Gauss --
+def test_gauss_draw_kl_golden(ops, golden):
+    g = golden("bbb.npz")
+    mean, rho, eps = T(g["a_mean"]), T(g["a_rho"]), T(g["a_eps"])
+    n = mean.numel()
+    mb, rb, eb = padded(mean), padded(rho), padded(eps)
+    w = torch.zeros_like(mb)
+    ops.gauss_draw_fwd(mb, rb, w, n, eps=eb)
+    assert np.max(np.abs(w[:n].cpu().numpy() - g["a_sample"])) < 2e-6 * (np.abs(g["a_sample"]).max() + 1)
+    gm, gr = torch.zeros_like(mb), torch.zeros_like(mb)
+    ops.gauss_draw_bwd(padded(T(g["a_gout"])), rb, gm, gr, n, eps=eb)
+    assert np.array_equal(gm[:n].cpu().numpy(), g["a_gmean"])
+    np.testing.assert_allclose(gr[:n].cpu().numpy(), g["a_grho"], rtol=3e-6, atol=1e-9)
+    # accumulate mode adds on top
+    ops.gauss_draw_bwd(padded(T(g["a_gout"])), rb, gm, gr, n, eps=eb, accumulate=True)
+    np.testing.assert_allclose(gr[:n].cpu().numpy(), 2 * g["a_grho"], rtol=3e-6, atol=1e-9)
+    ws = ops.reduce_ws(DEV)
+    for pi, (mu, sigma) in enumerate(g["a_priors"]):
+        si, mi = pi // 2, pi % 2
+        kl = torch.zeros(1, device=DEV)
+        gm.zero_(); gr.zero_()
+        ops.gauss_kl(mb, rb, float(mu), float(sigma), n, ws, kl_out=kl, gmean=gm, grho=gr, grad_scale=0.25)
+        want = float(g[f"a_kl_{si}_{mi}"])
+        assert abs(kl.item() - want) <= 3e-6 * abs(want), (kl.item(), want)
+        np.testing.assert_allclose(gm[:n].cpu().numpy(), 0.25 * g[f"a_kl_gmean_{si}_{mi}"], rtol=3e-6, atol=1e-9)
+        s = O.gauss_std(rho).numpy()
+        scale = 0.25 * (1.0 / s + s / float(sigma) ** 2)
+        assert np.max(np.abs(gr[:n].cpu().numpy() - 0.25 * g[f"a_kl_grho_{si}_{mi}"]) / scale) < 3e-6
+        # value-only call and device-side scale factor
+        kl2 = torch.zeros(1, device=DEV)
+        ops.gauss_kl(mb, rb, float(mu), float(sigma), n, ws, kl_out=kl2)
+        assert kl2.item() == kl.item()
+        gm2, gr2 = torch.zeros_like(mb), torch.zeros_like(mb)
+        ops.gauss_kl(mb, rb, float(mu), float(sigma), n, ws, gmean=gm2, grho=gr2, grad_scale=0.125,
+                     grad_scale_dev=torch.full((1,), 2.0, device=DEV))
+        assert torch.equal(gm2[:n], gm[:n]) and torch.equal(gr2[:n], gr[:n])
+
+
+def test_gauss_kl_large_and_l2(ops):
+    torch.manual_seed(4)
+    n = 300007
+    mean, rho = torch.randn(n) * 0.1, torch.randn(n) - 3
+    ws = ops.reduce_ws(DEV)
+    kl = torch.zeros(1, device=DEV)
+    ops.gauss_kl(padded(mean), padded(rho), 0.0, 1.0, n, ws, kl_out=kl)
+    want = O.gauss_kl(mean.double(), rho.double(), 0.0, 1.0).item()
+    assert abs(kl.item() - want) <= 2e-6 * abs(want)
+    val = torch.zeros(1, device=DEV)
+    g = torch.zeros((n + 63) // 64 * 64, device=DEV)
+    ops.l2(padded(mean), 0.3, n, ws, val_out=val, g=g, grad_scale=0.5)
+    assert abs(val.item() - O.l2_term(mean.double(), 0.3).item()) <= 2e-6 * val.item()
+    np.testing.assert_allclose(g[:n].cpu().numpy(), (0.5 * 0.3 * mean).numpy(), rtol=1e-6, atol=1e-12)
+
+
+def test_gauss_draw_philox(ops):
+    n = 100003
+    mean, rho = torch.randn(n) * 0.1, torch.randn(n) - 3
+    mb, rb = padded(mean), padded(rho)
+    w, e = torch.zeros_like(mb), torch.zeros_like(mb)
+    ops.gauss_draw_fwd(mb, rb, w, n, seed=7, stream_id=3, eps_out=e)
+    w2 = torch.zeros_like(mb)
+    ops.gauss_draw_fwd(mb, rb, w2, n, eps=e)
+    assert torch.equal(w[:n], w2[:n])
+    gout = padded(torch.randn(n))
+    gm1, gr1, gm2, gr2 = (torch.zeros_like(mb) for _ in range(4))
+    ops.gauss_draw_bwd(gout, rb, gm1, gr1, n, seed=7, stream_id=3)       # regenerates the forward's noise
+    ops.gauss_draw_bwd(gout, rb, gm2, gr2, n, eps=e)
+    assert torch.equal(gr1[:n], gr2[:n]) and torch.equal(gm1[:n], gm2[:n])
+
+
+# ------------------------------------------------------------------ iVON --
+def test_ivon_golden_bit_exact(ops, golden):
+    g = golden("ivon.npz")
+    for ci, (aug, mc, damping, temp) in enumerate(g["cases"]):
+        mc = int(mc)
+        n_data = 48.0
+        init = T(g[f"init_{ci}"])
+        d = init.numel()
+        mean = padded(init)
+        mom = torch.zeros_like(mean)
+        prec = torch.full_like(mean, 50.0 / n_data)
+        param, dsum = torch.zeros_like(mean), torch.zeros_like(mean)
+        eps = T(g[f"eps_{ci}"])
+        n_eff = n_data * float(aug)
+        for t in range(3):
+            for k in range(mc):
+                ops.ivon_sample(mean, prec, param, dsum, d, n_eff, first=(k == 0), eps=padded(eps[t * mc + k]))
+            # the draw is IEEE-exact here; torch's CPU sqrt (MKL VML) is 1 ulp off for long vectors,
+            # so the draw is compared within a few ulp of the noise magnitude, the update bit for bit
+            want_ds = g[f"delta_sum_{ci}"][t]
+            tol = 1e-6 * np.abs(want_ds).max()
+            assert np.max(np.abs(dsum[:d].cpu().numpy() - want_ds)) <= tol
+            assert np.max(np.abs(param[:d].cpu().numpy() - g[f"after_{ci}"][t])) <= tol
+            dsum[:d] = T(want_ds).to(DEV)
+            ops.ivon_update(mean, mom, prec, dsum, padded(T(g[f"acc_grad_{ci}"][t])), d,
+                            lam=float(temp) * 50.0 / n_eff, n_eff=n_eff, mc=mc, beta1=0.9, beta2=0.999, t=t + 1,
+                            lr=1e-2, damping=float(damping))
+            assert np.array_equal(mean[:d].cpu().numpy(), g[f"means_{ci}"][t]), (ci, t)
+            assert np.array_equal(mom[:d].cpu().numpy(), g[f"moms_{ci}"][t]), (ci, t)
+            assert np.array_equal(prec[:d].cpu().numpy(), g[f"precs_{ci}"][t]), (ci, t)
+        ops.ivon_sample(mean, prec, param, dsum, d, n_eff, first=True, eps=padded(eps[3 * mc]))
+        assert np.max(np.abs(param[:d].cpu().numpy() - g[f"eval_sample_{ci}"])) <= 1e-6 * np.abs(eps[3 * mc].numpy()).max()
+        ops.ivon_sample(mean, prec, param, dsum, d, n_eff, first=True, deterministic=True)
+        assert torch.equal(param[:d], mean[:d])
