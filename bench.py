@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SVGD posterior-update steps/s (+ SWAG samples/s and the
+other hot-path kernels as extras) on ResNet-50-sized flat weight buffers.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one SVGD posterior update (src/algos/svgd.py:83-89 of the
+reference) of M = 8 particles with D = 23,880,950 parameters each (the
+reference's iWildCam ResNet-50), from P and G resident in
+HBM to -phi: three launches (MFMA Gram, kernel statistics, streaming combine),
+16*M*D algorithmic bytes.  Model forward/backward is not part of the path.
+
+N > 1: the 8 particles are sharded M/N per rank; a step is then ONE RCCL
+all-gather of the ranks' gradient rows (xGMI) followed by the update on the
+replicated particles -- total work fixed ("strong").
+
+One JSON line on stdout (rank 0); progress goes to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+M = 8
+D_RESNET50 = 23_880_950     # torchvision ResNet-50 backbone + 182-class head (iWildCam), SURVEY.md section 8
+D_RESNET20 = 273_610        # CIFAR ResNet-20 (swish/FRN)
+D_DENSENET = 6_955_906      # Camelyon DenseNet-121
+K_SWAG, S_SWAG = 20, 30
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+DATASET_SIZE = 129_809.0    # iwildcam.yaml:217-221
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def pad_ld(d):
+    return (d + 16 + 63) // 64 * 64
+
+
+def make_svgd_inputs(d, dev, seed, shared_backbone=True):
+    """P = theta0 + head-only perturbation (mimics iwildcam/models.py:118-119: particles
+    share the pretrained backbone, only the head is re-initialised); G ~ N(0, 0.01^2)."""
+    ld = pad_ld(d)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    P = torch.zeros(M, ld, device=dev)
+    if shared_backbone:
+        theta0 = torch.randn(d, device=dev, generator=g) * 0.05
+        P[:, :d] = theta0
+        head = min(d, 372_918)
+        P[:, d - head:d] += (torch.rand(M, head, device=dev, generator=g) * 2 - 1) / (2048 ** 0.5)
+    else:
+        P[:, :d] = torch.randn(M, d, device=dev, generator=g) * 0.05
+    G = torch.zeros(M, ld, device=dev)
+    G[:, :d] = torch.randn(M, d, device=dev, generator=g) * 0.01
+    return P, G
+
+
+def time_loop(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def extras(ops, dev, quick):
+    """Secondary hot-path kernels: seconds per launch, algorithmic GB/s, fraction of the 8 TB/s HBM peak."""
+    out = {}
+    it = 10 if quick else 20
+
+    def rec(name, t, nbytes, unit_count=None, unit=None):
+        e = {"ms": round(t * 1e3, 4), "GBps": round(nbytes / t / 1e9, 1), "hbm_frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4)}
+        if unit_count is not None:
+            e[unit] = round(unit_count / t, 1)
+        out[name] = e
+        log(f"  {name:34s} {t*1e3:9.3f} ms {nbytes/t/1e9:8.1f} GB/s {e['hbm_frac']*100:5.1f}%")
+
+    d = D_RESNET50
+    ld = pad_ld(d)
+    g = torch.Generator(device=dev).manual_seed(99)
+    # --- SVGD variants
+    P, G = make_svgd_inputs(d, dev, 1234)
+    outb = torch.empty_like(G)
+    ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
+    rec("svgd_gram_M8_resnet50", time_loop(lambda: ops.svgd_gram(P, d, ws), it), 4 * M * d)
+    rec("svgd_combine_M8_resnet50", time_loop(lambda: ops.svgd_combine(P, G, outb, d, ks), it), 12 * M * d)
+    buf = torch.zeros(ld, device=dev)
+    t = time_loop(lambda: (ops.svgd_step(P, G, outb, d, 0.0, 1.0, DATASET_SIZE, -1.0, ws, ks),
+                           ops.svgd_apply_sgd(P, outb, buf, d, 1e-12, 0.9, 0.0, 3e-4, True, False)), it)
+    rec("svgd_step_plus_fused_sgd_M8_resnet50", t, (16 * M + 12 * M + 8) * d, 1, "steps_per_s")
+    Pi, Gi = make_svgd_inputs(d, dev, 1234, shared_backbone=False)
+    rec("svgd_step_M8_resnet50_independent_particles",
+        time_loop(lambda: ops.svgd_step(Pi, Gi, outb, d, 0.0, 1.0, DATASET_SIZE, -1.0, ws, ks), it), 16 * M * d, 1, "steps_per_s")
+    del Pi, Gi, P, G, outb
+    d20 = D_RESNET20
+    P2, G2 = make_svgd_inputs(d20, dev, 1234)
+    o2 = torch.empty_like(G2)
+    rec("svgd_step_M8_resnet20", time_loop(lambda: ops.svgd_step(P2, G2, o2, d20, 3e-4, 1.0, 50000.0, -1.0, ws, ks), 50),
+        16 * M * d20, 1, "steps_per_s")
+    del P2, G2, o2
+    # --- SWAG
+    mean = torch.randn(ld, device=dev, generator=g) * 0.05
+    sq = mean * mean + 1e-4
+    ring = torch.randn(K_SWAG, ld, device=dev, generator=g) * 1e-3
+    theta = torch.randn(ld, device=dev, generator=g) * 0.05
+    o = torch.empty(ld, device=dev)
+    rec("swag_update_resnet50", time_loop(lambda: ops.swag_update(theta, mean, sq, ring[3], 5, d), it), 24 * d)
+    t = time_loop(lambda: ops.swag_sample(mean, sq, ring, 3, o, d, seed=1, stream_id=2), it)
+    rec("swag_sample_K20_resnet50", t, 4 * d * (K_SWAG + 3), 1, "samples_per_s")
+    ob = torch.empty(S_SWAG, ld, device=dev)
+    t = time_loop(lambda: ops.swag_sample_batched(mean, sq, ring, 3, ob, d, seed=1, stream_id0=0), max(3, it // 2))
+    rec("swag_sample_batched_K20_S30_resnet50", t, 4 * d * (K_SWAG + 2 + S_SWAG), S_SWAG, "samples_per_s")
+    del ob, ring
+    # --- BBB
+    rho = torch.full((ld,), -3.0, device=dev)
+    w = torch.empty(ld, device=dev)
+    gm, gr = torch.zeros(ld, device=dev), torch.zeros(ld, device=dev)
+    rws, kl = ops.reduce_ws(dev), torch.zeros(1, device=dev)
+    rec("bbb_draw_fwd_resnet50", time_loop(lambda: ops.gauss_draw_fwd(mean, rho, w, d, seed=1, stream_id=0), it), 12 * d)
+    rec("bbb_draw_bwd_resnet50", time_loop(lambda: ops.gauss_draw_bwd(w, rho, gm, gr, d, seed=1, stream_id=0, accumulate=True), it), 24 * d)
+    rec("bbb_kl_fwd_bwd_resnet50", time_loop(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, d, rws, kl_out=kl, gmean=gm, grho=gr), it), 16 * d)
+    # --- iVON
+    prec = torch.full((ld,), 100.0 / DATASET_SIZE, device=dev)
+    ds, mom = torch.zeros(ld, device=dev), torch.zeros(ld, device=dev)
+    rec("ivon_sample_resnet50", time_loop(lambda: ops.ivon_sample(mean, prec, w, ds, d, DATASET_SIZE, first=False, seed=1, stream_id=0), it), 20 * d)
+    rec("ivon_update_resnet50", time_loop(lambda: ops.ivon_update(mean, mom, prec, ds, gm, d, lam=100.0 / DATASET_SIZE, n_eff=DATASET_SIZE, mc=2,
+                                                                   beta1=0.9, beta2=0.999, t=1, lr=1e-12, damping=1e-3), it), 32 * d)
+    return out
+
+
+def cpu_baseline(P, G, d, budget_s=25.0):
+    """The reference's CPU path for the same step: the oracle's torch-CPU restatement
+    (same ATen op sequence as svgd.py:86-89) on the host cores, same inputs."""
+    from oracle import bde_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Pc, Gc = P[:, :d].cpu().contiguous(), G[:, :d].cpu().contiguous()
+    t0 = time.perf_counter()
+    O.cpu_svgd_step(Pc, Gc, 0.0, 1.0, DATASET_SIZE)             # warm-up
+    warm = time.perf_counter() - t0
+    reps = int(max(1, min(5, (budget_s - warm) // max(warm, 1e-3))))
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        O.cpu_svgd_step(Pc, Gc, 0.0, 1.0, DATASET_SIZE)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(1.0 / best, 4), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"the full workload (M=8, D={d}): 1 warm-up + min of {reps} timed steps of oracle.cpu_svgd_step, "
+                      f"torch {torch.__version__} CPU, {cores} threads", "ms_per_step": round(best * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dim", type=int, default=D_RESNET50)
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+        if M % world:
+            raise SystemExit(f"M={M} particles cannot be sharded over {world} ranks")
+
+    from beyond_deep_ensembles_amd.ops import HipOps
+    ops = HipOps()                                 # raises if libbde_hip.so is missing: no fallback
+    d = args.dim
+    P, G = make_svgd_inputs(d, dev, 1234)          # replicated particles: same seed on every rank
+    per = M // world
+    if world > 1:                                  # own gradient rows differ per rank
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        G[rank * per:(rank + 1) * per, :d] = torch.randn(per, d, device=dev, generator=g) * 0.01
+    out = torch.empty_like(G)
+    ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
+    own = G[rank * per:(rank + 1) * per].reshape(-1)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if world > 1:
+            dist.all_gather_into_tensor(G.view(-1), own)      # RCCL over xGMI: the particles' gradient rows
+        ops.svgd_gram(P, d, ws)
+        ops.svgd_kstats(ws, M, 0.0, 1.0, DATASET_SIZE, -1.0, ks)
+        if i is not None:
+            ev[i][0].record()
+        ops.svgd_combine(P, G, out, d, ks)
+        if i is not None:
+            ev[i][1].record()
+
+    for _ in range(args.warmup):
+        step()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    combine_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    assert torch.isfinite(out[:, :d]).all()
+
+    if rank == 0:
+        alg_bytes = 12 * M * d                       # dominant kernel: combine reads P and G, writes out
+        achieved = alg_bytes / (combine_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath) and d == D_RESNET50:
+            try:
+                traffic = json.load(open(tpath)).get("svgd_combine_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "svgd_steps_per_s", "value": round(1e3 / ms_per_step, 2), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SVGD posterior update (svgd.py:83-89): 8 particles x ResNet-50-sized flat weights "
+                                   "(iWildCam config, BASELINE configs[3] shape on N GPUs / its 1-GPU form at N=1); "
+                                   "gram + kernel stats + combine, P and G resident in HBM",
+                       "particles": M, "D": d, "ld": pad_ld(d), "l2_reg": 0.0, "kernel_grad_scale": 1.0,
+                       "dataset_size": DATASET_SIZE, "particles_per_rank": per,
+                       "exchange": "none" if world == 1 else "rccl all_gather of gradient rows",
+                       "algorithmic_bytes_per_step": 16 * M * d},
+            "step_hbm_frac": round(16 * M * d / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {"kernel": "svgd_combine_kernel<8,true>", "bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": round(combine_ms, 4)},
+        }
+        log(f"svgd_step: {ms_per_step:.4f} ms/step = {res['value']} steps/s; combine {combine_ms:.4f} ms = {achieved:.0f} GB/s")
+        if world == 1:
+            if not args.no_cpu_baseline:
+                log("cpu baseline ...")
+                res["cpu_baseline"] = cpu_baseline(P, G, d)
+                log(f"  {res['cpu_baseline']}")
+            del P, G, out
+            torch.cuda.empty_cache()
+            if not args.no_extras and d == D_RESNET50:
+                log("extras ...")
+                res["extra"] = extras(ops, dev, quick=False)
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

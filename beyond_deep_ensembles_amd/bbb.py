@@ -1,0 +1,202 @@
+"""Bayes by Backprop behind the reference's BBBOptimizer API.
+
+Reference: ``src/algos/bbb.py`` -- ``GaussianPrior`` (:9-21), ``MixturePrior``
+(:23-37) and ``BBBOptimizer`` (:43-99).  Same constructor, loss formula, NaN
+guard and return value.  What changes: the means and rhos of all Gaussian
+parameters are gathered ONCE into two flat device buffers (the parameters
+become views), and the per-step KL collection loop (bbb.py:70-76: one
+closed-form KL expression per tensor, differentiated again by autograd in
+backward) is ONE fused kernel that returns the KL value and writes
+``pi * dKL/dmean`` and ``pi * dKL/drho`` straight into the flat gradient
+buffers before ``backward_closure`` accumulates the data-loss gradients on top.
+Plain parameters get the same treatment for the ``l2_scale / 2 * ||p||^2`` term.
+Priors other than ``GaussianPrior`` keep the reference's autograd path.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, _default_ops
+from .util import GaussianParameter
+
+
+class GaussianPrior:
+    def __init__(self, mu, sigma):
+        self.mu = mu
+        self.sigma = sigma
+        self.dist = torch.distributions.Normal(mu, sigma)
+
+    def log_prob(self, x):
+        return self.dist.log_prob(x)
+
+    def kl_divergence(self, mu2, sigma2):
+        # bbb.py:18-21, torch path (used by layers; the optimizer uses the fused kernel)
+        kl = 0.5 * (2 * torch.log(self.sigma / sigma2) - 1 + (sigma2 / self.sigma).pow(2)
+                    + ((self.mu - mu2) / self.sigma).pow(2))
+        return kl.sum()
+
+
+class MixturePrior:
+    def __init__(self, pi, sigma1, sigma2, validate_args=None):
+        self.pi = torch.tensor(pi)
+        self.sigma1 = sigma1
+        self.sigma2 = sigma2
+        self.dist1 = torch.distributions.Normal(0, sigma1, validate_args)
+        self.dist2 = torch.distributions.Normal(0, sigma2, validate_args)
+
+    def log_prob(self, value):
+        prob1 = torch.log(self.pi) + torch.clamp(self.dist1.log_prob(value), -23, 0)
+        prob2 = torch.log(1 - self.pi) + torch.clamp(self.dist2.log_prob(value), -23, 0)
+        return torch.logaddexp(prob1, prob2)
+
+    def kl_divergence(self, mu2, sigma2):
+        return -self.log_prob(mu2).sum()
+
+
+def collect_kl(model) -> torch.Tensor:
+    return sum(getattr(layer, "kl", 0) + collect_kl(layer) for layer in model.children())
+
+
+class _Group:
+    """Flat storage of one param group: Gaussian (mean, rho) pairs and plain parameters."""
+
+    def __init__(self, group, ops, device):
+        self.prior = group["prior"]
+        means, rhos, plain, generic = [], [], [], []
+        claimed = set()
+        params = group["params"]
+        fused_ok = isinstance(self.prior, GaussianPrior) and not torch.is_tensor(self.prior.mu) \
+            and not torch.is_tensor(self.prior.sigma)
+        for p in params:
+            mod = getattr(p, "_bde_gaussian", None)
+            if hasattr(p, "get_parameter_kl") and fused_ok and isinstance(mod, GaussianParameter) \
+                    and any(mod.rho is q for q in params):
+                means.append(p)
+                rhos.append(mod.rho)
+                claimed.add(id(p))
+                claimed.add(id(mod.rho))
+        for p in params:
+            if id(p) in claimed:
+                continue
+            if hasattr(p, "get_parameter_kl"):
+                generic.append(p)                   # autograd path of the reference (bbb.py:73-74)
+            elif not getattr(p, "_is_gaussian_mean", False) and not getattr(p, "_is_gaussian_rho", False):
+                plain.append(p)                     # l2 term (bbb.py:75-76)
+        self.means, self.rhos, self.plain, self.generic = means, rhos, plain, generic
+        self.gl = FlatLayout(means) if means else None
+        self.pl = FlatLayout(plain) if plain else None
+
+        def flatten(layout, plist):
+            buf = torch.zeros(layout.ld, dtype=torch.float32, device=device)
+            views = layout.views(buf)
+            with torch.no_grad():
+                torch._foreach_copy_(views, [p.detach() for p in plist])
+            for p, v in zip(plist, views):
+                p.data = v
+            gbuf = torch.zeros(layout.ld, dtype=torch.float32, device=device)
+            return buf, gbuf, layout.views(gbuf)
+
+        if means:
+            self.mu, self.gmu, self.gmu_views = flatten(self.gl, means)
+            self.rho, self.grho, self.grho_views = flatten(self.gl, rhos)
+        if plain:
+            self.p, self.gp, self.gp_views = flatten(self.pl, plain)
+
+
+class BBBOptimizer(BayesianOptimizer):
+    '''
+        Bayes By Backprop (drop-in for src/algos/bbb.py:43-99).  Use Bayesian layers built on
+        GaussianParameter for the layers that should be treated as Bayesian.
+    '''
+
+    def __init__(self, params, base_optimizer, prior, dataset_size, mc_samples=1, kl_rescaling=1, components=1,
+                 l2_scale=0, *, _ops=None):
+        defaults = {"prior": prior, "l2_scale": l2_scale}
+        super().__init__(params, defaults)
+        self._ops = _ops or _default_ops()
+        self.state["__base_optimizer"] = base_optimizer
+        self.mc_samples = mc_samples
+        self.kl_rescaling = kl_rescaling
+        self.components = components
+        self.dataset_size = dataset_size
+        check_params(list(self._params()), self._ops)
+        dev = self._params_device()
+        self._groups: List[_Group] = [_Group(g, self._ops, dev) for g in self.param_groups]
+        self._rws = self._ops.reduce_ws(dev)
+        self._kl_parts = torch.zeros(2 * len(self._groups), dtype=torch.float32, device=dev)
+
+    def step(self, forward_closure, backward_closure, grad_scaler=None):
+        # base_optimizer.zero_grad() (bbb.py:60) is folded into the KL kernels below: they OVERWRITE the flat
+        # gradient buffers with pi * dKL, so nothing has to be zeroed first.
+        pi = self.kl_rescaling / self.dataset_size
+        scale_dev = None
+        if grad_scaler is not None and grad_scaler.is_enabled():
+            if grad_scaler._scale is None:
+                self.init_grad_scaler(grad_scaler)
+            scale_dev = grad_scaler._scale              # backward_closure scales the loss by this tensor
+
+        total_data_loss = None
+        for _ in range(self.mc_samples):
+            if total_data_loss is None:
+                total_data_loss = forward_closure()
+            else:
+                total_data_loss += forward_closure()
+
+        # collect KL loss & reg only once (bbb.py:69-76)
+        total_kl_loss = torch.tensor(0.0, device=self._params_device())
+        with torch.no_grad():
+            for gi, (group, fg) in enumerate(zip(self.param_groups, self._groups)):
+                for p in fg.generic:
+                    p.grad = None
+                if fg.means:
+                    kl = self._kl_parts[2 * gi:2 * gi + 1]
+                    self._ops.gauss_kl(fg.mu, fg.rho, float(fg.prior.mu), float(fg.prior.sigma), fg.gl.d, self._rws,
+                                       kl_out=kl, gmean=fg.gmu, grho=fg.grho, grad_scale=pi, grad_scale_dev=scale_dev,
+                                       accumulate=False)
+                    total_kl_loss = total_kl_loss + kl[0]
+                    for p, v in zip(fg.means, fg.gmu_views):
+                        p.grad = v
+                    for p, v in zip(fg.rhos, fg.grho_views):
+                        p.grad = v
+                if fg.plain:
+                    l2_scale = float(group["l2_scale"])
+                    if l2_scale != 0.0:
+                        val = self._kl_parts[2 * gi + 1:2 * gi + 2]
+                        self._ops.l2(fg.p, l2_scale, fg.pl.d, self._rws, val_out=val, g=fg.gp, grad_scale=pi,
+                                     grad_scale_dev=scale_dev, accumulate=False)
+                        total_kl_loss = total_kl_loss + val[0]
+                    else:
+                        fg.gp.zero_()
+                    for p, v in zip(fg.plain, fg.gp_views):
+                        p.grad = v
+        # priors without a fused kernel keep the reference's autograd path
+        for group, fg in zip(self.param_groups, self._groups):
+            for p in fg.generic:
+                total_kl_loss = total_kl_loss + p.get_parameter_kl(group["prior"])
+
+        # don't divide the kl loss by the mc sample count as it has been collected only once (bbb.py:78-80)
+        loss = pi * total_kl_loss + total_data_loss / (self.mc_samples * self.components)
+        if not loss.isnan().any():
+            backward_closure(loss)
+            for fg in self._groups:
+                if fg.means:
+                    adopt_grads(fg.means, fg.gmu_views, add=True)
+                    adopt_grads(fg.rhos, fg.grho_views, add=True)
+                if fg.plain:
+                    adopt_grads(fg.plain, fg.gp_views, add=True)
+
+            if grad_scaler is not None:
+                grad_scaler.step(self.state["__base_optimizer"])
+            else:
+                self.state["__base_optimizer"].step()
+
+        return loss
+
+    def sample_parameters(self):
+        '''The parameters sample themselves'''
+        pass
+
+    def get_base_optimizer(self):
+        return self.state["__base_optimizer"]

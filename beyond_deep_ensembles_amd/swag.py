@@ -1,0 +1,237 @@
+"""Stochastic Weight Averaging-Gaussian behind the reference's SwagOptimizer API.
+
+Reference: ``src/algos/swag.py:10-114``.  Same constructor, step /
+sample_parameters / complete_epoch behaviour, integer schedule and
+``self.state`` keys.  What changes:
+
+* the model's parameters are views into ONE flat device vector ``theta``, so
+  the moment update reads the weights in place -- the reference flattens them
+  with ``parameters_to_vector(...).cpu()`` every update (swag.py:100);
+* ``__mean`` / ``__sq_weights`` stay on the device and ``__deviations`` is a
+  ring ``[K, ld]`` (``__dev_head`` = row the next update overwrites) instead of
+  a CPU ``[D, K]`` matrix that is physically rolled (swag.py:103);
+  ``deviations_dk()`` / ``state_dict()`` give the reference's layout back;
+* a posterior sample is one kernel (``bde_swag_sample``) that writes straight
+  into a second flat vector the parameters are re-pointed at; restoring the
+  training weights (swag.py:76-82) is a pointer swap, not a clone;
+* no ``LowRankMultivariateNormal`` object is built: its constructor's
+  capacitance matrix / Cholesky is never needed to SAMPLE (swag.py:114).
+
+Noise: ``rng="torch"`` (default) draws ``eps_W [K]`` then ``eps_D [D]`` from
+torch's generator exactly as ``rsample`` would on this device, so a seeded run
+consumes the reference's random stream; ``rng="philox"`` generates the noise
+inside the kernel (no extra HBM traffic; stream = sample counter).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+from .algo import BayesianOptimizer, FlatLayout, check_params, _default_ops
+
+
+class SwagOptimizer(BayesianOptimizer):
+    '''
+        Stochastic Weight Averaging-Gaussian (drop-in for src/algos/swag.py:10-114)
+    '''
+
+    def __init__(self, params, base_optimizer, update_interval, start_epoch=0, deviation_samples=30, *,
+                 rng="torch", seed=0, _ops=None):
+        super().__init__(params, {})
+        self._ops = _ops or _default_ops()
+        if rng not in ("torch", "philox"):
+            raise ValueError("rng must be 'torch' or 'philox'")
+
+        self.start_epoch = start_epoch
+        self.update_interval = math.floor(update_interval)
+        self.param_dist = None                      # kept for attribute compatibility; never built
+        self.deviation_samples = deviation_samples
+        self.rng = rng
+        self.seed = int(seed)
+        self.noise_source: Optional[Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]]] = None
+        self._sample_counter = 0
+
+        plist = list(self._params())
+        check_params(plist, self._ops)
+        self._plist = plist
+        self._layout = FlatLayout(plist)
+        dev = self._params_device()
+        d, ld, k = self._layout.d, self._layout.ld, deviation_samples
+
+        # flat training weights; the parameters become views of it
+        self._theta = torch.zeros(ld, dtype=torch.float32, device=dev)
+        self._theta_views = self._layout.views(self._theta)
+        with torch.no_grad():
+            torch._foreach_copy_(self._theta_views, [p.detach() for p in plist])
+        # flat target of posterior samples
+        self._sample = torch.zeros(ld, dtype=torch.float32, device=dev)
+        self._sample_views = self._layout.views(self._sample)
+        for param, view in zip(plist, self._theta_views):
+            param.data = view
+            self.state[param]["original_param"] = view          # swag.py:26 (a clone there)
+
+        self.state["__base_optimizer"] = base_optimizer
+        self.state["__epoch"] = 0
+        self.state["__steps_since_swag_start"] = 0
+        self.state["__updates"] = 0
+        self.state["__mean"] = self._theta.clone()                              # swag.py:32 (initial weights = sample #1)
+        self.state["__sq_weights"] = self.state["__mean"] ** 2                  # swag.py:33
+        self.state["__deviations"] = torch.zeros((k, ld), dtype=torch.float32, device=dev)   # ring, swag.py:34
+        self.state["__dev_head"] = 0
+        self.state["__params_dirty"] = False
+
+    # ------------------------------------------------------------------
+    def step(self, forward_closure, backward_closure, grad_scaler=None):
+        self._restore_original_params()
+        self.state["__base_optimizer"].zero_grad()
+
+        loss = forward_closure()
+        backward_closure(loss)
+
+        if grad_scaler is not None:
+            grad_scaler.step(self.state["__base_optimizer"])
+        else:
+            self.state["__base_optimizer"].step()
+
+        self._swag_update()
+        return loss
+
+    def sample_parameters(self):
+        self._save_original_params()
+        self.state["__params_dirty"] = True
+        d, k = self._layout.d, self.deviation_samples
+        eps_w = eps_d = None
+        if self.noise_source is not None:
+            eps_w, eps_d = self.noise_source(k, d)
+            eps_d = self._pad(eps_d)
+        elif self.rng == "torch":
+            # rsample() draws eps_W first, then eps_D (torch LowRankMultivariateNormal.rsample)
+            dev = self._params_device()
+            eps_w = torch.empty(k, dtype=torch.float32, device=dev).normal_()
+            eps_d = torch.empty(d, dtype=torch.float32, device=dev).normal_()
+            eps_d = self._pad(eps_d)
+        with torch.no_grad():
+            self._ops.swag_sample(self.state["__mean"], self.state["__sq_weights"], self.state["__deviations"],
+                                  self.state["__dev_head"], self._sample, d, eps_w=eps_w, eps_d=eps_d,
+                                  seed=self.seed, stream_id=self._sample_counter)
+        self._sample_counter += 1
+        # vector_to_parameters (swag.py:58): the parameters become views of the sampled vector
+        for param, view in zip(self._plist, self._sample_views):
+            param.data = view
+
+    def complete_epoch(self):
+        self.state["__epoch"] += 1
+
+    def get_base_optimizer(self):
+        return self.state["__base_optimizer"]
+
+    # ------------------------------------------------------------------
+    def _pad(self, v: torch.Tensor) -> torch.Tensor:
+        """16-byte aligned, contiguous noise vector (no copy when it already is)."""
+        if v.is_contiguous() and v.data_ptr() % 16 == 0:
+            return v
+        out = torch.empty(self._layout.ld, dtype=torch.float32, device=v.device)
+        out[:v.numel()] = v
+        return out
+
+    def _restore_original_params(self):
+        if self.state["__params_dirty"]:
+            for param, view in zip(self._plist, self._theta_views):
+                param.data = view                      # swag.py:81 clones; here the weights were never overwritten
+            self.state["__params_dirty"] = False
+
+    def _save_original_params(self):
+        # swag.py:84-89: the training weights live in self._theta and sampling never writes there
+        pass
+
+    def _swag_update(self):
+        if self.state["__epoch"] >= self.start_epoch:
+            self.state["__steps_since_swag_start"] += 1
+
+            if self.state["__steps_since_swag_start"] % self.update_interval == 0:
+                assert not self.state["__params_dirty"]
+                with torch.no_grad():
+                    self.state["__updates"] += 1
+                    updates = self.state["__updates"]
+                    head = self.state["__dev_head"]
+                    self._ops.swag_update(self._theta, self.state["__mean"], self.state["__sq_weights"],
+                                          self.state["__deviations"][head], updates, self._layout.d)
+                    self.state["__dev_head"] = (head + 1) % self.deviation_samples
+                    self.param_dist = None
+
+    # ---- reference-layout accessors ------------------------------------
+    def mean_vector(self) -> torch.Tensor:
+        return self.state["__mean"][:self._layout.d]
+
+    def sq_vector(self) -> torch.Tensor:
+        return self.state["__sq_weights"][:self._layout.d]
+
+    def deviations_dk(self) -> torch.Tensor:
+        """The deviation matrix in the reference's layout: ``[D, K]``, oldest
+        column first, newest last (what swag.py:103-104 maintains by rolling)."""
+        k, d, head = self.deviation_samples, self._layout.d, self.state["__dev_head"]
+        order = [(head + c) % k for c in range(k)]
+        return self.state["__deviations"][order, :d].t().contiguous()
+
+    def sample_batch(self, n_samples: int, seed: Optional[int] = None, stream_id0: Optional[int] = None) -> torch.Tensor:
+        """``n_samples`` posterior samples ``[S, D]`` in one pass over the statistics
+        (bde_swag_sample_batched, MFMA low-rank product); Philox noise with streams
+        ``stream_id0 + s`` -- identical to ``n_samples`` rng="philox" calls."""
+        d, ld = self._layout.d, self._layout.ld
+        out = torch.empty((n_samples, ld), dtype=torch.float32, device=self._params_device())
+        s0 = self._sample_counter if stream_id0 is None else stream_id0
+        with torch.no_grad():
+            for lo in range(0, n_samples, 32):
+                hi = min(n_samples, lo + 32)
+                self._ops.swag_sample_batched(self.state["__mean"], self.state["__sq_weights"],
+                                              self.state["__deviations"], self.state["__dev_head"], out[lo:hi], d,
+                                              seed=self.seed if seed is None else seed, stream_id0=s0 + lo)
+        if stream_id0 is None:
+            self._sample_counter += n_samples
+        return out[:, :d]
+
+    def use_sample(self, flat_sample: torch.Tensor) -> None:
+        """Point the parameters at a row of ``sample_batch`` (no copy)."""
+        self.state["__params_dirty"] = True
+        for param, view in zip(self._plist, self._layout.views(flat_sample)):
+            param.data = view
+
+    # ---- checkpoints in the reference's wire layout ---------------------
+    def state_dict(self):
+        sd = super().state_dict()
+        st = sd["state"]
+        d = self._layout.d
+        st["__mean"] = self.mean_vector().detach().cpu()
+        st["__sq_weights"] = self.sq_vector().detach().cpu()
+        st["__deviations"] = self.deviations_dk().detach().cpu()
+        st.pop("__dev_head", None)
+        return sd
+
+    def load_state_dict(self, state_dict: dict):
+        super().load_state_dict(state_dict)
+        dev, d, ld, k = self._params_device(), self._layout.d, self._layout.ld, self.deviation_samples
+
+        def flat(v):
+            out = torch.zeros(ld, dtype=torch.float32, device=dev)
+            out[:d] = v.to(dev).float()[:d]
+            return out
+
+        self.state["__mean"] = flat(self.state["__mean"])
+        self.state["__sq_weights"] = flat(self.state["__sq_weights"])
+        devs = self.state["__deviations"]
+        ring = torch.zeros((k, ld), dtype=torch.float32, device=dev)
+        if devs.dim() == 2 and devs.shape[0] == d and devs.shape[1] == k and not (d == k and "__dev_head" in self.state):
+            ring[:, :d] = devs.to(dev).float().t()          # reference layout [D, K]: column c -> row c, head 0
+            self.state["__dev_head"] = 0
+        else:
+            ring[:, :d] = devs.to(dev).float()[:, :d]
+        self.state["__deviations"] = ring
+        # re-alias the parameters to the flat weight vector (values come from the model's own state_dict)
+        with torch.no_grad():
+            torch._foreach_copy_(self._theta_views, [p.detach() for p in self._plist])
+        for param, view in zip(self._plist, self._theta_views):
+            param.data = view
+            self.state[param]["original_param"] = view
+        self.state["__params_dirty"] = False

@@ -1,0 +1,118 @@
+"""Mean-field Gaussian parameter (Bayes by Backprop building block).
+
+Reference: ``src/algos/util.py:151-202`` -- ``GaussianParameter`` (mean/rho
+pair, ``std = softplus(rho)``, ``sample() = mean + eps * std``,
+``kl_divergence(prior)``), ``normal_like`` and ``reset_model_params``.
+``sample()`` runs the HIP draw kernel (forward) and its analytic backward
+instead of ~4 ATen launches plus an autograd graph per tensor; the noise is
+either drawn by torch (``rng="torch"``, the reference's stream) or generated
+inside the kernel and re-generated in backward (``rng="philox"``: nothing is
+saved for backward but the seed).
+"""
+from __future__ import annotations
+
+import itertools
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_philox_stream = itertools.count()
+
+
+def normal_like(tensor) -> torch.Tensor:
+    """``torch.empty_like(tensor).normal_(0, 1)`` (util.py:185-186)."""
+    return torch.empty_like(tensor).normal_(0, 1)
+
+
+def non_mle_params(params):
+    return filter(lambda p: getattr(p, "use_mle_training", False) is False, params)
+
+
+def reset_model_params(model):
+    '''Resets all parameters of the model that implement reset_parameters() (util.py:191-202)'''
+    def weight_reset(m):
+        reset_parameters = getattr(m, "reset_parameters", None)
+        if callable(reset_parameters):
+            m.reset_parameters()
+    model.apply(weight_reset)
+
+
+class _GaussDraw(torch.autograd.Function):
+    """w = mean + softplus(rho) * eps with the HIP kernels (bde_gauss_draw_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, mean, rho, eps, seed, stream_id, ops):
+        m, r = mean.detach().contiguous().view(-1), rho.detach().contiguous().view(-1)
+        n = m.numel()
+        w = torch.empty_like(m)
+        e = None if eps is None else eps.contiguous().view(-1)
+        ops.gauss_draw_fwd(m, r, w, n, eps=e, seed=seed, stream_id=stream_id)
+        ctx.save_for_backward(r, e)
+        ctx.meta = (seed, stream_id, ops, n, mean.shape)
+        return w.view(mean.shape)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        r, e = ctx.saved_tensors
+        seed, stream_id, ops, n, shape = ctx.meta
+        g = grad_out.contiguous().view(-1)
+        gmean, grho = torch.empty_like(g), torch.empty_like(g)
+        ops.gauss_draw_bwd(g, r, gmean, grho, n, eps=e, seed=seed, stream_id=stream_id, accumulate=False)
+        return gmean.view(shape), grho.view(shape), None, None, None, None
+
+
+class GaussianParameter(nn.Module):
+    '''
+        A mean-field Gaussian parameter (drop-in for src/algos/util.py:151-183).
+        Don't overwrite the rho *parameter*, or make sure to set _is_gaussian_rho on the new one.
+    '''
+
+    def __init__(self, size, device=None, *, rng="torch", seed=0, _ops=None):
+        super().__init__()
+        self.overwrite_mean(torch.empty(size, device=device))
+        self.rho = nn.Parameter(torch.empty(size, device=device))
+        self.rho._is_gaussian_rho = True   # required e.g. by BBB
+        self.rng = rng
+        self.seed = int(seed)
+        self.noise_source: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
+        self._ops = _ops
+
+    def blundell_init(self, mean_std=0.1):
+        torch.nn.init.normal_(self.mean, 0, mean_std)
+        torch.nn.init.constant_(self.rho, -3)
+
+    def sign_init(self):
+        with torch.no_grad():
+            self.mean.data = (torch.rand_like(self.mean) > 0.5).float() * 2 - 1
+        torch.nn.init.constant_(self.rho, -3)
+
+    def _get_ops(self):
+        if self._ops is None:
+            from .algo import _default_ops
+            self._ops = _default_ops()
+        return self._ops
+
+    def sample(self) -> torch.Tensor:
+        # util.py:170-171: mean + normal_like(std) * std
+        if self.noise_source is not None:
+            eps = self.noise_source(self.rho)
+        elif self.rng == "torch":
+            eps = normal_like(self.rho)
+        else:
+            eps = None
+        return _GaussDraw.apply(self.mean, self.rho, eps, self.seed, next(_philox_stream), self._get_ops())
+
+    def kl_divergence(self, prior):
+        return prior.kl_divergence(self.mean, self.std)
+
+    def overwrite_mean(self, mean):
+        self.mean = nn.Parameter(mean)
+        self.mean.get_parameter_kl = self.kl_divergence
+        self.mean._is_gaussian_mean = True   # required e.g. by BBB
+        self.mean._bde_gaussian = self       # lets BBBOptimizer pair mean and rho for the fused KL kernel
+
+    @property
+    def std(self) -> torch.Tensor:
+        return F.softplus(self.rho)

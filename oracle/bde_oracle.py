@@ -282,10 +282,17 @@ def ivon_update(mean, momentum, precision, delta_sum, acc_grad, *, step_t: int, 
     is the already incremented step counter (line 69).  Returns the new
     ``(mean, momentum, precision)`` without touching the inputs.
     """
-    beta1, beta2 = betas
-    t = step_t
     n = dataset_size * augmentation                       # line 72
     delta = tempering * prior_prec / n                    # line 74
+    return ivon_update_scalars(mean, momentum, precision, delta_sum, acc_grad, step_t=step_t, lr=lr, betas=betas,
+                               lam=delta, n_eff=n, damping=damping, mc_samples=mc_samples)
+
+
+def ivon_update_scalars(mean, momentum, precision, delta_sum, acc_grad, *, step_t: int, lr: float, betas,
+                        lam: float, n_eff: float, damping: float, mc_samples: int):
+    """Lines 79-89 of ``src/algos/ivorn.py`` given ``delta`` (= lam, line 74) and ``N`` (= n_eff, line 72)."""
+    beta1, beta2 = betas
+    t, n, delta = step_t, n_eff, lam
     gradient = acc_grad / mc_samples                      # line 79
     g_mu = delta * mean + gradient                        # line 80
     momentum = beta1 * momentum + (1 - beta1) * g_mu      # line 81

@@ -1,0 +1,170 @@
+"""A CHECKER with the interface of beyond_deep_ensembles_amd.ops.HipOps, built
+on the CPU oracle.  Test infrastructure only: it lets the CPU test-suite drive
+the optimizer shells' HOST logic (flat layouts, ring indexing, schedules,
+sharding, gradient hand-over) without a GPU, and lets world_size-2 gloo tests
+run here.  The product never constructs it."""
+import math
+
+import torch
+
+from oracle import bde_oracle as O
+
+
+def pad4(n, mult=64):
+    return (n + mult - 1) // mult * mult
+
+
+class OracleOps:
+    name = "oracle"
+
+    # ------------------------------------------------------------ SVGD --
+    def svgd_ws(self, m, device):
+        if not 1 <= m <= 16:
+            raise RuntimeError("M out of range")
+        return torch.zeros(16 + 2048 * 256)
+
+    def svgd_kstat(self, m, device):
+        return torch.zeros(4 * m * m + m + 4)
+
+    def svgd_step(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat):
+        p, g = P[:, :d].clone(), G[:, :d].clone()
+        m = p.shape[0]
+        phi = O.svgd_phi(p, g, l2_reg, kernel_grad_scale, dataset_size)
+        out[:, :d] = sign * phi
+        kernel, _ = O.svgd_rbf(p)
+        kstat[:m * m] = kernel.reshape(-1)
+        kstat[m * m:2 * m * m] = (torch.cdist(p, p) ** 2).reshape(-1)
+        kstat[2 * m * m + m] = O.svgd_bandwidth(p)
+
+    def svgd_gram(self, P, d, ws):
+        self._gram_P = P[:, :d].clone()
+
+    def svgd_kstats(self, ws, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override=0.0, mode=0):
+        p = self._gram_P
+        kernel, gradk = O.svgd_rbf(p, h_override if h_override > 0 else None)
+        kstat[:m * m] = kernel.reshape(-1)
+        self._pending = (mode, kernel, gradk, l2_reg, kernel_grad_scale, dataset_size, sign)
+
+    def svgd_combine(self, P, G, out, d, kstat):
+        mode, kernel, gradk, l2_reg, scale, n, sign = self._pending
+        if mode == 1:
+            out[:, :d] = gradk
+        else:
+            out[:, :d] = sign * O.svgd_phi(P[:, :d].clone(), G[:, :d].clone(), l2_reg, scale, n)
+
+    def svgd_apply_sgd(self, P, grad, buf, d, lr, momentum, dampening, weight_decay, nesterov, first):
+        b = buf[:d]
+        for i in range(P.shape[0]):
+            p, g = P[i, :d], grad[i, :d].clone()
+            if weight_decay != 0:
+                g = g + weight_decay * p
+            if momentum != 0:
+                if first and i == 0:
+                    b.copy_(g)
+                else:
+                    b.mul_(momentum).add_(g, alpha=1 - dampening)
+                g = g + momentum * b if nesterov else b.clone()
+            p.add_(g, alpha=-lr)
+
+    def svgd_apply_adam(self, P, grad, exp_avg, exp_avg_sq, d, lr, beta1, beta2, eps, weight_decay, step0):
+        m_, v_ = exp_avg[:d], exp_avg_sq[:d]
+        for i in range(P.shape[0]):
+            t = step0 + i + 1
+            p, g = P[i, :d], grad[i, :d].clone()
+            if weight_decay != 0:
+                g = g + weight_decay * p
+            m_.lerp_(g, 1 - beta1)
+            v_.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+            denom = (v_.sqrt() / math.sqrt(1 - beta2 ** t)).add_(eps)
+            p.addcdiv_(m_, denom, value=-(lr / (1 - beta1 ** t)))
+
+    # ------------------------------------------------------------ SWAG --
+    def swag_update(self, theta, mean, sq, dev_row, n, d):
+        t = theta[:d]
+        mean[:d] = (n * mean[:d] + t) / (n + 1)
+        sq[:d] = (n * sq[:d] + t ** 2) / (n + 1)
+        dev_row[:d] = t - mean[:d]
+
+    def _logical(self, dev, head, d):
+        k = dev.shape[0]
+        return torch.stack([dev[(head + c) % k, :d] for c in range(k)], dim=1)   # [D, K]
+
+    def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0):
+        k = dev.shape[0]
+        if eps_w is None:
+            g = torch.Generator().manual_seed(seed * 1000003 + stream_id)
+            eps_w, eps_d = torch.randn(k, generator=g), torch.randn(d, generator=g)
+        out[:d] = O.swag_sample(mean[:d], sq[:d], self._logical(dev, head, d), eps_w, eps_d[:d])
+
+    def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0):
+        for s in range(out.shape[0]):
+            self.swag_sample(mean, sq, dev, head, out[s], d, None if eps_w is None else eps_w[s],
+                             None if eps_d is None else eps_d[s], seed, stream_id0 + s)
+
+    # ----------------------------------------------------------- Gauss --
+    def reduce_ws(self, device):
+        return torch.zeros(8)
+
+    def gauss_draw_fwd(self, mean, rho, out, n, eps=None, seed=0, stream_id=0, eps_out=None):
+        if eps is None:
+            eps = torch.randn(mean.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+            if eps_out is not None:
+                eps_out.copy_(eps)
+        out[:n] = O.gauss_sample(mean[:n], rho[:n], eps[:n])
+
+    def gauss_draw_bwd(self, g, rho, gmean, grho, n, eps=None, seed=0, stream_id=0, accumulate=False):
+        if eps is None:
+            eps = torch.randn(rho.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+        gm, gr = O.gauss_sample_backward(g[:n], rho[:n], eps[:n])
+        if accumulate:
+            gmean[:n] += gm
+            grho[:n] += gr
+        else:
+            gmean[:n] = gm
+            grho[:n] = gr
+
+    def gauss_kl(self, mean, rho, prior_mu, prior_sigma, n, ws, kl_out=None, gmean=None, grho=None, grad_scale=1.0,
+                 grad_scale_dev=None, accumulate=False):
+        c = grad_scale * (float(grad_scale_dev) if grad_scale_dev is not None else 1.0)
+        if kl_out is not None:
+            kl_out[0] = O.gauss_kl(mean[:n], rho[:n], prior_mu, prior_sigma)
+        if gmean is not None:
+            gm, gr = O.gauss_kl_grads(mean[:n], rho[:n], prior_mu, prior_sigma)
+            if accumulate:
+                gmean[:n] += c * gm
+                grho[:n] += c * gr
+            else:
+                gmean[:n] = c * gm
+                grho[:n] = c * gr
+
+    def l2(self, p, l2_scale, n, ws, val_out=None, g=None, grad_scale=1.0, grad_scale_dev=None, accumulate=False):
+        c = grad_scale * (float(grad_scale_dev) if grad_scale_dev is not None else 1.0)
+        if val_out is not None:
+            val_out[0] = O.l2_term(p[:n], l2_scale)
+        if g is not None:
+            if accumulate:
+                g[:n] += c * l2_scale * p[:n]
+            else:
+                g[:n] = c * l2_scale * p[:n]
+
+    # ------------------------------------------------------------ iVON --
+    def ivon_sample(self, mean, prec, param, delta_sum, n, n_eff, first, eps=None, seed=0, stream_id=0,
+                    deterministic=False):
+        if deterministic:
+            delta = torch.zeros(n)
+        else:
+            if eps is None:
+                eps = torch.randn(mean.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+            delta = O.ivon_sample(mean[:n], prec[:n], n_eff, eps[:n])
+        param[:n] = mean[:n] + delta
+        if first:
+            delta_sum[:n] = delta
+        else:
+            delta_sum[:n] += delta
+
+    def ivon_update(self, mean, momentum, prec, delta_sum, acc_grad, n, *, lam, n_eff, mc, beta1, beta2, t, lr,
+                    damping):
+        m, mo, pr = O.ivon_update_scalars(mean[:n], momentum[:n], prec[:n], delta_sum[:n], acc_grad[:n], step_t=t,
+                                          lr=lr, betas=(beta1, beta2), lam=lam, n_eff=n_eff, damping=damping,
+                                          mc_samples=mc)
+        mean[:n], momentum[:n], prec[:n] = m, mo, pr

@@ -1,0 +1,121 @@
+"""world_size-2 gloo tests of the multi-GPU paths (run on CPU with the oracle
+checker backend): SVGD particle sharding with ONE all-gather of gradient rows
+reproduces the single-process trajectory; MultiSWAG fan-out covers every
+(member, sample) unit exactly once and is independent of the world size."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make(seed, m, ops, pg=None, fuse=False):
+    import beyond_deep_ensembles_amd as bde
+    torch.manual_seed(seed)
+    model = nn.Sequential(nn.Linear(13, 20), nn.Tanh(), nn.Linear(20, 1))
+    base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=m,
+                            dataset_size=64, l2_reg=0.01, process_group=pg, fuse_base_optimizer=fuse, _ops=ops)
+    return model, opt
+
+
+def _run_steps(model, opt, steps=3):
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(64, 13, generator=g), torch.randn(64, 1, generator=g)
+    losses = []
+    for t in range(steps):
+        xb, yb = x[t * 16:(t + 1) * 16], y[t * 16:(t + 1) * 16]
+        losses.append(float(opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())))
+    return losses
+
+
+def _svgd_worker(rank, world, port, m, fuse, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.oracle_ops import OracleOps
+        torch.set_num_threads(1)
+        # different local RNG state per rank: the constructor must still agree on the particles (broadcast)
+        model, opt = _make(100 + rank, m, OracleOps(), pg=dist.group.WORLD, fuse=fuse)
+        fwd_calls = [0]
+        orig = model.forward
+
+        def counting_forward(*a, **k):
+            fwd_calls[0] += 1
+            return orig(*a, **k)
+        model.forward = counting_forward
+        losses = _run_steps(model, opt)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=opt.particles.numpy(), losses=np.array(losses),
+                 fwd=np.array(fwd_calls[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("m,fuse", [(4, False), (2, True)])
+def test_svgd_sharded_equals_single_process(tmp_path, m, fuse):
+    from tests.oracle_ops import OracleOps
+    world = 2
+    port = _free_port()
+    mp.spawn(_svgd_worker, args=(world, port, m, fuse, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    # replicas stay bit-identical across ranks
+    np.testing.assert_array_equal(r0["particles"], r1["particles"])
+    np.testing.assert_array_equal(r0["losses"], r1["losses"])
+    # each rank ran forward/backward only for its own M/W particles
+    assert int(r0["fwd"]) == 3 * m // world and int(r1["fwd"]) == 3 * m // world
+    # single-process run from rank 0's initial state
+    torch.set_num_threads(1)
+    model, opt = _make(100, m, OracleOps(), fuse=fuse)
+    losses = _run_steps(model, opt)
+    np.testing.assert_allclose(r0["particles"], opt.particles.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=1e-6)
+
+
+def _swag_member(seed, ops):
+    import beyond_deep_ensembles_amd as bde
+    torch.manual_seed(seed)
+    model = nn.Linear(6, 2)
+    opt = bde.SwagOptimizer(model.parameters(), torch.optim.SGD(model.parameters(), lr=0.1), update_interval=1,
+                            deviation_samples=4, rng="philox", seed=seed, _ops=ops)
+    x = torch.randn(8, 6)
+    for _ in range(6):
+        opt.step(lambda: model(x).pow(2).mean(), lambda l: l.backward())
+    return model, opt
+
+
+def test_multiswag_fan_out_is_world_size_independent():
+    """MultiSWAG (BASELINE config 5 shape: members x samples fanned over GPUs):
+    the union of the ranks' outputs, put back in unit order, does not depend
+    on the number of ranks."""
+    import beyond_deep_ensembles_amd as bde
+    from beyond_deep_ensembles_amd.ensemble import fan_out
+    from tests.oracle_ops import OracleOps
+    ops = OracleOps()
+    samples, members = 13, 3
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(1))
+
+    def run(world):
+        outs = {}
+        for rank in range(world):
+            ens = bde.DeepEnsemble([_swag_member(10 + i, ops) for i in range(members)])
+            res = ens.predict(lambda m: m(x).detach(), samples, rank=rank, world_size=world)
+            for (u, _, _), o in zip(fan_out(samples, members, rank, world), res):
+                outs[u] = o
+        return torch.stack([outs[u] for u in range(samples)])
+
+    a, b, c = run(2), run(3), run(8)
+    assert torch.equal(a, b) and torch.equal(a, c)

@@ -1,0 +1,336 @@
+"""The optimizer shells (the drop-in boundary) replayed against the golden
+trajectories captured from the imported reference.
+
+Each test runs twice:
+  * backend "oracle" (CPU, `-m "not gpu"`): the shells' HOST logic -- flat
+    layouts, particle/ring indexing, schedules, gradient hand-over, state keys
+    -- with the arithmetic done by the CPU oracle (tests/oracle_ops.py);
+  * backend "hip" (`-m gpu`): the product path, libbde_hip.so on cuda:0.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import beyond_deep_ensembles_amd as bde
+from tests.oracle_ops import OracleOps
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    if request.param == "oracle":
+        return OracleOps(), torch.device("cpu")
+    from beyond_deep_ensembles_amd.ops import HipOps
+    return HipOps(), torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def make_mlp():
+    return nn.Sequential(nn.Linear(13, 50), nn.ReLU(), nn.Linear(50, 1))
+
+
+def set_flat(params, flat):
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+
+def flat(ts):
+    return torch.cat([t.detach().reshape(-1) for t in ts])
+
+
+# ------------------------------------------------------------------ SVGD --
+@pytest.mark.parametrize("name,make_opt,fuse", [
+    ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), False),
+    ("adam", lambda ps: torch.optim.Adam(ps, lr=1e-3), False),
+    ("adam_wd", lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2), False),
+    ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), True),
+    ("adam", lambda ps: torch.optim.Adam(ps, lr=1e-3), True),
+])
+def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
+    ops, dev = backend
+    g = golden(f"svgd_traj_{name}.npz")
+    m = int(g["m"])
+    model = make_mlp().to(dev)
+    params = list(model.parameters())
+    init = T(g["init"]).to(dev)
+    set_flat(params, init[0])
+    k = [0]
+
+    def reset():            # the reference's reset closure produced particle k+1
+        k[0] += 1
+        set_flat(params, init[k[0]])
+
+    base = make_opt(model.parameters())
+    opt = bde.SVGDOptimizer(model.parameters(), reset, base, particle_count=m, dataset_size=64,
+                            l2_reg=float(g["l2_reg"]), kernel_grad_scale=float(g["scale"]), fuse_base_optimizer=fuse,
+                            _ops=ops)
+    assert torch.equal(opt.particles.cpu(), init.cpu())
+    for i in range(m):      # reference state keys (svgd.py:57)
+        assert f"particle_{i}" in opt.state[params[0]]
+    x, y = T(g["x"]).to(dev), T(g["y"]).to(dev)
+    for t in range(g["traj"].shape[0]):
+        xb, yb = x[(t % 4) * 16:(t % 4 + 1) * 16], y[(t % 4) * 16:(t % 4 + 1) * 16]
+        loss = opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+        assert abs(float(loss) - g["losses"][t]) <= 2e-5 * abs(g["losses"][t]) + 1e-7   # model forward is torch (GPU vs CPU fp32)
+        got = opt.particles.cpu().numpy()
+        np.testing.assert_allclose(got, g["traj"][t], rtol=2e-5, atol=3e-6)
+    if not fuse and float(g["base_step_count"]) >= 0:   # shared optimizer state advanced M times per step (Q5)
+        assert float(base.state[params[0]]["step"]) == float(g["base_step_count"])
+    # after step() the model aliases the LAST particle (svgd.py:96)
+    np.testing.assert_allclose(flat(params).cpu().numpy(), g["model_after"], rtol=2e-5, atol=3e-6)
+    # sample_parameters cycles through the particles without copying (svgd.py:107-112)
+    for i in range(m + 1):
+        opt.sample_parameters()
+        assert params[0].data_ptr() == opt.state[params[0]][f"particle_{i % m}"].data_ptr()
+    assert opt.get_base_optimizer() is base
+
+
+def test_svgd_state_dict_roundtrip(backend):
+    ops, dev = backend
+    torch.manual_seed(0)
+    model = make_mlp().to(dev)
+    mk = lambda: bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model),
+                                   torch.optim.SGD(model.parameters(), lr=0.1), particle_count=3, dataset_size=10,
+                                   _ops=ops)
+    a = mk()
+    want = a.particles.clone()
+    sd = a.state_dict()
+    b = mk()
+    assert not torch.equal(b.particles, want)
+    b.load_state_dict(sd)
+    assert torch.equal(b.particles, want)
+    assert b.state[list(model.parameters())[0]]["particle_1"].data_ptr() == b._pviews[1][0].data_ptr()
+
+
+# ------------------------------------------------------------------ SWAG --
+def test_swag_schedule_bit_exact(golden, backend):
+    ops, dev = backend
+    g = golden("swag_schedule.npz")
+    for ci, (steps_per_epoch, start_epoch, interval, epochs) in enumerate(g["cfgs"]):
+        p = nn.Parameter(torch.zeros(3, device=dev))
+        base = torch.optim.SGD([p], lr=1.0)
+        opt = bde.SwagOptimizer([p], base, update_interval=float(interval), start_epoch=int(start_epoch),
+                                deviation_samples=4, _ops=ops)
+        trace = []
+        for e in range(int(epochs)):
+            for b in range(int(steps_per_epoch)):
+                opt.step(lambda: p.sum(), lambda l: l.backward())
+                trace.append([e, b, opt.state["__epoch"], opt.state["__steps_since_swag_start"], opt.state["__updates"]])
+            opt.complete_epoch()
+        np.testing.assert_array_equal(np.array(trace, dtype=np.int64), g[f"trace_{ci}"])
+
+
+def test_swag_statistics_columns_and_samples(golden, backend):
+    ops, dev = backend
+    g = golden("swag_stats.npz")
+    for ci, (total_updates, tagged, lr, interval, k) in enumerate(g["cases"]):
+        k = int(k)
+        theta0 = T(g[f"theta0_{ci}"])
+        c = T(g[f"c_{ci}"]).to(dev)
+        p1 = nn.Parameter(theta0[:7].clone().to(dev))
+        p2 = nn.Parameter(theta0[7:].clone().view(2, 3).to(dev))
+        base = torch.optim.SGD([p1, p2], lr=float(lr))
+        opt = bde.SwagOptimizer([p1, p2], base, update_interval=int(interval), start_epoch=0, deviation_samples=k,
+                                _ops=ops)
+        c1, c2 = c[:7], c[7:].view(2, 3)
+        fwd = lambda: (p1 * c1).sum() + (p2 * c2).sum()
+        for t in range(int(total_updates) * int(interval)):
+            opt.step(fwd, lambda l: l.backward())
+            np.testing.assert_array_equal(flat([p1, p2]).cpu().numpy(), g[f"thetas_{ci}"][t])
+        assert opt.state["__updates"] == int(total_updates)
+        # statistics in the reference's layout: bit-exact (iterate <-> column mapping included)
+        np.testing.assert_array_equal(opt.mean_vector().cpu().numpy(), g[f"mean_{ci}"])
+        np.testing.assert_array_equal(opt.sq_vector().cpu().numpy(), g[f"sq_{ci}"])
+        np.testing.assert_array_equal(opt.deviations_dk().cpu().numpy(), g[f"dev_{ci}"])
+        # samples with the recorded noise (eps_W first, then eps_D)
+        before = flat([p1, p2]).clone()
+        for s in range(3):
+            ew, ed = T(g[f"eps_w_{ci}"][s]).to(dev), T(g[f"eps_d_{ci}"][s]).to(dev)
+            opt.noise_source = lambda kk, dd: (ew, ed)
+            opt.sample_parameters()
+            want = g[f"samples_{ci}"][s]
+            mag = np.abs(g[f"mean_{ci}"]) + np.abs(want) + 1e-3
+            assert np.max(np.abs(flat([p1, p2]).cpu().numpy() - want) / mag) < 2e-6
+            assert opt.state["__params_dirty"]
+        # the next step() first restores the training weights (swag.py:38)
+        opt.step(fwd, lambda l: l.backward())
+        np.testing.assert_array_equal(flat([p1, p2]).cpu().numpy(), g[f"theta_after_restore_step_{ci}"])
+        assert not opt.state["__params_dirty"]
+        # checkpoint in the reference's wire layout, and back
+        sd = opt.state_dict()
+        assert tuple(sd["state"]["__deviations"].shape) == (13, k)
+        np.testing.assert_array_equal(sd["state"]["__deviations"].numpy(), opt.deviations_dk().cpu().numpy())
+        q1, q2 = nn.Parameter(p1.detach().clone()), nn.Parameter(p2.detach().clone())
+        opt2 = bde.SwagOptimizer([q1, q2], torch.optim.SGD([q1, q2], lr=float(lr)), update_interval=int(interval),
+                                 start_epoch=0, deviation_samples=k, _ops=ops)
+        sd2 = {"state": dict(sd["state"]), "param_groups": sd["param_groups"]}
+        sd2["state"]["__base_optimizer"] = opt2.state["__base_optimizer"]
+        opt2.load_state_dict(sd2)
+        np.testing.assert_array_equal(opt2.deviations_dk().cpu().numpy(), opt.deviations_dk().cpu().numpy())
+        np.testing.assert_array_equal(opt2.mean_vector().cpu().numpy(), opt.mean_vector().cpu().numpy())
+        assert opt2.state["__updates"] == opt.state["__updates"]
+
+
+def test_swag_torch_rng_matches_reference_stream(backend):
+    """rng='torch' consumes the generator exactly as LowRankMultivariateNormal.rsample does."""
+    ops, dev = backend
+    torch.manual_seed(0)
+    p = nn.Parameter(torch.randn(37, device=dev))
+    opt = bde.SwagOptimizer([p], torch.optim.SGD([p], lr=0.1), update_interval=1, deviation_samples=3, _ops=ops)
+    for _ in range(4):
+        opt.step(lambda: (p ** 2).sum(), lambda l: l.backward())
+    torch.manual_seed(123)
+    opt.sample_parameters()
+    got = p.detach().clone()
+    torch.manual_seed(123)
+    ew = torch.empty(3, device=dev).normal_()
+    ed = torch.empty(37, device=dev).normal_()
+    opt.noise_source = lambda k, d: (ew, ed)
+    opt.sample_parameters()
+    assert torch.equal(got, p.detach())
+
+
+# ------------------------------------------------------------------- BBB --
+class LocalReparamLinear(nn.Module):
+    """Test model layer: the local-reparameterisation forward of the reference's
+    BBBLinear (bbb_layers.py:70-80) on bde.GaussianParameter.  The layer is model
+    code (out of scope, stays PyTorch); the noise is replayed from the fixture."""
+
+    def __init__(self, i, o, tape, ops):
+        super().__init__()
+        self.weight = bde.GaussianParameter((o, i), _ops=ops)
+        self.bias = bde.GaussianParameter((o,), _ops=ops)
+        self.tape = tape
+
+    def forward(self, x):
+        mean = F.linear(x, self.weight.mean, self.bias.mean)
+        var = F.linear((x ** 2).clamp(min=1e-4), (self.weight.std ** 2).clamp(min=1e-4),
+                       (self.bias.std ** 2).clamp(min=1e-4))
+        return mean + torch.sqrt(var) * self.tape.pop(0).to(x.device)
+
+
+class SampledLinear(nn.Module):
+    def __init__(self, i, o, tape, ops):
+        super().__init__()
+        self.weight = bde.GaussianParameter((o, i), _ops=ops)
+        self.bias = bde.GaussianParameter((o,), _ops=ops)
+        self.weight.noise_source = lambda rho: tape.pop(0).to(rho.device)
+        self.bias.noise_source = lambda rho: tape.pop(0).to(rho.device)
+
+    def forward(self, x):
+        return F.linear(x, self.weight.sample(), self.bias.sample())
+
+
+@pytest.mark.parametrize("tag,layer", [("b", LocalReparamLinear), ("c", SampledLinear)])
+def test_bbb_trajectory(golden, backend, tag, layer):
+    """BASELINE config #1: UCI-housing-shaped 13-50-1 mean-field MLP, BBBOptimizer with Adam."""
+    ops, dev = backend
+    g = golden("bbb.npz")
+    tape = [T(g[f"{tag}_eps_{i}"]) for i in range(int(g[f"{tag}_n_eps"]))]
+    model = nn.Sequential(layer(13, 50, tape, ops), nn.ReLU(), layer(50, 1, tape, ops)).to(dev)
+    extra = nn.Parameter(torch.zeros(4, device=dev))
+    names = [str(n) for n in g[f"{tag}_names"]]
+    named = dict(model.named_parameters())
+    named["extra"] = extra
+    with torch.no_grad():
+        for n in names:
+            named[n].copy_(T(g[f"{tag}_init/{n}"]).to(dev))
+    params = [named[n] for n in names]
+    prior = bde.GaussianPrior(0, 1.0)
+    base = torch.optim.Adam(params, lr=1e-2)
+    opt = bde.BBBOptimizer(params, base, prior, dataset_size=48, mc_samples=2, kl_rescaling=0.5, components=1,
+                           l2_scale=0.3, _ops=ops)
+    x, y = T(g[f"{tag}_x"]).to(dev), T(g[f"{tag}_y"]).to(dev)
+    for t in range(3):
+        xb, yb = x[(t % 3) * 16:(t % 3 + 1) * 16], y[(t % 3) * 16:(t % 3 + 1) * 16]
+        loss = opt.step(lambda: F.mse_loss(model(xb), yb) + extra.sum() * 0.01, lambda l: l.backward())
+        want = g[f"{tag}_losses"][t]
+        assert abs(float(loss) - want) <= 5e-6 * abs(want), (t, float(loss), want)
+        np.testing.assert_allclose(flat(params).cpu().numpy(), g[f"{tag}_traj"][t], rtol=1e-4, atol=2e-5)
+    assert not tape
+    assert opt.get_base_optimizer() is base
+
+
+def test_bbb_nan_loss_skips_update(backend):
+    ops, dev = backend
+    gp = bde.GaussianParameter((5,), _ops=ops).to(dev)
+    gp.blundell_init()
+    params = list(gp.parameters())
+    opt = bde.BBBOptimizer(params, torch.optim.SGD(params, lr=0.1), bde.GaussianPrior(0, 1.0), dataset_size=10, _ops=ops)
+    before = gp.mean.detach().clone()
+    loss = opt.step(lambda: gp.mean.sum() * float("nan"), lambda l: l.backward())
+    assert torch.isnan(loss)
+    assert torch.equal(before, gp.mean.detach())      # bbb.py:81: update skipped, loss still returned
+
+
+# ------------------------------------------------------------------ iVON --
+def test_ivon_trajectory(golden, backend):
+    ops, dev = backend
+    g = golden("ivon.npz")
+    for ci, (aug, mc, damping, temp) in enumerate(g["cases"]):
+        mc = int(mc)
+        model = make_mlp().to(dev)
+        params = list(model.parameters())
+        set_flat(params, T(g[f"init_{ci}"]).to(dev))
+        opt = bde.iVONOptimizer(params, lr=1e-2, prior_prec=50.0, dataset_size=48, damping=float(damping),
+                                tempering=float(temp), augmentation=float(aug), mc_samples=mc, _ops=ops)
+        eps = [T(e).to(dev) for e in g[f"eps_{ci}"]]
+        opt.noise_source = lambda d: eps.pop(0)
+        x, y = T(g[f"x_{ci}"]).to(dev), T(g[f"y_{ci}"]).to(dev)
+        assert opt.get_base_optimizer() is opt
+        for t in range(3):
+            xb, yb = x[(t % 3) * 16:(t % 3 + 1) * 16], y[(t % 3) * 16:(t % 3 + 1) * 16]
+            loss = opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+            assert abs(float(loss) - g[f"losses_{ci}"][t]) <= 3e-6 * abs(g[f"losses_{ci}"][t])
+            st = lambda key: flat([opt.state[p][key] for p in params]).cpu().numpy()
+            np.testing.assert_allclose(st("mean"), g[f"means_{ci}"][t], rtol=3e-5, atol=1e-6)
+            np.testing.assert_allclose(st("momentum"), g[f"moms_{ci}"][t], rtol=3e-4, atol=1e-6)
+            np.testing.assert_allclose(st("precision"), g[f"precs_{ci}"][t], rtol=3e-5, atol=1e-7)
+            # the parameters stay at the last noisy sample (Q13)
+            np.testing.assert_allclose(flat(params).cpu().numpy(), g[f"after_{ci}"][t], rtol=3e-5, atol=2e-6)
+        opt.sample_parameters()
+        np.testing.assert_allclose(flat(params).cpu().numpy(), g[f"eval_sample_{ci}"], rtol=3e-5, atol=2e-6)
+        assert not eps
+
+
+# -------------------------------------------------------------- ensemble --
+class _Counting:
+    def __init__(self):
+        self.n = 0
+
+    def sample_parameters(self):
+        self.n += 1
+
+
+def test_ensemble_split_and_fan_out(golden):
+    from beyond_deep_ensembles_amd.ensemble import fan_out, split_samples
+    for r in golden("ensemble.npz")["rows"]:
+        samples, members, n_out = int(r[0]), int(r[1]), int(r[2])
+        counts = [int(c) for c in r[3:3 + members]]
+        pairs = [(nn.Linear(1, 1), _Counting()) for _ in range(members)]
+        ens = bde.DeepEnsemble(pairs)
+        out = ens.predict(lambda m: torch.zeros(1), samples)
+        assert out.shape[0] == n_out and [o.n for _, o in pairs] == counts
+        assert split_samples(samples, members) == counts
+        for world in (2, 8):
+            units = [u for rk in range(world) for u in fan_out(samples, members, rk, world)]
+            assert sorted(u[0] for u in units) == list(range(n_out))          # every unit exactly once
+            sizes = [len(fan_out(samples, members, rk, world)) for rk in range(world)]
+            assert max(sizes) - min(sizes) <= 1                               # balanced
+    sd = bde.DeepEnsemble([(nn.Linear(2, 2), torch.optim.SGD(nn.Linear(2, 2).parameters(), lr=0.1))]).state_dict()
+    assert set(sd) == {"models", "optimizers"}                                 # ensemble.py:17-21
+
+
+def test_product_has_no_cpu_path():
+    """Without _ops the shells use libbde_hip.so and refuse CPU parameters."""
+    p = nn.Parameter(torch.zeros(4))
+    with pytest.raises(RuntimeError):
+        bde.SwagOptimizer([p], torch.optim.SGD([p], lr=0.1), update_interval=1)
