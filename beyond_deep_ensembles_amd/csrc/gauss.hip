@@ -89,29 +89,72 @@ __global__ __launch_bounds__(kBlock) void gauss_draw_bwd_kernel(const float* __r
   }
 }
 
+// Scalar variants for operands that are not 16-byte aligned (per-tensor views into a flat
+// buffer, e.g. the small rank-1 vectors): one element per thread, same Philox indexing.
+template <bool RNG>
+__global__ __launch_bounds__(kBlock) void gauss_draw_fwd_scalar_kernel(const float* __restrict__ mean,
+                                                                      const float* __restrict__ rho,
+                                                                      const float* __restrict__ eps, uint64_t seed,
+                                                                      uint64_t stream_id, float* __restrict__ w,
+                                                                      float* __restrict__ eps_out, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride) {
+    float e;
+    if (RNG) {
+      e = philox_normal4(seed, stream_id, static_cast<uint64_t>(k >> 2), kDomainDiag)[k & 3];
+      if (eps_out) eps_out[k] = e;
+    } else {
+      e = eps[k];
+    }
+    w[k] = mean[k] + e * softplus(rho[k]);
+  }
+}
+
+template <bool RNG, bool ACC>
+__global__ __launch_bounds__(kBlock) void gauss_draw_bwd_scalar_kernel(const float* __restrict__ g,
+                                                                      const float* __restrict__ rho,
+                                                                      const float* __restrict__ eps, uint64_t seed,
+                                                                      uint64_t stream_id, float* __restrict__ gmean,
+                                                                      float* __restrict__ grho, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const float e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(k >> 2), kDomainDiag)[k & 3] : eps[k];
+    const float gm = g[k], gr = (g[k] * e) * sigmoidf(rho[k]);
+    gmean[k] = ACC ? gmean[k] + gm : gm;
+    grho[k] = ACC ? grho[k] + gr : gr;
+  }
+}
+
 // -------------------------------------------------------------------- KL --
 // Per element (bbb.py:20): 0.5 * (2 ln(sp/s) - 1 + (s/sp)^2 + ((mp - m)/sp)^2).
-__device__ __forceinline__ float kl_elem(float m, float r, float pmu, float psig, float c, bool want_grad, float& gm,
-                                        float& gr) {
-  const float s = softplus(r);
-  const float a = s / psig;
-  const float b = (pmu - m) / psig;
-  const float kl = 0.5f * (2.0f * logf(psig / s) - 1.0f + a * a + b * b);
+// One exp, two hardware logs and two hardware reciprocals per element; the divisions by the
+// prior sigma are multiplications by host-computed reciprocals (<= 1 ulp from the reference's
+// divides, inside the stated 3e-6 tolerance) so that the kernel stays HBM-bound.
+struct KlConsts {
+  float pmu, psig, ipsig, ipsig2, c;
+};
+__device__ __forceinline__ float kl_elem(float m, float r, const KlConsts& k, bool want_grad, float& gm, float& gr) {
+  const SoftplusSigmoid ss = softplus_sigmoid(r);
+  const float s = ss.sp;
+  const float rs = __builtin_amdgcn_rcpf(s);
+  const float a = s * k.ipsig;
+  const float b = (k.pmu - m) * k.ipsig;
+  const float kl = 0.5f * (2.0f * __logf(k.psig * rs) - 1.0f + a * a + b * b);
   if (want_grad) {
-    gm = c * ((m - pmu) / (psig * psig));
-    gr = c * ((-1.0f / s + s / (psig * psig)) * sigmoidf(r));
+    gm = k.c * ((m - k.pmu) * k.ipsig2);
+    gr = k.c * ((s * k.ipsig2 - rs) * ss.sg);
   }
   return kl;
 }
 
 template <bool GRAD, bool ACC>
 __global__ __launch_bounds__(kBlock) void gauss_kl_kernel(const float* __restrict__ mean, const float* __restrict__ rho,
-                                                         float pmu, float psig, float grad_scale,
-                                                         const float* __restrict__ grad_scale_dev,
+                                                         float pmu, float psig, float ipsig, float ipsig2,
+                                                         float grad_scale, const float* __restrict__ grad_scale_dev,
                                                          float* __restrict__ gmean, float* __restrict__ grho,
                                                          double* __restrict__ partials, int64_t n) {
   __shared__ double smem[kBlock / 64];
-  const float c = grad_scale * (grad_scale_dev ? grad_scale_dev[0] : 1.0f);
+  const KlConsts kc{pmu, psig, ipsig, ipsig2, grad_scale * (grad_scale_dev ? grad_scale_dev[0] : 1.0f)};
   const int64_t n4 = n >> 2;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   float local = 0.f;
@@ -122,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float a = 0.f, b = 0.f;
-      part += kl_elem(m[j], r[j], pmu, psig, c, GRAD, a, b);
+      part += kl_elem(m[j], r[j], kc, GRAD, a, b);
       gm[j] = a;
       gr[j] = b;
     }
@@ -141,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_kernel(const float* __restric
     const int64_t k = (n4 << 2) + threadIdx.x;
     if (k < n) {
       float gm, gr;
-      acc += static_cast<double>(kl_elem(mean[k], rho[k], pmu, psig, c, GRAD, gm, gr));
+      acc += static_cast<double>(kl_elem(mean[k], rho[k], kc, GRAD, gm, gr));
       if (GRAD) {
         gmean[k] = ACC ? gmean[k] + gm : gm;
         grho[k] = ACC ? grho[k] + gr : gr;
@@ -213,17 +256,26 @@ extern "C" size_t bde_reduce_ws_bytes(void) { return sizeof(double) * (kReduceHe
 extern "C" int bde_gauss_draw_fwd(const float* mean, const float* rho, const float* eps, uint64_t seed,
                                   uint64_t stream_id, float* w, float* eps_out, int64_t n, void* stream) {
   if (!mean || !rho || !w || n <= 0) return BDE_ERR_INVALID;
-  if (!aligned16(mean) || !aligned16(rho) || !aligned16(w) || (eps && !aligned16(eps)) ||
-      (eps_out && !aligned16(eps_out)))
-    return BDE_ERR_INVALID;
-  const int grid = stream_grid((n + 3) / 4);
+  const bool vec = aligned16(mean) && aligned16(rho) && aligned16(w) && (!eps || aligned16(eps)) &&
+                   (!eps_out || aligned16(eps_out));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (eps)
-    hipLaunchKernelGGL(gauss_draw_fwd_kernel<false>, dim3(grid), dim3(kBlock), 0, s, mean, rho, eps, seed, stream_id, w,
-                       eps_out, n);
-  else
-    hipLaunchKernelGGL(gauss_draw_fwd_kernel<true>, dim3(grid), dim3(kBlock), 0, s, mean, rho, eps, seed, stream_id, w,
-                       eps_out, n);
+  if (vec) {
+    const int grid = stream_grid((n + 3) / 4);
+    if (eps)
+      hipLaunchKernelGGL(gauss_draw_fwd_kernel<false>, dim3(grid), dim3(kBlock), 0, s, mean, rho, eps, seed, stream_id,
+                         w, eps_out, n);
+    else
+      hipLaunchKernelGGL(gauss_draw_fwd_kernel<true>, dim3(grid), dim3(kBlock), 0, s, mean, rho, eps, seed, stream_id,
+                         w, eps_out, n);
+  } else {
+    const int grid = stream_grid(n);
+    if (eps)
+      hipLaunchKernelGGL(gauss_draw_fwd_scalar_kernel<false>, dim3(grid), dim3(kBlock), 0, s, mean, rho, eps, seed,
+                         stream_id, w, eps_out, n);
+    else
+      hipLaunchKernelGGL(gauss_draw_fwd_scalar_kernel<true>, dim3(grid), dim3(kBlock), 0, s, mean, rho, eps, seed,
+                         stream_id, w, eps_out, n);
+  }
   return to_err(hipGetLastError());
 }
 
@@ -231,18 +283,21 @@ extern "C" int bde_gauss_draw_bwd(const float* g, const float* rho, const float*
                                   uint64_t stream_id, float* gmean, float* grho, int accumulate, int64_t n,
                                   void* stream) {
   if (!g || !rho || !gmean || !grho || n <= 0) return BDE_ERR_INVALID;
-  if (!aligned16(g) || !aligned16(rho) || !aligned16(gmean) || !aligned16(grho) || (eps && !aligned16(eps)))
-    return BDE_ERR_INVALID;
-  const int grid = stream_grid((n + 3) / 4);
+  const bool vec = aligned16(g) && aligned16(rho) && aligned16(gmean) && aligned16(grho) && (!eps || aligned16(eps));
+  const int grid = vec ? stream_grid((n + 3) / 4) : stream_grid(n);
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define BDE_LAUNCH(R, A)                                                                                         \
-  hipLaunchKernelGGL((gauss_draw_bwd_kernel<R, A>), dim3(grid), dim3(kBlock), 0, s, g, rho, eps, seed, stream_id, \
-                     gmean, grho, n)
-  if (eps) {
-    if (accumulate) BDE_LAUNCH(false, true); else BDE_LAUNCH(false, false);
-  } else {
-    if (accumulate) BDE_LAUNCH(true, true); else BDE_LAUNCH(true, false);
+#define BDE_LAUNCH(KERNEL, R, A) \
+  hipLaunchKernelGGL((KERNEL<R, A>), dim3(grid), dim3(kBlock), 0, s, g, rho, eps, seed, stream_id, gmean, grho, n)
+#define BDE_DISPATCH(KERNEL)                                       \
+  if (eps) {                                                       \
+    if (accumulate) BDE_LAUNCH(KERNEL, false, true);               \
+    else BDE_LAUNCH(KERNEL, false, false);                         \
+  } else {                                                         \
+    if (accumulate) BDE_LAUNCH(KERNEL, true, true);                \
+    else BDE_LAUNCH(KERNEL, true, false);                          \
   }
+  if (vec) { BDE_DISPATCH(gauss_draw_bwd_kernel) } else { BDE_DISPATCH(gauss_draw_bwd_scalar_kernel) }
+#undef BDE_DISPATCH
 #undef BDE_LAUNCH
   return to_err(hipGetLastError());
 }
@@ -256,9 +311,11 @@ extern "C" int bde_gauss_kl(const float* mean, const float* rho, float prior_mu,
   const int grid = stream_grid((n + 3) / 4, kBlock, kReduceMaxBlocks);
   hipStream_t s = static_cast<hipStream_t>(stream);
   double* part = static_cast<double*>(ws);
+  const float ipsig = static_cast<float>(1.0 / static_cast<double>(prior_sigma));
+  const float ipsig2 = static_cast<float>(1.0 / (static_cast<double>(prior_sigma) * static_cast<double>(prior_sigma)));
 #define BDE_LAUNCH(G, A)                                                                                         \
   hipLaunchKernelGGL((gauss_kl_kernel<G, A>), dim3(grid), dim3(kBlock), 0, s, mean, rho, prior_mu, prior_sigma, \
-                     grad_scale, grad_scale_dev, gmean, grho, part, n)
+                     ipsig, ipsig2, grad_scale, grad_scale_dev, gmean, grho, part, n)
   if (!gmean) BDE_LAUNCH(false, false);
   else if (accumulate) BDE_LAUNCH(true, true);
   else BDE_LAUNCH(true, false);

@@ -29,7 +29,7 @@ namespace bde {
 constexpr int kGramBlock = 256;            // 4 waves
 constexpr int kGramU = 4;                  // float4 loads in flight per lane per iteration
 constexpr int kWsHeaderFloats = 16;        // [0] = #partial tiles, [1] = padded M (8 or 16)
-constexpr int kGramMaxBlocks = 2048;
+constexpr int kGramMaxBlocks = 1024;          // 4 workgroups per CU: best measured (tools/kexp.hip)
 
 using f32x4acc = __attribute__((ext_vector_type(4))) float;
 
@@ -49,7 +49,35 @@ __device__ __forceinline__ float group_sum(float x) {
   return s;
 }
 
+// One tile = kGramU float4 columns per lane.  Full tiles take the branch-free path; the ragged
+// last tile masks by index (never by multiplication: the row padding may hold NaNs).
+template <int W4>
+__device__ __forceinline__ void gram_load_tile(f32x4 (&v)[kGramU], const float* __restrict__ rowp, bool valid,
+                                               int64_t t, int64_t tile4, int c4, int64_t n4, int64_t D) {
+  const int64_t base4 = t * tile4 + c4;
+  if ((t + 1) * tile4 * 4 <= D) {                    // wave-uniform: every column full
+#pragma unroll
+    for (int u = 0; u < kGramU; ++u) v[u] = ld4(rowp + 4 * (base4 + u * W4));
+  } else {
+#pragma unroll
+    for (int u = 0; u < kGramU; ++u) {
+      const int64_t col = base4 + u * W4;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (valid && col < n4) {
+        x = ld4(rowp + 4 * col);                     // in bounds: ld >= roundup4(D)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * col + j >= D) x[j] = 0.f;
+      }
+      v[u] = x;
+    }
+  }
+}
+
 // PACK = 2: M <= 8, the 16 tile rows are (particle, d-chunk 0/1); PACK = 1: M <= 16.
+// Lanes of padded particle rows (prow >= M) read row 0 and are zeroed after the load, so the
+// hot loop has no divergent branches.  The next tile's loads are issued before this tile's
+// DPP/MFMA work (register double buffering).
 template <int PACK>
 __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __restrict__ P, int M, int64_t D,
                                                               int64_t ld, float* __restrict__ ws) {
@@ -71,32 +99,17 @@ __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __re
   const int64_t waves_total = static_cast<int64_t>(gridDim.x) * (kGramBlock / 64);
 
   f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-
-  for (int64_t t = static_cast<int64_t>(blockIdx.x) * (kGramBlock / 64) + wave; t < n_tiles; t += waves_total) {
-    const int64_t base4 = t * tile4 + c4;
-    f32x4 v[kGramU];
-    if ((t + 1) * tile4 * 4 <= D) {                  // wave-uniform: every column full
-#pragma unroll
-      for (int u = 0; u < kGramU; ++u) v[u] = valid ? ld4(rowp + 4 * (base4 + u * W4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-#pragma unroll
-      for (int u = 0; u < kGramU; ++u) {
-        const int64_t col = base4 + u * W4;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (valid && col < n4) {
-          x = ld4(rowp + 4 * col);                   // in bounds: ld >= roundup4(D)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (4 * col + j >= D) x[j] = 0.f;        // select, never multiply (padding may be NaN)
-        }
-        v[u] = x;
-      }
-    }
+  f32x4 cur[kGramU], nxt[kGramU];
+  int64_t t = static_cast<int64_t>(blockIdx.x) * (kGramBlock / 64) + wave;
+  if (t < n_tiles) gram_load_tile<W4>(cur, rowp, valid, t, tile4, c4, n4, D);
+  for (; t < n_tiles; t += waves_total) {
+    const int64_t tn = t + waves_total;
+    if (tn < n_tiles) gram_load_tile<W4>(nxt, rowp, valid, tn, tile4, c4, n4, D);
 #pragma unroll
     for (int u = 0; u < kGramU; ++u) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float x = v[u][j];
+        const float x = valid ? cur[u][j] : 0.f;
         const float s = group_sum<PACK>(x);
         const float q = valid ? (x - s * inv_m) : 0.f;
         if ((j & 1) == 0)
@@ -105,6 +118,8 @@ __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __re
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q, q, acc1, 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int u = 0; u < kGramU; ++u) cur[u] = nxt[u];
   }
 
   // C[i][j]: lane holds column j = lane & 15, rows i = 4 * (lane >> 4) + r
@@ -151,10 +166,17 @@ __global__ __launch_bounds__(kStatsBlock) void svgd_kstats_kernel(const float* _
   // fixed-order fp64 reduction of the per-workgroup partial Gram tiles
   const int nslices = kStatsBlock / mp2;
   {
+    // 8 independent accumulators keep 8 loads in flight (a single dependent chain made this
+    // latency-bound: 45 us for 2048 partials); the summation order is still fixed.
     const int e = tid % mp2, slice = tid / mp2;
-    double s = 0.0;
-    for (int b = slice; b < nb; b += nslices) s += static_cast<double>(part[static_cast<int64_t>(b) * mp2 + e]);
-    red[tid] = s;
+    double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int b = slice;
+    for (; b + 7 * nslices < nb; b += 8 * nslices) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s8[u] += static_cast<double>(part[static_cast<int64_t>(b + u * nslices) * mp2 + e]);
+    }
+    for (int u = 0; b < nb; b += nslices, ++u) s8[u] += static_cast<double>(part[static_cast<int64_t>(b) * mp2 + e]);
+    red[tid] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   }
   __syncthreads();
   if (tid < mp2) {
@@ -249,9 +271,11 @@ __global__ __launch_bounds__(kBlock) void svgd_combine_kernel(const float* __res
     for (int i = 0; i < M; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      const f32x4 p = ld4(P + j * ld + 4 * i4);
+      // streamed once: non-temporal loads/stores (+4 % measured; P often still hits in the
+      // Infinity Cache behind the Gram pass when traversed in the same forward order)
+      const f32x4 p = ld4_nt(P + j * ld + 4 * i4);
       if (HAS_G) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(G + j * ld + 4 * i4);
+        const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + j * ld + 4 * i4));
 #pragma unroll
         for (int i = 0; i < M; ++i) {
           const float a = cgT[j * M + i];
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void svgd_combine_kernel(const float* __res
       }
     }
 #pragma unroll
-    for (int i = 0; i < M; ++i) *reinterpret_cast<f32x4*>(out + i * ld + 4 * i4) = acc[i];
+    for (int i = 0; i < M; ++i) __builtin_nontemporal_store(acc[i], reinterpret_cast<f32x4*>(out + i * ld + 4 * i4));
   }
   if (blockIdx.x == 0) {
     const int64_t e = (n4 << 2) + threadIdx.x;

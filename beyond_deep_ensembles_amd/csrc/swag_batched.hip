@@ -27,13 +27,16 @@ __device__ __forceinline__ float lowrank_noise_b(const float* __restrict__ eps_w
   return z[c & 3];
 }
 
+constexpr int kBatchCH = 8;    // k-steps (2 ring rows each) whose loads are issued back to back
+
 template <bool RNG>
-__global__ __launch_bounds__(kBlock) void swag_sample_batched_kernel(
+__global__ __launch_bounds__(kBlock, 2) void swag_sample_batched_kernel(
     const float* __restrict__ mean, const float* __restrict__ sq, const float* __restrict__ dev, int K, int64_t ld,
     int head, const float* __restrict__ eps_w, const float* __restrict__ eps_d, uint64_t seed, uint64_t stream0,
     float* __restrict__ out, int64_t ld_out, int S, int64_t D) {
   extern __shared__ __attribute__((aligned(16))) float w[];   // [K + (K & 1)][32]: weight of ring row r for sample s
   const int kpad = K + (K & 1);
+  const int ksteps = kpad >> 1;
   const float denom = __builtin_sqrtf(2.0f * static_cast<float>(K - 1));   // swag.py:113
   for (int idx = threadIdx.x; idx < kpad * 32; idx += blockDim.x) {
     const int r = idx >> 5, s = idx & 31;
@@ -58,15 +61,25 @@ __global__ __launch_bounds__(kBlock) void swag_sample_batched_kernel(
     const bool ok = g4 < n4;
     const float* col = dev + 4 * g4;
     f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
-    for (int r0 = 0; r0 < kpad; r0 += 2) {
-      const int r = r0 + half;
-      f32x4 b = {0.f, 0.f, 0.f, 0.f};
-      if (ok && r < K) b = ld4(col + static_cast<int64_t>(r) * ld);
-      const float a = w[r * 32 + j];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[1], acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[2], acc2, 0, 0, 0);
-      acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[3], acc3, 0, 0, 0);
+    // The whole [K, 128] slab of the ring is requested before the first MFMA waits on it: a
+    // load -> MFMA -> load chain exposed one HBM latency per k-step (2.7x off the roofline).
+    for (int c0 = 0; c0 < ksteps; c0 += kBatchCH) {
+      f32x4 b[kBatchCH];
+#pragma unroll
+      for (int u = 0; u < kBatchCH; ++u) {
+        const int r = 2 * (c0 + u) + half;
+        b[u] = (ok && r < K) ? ld4_nt(col + static_cast<int64_t>(r) * ld) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < kBatchCH; ++u) {
+        if (c0 + u < ksteps) {                                // wave-uniform
+          const float a = w[(2 * (c0 + u) + half) * 32 + j];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][1], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][2], acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][3], acc3, 0, 0, 0);
+        }
+      }
     }
     if (ok) {
       const f32x4 m = ld4(mean + 4 * g4);
@@ -79,10 +92,12 @@ __global__ __launch_bounds__(kBlock) void swag_sample_batched_kernel(
         const int s = (reg & 3) + 8 * (reg >> 2) + 4 * half;   // C/D row of the 32x32 tile
         if (s < S) {
           const f32x4 z = RNG ? philox_normal4(seed, stream0 + s, static_cast<uint64_t>(g4), kDomainDiag)
-                              : ld4(eps_d + static_cast<int64_t>(s) * ld_out + 4 * g4);
+                              : ld4_nt(eps_d + static_cast<int64_t>(s) * ld_out + 4 * g4);
           const f32x4 lr = {acc0[reg], acc1[reg], acc2[reg], acc3[reg]};
           st4_nt(out + static_cast<int64_t>(s) * ld_out + 4 * g4, (m + lr) + sd * z);
         }
+        // keep the 16 Philox chains from being interleaved (which costs > 250 VGPRs and spills)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

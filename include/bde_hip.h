@@ -16,8 +16,9 @@
  *     no host<->device copies -- every call is hipGraph-capturable;
  *   - return 0 on success, a negative hipError_t on a launch failure, or
  *     BDE_ERR_INVALID (-1) for a rejected argument (nothing is enqueued);
- *   - every vector pointer must be 16-byte aligned; leading dimensions `ld`
- *     are in floats and must be multiples of 4 with ld >= D;
+ *   - every vector pointer must be 16-byte aligned (bde_gauss_draw_fwd/bwd also
+ *     accept unaligned operands and then run a scalar path); leading dimensions
+ *     `ld` are in floats and must be multiples of 4 with ld >= D;
  *   - scratch memory is supplied by the caller (sizes from bde_*_ws_bytes);
  *   - results are deterministic run to run (two-stage reductions, no float
  *     atomics).

@@ -358,6 +358,15 @@ def test_gauss_draw_philox(ops):
     ops.gauss_draw_bwd(gout, rb, gm1, gr1, n, seed=7, stream_id=3)       # regenerates the forward's noise
     ops.gauss_draw_bwd(gout, rb, gm2, gr2, n, eps=e)
     assert torch.equal(gr1[:n], gr2[:n]) and torch.equal(gm1[:n], gm2[:n])
+    # operands that are not 16-byte aligned (per-tensor views into a flat buffer) take the scalar path
+    m1, r1, e1 = mb[1:n], rb[1:n], e[1:n]
+    wa = torch.zeros(n + 3, device=DEV)
+    ops.gauss_draw_fwd(m1, r1, wa[3:3 + n - 1], n - 1, eps=e1)
+    ops.gauss_draw_fwd(mb, rb, w2, n, eps=e)
+    assert torch.equal(wa[3:3 + n - 1], w2[1:n])
+    ga, gb = torch.zeros(n + 1, device=DEV), torch.zeros(n + 1, device=DEV)
+    ops.gauss_draw_bwd(gout[1:n], r1, ga[1:n], gb[1:n], n - 1, eps=e1)
+    assert torch.equal(ga[1:n], gm2[1:n]) and torch.equal(gb[1:n], gr2[1:n])
 
 
 # ------------------------------------------------------------------ iVON --
