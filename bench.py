@@ -100,7 +100,14 @@ def extras(ops, dev, quick):
     buf = torch.zeros(ld, device=dev)
     t = time_loop(lambda: (ops.svgd_step(P, G, outb, d, 0.0, 1.0, DATASET_SIZE, -1.0, ws, ks),
                            ops.svgd_apply_sgd(P, outb, buf, d, 1e-12, 0.9, 0.0, 3e-4, True, False)), it)
-    rec("svgd_step_plus_fused_sgd_M8_resnet50", t, (16 * M + 12 * M + 8) * d, 1, "steps_per_s")
+    rec("svgd_step_then_apply_sgd_M8_resnet50", t, (16 * M + 12 * M + 8) * d, 1, "steps_per_s")
+    # whole SVGDOptimizer.step minus forward/backward, fused: kernel stats + ONE pass (-phi in registers, M
+    # shared-state SGD applications, updated particles out, Gram partials of the updated particles for the next step)
+    wsn = ops.svgd_ws(M, dev)
+    ops.svgd_gram(P, d, wsn)
+    t = time_loop(lambda: (ops.svgd_kstats(wsn, M, 0.0, 1.0, DATASET_SIZE, -1.0, ks),
+                           ops.svgd_fused_sgd(P, G, buf, d, ks, 1e-12, 0.9, 0.0, 3e-4, True, False, ws_next=wsn)), it)
+    rec("svgd_full_step_fused_sgd_reuse_gram_M8_resnet50", t, (12 * M + 8) * d, 1, "steps_per_s")
     Pi, Gi = make_svgd_inputs(d, dev, 1234, shared_backbone=False)
     rec("svgd_step_M8_resnet50_independent_particles",
         time_loop(lambda: ops.svgd_step(Pi, Gi, outb, d, 0.0, 1.0, DATASET_SIZE, -1.0, ws, ks), it), 16 * M * d, 1, "steps_per_s")

@@ -31,6 +31,11 @@ SIGNATURES = {
                                    c_int, c_int, _P]),
     "bde_svgd_apply_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, c_double, c_double, c_double, c_double,
                                     c_double, c_int64, _P]),
+    "bde_svgd_fused_gram_supported": (c_int, [c_int]),
+    "bde_svgd_fused_sgd": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, _P, c_double, c_double, c_double, c_double,
+                                   c_int, c_int, _P, _P]),
+    "bde_svgd_fused_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, _P, c_double, c_double, c_double,
+                                    c_double, c_double, c_int64, _P, _P]),
     "bde_swag_update": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P]),
     "bde_swag_sample": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_swag_sample_batched": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64,

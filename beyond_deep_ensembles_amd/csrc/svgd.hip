@@ -22,14 +22,12 @@
 // fp32 ridge (~20 flop/B) -> HBM-bound; the MFMA is used for the Gram
 // contraction because it leaves the VALU free for the centring, not because
 // the kernel is matrix-bound.
-#include "bde_common.hpp"
+#include "svgd_shared.hpp"
 
 namespace bde {
 
 constexpr int kGramBlock = 256;            // 4 waves
 constexpr int kGramU = 4;                  // float4 loads in flight per lane per iteration
-constexpr int kWsHeaderFloats = 16;        // [0] = #partial tiles, [1] = padded M (8 or 16)
-constexpr int kGramMaxBlocks = 1024;          // 4 workgroups per CU: best measured (tools/kexp.hip)
 
 using f32x4acc = __attribute__((ext_vector_type(4))) float;
 
@@ -332,50 +330,26 @@ static int launch_combine(const float* P, const float* G, float* out, int64_t D,
 // ------------------------------------------- fused shared-state optimizers --
 // One thread owns a float4 column of all M particles and walks the particles
 // in order, carrying the SHARED optimizer state in registers.
-struct AdamSteps {
-  float step_size[BDE_MAX_PARTICLES];     // lr / (1 - beta1^t)
-  float bc2_sqrt[BDE_MAX_PARTICLES];      // sqrt(1 - beta2^t)
-};
-
 __global__ __launch_bounds__(kBlock) void svgd_apply_sgd_kernel(float* __restrict__ P, const float* __restrict__ grad,
                                                                float* __restrict__ buf, int M, int64_t D, int64_t ld,
-                                                               float lr, float momentum, float omd, float wd,
-                                                               int nesterov, int first) {
+                                                               SgdParams k) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < D; e += stride) {
-    float b = (momentum != 0.f && !first) ? buf[e] : 0.f;
-    for (int i = 0; i < M; ++i) {
-      float p = P[i * ld + e];
-      float g = grad[i * ld + e];
-      if (wd != 0.f) g = __builtin_fmaf(wd, p, g);
-      if (momentum != 0.f) {
-        if (first && i == 0) b = g;
-        else b = momentum * b + omd * g;
-        g = nesterov ? __builtin_fmaf(momentum, b, g) : b;
-      }
-      P[i * ld + e] = p - lr * g;
-    }
-    if (momentum != 0.f) buf[e] = b;
+    float b = (k.momentum != 0.f && !k.first) ? buf[e] : 0.f;
+    for (int i = 0; i < M; ++i) P[i * ld + e] = sgd_apply(P[i * ld + e], grad[i * ld + e], b, k, i == 0);
+    if (k.momentum != 0.f) buf[e] = b;
   }
 }
 
 __global__ __launch_bounds__(kBlock) void svgd_apply_adam_kernel(float* __restrict__ P, const float* __restrict__ grad,
                                                                 float* __restrict__ exp_avg,
                                                                 float* __restrict__ exp_avg_sq, int M, int64_t D,
-                                                                int64_t ld, float beta1, float beta2, float omb1,
-                                                                float omb2, float eps, float wd, AdamSteps st) {
+                                                                int64_t ld, AdamParams k, AdamSteps st) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < D; e += stride) {
     float m = exp_avg[e], v = exp_avg_sq[e];
-    for (int i = 0; i < M; ++i) {
-      float p = P[i * ld + e];
-      float g = grad[i * ld + e];
-      if (wd != 0.f) g = __builtin_fmaf(wd, p, g);
-      m = m + (g - m) * omb1;                       // exp_avg.lerp_(grad, 1 - beta1)
-      v = __builtin_fmaf(omb2 * g, g, beta2 * v);   // mul_(beta2).addcmul_(g, g, value=1-beta2)
-      const float denom = __builtin_sqrtf(v) / st.bc2_sqrt[i] + eps;
-      P[i * ld + e] = p - st.step_size[i] * (m / denom);
-    }
+    for (int i = 0; i < M; ++i)
+      P[i * ld + e] = adam_apply(P[i * ld + e], grad[i * ld + e], m, v, k, st.step_size[i], st.bc2_sqrt[i]);
     exp_avg[e] = m;
     exp_avg_sq[e] = v;
   }
@@ -394,10 +368,6 @@ extern "C" size_t bde_svgd_ws_bytes(int M) {
 extern "C" size_t bde_svgd_kstat_floats(int M) {
   if (M < 1 || M > BDE_MAX_PARTICLES) return 0;
   return static_cast<size_t>(4 * M * M + M + 4);
-}
-
-static bool svgd_args_ok(const float* P, int M, int64_t D, int64_t ld) {
-  return P && M >= 1 && M <= BDE_MAX_PARTICLES && D >= 1 && ld >= D && (ld & 3) == 0 && aligned16(P);
 }
 
 extern "C" int bde_svgd_gram(const float* P, int M, int64_t D, int64_t ld, void* ws, void* stream) {
@@ -457,10 +427,11 @@ extern "C" int bde_svgd_apply_sgd(float* P, const float* grad, float* momentum_b
                                   double lr, double momentum, double dampening, double weight_decay, int nesterov,
                                   int first, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || !grad || (momentum != 0.0 && !momentum_buf)) return BDE_ERR_INVALID;
+  const SgdParams k{static_cast<float>(lr), static_cast<float>(momentum), static_cast<float>(1.0 - dampening),
+                    static_cast<float>(weight_decay), nesterov, first};
   const int grid = stream_grid(D);
   hipLaunchKernelGGL(svgd_apply_sgd_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), P, grad,
-                     momentum_buf, M, D, ld, static_cast<float>(lr), static_cast<float>(momentum),
-                     static_cast<float>(1.0 - dampening), static_cast<float>(weight_decay), nesterov, first);
+                     momentum_buf, M, D, ld, k);
   return to_err(hipGetLastError());
 }
 
@@ -468,16 +439,10 @@ extern "C" int bde_svgd_apply_adam(float* P, const float* grad, float* exp_avg, 
                                    int64_t ld, double lr, double beta1, double beta2, double eps, double weight_decay,
                                    int64_t step0, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || !grad || !exp_avg || !exp_avg_sq || step0 < 0) return BDE_ERR_INVALID;
-  AdamSteps st;
-  for (int i = 0; i < BDE_MAX_PARTICLES; ++i) {
-    const double t = static_cast<double>(step0 + i + 1);
-    st.step_size[i] = static_cast<float>(lr / (1.0 - std::pow(beta1, t)));
-    st.bc2_sqrt[i] = static_cast<float>(std::sqrt(1.0 - std::pow(beta2, t)));
-  }
+  const AdamParams k{static_cast<float>(beta1), static_cast<float>(beta2), static_cast<float>(1.0 - beta1),
+                     static_cast<float>(1.0 - beta2), static_cast<float>(eps), static_cast<float>(weight_decay)};
   const int grid = stream_grid(D);
   hipLaunchKernelGGL(svgd_apply_adam_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), P, grad,
-                     exp_avg, exp_avg_sq, M, D, ld, static_cast<float>(beta1), static_cast<float>(beta2),
-                     static_cast<float>(1.0 - beta1), static_cast<float>(1.0 - beta2), static_cast<float>(eps),
-                     static_cast<float>(weight_decay), st);
+                     exp_avg, exp_avg_sq, M, D, ld, k, make_adam_steps(lr, beta1, beta2, step0));
   return to_err(hipGetLastError());
 }

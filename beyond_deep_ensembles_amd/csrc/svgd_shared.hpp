@@ -1,0 +1,56 @@
+// Definitions shared by svgd.hip and svgd_fused.hip.
+#pragma once
+#include "bde_common.hpp"
+
+namespace bde {
+
+constexpr int kWsHeaderFloats = 16;        // ws[0] = #partial tiles, ws[1] = padded M (8 or 16)
+constexpr int kGramMaxBlocks = 1024;       // 4 workgroups per CU: best measured (tools/kexp.hip)
+
+// Per-particle Adam scalars of the SHARED step counter (advanced once per particle).
+struct AdamSteps {
+  float step_size[BDE_MAX_PARTICLES];     // lr / (1 - beta1^t)
+  float bc2_sqrt[BDE_MAX_PARTICLES];      // sqrt(1 - beta2^t)
+};
+
+static inline AdamSteps make_adam_steps(double lr, double beta1, double beta2, int64_t step0) {
+  AdamSteps st;
+  for (int i = 0; i < BDE_MAX_PARTICLES; ++i) {
+    const double t = static_cast<double>(step0 + i + 1);
+    st.step_size[i] = static_cast<float>(lr / (1.0 - std::pow(beta1, t)));
+    st.bc2_sqrt[i] = static_cast<float>(std::sqrt(1.0 - std::pow(beta2, t)));
+  }
+  return st;
+}
+
+static inline bool svgd_args_ok(const float* P, int M, int64_t D, int64_t ld) {
+  return P && M >= 1 && M <= BDE_MAX_PARTICLES && D >= 1 && ld >= D && (ld & 3) == 0 && aligned16(P);
+}
+
+// One optimizer application to one element, torch.optim semantics, state carried in registers.
+struct SgdParams {
+  float lr, momentum, omd, wd;
+  int nesterov, first;
+};
+__device__ __forceinline__ float sgd_apply(float p, float g, float& b, const SgdParams& k, bool first_particle) {
+  if (k.wd != 0.f) g = __builtin_fmaf(k.wd, p, g);
+  if (k.momentum != 0.f) {
+    if (k.first && first_particle) b = g;              // torch initialises the buffer with the first gradient
+    else b = k.momentum * b + k.omd * g;
+    g = k.nesterov ? __builtin_fmaf(k.momentum, b, g) : b;
+  }
+  return p - k.lr * g;
+}
+struct AdamParams {
+  float beta1, beta2, omb1, omb2, eps, wd;
+};
+__device__ __forceinline__ float adam_apply(float p, float g, float& m, float& v, const AdamParams& k, float step_size,
+                                            float bc2_sqrt) {
+  if (k.wd != 0.f) g = __builtin_fmaf(k.wd, p, g);
+  m = m + (g - m) * k.omb1;                             // exp_avg.lerp_(grad, 1 - beta1)
+  v = __builtin_fmaf(k.omb2 * g, g, k.beta2 * v);       // mul_(beta2).addcmul_(g, g, value=1-beta2)
+  const float denom = __builtin_sqrtf(v) / bc2_sqrt + k.eps;
+  return p - step_size * (m / denom);
+}
+
+}  // namespace bde

@@ -104,6 +104,21 @@ class HipOps:
                                             _ld(P), lr, beta1, beta2, eps, weight_decay, int(step0), _stream()),
                "bde_svgd_apply_adam")
 
+    def svgd_fused_gram_supported(self, m: int) -> bool:
+        return bool(self.lib.bde_svgd_fused_gram_supported(m))
+
+    def svgd_fused_sgd(self, P, G, buf, d, kstat, lr, momentum, dampening, weight_decay, nesterov, first, ws_next=None):
+        """combine + M shared-state SGD applications in one pass; optionally the next step's Gram partials."""
+        _check(self.lib.bde_svgd_fused_sgd(_ptr(P, "P"), _ptr(G, "G"), _ptr(buf), P.shape[0], d, _ld(P), _ptr(kstat),
+                                           lr, momentum, dampening, weight_decay, int(nesterov), int(first),
+                                           _ptr(ws_next), _stream()), "bde_svgd_fused_sgd")
+
+    def svgd_fused_adam(self, P, G, exp_avg, exp_avg_sq, d, kstat, lr, beta1, beta2, eps, weight_decay, step0,
+                        ws_next=None):
+        _check(self.lib.bde_svgd_fused_adam(_ptr(P, "P"), _ptr(G, "G"), _ptr(exp_avg), _ptr(exp_avg_sq), P.shape[0], d,
+                                            _ld(P), _ptr(kstat), lr, beta1, beta2, eps, weight_decay, int(step0),
+                                            _ptr(ws_next), _stream()), "bde_svgd_fused_adam")
+
     # ------------------------------------------------------------ SWAG --
     def swag_update(self, theta, mean, sq, dev_row, n, d):
         _check(self.lib.bde_swag_update(_ptr(theta, "theta"), _ptr(mean), _ptr(sq), _ptr(dev_row), int(n), d,

@@ -63,11 +63,15 @@ class SVGDOptimizer(BayesianOptimizer):
 
         Extra keyword-only arguments (not in the reference):
           process_group       shard the particles' forward/backward passes over the ranks of this group
-          fuse_base_optimizer apply a torch.optim.SGD / Adam base optimizer with the fused HIP kernel
+          fuse_base_optimizer apply a torch.optim.SGD / Adam base optimizer inside the update kernel (one pass over
+                              P and G that writes the updated particles; -phi is never materialised)
+          reuse_gram          with fuse_base_optimizer: the fused kernel also emits the Gram partials of the updated
+                              particles, so the next step skips the Gram pass.  Only valid while nothing but this
+                              optimizer modifies the particles between two steps (call invalidate_gram() otherwise).
     '''
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
-                 kernel_grad_scale=1.0, *, process_group=None, fuse_base_optimizer=False, _ops=None):
+                 kernel_grad_scale=1.0, *, process_group=None, fuse_base_optimizer=False, reuse_gram=False, _ops=None):
         super().__init__(map(lambda p: {"params": p}, params), {})
         self._ops = _ops or _default_ops()
         self.state["__base_optimizer"] = base_optimizer
@@ -112,6 +116,8 @@ class SVGDOptimizer(BayesianOptimizer):
             dist.broadcast(self._P, src=dist.get_global_rank(process_group, 0), group=process_group)
         self._fuse = bool(fuse_base_optimizer)
         self._fused_state = None
+        self._reuse_gram = bool(reuse_gram) and self._fuse and self._ops.svgd_fused_gram_supported(particle_count)
+        self._gram_valid = False
 
     # ------------------------------------------------------------------
     def _local_particles(self) -> range:
@@ -142,15 +148,22 @@ class SVGDOptimizer(BayesianOptimizer):
         with torch.no_grad():
             if self._world > 1:
                 total_loss = self._exchange_gradients(total_loss)
-            # svgd.py:86-89 in three launches; -phi overwrites the gradient rows
-            self._ops.svgd_step(self._P, self._G, self._G, d, float(self.state["__l2_reg"]),
-                                float(self.state["__kernel_grad_scale"]), float(self.state["__dataset_size"]), -1.0,
-                                self._ws, self._kstat)
-
             if self._fuse and (grad_scaler is None or not grad_scaler.is_enabled()):
+                # Gram (skipped when the previous fused kernel already produced it) -> kernel statistics ->
+                # ONE pass: -phi in registers, M shared-state optimizer applications, updated particles out
+                if not (self._reuse_gram and self._gram_valid):
+                    self._ops.svgd_gram(self._P, d, self._ws)
+                self._ops.svgd_kstats(self._ws, m, float(self.state["__l2_reg"]), float(self.state["__kernel_grad_scale"]),
+                                      float(self.state["__dataset_size"]), -1.0, self._kstat)
                 self._fused_apply(base)
+                self._gram_valid = self._reuse_gram
                 self._use_particle(m - 1)    # the reference leaves the model aliased to the last particle
             else:
+                self._gram_valid = False
+                # svgd.py:86-89 in three launches; -phi overwrites the gradient rows
+                self._ops.svgd_step(self._P, self._G, self._G, d, float(self.state["__l2_reg"]),
+                                    float(self.state["__kernel_grad_scale"]), float(self.state["__dataset_size"]), -1.0,
+                                    self._ws, self._kstat)
                 # write the modified gradients TO THE ORIGINAL PARAMETERS and call the optimizer on them (svgd.py:92-103)
                 for particle_idx in range(m):
                     for model_param, pview, gview in zip(self._plist, self._pviews[particle_idx], self._gviews[particle_idx]):
@@ -184,9 +197,9 @@ class SVGDOptimizer(BayesianOptimizer):
         return total
 
     def _fused_apply(self, base) -> None:
-        """M sequential base-optimizer applications with shared state in ONE kernel
-        (bde_svgd_apply_sgd / bde_svgd_apply_adam); hyper-parameters are read from
-        the base optimizer's param_groups every step, so LR schedulers keep working."""
+        """-phi and the M sequential base-optimizer applications with shared state in ONE
+        kernel (bde_svgd_fused_sgd / bde_svgd_fused_adam); hyper-parameters are read from the
+        base optimizer's param_groups every step, so LR schedulers keep working."""
         groups = base.param_groups
         g0 = groups[0]
         keys = [k for k in g0 if k != "params"]
@@ -201,8 +214,9 @@ class SVGDOptimizer(BayesianOptimizer):
             if self._fused_state is None:
                 self._fused_state = {"kind": "sgd", "buf": torch.zeros(ld, device=dev), "first": True}
             st = self._fused_state
-            self._ops.svgd_apply_sgd(self._P, self._G, st["buf"], d, g0["lr"], g0["momentum"], g0["dampening"],
-                                     g0["weight_decay"], g0["nesterov"], st["first"])
+            self._ops.svgd_fused_sgd(self._P, self._G, st["buf"], d, self._kstat, g0["lr"], g0["momentum"],
+                                     g0["dampening"], g0["weight_decay"], g0["nesterov"], st["first"],
+                                     ws_next=self._ws if self._reuse_gram else None)
             st["first"] = False
         elif type(base) is torch.optim.Adam:
             if g0.get("amsgrad", False) or g0.get("maximize", False):
@@ -212,8 +226,9 @@ class SVGDOptimizer(BayesianOptimizer):
                                      "exp_avg_sq": torch.zeros(ld, device=dev), "step": 0}
             st = self._fused_state
             lr = g0["lr"]
-            self._ops.svgd_apply_adam(self._P, self._G, st["exp_avg"], st["exp_avg_sq"], d, float(lr), g0["betas"][0],
-                                      g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"])
+            self._ops.svgd_fused_adam(self._P, self._G, st["exp_avg"], st["exp_avg_sq"], d, self._kstat, float(lr),
+                                      g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"],
+                                      ws_next=self._ws if self._reuse_gram else None)
             st["step"] += self.state["__particle_count"]
         else:
             raise RuntimeError(f"fuse_base_optimizer supports torch.optim.SGD and torch.optim.Adam, got {type(base)}")
@@ -251,10 +266,15 @@ class SVGDOptimizer(BayesianOptimizer):
         return {"kernel": ks[:m * m].view(m, m), "d2": ks[m * m:2 * m * m].view(m, m),
                 "h": ks[2 * m * m + m], "median": ks[2 * m * m + m + 1]}
 
+    def invalidate_gram(self) -> None:
+        """Call after modifying the particles outside this optimizer when reuse_gram=True."""
+        self._gram_valid = False
+
     def load_state_dict(self, state_dict):
         """Accepts the reference's layout (per-tensor ``particle_i`` entries): the
         values are copied into the flat buffer and the state re-aliased to it."""
         super().load_state_dict(state_dict)
+        self._gram_valid = False
         m = self.state["__particle_count"]
         with torch.no_grad():
             for i in range(m):

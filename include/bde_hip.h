@@ -116,6 +116,21 @@ int bde_svgd_apply_adam(float* P, const float* grad, float* exp_avg, float* exp_
                         int64_t ld, double lr, double beta1, double beta2, double eps, double weight_decay,
                         int64_t step0, void* stream);
 
+/* Posterior update + shared-state base-optimizer apply in ONE pass (svgd.py:86-103):
+ * equivalent to bde_svgd_combine(P, G, tmp) followed by bde_svgd_apply_sgd/adam(P, tmp)
+ * with the coefficients of `kstat` (from bde_svgd_kstats, sign = -1), but -phi is never
+ * written: (12*M + 8)*D bytes instead of (24*M + 8)*D.  If ws_next != NULL (M <= 8 only,
+ * see bde_svgd_fused_gram_supported) the kernel also leaves the Gram partials of the
+ * UPDATED particles in ws_next, in the format bde_svgd_kstats reads, so the next step can
+ * skip bde_svgd_gram as long as nothing else modifies P in between. */
+int bde_svgd_fused_gram_supported(int M);
+int bde_svgd_fused_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
+                       const float* kstat, double lr, double momentum, double dampening, double weight_decay,
+                       int nesterov, int first, void* ws_next, void* stream);
+int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D, int64_t ld,
+                        const float* kstat, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int64_t step0, void* ws_next, void* stream);
+
 /* ------------------------------------------------------------------ SWAG --
  * Statistics live on the device: mean [D], sq [D], and the deviation matrix as
  * a ring dev [K, ld] (row = one iterate) instead of the reference's CPU

@@ -78,6 +78,31 @@ class OracleOps:
             denom = (v_.sqrt() / math.sqrt(1 - beta2 ** t)).add_(eps)
             p.addcdiv_(m_, denom, value=-(lr / (1 - beta1 ** t)))
 
+    def svgd_fused_gram_supported(self, m):
+        return m <= 8
+
+    def _neg_phi_from_pending(self, P, G, d):
+        mode, kernel, gradk, l2_reg, scale, n, sign = self._pending
+        assert mode == 0 and sign == -1.0
+        # the kernel statistics were formed from the particles handed to svgd_gram / the previous fused call
+        assert torch.equal(self._gram_P, P[:, :d]), "stale Gram: particles changed since the statistics were formed"
+        return sign * O.svgd_phi(P[:, :d].clone(), G[:, :d].clone(), l2_reg, scale, n)
+
+    def svgd_fused_sgd(self, P, G, buf, d, kstat, lr, momentum, dampening, weight_decay, nesterov, first, ws_next=None):
+        tmp = torch.zeros_like(P)
+        tmp[:, :d] = self._neg_phi_from_pending(P, G, d)
+        self.svgd_apply_sgd(P, tmp, buf, d, lr, momentum, dampening, weight_decay, nesterov, first)
+        if ws_next is not None:
+            self._gram_P = P[:, :d].clone()
+
+    def svgd_fused_adam(self, P, G, exp_avg, exp_avg_sq, d, kstat, lr, beta1, beta2, eps, weight_decay, step0,
+                        ws_next=None):
+        tmp = torch.zeros_like(P)
+        tmp[:, :d] = self._neg_phi_from_pending(P, G, d)
+        self.svgd_apply_adam(P, tmp, exp_avg, exp_avg_sq, d, lr, beta1, beta2, eps, weight_decay, step0)
+        if ws_next is not None:
+            self._gram_P = P[:, :d].clone()
+
     # ------------------------------------------------------------ SWAG --
     def swag_update(self, theta, mean, sq, dev_row, n, d):
         t = theta[:d]

@@ -177,6 +177,43 @@ def test_svgd_fused_optimizers_match_torch_shared_state(ops):
             assert torch.allclose(got, want, rtol=2e-6, atol=2e-7), (kind, it, (got - want).abs().max())
 
 
+def test_svgd_fused_equals_combine_plus_apply(ops):
+    """bde_svgd_fused_* == bde_svgd_combine followed by bde_svgd_apply_* (svgd.py:86-103), and the Gram
+    partials it leaves for the next step give the same kernel statistics as a fresh bde_svgd_gram."""
+    torch.manual_seed(5)
+    for m, d in [(8, 4099), (5, 1003), (3, 17), (12, 515)]:
+        P0 = torch.randn(m, d) * 0.05
+        G0 = torch.randn(m, d) * 0.01
+        for kind in ("sgd", "adam"):
+            Pa, Pb, Gb = flat_rows(P0), flat_rows(P0), flat_rows(G0)
+            tmp = torch.zeros_like(Gb)
+            ws, ks = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV)
+            wsn = ops.svgd_ws(m, DEV) if m <= 8 else None
+            s0a, s1a, s0b, s1b = (torch.zeros(Pa.shape[1], device=DEV) for _ in range(4))
+            for it in range(3):
+                Gb[:, :d] = (G0 * (1 + it)).to(DEV)
+                ops.svgd_gram(Pa, d, ws)
+                ops.svgd_kstats(ws, m, 0.01, 1.0, 500.0, -1.0, ks)
+                ksa = ks.clone()
+                ops.svgd_combine(Pa, Gb, tmp, d, ks)
+                if kind == "sgd":
+                    ops.svgd_apply_sgd(Pa, tmp, s0a, d, 0.05, 0.9, 0.0, 3e-4, True, it == 0)
+                else:
+                    ops.svgd_apply_adam(Pa, tmp, s0a, s1a, d, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m)
+                if it == 0 or wsn is None:
+                    ops.svgd_gram(Pb, d, ws)
+                    ops.svgd_kstats(ws, m, 0.01, 1.0, 500.0, -1.0, ks)
+                else:                       # statistics from the Gram partials the previous fused call left
+                    ops.svgd_kstats(wsn, m, 0.01, 1.0, 500.0, -1.0, ks)
+                    np.testing.assert_allclose(ks[:m * m].cpu().numpy(), ksa[:m * m].cpu().numpy(), rtol=2e-5, atol=1e-7)
+                if kind == "sgd":
+                    ops.svgd_fused_sgd(Pb, Gb, s0b, d, ks, 0.05, 0.9, 0.0, 3e-4, True, it == 0, ws_next=wsn)
+                else:
+                    ops.svgd_fused_adam(Pb, Gb, s0b, s1b, d, ks, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m, ws_next=wsn)
+                np.testing.assert_allclose(Pb[:, :d].cpu().numpy(), Pa[:, :d].cpu().numpy(), rtol=3e-6, atol=3e-7)
+                np.testing.assert_allclose(s0b[:d].cpu().numpy(), s0a[:d].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
 # ------------------------------------------------------------------ SWAG --
 def test_swag_update_bit_exact(ops):
     torch.manual_seed(2)

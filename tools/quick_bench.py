@@ -43,6 +43,11 @@ report("svgd_step", timeit(lambda: ops.svgd_step(P, G, out, D, 0.0, 1.0, 129809.
 buf = torch.zeros(ld, device=dev); ea = torch.zeros(ld, device=dev); eas = torch.zeros(ld, device=dev)
 report("svgd_apply_sgd", timeit(lambda: ops.svgd_apply_sgd(P, out, buf, D, 1e-9, 0.9, 0.0, 3e-4, True, False)), (12 * M + 8) * D)
 report("svgd_apply_adam", timeit(lambda: ops.svgd_apply_adam(P, out, ea, eas, D, 1e-9, 0.9, 0.999, 1e-8, 0.0, 0)), (12 * M + 16) * D)
+wsn = ops.svgd_ws(M, dev)
+report("svgd_fused_sgd (no gram)", timeit(lambda: ops.svgd_fused_sgd(P, G, buf, D, ks, 1e-12, 0.9, 0.0, 3e-4, True, False)), (12 * M + 8) * D)
+report("svgd_fused_sgd (+next gram)", timeit(lambda: ops.svgd_fused_sgd(P, G, buf, D, ks, 1e-12, 0.9, 0.0, 3e-4, True, False, ws_next=wsn)), (12 * M + 8) * D)
+report("svgd_fused_adam (+next gram)", timeit(lambda: ops.svgd_fused_adam(P, G, ea, eas, D, ks, 1e-12, 0.9, 0.999, 1e-8, 0.0, 0, ws_next=wsn)), (12 * M + 16) * D)
+report("FULL STEP kstats+fused_sgd(+gram)", timeit(lambda: (ops.svgd_kstats(wsn, M, 0.0, 1.0, 129809.0, -1.0, ks), ops.svgd_fused_sgd(P, G, buf, D, ks, 1e-12, 0.9, 0.0, 3e-4, True, False, ws_next=wsn))), (12 * M + 8) * D)
 del G, out
 
 mean = torch.randn(ld, device=dev, generator=g) * 0.05
