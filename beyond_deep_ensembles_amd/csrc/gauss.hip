@@ -27,13 +27,13 @@ __global__ __launch_bounds__(kBlock) void gauss_draw_fwd_kernel(const float* __r
   const int64_t n4 = n >> 2;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const f32x4 m = ld4(mean + 4 * i), r = ld4(rho + 4 * i);
-    const f32x4 e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag) : ld4(eps + 4 * i);
+    const f32x4 m = ld4_nt(mean + 4 * i), r = ld4_nt(rho + 4 * i);
+    const f32x4 e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag) : ld4_nt(eps + 4 * i);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = m[j] + e[j] * softplus(r[j]);   // util.py:171: mean + eps * std
-    st4(w + 4 * i, o);
-    if (RNG && eps_out) st4(eps_out + 4 * i, e);
+    st4_nt(w + 4 * i, o);
+    if (RNG && eps_out) st4_nt(eps_out + 4 * i, e);
   }
   if (blockIdx.x == 0) {
     const int64_t k = (n4 << 2) + threadIdx.x;
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(kBlock) void gauss_draw_bwd_kernel(const float* __r
   const int64_t n4 = n >> 2;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const f32x4 go = ld4(g + 4 * i), r = ld4(rho + 4 * i);
-    const f32x4 e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag) : ld4(eps + 4 * i);
+    const f32x4 go = ld4_nt(g + 4 * i), r = ld4_nt(rho + 4 * i);
+    const f32x4 e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag) : ld4_nt(eps + 4 * i);
     f32x4 gm = go, gr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) gr[j] = (go[j] * e[j]) * sigmoidf(r[j]);   // d softplus = sigmoid
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_kernel(const float* __restric
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   float local = 0.f;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const f32x4 m = ld4(mean + 4 * i), r = ld4(rho + 4 * i);
+    const f32x4 m = ld4_nt(mean + 4 * i), r = ld4_nt(rho + 4 * i);
     f32x4 gm, gr;
     float part = 0.f;
 #pragma unroll
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void l2_kernel(const float* __restrict__ p,
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   float local = 0.f;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const f32x4 v = ld4(p + 4 * i);
+    const f32x4 v = ld4_nt(p + 4 * i);
     local += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     if (GRAD) {
       f32x4 o = c * v;

@@ -235,6 +235,8 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL((combine_m_kernel<8, 0>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
   vs.push_back({"PAIR gram(pref g1024)+combine nt REV", [&] { hipLaunchKernelGGL(gram_prefetch_kernel<4>, dim3(1024), dim3(256), 0, st, P, M, D, ld, ws);
       hipLaunchKernelGGL((combine_m_kernel<8, 3>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
+  vs.push_back({"PAIR product gram + product combine", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, G, O, M, D, ld, ks, st); }, 4 * B});
+  vs.push_back({"PAIR product gram + product combine INPLACE", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, O, O, M, D, ld, ks, st); }, 4 * B});
   vs.push_back({"PAIR product gram+kstats+combine", [&] { bde_svgd_step(P, G, O, M, D, ld, 0.f, 1.f, 129809.f, -1.f, ws, ks, st); }, 4 * B});
   const int rounds = 7, inner = 5;
   std::vector<std::vector<float>> times(vs.size());
