@@ -97,6 +97,7 @@ def extras(ops, dev, quick):
     ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
     rec("svgd_gram_M8_resnet50", time_loop(lambda: ops.svgd_gram(P, d, ws), it), 4 * M * d)
     rec("svgd_combine_M8_resnet50", time_loop(lambda: ops.svgd_combine(P, G, outb, d, ks), it), 12 * M * d)
+    rec("svgd_combine_inplace_M8_resnet50", time_loop(lambda: ops.svgd_combine(P, outb, outb, d, ks), it), 12 * M * d)
     buf = torch.zeros(ld, device=dev)
     t = time_loop(lambda: (ops.svgd_step(P, G, outb, d, 0.0, 1.0, DATASET_SIZE, -1.0, ws, ks),
                            ops.svgd_apply_sgd(P, outb, buf, d, 1e-12, 0.9, 0.0, 3e-4, True, False)), it)

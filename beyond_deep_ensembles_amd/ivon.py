@@ -176,6 +176,27 @@ class iVONOptimizer(BayesianOptimizer):
     def get_base_optimizer(self):
         return self
 
+    def load_state_dict(self, state_dict):
+        """Accepts the reference's layout (per-tensor ``mean`` / ``momentum`` / ``precision`` entries):
+        the values are copied into the flat buffers and the state re-aliased to their views."""
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            for fg in self._groups:
+                views = {"mean": fg.layout.views(fg.mean), "momentum": fg.layout.views(fg.momentum),
+                         "precision": fg.layout.views(fg.precision), "delta": fg.layout.views(fg.delta),
+                         "acc_grad": fg.grad_views}
+                for i, param in enumerate(fg.params):
+                    state = self.state[param]
+                    for key, vs in views.items():
+                        loaded = state.get(key)
+                        if torch.is_tensor(loaded) and loaded.data_ptr() != vs[i].data_ptr():
+                            vs[i].copy_(loaded)
+                        state[key] = vs[i]
+                    # the model's weights were loaded by the model's own state_dict: adopt them as theta
+                    fg.theta_views[i].copy_(param.detach())
+                    param.data = fg.theta_views[i]
+                fg.have_delta = False
+
     def _store_gradients(self, scaler_on=False, first=True):
         for fg in self._groups:
             if scaler_on:

@@ -212,7 +212,7 @@ class SVGDOptimizer(BayesianOptimizer):
             if g0.get("maximize", False):
                 raise RuntimeError("fuse_base_optimizer: maximize=True is not supported")
             if self._fused_state is None:
-                self._fused_state = {"kind": "sgd", "buf": torch.zeros(ld, device=dev), "first": True}
+                self._fused_state = self.state["__fused"] = {"kind": "sgd", "buf": torch.zeros(ld, device=dev), "first": True}
             st = self._fused_state
             self._ops.svgd_fused_sgd(self._P, self._G, st["buf"], d, self._kstat, g0["lr"], g0["momentum"],
                                      g0["dampening"], g0["weight_decay"], g0["nesterov"], st["first"],
@@ -222,8 +222,8 @@ class SVGDOptimizer(BayesianOptimizer):
             if g0.get("amsgrad", False) or g0.get("maximize", False):
                 raise RuntimeError("fuse_base_optimizer: amsgrad / maximize are not supported")
             if self._fused_state is None:
-                self._fused_state = {"kind": "adam", "exp_avg": torch.zeros(ld, device=dev),
-                                     "exp_avg_sq": torch.zeros(ld, device=dev), "step": 0}
+                self._fused_state = self.state["__fused"] = {"kind": "adam", "exp_avg": torch.zeros(ld, device=dev),
+                                                             "exp_avg_sq": torch.zeros(ld, device=dev), "step": 0}
             st = self._fused_state
             lr = g0["lr"]
             self._ops.svgd_fused_adam(self._P, self._G, st["exp_avg"], st["exp_avg_sq"], d, self._kstat, float(lr),
@@ -275,6 +275,11 @@ class SVGDOptimizer(BayesianOptimizer):
         values are copied into the flat buffer and the state re-aliased to it."""
         super().load_state_dict(state_dict)
         self._gram_valid = False
+        self._fused_state = self.state.get("__fused")          # shared optimizer state of the fused path
+        if self._fused_state is not None:
+            for k, v in self._fused_state.items():
+                if torch.is_tensor(v):
+                    self._fused_state[k] = v.to(self._P.device)
         m = self.state["__particle_count"]
         with torch.no_grad():
             for i in range(m):

@@ -304,6 +304,39 @@ def test_ivon_trajectory(golden, backend):
         assert not eps
 
 
+def test_ivon_state_dict_roundtrip(backend):
+    ops, dev = backend
+    torch.manual_seed(0)
+    x, y = torch.randn(16, 13, device=dev), torch.randn(16, 1, device=dev)
+
+    def make():
+        model = make_mlp().to(dev)
+        opt = bde.iVONOptimizer(model.parameters(), lr=1e-2, prior_prec=50.0, dataset_size=16, mc_samples=2,
+                                rng="torch", _ops=ops)
+        return model, opt
+    m1, o1 = make()
+    for _ in range(3):
+        o1.step(lambda: F.mse_loss(m1(x), y), lambda l: l.backward())
+    sd_model, sd_opt = m1.state_dict(), o1.state_dict()
+    m2, o2 = make()
+    m2.load_state_dict(sd_model)
+    o2.load_state_dict(sd_opt)
+    p1, p2 = list(m1.parameters()), list(m2.parameters())
+    for a, b in zip(p1, p2):
+        for key in ("mean", "momentum", "precision"):
+            assert torch.equal(o1.state[a][key], o2.state[b][key])
+    assert o2.state[p2[0]]["mean"].data_ptr() == o2._groups[0].mean.data_ptr()      # re-aliased to the flat buffer
+    assert o2.param_groups[0]["step"] == 3
+    # both continue identically from here
+    for o, m in ((o1, m1), (o2, m2)):
+        o.noise_source = lambda d, _g=torch.Generator(device=dev).manual_seed(5): torch.randn(d, device=dev, generator=_g)
+    l1 = o1.step(lambda: F.mse_loss(m1(x), y), lambda l: l.backward())
+    l2 = o2.step(lambda: F.mse_loss(m2(x), y), lambda l: l.backward())
+    assert torch.equal(l1, l2)
+    for a, b in zip(p1, p2):
+        assert torch.equal(o1.state[a]["mean"], o2.state[b]["mean"])
+
+
 # -------------------------------------------------------------- ensemble --
 class _Counting:
     def __init__(self):
