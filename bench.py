@@ -185,13 +185,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BDE_BENCH_DEVICE / BDE_BENCH_BACKEND exist only to smoke-test the N > 1 code path on a 1-GPU box
+    # (all ranks on one device over gloo); the driver never sets them.
+    dev_index = int(os.environ.get("BDE_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BDE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         if M % world:
             raise SystemExit(f"M={M} particles cannot be sharded over {world} ranks")
 
@@ -206,6 +213,8 @@ def main():
     out = torch.empty_like(G)
     ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
     own = G[rank * per:(rank + 1) * per].reshape(-1)
+    if world > 1 and dist.get_backend() != "nccl":
+        own = own.clone()                              # gloo wants disjoint input/output
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):

@@ -69,6 +69,8 @@ def adopt_grads(params: Sequence[torch.nn.Parameter], views: Sequence[torch.Tens
     src, dst = [], []
     for p, v in zip(params, views):
         g = p.grad
+        if g is v:            # in-place accumulation keeps the very tensor object we installed (the common case)
+            continue
         if g is None:
             if not add:
                 v.zero_()

@@ -131,11 +131,12 @@ class SVGDOptimizer(BayesianOptimizer):
         total_loss = torch.tensor(0.0, device=self._params_device())
         for particle_idx in self._local_particles():
             self._set_grad_scaler_state(grad_scaler, OptState.READY, base)
-            self._use_particle(particle_idx)
-            # base_optimizer.zero_grad() of the reference (svgd.py:70): the gradient row is zeroed and
-            # param.grad pointed at it, so backward() accumulates into the flat buffer
+            # _use_particle (svgd.py:120-127) and base_optimizer.zero_grad() (svgd.py:70) in one pass over the
+            # tensors: the gradient row is zeroed and param.grad pointed at it, so backward() accumulates
+            # into the flat buffer
             self._G[particle_idx].zero_()
-            for param, gview in zip(self._plist, self._gviews[particle_idx]):
+            for param, pview, gview in zip(self._plist, self._pviews[particle_idx], self._gviews[particle_idx]):
+                param.data = pview
                 param.grad = gview
 
             loss = forward_closure()
