@@ -218,10 +218,15 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
+        work = None
         if world > 1:
-            dist.all_gather_into_tensor(G.view(-1), own)      # RCCL over xGMI: the particles' gradient rows
+            # RCCL over xGMI: the particles' gradient rows.  The Gram pass and the kernel statistics only
+            # need the (replicated) particles, so they run while the collective is in flight.
+            work = dist.all_gather_into_tensor(G.view(-1), own, async_op=True)
         ops.svgd_gram(P, d, ws)
         ops.svgd_kstats(ws, M, 0.0, 1.0, DATASET_SIZE, -1.0, ks)
+        if work is not None:
+            work.wait()
         if i is not None:
             ev[i][0].record()
         ops.svgd_combine(P, G, out, d, ks)

@@ -147,24 +147,25 @@ class SVGDOptimizer(BayesianOptimizer):
             adopt_grads(self._plist, self._gviews[particle_idx])      # _store_grads (svgd.py:129-133)
 
         with torch.no_grad():
-            if self._world > 1:
-                total_loss = self._exchange_gradients(total_loss)
-            if self._fuse and (grad_scaler is None or not grad_scaler.is_enabled()):
-                # Gram (skipped when the previous fused kernel already produced it) -> kernel statistics ->
+            pending = self._start_gradient_exchange(total_loss) if self._world > 1 else None
+            fused = self._fuse and (grad_scaler is None or not grad_scaler.is_enabled())
+            # The Gram pass and the kernel statistics need only the (replicated) particles: they run while the
+            # gradient all-gather is in flight.  (Skipped when the previous fused kernel already left the Gram.)
+            if not (fused and self._reuse_gram and self._gram_valid):
+                self._ops.svgd_gram(self._P, d, self._ws)
+            self._ops.svgd_kstats(self._ws, m, float(self.state["__l2_reg"]), float(self.state["__kernel_grad_scale"]),
+                                  float(self.state["__dataset_size"]), -1.0, self._kstat)
+            if pending is not None:
+                total_loss = self._finish_gradient_exchange(pending)
+            if fused:
                 # ONE pass: -phi in registers, M shared-state optimizer applications, updated particles out
-                if not (self._reuse_gram and self._gram_valid):
-                    self._ops.svgd_gram(self._P, d, self._ws)
-                self._ops.svgd_kstats(self._ws, m, float(self.state["__l2_reg"]), float(self.state["__kernel_grad_scale"]),
-                                      float(self.state["__dataset_size"]), -1.0, self._kstat)
                 self._fused_apply(base)
                 self._gram_valid = self._reuse_gram
                 self._use_particle(m - 1)    # the reference leaves the model aliased to the last particle
             else:
                 self._gram_valid = False
-                # svgd.py:86-89 in three launches; -phi overwrites the gradient rows
-                self._ops.svgd_step(self._P, self._G, self._G, d, float(self.state["__l2_reg"]),
-                                    float(self.state["__kernel_grad_scale"]), float(self.state["__dataset_size"]), -1.0,
-                                    self._ws, self._kstat)
+                # svgd.py:86-89: -phi overwrites the gradient rows
+                self._ops.svgd_combine(self._P, self._G, self._G, d, self._kstat)
                 # write the modified gradients TO THE ORIGINAL PARAMETERS and call the optimizer on them (svgd.py:92-103)
                 for particle_idx in range(m):
                     for model_param, pview, gview in zip(self._plist, self._pviews[particle_idx], self._gviews[particle_idx]):
@@ -179,10 +180,10 @@ class SVGDOptimizer(BayesianOptimizer):
         return total_loss / self.state["__particle_count"]
 
     # ------------------------------------------------------------------
-    def _exchange_gradients(self, local_loss_sum: torch.Tensor) -> torch.Tensor:
-        """ONE all-gather of the gradient rows (RCCL over xGMI on the GPU box).
-        The particle's loss rides in the spare floats behind the D gradients of
-        its row, so no second collective is needed for the returned loss."""
+    def _start_gradient_exchange(self, local_loss_sum: torch.Tensor):
+        """ONE all-gather of the gradient rows (RCCL over xGMI on the GPU box), asynchronous.
+        The particle's loss rides in the spare floats behind the D gradients of its row, so no
+        second collective is needed for the returned loss."""
         import torch.distributed as dist
         m, d = self.state["__particle_count"], self._layout.d
         per = m // self._world
@@ -192,7 +193,11 @@ class SVGDOptimizer(BayesianOptimizer):
         own = self._G[lo:lo + per].reshape(-1)
         if dist.get_backend(self._pg) == "gloo":
             own = own.clone()                  # gloo wants disjoint input/output
-        dist.all_gather_into_tensor(self._G.view(-1), own, group=self._pg)
+        return dist.all_gather_into_tensor(self._G.view(-1), own, group=self._pg, async_op=True)
+
+    def _finish_gradient_exchange(self, work) -> torch.Tensor:
+        d = self._layout.d
+        work.wait()
         total = self._G[:, d].sum()
         self._G[:, d] = 0
         return total
