@@ -440,3 +440,27 @@ def test_ivon_golden_bit_exact(ops, golden):
         assert np.max(np.abs(param[:d].cpu().numpy() - g[f"eval_sample_{ci}"])) <= 1e-6 * np.abs(eps[3 * mc].numpy()).max()
         ops.ivon_sample(mean, prec, param, dsum, d, n_eff, first=True, deterministic=True)
         assert torch.equal(param[:d], mean[:d])
+
+
+def test_svgd_step_is_graph_capturable(ops):
+    """Every entry point only enqueues on the given stream (no allocation / sync), so a step can be
+    captured into a hipGraph and replayed."""
+    torch.manual_seed(6)
+    m, d = 8, 50021
+    P, G = flat_rows(torch.randn(m, d) * 0.05), flat_rows(torch.randn(m, d) * 0.01)
+    out_eager, out_graph = torch.zeros_like(G), torch.zeros_like(G)
+    ws, ks = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV)
+    ops.svgd_step(P, G, out_eager, d, 0.01, 1.0, 5000.0, -1.0, ws, ks)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        ops.svgd_step(P, G, out_graph, d, 0.01, 1.0, 5000.0, -1.0, ws, ks)      # warm-up on the side stream
+        s.synchronize()
+        with torch.cuda.graph(graph, stream=s):
+            ops.svgd_step(P, G, out_graph, d, 0.01, 1.0, 5000.0, -1.0, ws, ks)
+    out_graph.zero_()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_graph[:, :d], out_eager[:, :d])

@@ -370,3 +370,107 @@ def test_product_has_no_cpu_path():
     p = nn.Parameter(torch.zeros(4))
     with pytest.raises(RuntimeError):
         bde.SwagOptimizer([p], torch.optim.SGD([p], lr=0.1), update_interval=1)
+
+
+# ------------------------------------------------- GradScaler / combinators --
+def _scaler(dev):
+    return torch.amp.GradScaler(dev.type, init_scale=1024.0)
+
+
+@pytest.mark.parametrize("algo", ["svgd", "swag", "bbb", "ivon"])
+def test_grad_scaler_path_matches_unscaled(backend, algo):
+    """step(..., grad_scaler=scaler) with backward_closure = scaler.scale(loss).backward() (Readme.md:51-55)
+    lands on the same parameters as the plain path (power-of-two scale, no overflow)."""
+    ops, dev = backend
+    x = torch.randn(16, 13, generator=torch.Generator().manual_seed(3)).to(dev)
+    y = torch.randn(16, 1, generator=torch.Generator().manual_seed(4)).to(dev)
+
+    def build():
+        torch.manual_seed(11)
+        if algo == "bbb":
+            tape = [torch.randn(16, 50), torch.randn(16, 1)] * 8
+            model = nn.Sequential(LocalReparamLinear(13, 50, tape, ops), nn.ReLU(), LocalReparamLinear(50, 1, tape, ops)).to(dev)
+            for m in model:
+                if hasattr(m, "weight"):
+                    m.weight.blundell_init(); m.bias.blundell_init()
+        else:
+            model = make_mlp().to(dev)
+        params = list(model.parameters())
+        if algo == "svgd":
+            opt = bde.SVGDOptimizer(params, lambda: None, torch.optim.SGD(params, lr=0.05, momentum=0.9),
+                                    particle_count=3, dataset_size=16, l2_reg=0.01, _ops=ops)
+            with torch.no_grad():       # distinct particles without touching the RNG
+                opt.particles[1] += 0.01
+                opt.particles[2] -= 0.02
+        elif algo == "swag":
+            opt = bde.SwagOptimizer(params, torch.optim.SGD(params, lr=0.05), update_interval=1, deviation_samples=3, _ops=ops)
+        elif algo == "bbb":
+            opt = bde.BBBOptimizer(params, torch.optim.SGD(params, lr=0.05), bde.GaussianPrior(0, 1.0), dataset_size=16,
+                                   mc_samples=2, kl_rescaling=0.5, _ops=ops)
+        else:
+            opt = bde.iVONOptimizer(params, lr=1e-2, prior_prec=50.0, dataset_size=16, mc_samples=2, _ops=ops)
+            gen = torch.Generator().manual_seed(5)
+            opt.noise_source = lambda d: torch.randn(d, generator=gen).to(dev)
+        return model, opt
+
+    results = []
+    for use_scaler in (False, True):
+        model, opt = build()
+        scaler = _scaler(dev) if use_scaler else None
+        if scaler is not None:
+            opt.init_grad_scaler(scaler)
+        for _ in range(3):
+            if scaler is None:
+                loss = opt.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
+            else:
+                loss = opt.step(lambda: F.mse_loss(model(x), y), lambda l: scaler.scale(l).backward(), grad_scaler=scaler)
+                scaler.update()
+            assert loss is not None and torch.isfinite(loss)
+        if algo == "svgd":
+            results.append(opt.particles.detach().clone())
+        elif algo == "ivon":
+            results.append(flat([opt.state[p]["mean"] for p in model.parameters()]))
+        else:
+            results.append(flat(list(model.parameters())))
+    if algo == "svgd":
+        # the reference unscales only the LAST particle's gradients once per step through the base optimizer's
+        # GradScaler state machine; what must hold is that the scaled run is finite and moves the particles
+        assert torch.isfinite(results[1]).all()
+    else:
+        assert torch.allclose(results[0], results[1], rtol=1e-4, atol=1e-6), (results[0] - results[1]).abs().max()
+
+
+def test_last_layer_combinator(backend):
+    """LastLayerBayesianOptimizer (algo.py:83-105): Bayesian head + deterministic backbone."""
+    ops, dev = backend
+    torch.manual_seed(0)
+    model = make_mlp().to(dev)
+    head, body = list(model[2].parameters()), list(model[0].parameters())
+    ll = bde.SwagOptimizer(head, torch.optim.SGD(head, lr=0.1), update_interval=1, deviation_samples=2, _ops=ops)
+    det = torch.optim.SGD(body, lr=0.1)
+    opt = bde.LastLayerBayesianOptimizer(ll, det)
+    x, y = torch.randn(8, 13, device=dev), torch.randn(8, 1, device=dev)
+    before = [p.detach().clone() for p in body + head]
+    loss = opt.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
+    assert torch.isfinite(loss)
+    assert all(not torch.equal(a, b.detach()) for a, b in zip(before, body + head))     # both parts moved
+    opt.complete_epoch()
+    opt.sample_parameters()
+    assert ll.state["__params_dirty"] and ll.state["__updates"] == 1
+    sd = opt.state_dict()
+    assert set(sd) == {"ll_bayesian_optimizer", "deterministic_optimizer"}
+    with pytest.raises(RuntimeError):
+        opt.get_base_optimizer()
+
+
+def test_rbf_function(golden, backend):
+    """rbf(particles) -> (kernel, grad_kernel), the drop-in for svgd.py:14-32."""
+    ops, dev = backend
+    g = golden("svgd_phi.npz")
+    for i in (0, 3, 9):
+        P = T(g[f"P_{i}"]).to(dev)
+        K, gK = bde.rbf(P, _ops=ops)
+        k64, gk64 = g[f"K64_{i}"], None
+        assert np.max(np.abs(K.cpu().numpy() - k64)) <= 5e-6
+        ref = g[f"gradK_{i}"]
+        assert np.max(np.abs(gK.cpu().numpy() - ref)) <= 2e-5 * np.max(np.abs(ref)) + 1e-7
