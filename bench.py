@@ -253,6 +253,32 @@ def main():
     combine_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     assert torch.isfinite(out[:, :d]).all()
 
+    # ---- SWAG posterior samples/s (the second half of BASELINE's metric): every rank samples independently
+    # (MultiSWAG fan-out, DeepEnsemble.predict(rank=, world_size=)); aggregate = sum over ranks ("weak").
+    swag = None
+    if d == D_RESNET50:
+        del out
+        torch.cuda.empty_cache()
+        ld = pad_ld(d)
+        gsw = torch.Generator(device=dev).manual_seed(99 + rank)
+        mean = torch.randn(ld, device=dev, generator=gsw) * 0.05
+        sq = mean * mean + 1e-4
+        ring = torch.randn(K_SWAG, ld, device=dev, generator=gsw) * 1e-3
+        o1 = torch.empty(ld, device=dev)
+        ob = torch.empty(S_SWAG, ld, device=dev)
+        if dist:
+            dist.barrier()
+        t_single = time_loop(lambda: ops.swag_sample(mean, sq, ring, 3, o1, d, seed=1, stream_id=2), 20)
+        t_batch = time_loop(lambda: ops.swag_sample_batched(mean, sq, ring, 3, ob, d, seed=1, stream_id0=0), 8)
+        rates = torch.tensor([1.0 / t_single, S_SWAG / t_batch], device=dev, dtype=torch.float64)
+        if dist:
+            dist.all_reduce(rates, op=dist.ReduceOp.SUM)
+        swag = {"samples_per_s": round(float(rates[0]), 1), "samples_per_s_batched_S30": round(float(rates[1]), 1),
+                "K": K_SWAG, "D": d, "scaling": "weak (independent posterior samples on every GPU)",
+                "per_sample_hbm_frac_rank0": round(4 * d * (K_SWAG + 3) / t_single / 1e9 / HBM_PEAK_GBS, 4)}
+        del mean, sq, ring, o1, ob
+        out = None
+
     if rank == 0:
         alg_bytes = 12 * M * d                       # dominant kernel: combine reads P and G, writes out
         achieved = alg_bytes / (combine_ms * 1e-3) / 1e9
@@ -280,13 +306,15 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": round(combine_ms, 4)},
         }
-        log(f"svgd_step: {ms_per_step:.4f} ms/step = {res['value']} steps/s; combine {combine_ms:.4f} ms = {achieved:.0f} GB/s")
+        if swag is not None:
+            res["swag"] = swag
+        log(f"svgd_step: {ms_per_step:.4f} ms/step = {res['value']} steps/s; combine {combine_ms:.4f} ms = {achieved:.0f} GB/s; swag {swag}")
         if world == 1:
             if not args.no_cpu_baseline:
                 log("cpu baseline ...")
                 res["cpu_baseline"] = cpu_baseline(P, G, d)
                 log(f"  {res['cpu_baseline']}")
-            del P, G, out
+            del P, G
             torch.cuda.empty_cache()
             if not args.no_extras and d == D_RESNET50:
                 log("extras ...")
