@@ -85,6 +85,40 @@ class DeepEnsemble(nn.Module):
                 output.append(predict_closure(model))
         return torch.stack(output)
 
+    def predict_distributed(self, predict_closure, samples, process_group=None):
+        """MultiX fan-out over the ranks of ``process_group`` (one GPU per rank): every rank evaluates its
+        share of the (member, sample) units, then ONE all-gather of the (small) prediction tensors puts the
+        full ``[samples, ...]`` result, in the reference's output order, on every rank.  Callers reduce it
+        exactly as they reduce ``predict()``'s output (e.g. ``logsumexp(out, 0) - log(S)``, camelyon.py:29-30)."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        local = self.predict(predict_closure, samples, rank=rank, world_size=world) if fan_out(
+            samples, len(self.models), rank, world) else None
+        counts = [len(fan_out(samples, len(self.models), r, world)) for r in range(world)]
+        most = max(counts)
+        # every rank needs the per-unit shape to size its padded contribution
+        shape_src = counts.index(most)
+        if local is None:
+            unit_shape = None
+        else:
+            unit_shape = list(local.shape[1:])
+        shapes = [None] * world
+        dist.all_gather_object(shapes, (unit_shape, str(local.dtype) if local is not None else None), group=process_group)
+        unit_shape, dtype_name = shapes[shape_src]
+        dtype = getattr(torch, dtype_name.split(".")[-1])
+        device = local.device if local is not None else next(self.models.parameters()).device
+        padded = torch.zeros([most] + unit_shape, dtype=dtype, device=device)
+        if local is not None:
+            padded[:local.shape[0]] = local
+        gathered = torch.empty([world * most] + unit_shape, dtype=dtype, device=device)
+        dist.all_gather_into_tensor(gathered, padded, group=process_group)
+        total = sum(counts)
+        out = torch.empty([total] + unit_shape, dtype=dtype, device=device)
+        for r in range(world):
+            for j, (u, _, _) in enumerate(fan_out(samples, len(self.models), r, world)):
+                out[u] = gathered[r * most + j]
+        return out
+
     @property
     def models_and_optimizers(self):
         return list(zip(self.models, self.optimizers))

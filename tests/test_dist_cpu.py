@@ -119,3 +119,43 @@ def test_multiswag_fan_out_is_world_size_independent():
 
     a, b, c = run(2), run(3), run(8)
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def _predict_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import beyond_deep_ensembles_amd as bde
+        from tests.oracle_ops import OracleOps
+        torch.set_num_threads(1)
+        ops = OracleOps()
+        ens = bde.DeepEnsemble([_swag_member(10 + i, ops) for i in range(3)])
+        x = torch.randn(4, 6, generator=torch.Generator().manual_seed(1))
+        out = ens.predict_distributed(lambda m: m(x).detach(), 13, dist.group.WORLD)
+        np.save(os.path.join(out_dir, f"pred{rank}.npy"), out.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_predict_distributed_gathers_in_reference_order(tmp_path):
+    """DeepEnsemble.predict_distributed: every rank ends with the full [S, ...] tensor, identical to the
+    single-process fan-out put back in unit order."""
+    import beyond_deep_ensembles_amd as bde
+    from beyond_deep_ensembles_amd.ensemble import fan_out
+    from tests.oracle_ops import OracleOps
+    world = 2
+    mp.spawn(_predict_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "pred0.npy"), np.load(tmp_path / "pred1.npy")
+    np.testing.assert_array_equal(a, b)
+    assert a.shape[0] == 13
+    ops = OracleOps()
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(1))
+    outs = {}
+    for rank in range(world):
+        ens = bde.DeepEnsemble([_swag_member(10 + i, ops) for i in range(3)])
+        res = ens.predict(lambda m: m(x).detach(), 13, rank=rank, world_size=world)
+        for (u, _, _), o in zip(fan_out(13, 3, rank, world), res):
+            outs[u] = o
+    want = torch.stack([outs[u] for u in range(13)]).numpy()
+    np.testing.assert_array_equal(a, want)
