@@ -71,6 +71,9 @@ class DeepEnsemble(nn.Module):
         if world_size == 1:
             for (model, optimizer), model_samples in zip(self.models_and_optimizers,
                                                          split_samples(samples, len(self.models))):
+                prefetch = getattr(optimizer, "prefetch_samples", None)
+                if prefetch is not None:
+                    prefetch(model_samples)      # SWAG, rng="philox": all of this member's samples in one pass
                 for _ in range(model_samples):
                     optimizer.sample_parameters()
                     output.append(predict_closure(model))

@@ -52,6 +52,7 @@ class SwagOptimizer(BayesianOptimizer):
         self.seed = int(seed)
         self.noise_source: Optional[Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]]] = None
         self._sample_counter = 0
+        self._prefetched = None          # (rows [n, ld], next row): samples generated ahead by prefetch_samples()
 
         plist = list(self._params())
         check_params(plist, self._ops)
@@ -84,6 +85,7 @@ class SwagOptimizer(BayesianOptimizer):
 
     # ------------------------------------------------------------------
     def step(self, forward_closure, backward_closure, grad_scaler=None):
+        self._prefetched = None
         self._restore_original_params()
         self.state["__base_optimizer"].zero_grad()
 
@@ -98,9 +100,37 @@ class SwagOptimizer(BayesianOptimizer):
         self._swag_update()
         return loss
 
+    def prefetch_samples(self, n_samples: int, max_bytes: int = 8 << 30) -> int:
+        """Generate the next ``n_samples`` posterior samples in ONE pass over the statistics
+        (bde_swag_sample_batched, MFMA low-rank product, 4*D*(K+2+S) bytes instead of S*4*D*(K+3));
+        the following ``sample_parameters()`` calls then only re-point the parameters at the stored rows.
+        Only with ``rng="philox"`` (stream id = sample counter, so the samples are the ones the unbatched
+        kernel would produce); otherwise a no-op.  Returns the number of samples prefetched.
+        ``DeepEnsemble.predict`` calls this for every member."""
+        if self.rng != "philox" or self.noise_source is not None or n_samples < 2:
+            return 0
+        n = int(min(n_samples, max(1, max_bytes // (4 * self._layout.ld))))
+        rows = torch.empty((n, self._layout.ld), dtype=torch.float32, device=self._params_device())
+        d = self._layout.d
+        with torch.no_grad():
+            for lo in range(0, n, 32):
+                hi = min(n, lo + 32)
+                self._ops.swag_sample_batched(self.state["__mean"], self.state["__sq_weights"],
+                                              self.state["__deviations"], self.state["__dev_head"], rows[lo:hi], d,
+                                              seed=self.seed, stream_id0=self._sample_counter + lo)
+        self._prefetched = [rows, 0]
+        return n
+
     def sample_parameters(self):
         self._save_original_params()
         self.state["__params_dirty"] = True
+        if self._prefetched is not None:
+            rows, nxt = self._prefetched
+            for param, view in zip(self._plist, self._layout.views(rows[nxt])):
+                param.data = view
+            self._sample_counter += 1
+            self._prefetched = [rows, nxt + 1] if nxt + 1 < rows.shape[0] else None
+            return
         d, k = self._layout.d, self.deviation_samples
         eps_w = eps_d = None
         if self.noise_source is not None:
@@ -160,6 +190,7 @@ class SwagOptimizer(BayesianOptimizer):
                                           self.state["__deviations"][head], updates, self._layout.d)
                     self.state["__dev_head"] = (head + 1) % self.deviation_samples
                     self.param_dist = None
+                    self._prefetched = None
 
     # ---- reference-layout accessors ------------------------------------
     def mean_vector(self) -> torch.Tensor:

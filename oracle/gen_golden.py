@@ -18,6 +18,7 @@ Fixture list:
   bbb.npz             GaussianParameter draw, KL, one BBBOptimizer trajectory
   ivon.npz            iVON trajectories with recorded noise (ivorn.py:41-115)
   ensemble.npz        DeepEnsemble.predict sample split     (ensemble.py:37-40)
+  ref_*_checkpoint.pt state_dict()s written by the reference optimizers (wire compatibility)
 """
 import math
 import os
@@ -374,6 +375,41 @@ def gen_ensemble():
     np.savez_compressed(os.path.join(OUT, "ensemble.npz"), rows=np.array(rows, dtype=np.int64))
 
 
+# ------------------------------------------------------------------ checkpoints
+def gen_checkpoints():
+    """state_dict()s written by the REFERENCE optimizers (data: tensors, counters and a pickled
+    torch.optim base optimizer -- no reference classes), for the wire-compatibility tests."""
+    torch.manual_seed(41)
+    p1, p2 = nn.Parameter(torch.randn(7) * 0.1), nn.Parameter(torch.randn(2, 3) * 0.1)
+    c1, c2 = torch.randn(7), torch.randn(2, 3)
+    base = torch.optim.SGD([p1, p2], lr=0.1, momentum=0.9)
+    opt = ref_swag.SwagOptimizer([p1, p2], base, update_interval=2, start_epoch=0, deviation_samples=4)
+    for t in range(14):
+        opt.step(lambda: (p1 * c1).sum() + (p2 * c2).sum(), lambda l: l.backward())
+    opt.complete_epoch()
+    torch.save({"optimizer": opt.state_dict(), "params": [p1.detach().clone(), p2.detach().clone()],
+                "mean": opt.state["__mean"].clone(), "sq": opt.state["__sq_weights"].clone(),
+                "dev": opt.state["__deviations"].clone(), "c": [c1, c2]},
+               os.path.join(OUT, "ref_swag_checkpoint.pt"))
+
+    torch.manual_seed(42)
+    model = make_mlp()
+    base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    sv = ref_svgd.SVGDOptimizer(model.parameters(), lambda: ref_util.reset_model_params(model), base,
+                                particle_count=3, dataset_size=64, l2_reg=0.01)
+    x, y = torch.randn(16, 13), torch.randn(16, 1)
+    for t in range(2):
+        sv.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
+    params = list(model.parameters())
+    particles = torch.stack([flat([sv.state[p][f"particle_{i}"] for p in params]) for i in range(3)])
+    torch.save({"optimizer": sv.state_dict(), "particles": particles, "x": x, "y": y,
+                "model": model.state_dict()}, os.path.join(OUT, "ref_svgd_checkpoint.pt"))
+    # one more reference step from this state: what a resumed run must reproduce
+    loss = sv.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
+    after = torch.stack([flat([sv.state[p][f"particle_{i}"] for p in params]) for i in range(3)])
+    torch.save({"particles_after": after, "loss": float(loss)}, os.path.join(OUT, "ref_svgd_checkpoint_next.pt"))
+
+
 if __name__ == "__main__":
     gen_svgd_phi()
     gen_svgd_traj("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4),
@@ -385,6 +421,7 @@ if __name__ == "__main__":
     gen_bbb()
     gen_ivon()
     gen_ensemble()
+    gen_checkpoints()
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} B")

@@ -201,6 +201,37 @@ def test_swag_torch_rng_matches_reference_stream(backend):
     assert torch.equal(got, p.detach())
 
 
+def test_swag_prefetch_equals_one_by_one(backend):
+    """DeepEnsemble.predict prefetches a SWAG member's samples in one batched pass (rng="philox");
+    the predictions equal those of one-by-one sampling."""
+    ops, dev = backend
+
+    def member():
+        torch.manual_seed(2)
+        model = nn.Linear(6, 3).to(dev)
+        opt = bde.SwagOptimizer(model.parameters(), torch.optim.SGD(model.parameters(), lr=0.1), update_interval=1,
+                                deviation_samples=4, rng="philox", seed=7, _ops=ops)
+        x = torch.randn(8, 6, generator=torch.Generator().manual_seed(1)).to(dev)
+        for _ in range(6):
+            opt.step(lambda: model(x).pow(2).mean(), lambda l: l.backward())
+        return model, opt, x
+    m1, o1, x = member()
+    m2, o2, _ = member()
+    one_by_one = []
+    for _ in range(7):
+        o1.sample_parameters()
+        one_by_one.append(m1(x).detach().clone())
+    ens = bde.DeepEnsemble([(m2, o2)])
+    batched = ens.predict(lambda m: m(x).detach().clone(), 7)
+    assert torch.allclose(torch.stack(one_by_one), batched, rtol=1e-6, atol=1e-7)
+    assert o2._sample_counter == 7 and o2._prefetched is None
+    # a training step drops any prefetched rows and restores the training weights
+    o2.prefetch_samples(5)
+    o2.sample_parameters()
+    o2.step(lambda: m2(x).pow(2).mean(), lambda l: l.backward())
+    assert o2._prefetched is None and not o2.state["__params_dirty"]
+
+
 # ------------------------------------------------------------------- BBB --
 class LocalReparamLinear(nn.Module):
     """Test model layer: the local-reparameterisation forward of the reference's
@@ -474,3 +505,72 @@ def test_rbf_function(golden, backend):
         assert np.max(np.abs(K.cpu().numpy() - k64)) <= 5e-6
         ref = g[f"gradK_{i}"]
         assert np.max(np.abs(gK.cpu().numpy() - ref)) <= 2e-5 * np.max(np.abs(ref)) + 1e-7
+
+
+# ------------------------------------------------ reference checkpoints --
+import os as _os
+
+_GOLD = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+
+
+def test_load_reference_swag_checkpoint(backend):
+    """A state_dict written by the REFERENCE SwagOptimizer ([D] CPU mean, [D, K] rolled deviations, pickled
+    base optimizer) loads into the flat / ring layout and resumes with the reference's counters."""
+    ops, dev = backend
+    ck = torch.load(_os.path.join(_GOLD, "ref_swag_checkpoint.pt"), weights_only=False)
+    p1, p2 = nn.Parameter(ck["params"][0].clone().to(dev)), nn.Parameter(ck["params"][1].clone().to(dev))
+    base = torch.optim.SGD([p1, p2], lr=0.1, momentum=0.9)
+    opt = bde.SwagOptimizer([p1, p2], base, update_interval=2, start_epoch=0, deviation_samples=4, _ops=ops)
+    sd = ck["optimizer"]
+    sd["state"]["__base_optimizer"] = base        # the caller owns the base optimizer (reference: pickled along)
+    opt.load_state_dict(sd)
+    assert opt.state["__updates"] == 7 and opt.state["__epoch"] == 1 and opt.state["__steps_since_swag_start"] == 14
+    np.testing.assert_array_equal(opt.mean_vector().cpu().numpy(), ck["mean"].numpy())
+    np.testing.assert_array_equal(opt.sq_vector().cpu().numpy(), ck["sq"].numpy())
+    np.testing.assert_array_equal(opt.deviations_dk().cpu().numpy(), ck["dev"].numpy())
+    # ...and keeps going: two more steps = one more update, written to ring row 0 (= the oldest column)
+    c1, c2 = ck["c"][0].to(dev), ck["c"][1].to(dev)
+    for _ in range(2):
+        opt.step(lambda: (p1 * c1).sum() + (p2 * c2).sum(), lambda l: l.backward())
+    assert opt.state["__updates"] == 8 and opt.state["__dev_head"] == 1
+    st = O_state_from_checkpoint(ck)
+    theta = flat([p1, p2]).cpu()
+    import oracle.bde_oracle as O
+    st.updates = 8
+    O.swag_moment_update(st, theta)
+    np.testing.assert_array_equal(opt.mean_vector().cpu().numpy(), st.mean.numpy())
+    np.testing.assert_array_equal(opt.deviations_dk().cpu().numpy(), st.deviations.numpy())
+    # round trip through our own state_dict (reference wire layout)
+    out = opt.state_dict()["state"]
+    assert tuple(out["__deviations"].shape) == (13, 4) and out["__mean"].device.type == "cpu"
+
+
+def O_state_from_checkpoint(ck):
+    import oracle.bde_oracle as O
+    return O.SwagState(mean=ck["mean"].clone(), sq_weights=ck["sq"].clone(), deviations=ck["dev"].clone(),
+                       epoch=1, steps_since_swag_start=14, updates=7, column_iterate=[0, 0, 0, 0])
+
+
+def test_load_reference_svgd_checkpoint_and_resume(backend):
+    """Per-tensor particle_i entries written by the REFERENCE SVGDOptimizer are copied into the flat particle
+    buffer; the next step reproduces the reference's next step."""
+    ops, dev = backend
+    ck = torch.load(_os.path.join(_GOLD, "ref_svgd_checkpoint.pt"), weights_only=False)
+    nxt = torch.load(_os.path.join(_GOLD, "ref_svgd_checkpoint_next.pt"), weights_only=False)
+    model = make_mlp().to(dev)
+    model.load_state_dict(ck["model"])
+    ref_base = ck["optimizer"]["state"]["__base_optimizer"]            # the reference's pickled torch.optim.SGD
+    base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    opt = bde.SVGDOptimizer(model.parameters(), lambda: None, base, particle_count=3, dataset_size=64, l2_reg=0.01,
+                            _ops=ops)
+    sd = ck["optimizer"]
+    sd["state"]["__base_optimizer"] = base
+    opt.load_state_dict(sd)
+    np.testing.assert_array_equal(opt.particles.cpu().numpy(), ck["particles"].numpy())
+    # carry the shared momentum buffers over from the reference's base optimizer (keyed on ITS parameters)
+    for p_new, p_old in zip(model.parameters(), ref_base.param_groups[0]["params"]):
+        base.state[p_new]["momentum_buffer"] = ref_base.state[p_old]["momentum_buffer"].clone().to(dev)
+    x, y = ck["x"].to(dev), ck["y"].to(dev)
+    loss = opt.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
+    assert abs(float(loss) - nxt["loss"]) <= 2e-5 * abs(nxt["loss"])
+    np.testing.assert_allclose(opt.particles.cpu().numpy(), nxt["particles_after"].numpy(), rtol=2e-5, atol=3e-6)
