@@ -16,6 +16,7 @@ _LAZY = {
     "BBBOptimizer": ".bbb", "GaussianPrior": ".bbb",
     "GaussianParameter": ".util", "normal_like": ".util", "reset_model_params": ".util",
     "iVONOptimizer": ".ivon",
+    "BBBLinear": ".bbb_layers", "BBBConv2d": ".bbb_layers", "make_module_bbb": ".bbb_layers",
     "DeepEnsemble": ".ensemble",
     "HipOps": ".ops",
 }

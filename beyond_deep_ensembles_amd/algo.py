@@ -87,65 +87,71 @@ def adopt_grads(params: Sequence[torch.nn.Parameter], views: Sequence[torch.Tens
 
 
 class BayesianOptimizer(Optimizer):
-    '''
-        An optimizer that optimizes a distribution over the parameters of a model (approximate inference).
-        Same contract as the reference's BayesianOptimizer (src/algos/algo.py:5-17):
+    """Base of the posterior-inference optimizers; the public surface is the reference's
+    (``src/algos/algo.py:5-80``):
 
-        Use the optimizer returned by get_base_optimizer() for learning rate schedulers.
-        If you are using a GradScaler, call optimizer.init_grad_scaler(grad_scaler) before the first step.
-    '''
+    ==========================================  ==================================================
+    ``step(forward_closure, backward_closure)``  one update; the forward closure returns the loss and
+                                                 must not clear gradients or call backward, the
+                                                 backward closure runs ``loss.backward()`` (or
+                                                 ``scaler.scale(loss).backward()``)
+    ``complete_epoch()``                         end-of-epoch bookkeeping
+    ``sample_parameters()``                      draw concrete weights before an eval forward
+    ``get_base_optimizer()``                     what LR schedulers must be attached to
+    ``init_grad_scaler(scaler)``                 call once before the first step when using AMP
+    ==========================================  ==================================================
+    """
 
     def __init__(self, params, defaults):
         super().__init__(params, defaults)
-        self._step_supports_amp_scaling = True
+        self._step_supports_amp_scaling = True     # lets torch.amp.GradScaler.step() pass its kwargs through
 
+    # -- the reference's abstract surface -----------------------------------
     def step(self, forward_closure, backward_closure):
-        '''
-            Makes a single step (algo.py:19-29).  forward_closure evaluates the loss for the current state of
-            the module and must neither clear gradients nor call backward(); backward_closure runs one backward
-            pass (call scale() on the loss there if you use a GradScaler).
-        '''
+        raise NotImplementedError()
+
+    def sample_parameters(self):
         raise NotImplementedError()
 
     def complete_epoch(self):
-        '''Completes a training epoch (algo.py:31-35).'''
         pass
-
-    def sample_parameters(self):
-        '''Samples concrete values for all parameters; call before forward() during evaluation (algo.py:37-42).'''
-        raise NotImplementedError()
-
-    def init_grad_scaler(self, grad_scaler):
-        '''GradScalers initialise lazily, but their scale is needed before the first step (algo.py:44-49).'''
-        if grad_scaler is not None and grad_scaler.is_enabled() and grad_scaler._scale is None:
-            grad_scaler._lazy_init_scale_growth_tracker(self._params_device())
 
     def get_base_optimizer(self):
-        '''The optimizer that does the actual parameter updates (algo.py:51-55).'''
         pass
+
+    def init_grad_scaler(self, grad_scaler):
+        # a GradScaler creates its scale tensor lazily, but step() needs it before the first unscale
+        needs_init = grad_scaler is not None and grad_scaler.is_enabled() and grad_scaler._scale is None
+        if needs_init:
+            grad_scaler._lazy_init_scale_growth_tracker(self._params_device())
+
+    # -- helpers shared by the subclasses ------------------------------------
+    def _params(self):
+        for group in self.param_groups:
+            yield from group["params"]
 
     def _params_device(self):
         return self.param_groups[0]["params"][0].device
 
-    def _params(self):
-        for group in self.param_groups:
-            for param in group["params"]:
-                yield param
+    @staticmethod
+    def _scaler_active(grad_scaler) -> bool:
+        return grad_scaler is not None and grad_scaler.is_enabled()
 
     def _prepare_and_check_grads(self, grad_scaler, optimizer=None):
-        # algo.py:65-73, including its quirk (SURVEY.md Q6): the inf check reads
-        # self.state["found_inf_per_device"], a fresh empty entry, so it never fails.
-        if grad_scaler is None or not grad_scaler.is_enabled():
+        """Unscale the gradients of ``optimizer`` (default: self) and report whether they are finite.
+        Mirrors algo.py:65-73 INCLUDING its quirk: the check reads
+        ``self.state["found_inf_per_device"]``, an empty defaultdict entry, so it always passes."""
+        if not self._scaler_active(grad_scaler):
             return True
-        opt = self if optimizer is None else optimizer
-        grad_scaler.unscale_(opt)
-        return sum(v.item() for v in self.state["found_inf_per_device"].values()) == 0
+        grad_scaler.unscale_(optimizer if optimizer is not None else self)
+        found = self.state["found_inf_per_device"]
+        return sum(v.item() for v in found.values()) == 0
 
     def _set_grad_scaler_state(self, grad_scaler, stage, optimizer=None):
-        if grad_scaler is None or not grad_scaler.is_enabled():
-            return
-        opt = self if optimizer is None else optimizer
-        grad_scaler._per_optimizer_states[id(opt)]["stage"] = stage
+        """Force the GradScaler's per-optimizer state machine (READY / UNSCALED / STEPPED), algo.py:75-80."""
+        if self._scaler_active(grad_scaler):
+            target = optimizer if optimizer is not None else self
+            grad_scaler._per_optimizer_states[id(target)]["stage"] = stage
 
 
 def _opt_state():
@@ -154,20 +160,25 @@ def _opt_state():
 
 
 class LastLayerBayesianOptimizer(BayesianOptimizer):
-    '''
-        Joins a Bayesian optimizer for the last layer(s) with a deterministic optimizer for the rest of the
-        network (algo.py:83-133).  Behaviour is undefined if the two optimizers share parameters.
-    '''
+    """A Bayesian optimizer for the head and a plain torch optimizer for the rest of the network, stepped
+    together (``src/algos/algo.py:83-133``).  The two must not share parameters.  GradScalers are not
+    supported, exactly as in the reference."""
 
     def __init__(self, ll_bayesian_optimizer: BayesianOptimizer, deterministic_optimizer: Optimizer):
+        # deliberately no Optimizer.__init__: this object owns no parameters of its own
         self.ll_bayesian_optimizer = ll_bayesian_optimizer
         self.deterministic_optimizer = deterministic_optimizer
 
+    @property
+    def _parts(self):
+        return {"ll_bayesian_optimizer": self.ll_bayesian_optimizer,
+                "deterministic_optimizer": self.deterministic_optimizer}
+
     def step(self, forward_closure, backward_closure, grad_scaler=None):
-        if grad_scaler is not None and grad_scaler.is_enabled():
+        if BayesianOptimizer._scaler_active(grad_scaler):
             raise ValueError("Doesn't support grad scaler")
         self.deterministic_optimizer.zero_grad()
-        # makes at least one forward & backward pass, which creates the gradients of the deterministic part
+        # the Bayesian part runs >= 1 forward/backward pass, which also fills the backbone's gradients
         loss = self.ll_bayesian_optimizer.step(forward_closure, backward_closure)
         self.deterministic_optimizer.step()
         return loss
@@ -187,16 +198,12 @@ class LastLayerBayesianOptimizer(BayesianOptimizer):
                            "directly on the passed ll bayesian optimizer")
 
     def state_dict(self) -> Dict[str, Any]:
-        return {
-            "ll_bayesian_optimizer": self.ll_bayesian_optimizer.state_dict(),
-            "deterministic_optimizer": self.deterministic_optimizer.state_dict(),
-        }
+        return {name: part.state_dict() for name, part in self._parts.items()}
 
     def load_state_dict(self, state_dict: Dict[str, Any]) -> None:
-        self.ll_bayesian_optimizer.load_state_dict(state_dict["ll_bayesian_optimizer"])
-        self.deterministic_optimizer.load_state_dict(state_dict["deterministic_optimizer"])
+        for name, part in self._parts.items():
+            part.load_state_dict(state_dict[name])
 
     def __repr__(self) -> str:
-        return ("LL Bayesian Optimizer: \n\n" + self.ll_bayesian_optimizer.__repr__()
-                + "\n==================================\nDeterministic Optimizer:\n\n"
-                + self.deterministic_optimizer.__repr__())
+        bar = "=" * 34
+        return f"LL Bayesian Optimizer: \n\n{self.ll_bayesian_optimizer!r}\n{bar}\nDeterministic Optimizer:\n\n{self.deterministic_optimizer!r}"

@@ -23,40 +23,52 @@ from .util import GaussianParameter
 
 
 class GaussianPrior:
+    """N(mu, sigma^2) prior over every weight (API of ``src/algos/bbb.py:9-21``)."""
+
     def __init__(self, mu, sigma):
-        self.mu = mu
-        self.sigma = sigma
+        self.mu, self.sigma = mu, sigma
         self.dist = torch.distributions.Normal(mu, sigma)
 
     def log_prob(self, x):
         return self.dist.log_prob(x)
 
     def kl_divergence(self, mu2, sigma2):
-        # bbb.py:18-21, torch path (used by layers; the optimizer uses the fused kernel)
-        kl = 0.5 * (2 * torch.log(self.sigma / sigma2) - 1 + (sigma2 / self.sigma).pow(2)
-                    + ((self.mu - mu2) / self.sigma).pow(2))
-        return kl.sum()
+        """KL(N(mu2, sigma2^2) || prior), summed; the torch path that layers use.  BBBOptimizer takes the
+        fused HIP kernel instead when the parameters come from GaussianParameter."""
+        ratio = sigma2 / self.sigma
+        shift = (self.mu - mu2) / self.sigma
+        per_weight = 0.5 * (2 * torch.log(self.sigma / sigma2) - 1 + ratio.pow(2) + shift.pow(2))
+        return per_weight.sum()
 
 
 class MixturePrior:
+    """Scale mixture of two zero-mean Gaussians (API of ``src/algos/bbb.py:23-37``); its
+    "KL" is the negative clamped log-density of the means, evaluated with torch autograd."""
+
+    _LO, _HI = -23, 0
+
     def __init__(self, pi, sigma1, sigma2, validate_args=None):
         self.pi = torch.tensor(pi)
-        self.sigma1 = sigma1
-        self.sigma2 = sigma2
+        self.sigma1, self.sigma2 = sigma1, sigma2
         self.dist1 = torch.distributions.Normal(0, sigma1, validate_args)
         self.dist2 = torch.distributions.Normal(0, sigma2, validate_args)
 
     def log_prob(self, value):
-        prob1 = torch.log(self.pi) + torch.clamp(self.dist1.log_prob(value), -23, 0)
-        prob2 = torch.log(1 - self.pi) + torch.clamp(self.dist2.log_prob(value), -23, 0)
-        return torch.logaddexp(prob1, prob2)
+        parts = []
+        for weight, dist in ((self.pi, self.dist1), (1 - self.pi, self.dist2)):
+            parts.append(torch.log(weight) + torch.clamp(dist.log_prob(value), self._LO, self._HI))
+        return torch.logaddexp(parts[0], parts[1])
 
     def kl_divergence(self, mu2, sigma2):
         return -self.log_prob(mu2).sum()
 
 
 def collect_kl(model) -> torch.Tensor:
-    return sum(getattr(layer, "kl", 0) + collect_kl(layer) for layer in model.children())
+    """Sum of the ``kl`` attributes of all (nested) child layers."""
+    total = 0
+    for layer in model.children():
+        total = total + getattr(layer, "kl", 0) + collect_kl(layer)
+    return total
 
 
 class _Group:

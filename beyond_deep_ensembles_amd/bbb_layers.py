@@ -1,0 +1,147 @@
+"""Mean-field Bayesian layers with the local reparameterisation trick, built on
+``GaussianParameter`` (SURVEY.md section 8f, row 4 -- the callers of the BBB hot path).
+
+Same constructor arguments, attributes (``weight`` / ``bias`` GaussianParameters,
+``is_bayesian``, ``kl``) and forward semantics as the reference's ``BBBLinear``
+(``src/algos/bbb_layers.py:10-90``) and ``BBBConv2d`` (``:105-160``) in their default
+``sampling="activations"`` mode: the layer's pre-activations are sampled from
+``N(x W_mu + b_mu, x^2 W_sigma^2 + b_sigma^2)`` (inputs^2 and variances clamped at 1e-4),
+with ONE noise draw shared across the batch in eval mode when ``freeze_on_eval``.
+The two GEMMs / convolutions stay stock PyTorch-ROCm (model code); what BBBOptimizer needs from
+the layer -- mean / rho parameters paired through GaussianParameter -- feeds the fused KL kernel.
+
+Differences from the reference, on purpose:
+* ``kl`` is evaluated lazily when read (the reference recomputes it on every forward although
+  BBBOptimizer never reads it); ``BBBConv2d.kl`` uses the BIAS parameters for
+  the bias term (the reference adds the weight KL twice).
+* ``sampling="parameters"`` draws the weights with ``GaussianParameter.sample()`` (HIP draw
+  kernel) and returns the plain layer output; the per-sample log-prob "kl" of the reference's
+  variant (which calls an undefined helper) is not reproduced.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .util import GaussianParameter, normal_like
+
+_CLAMP = 1e-4
+
+
+class _LocalReparamLayer(nn.Module):
+    """Shared machinery: Gaussian weight/bias, noise policy, lazy KL."""
+
+    def _init_common(self, weight_shape, bias_shape, weight_prior, bias_prior, kwargs):
+        self.is_bayesian = True
+        self.sampling = kwargs.get("sampling", "activations")
+        self.freeze_on_eval = kwargs.get("freeze_on_eval", True)
+        self.kl_on_eval = kwargs.get("kl_on_eval", False)
+        self.use_bias = kwargs.get("bias", True)
+        self.weight_prior, self.bias_prior = weight_prior, bias_prior
+        gp_kwargs = {k: kwargs[k] for k in ("rng", "seed", "_ops") if k in kwargs}
+        self.weight = GaussianParameter(weight_shape, **gp_kwargs)
+        if self.use_bias:
+            self.bias = GaussianParameter(bias_shape, **gp_kwargs)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.weight.blundell_init()
+        if self.use_bias:
+            self.bias.blundell_init()
+
+    @property
+    def kl(self):
+        if not (self.training or self.kl_on_eval):
+            return 0
+        total = self.weight_prior.kl_divergence(self.weight.mean, self.weight.std)
+        if self.use_bias:
+            total = total + self.bias_prior.kl_divergence(self.bias.mean, self.bias.std)
+        return total
+
+    def _noise(self, mean: torch.Tensor) -> torch.Tensor:
+        if not self.training and self.freeze_on_eval:
+            # one draw for the whole batch, so an eval pass uses ONE set of weights per call
+            eps = torch.empty(mean.shape[1:], device=mean.device, dtype=mean.dtype).normal_(0, 1)
+            return eps.unsqueeze(0).expand(mean.shape)
+        return normal_like(mean)
+
+    def _sample_activations(self, mean: torch.Tensor, var: torch.Tensor) -> torch.Tensor:
+        return mean + torch.sqrt(var) * self._noise(mean)
+
+
+class BBBLinear(_LocalReparamLayer):
+    def __init__(self, in_features: int, out_features: int, weight_prior, bias_prior, **kwargs):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.mc_sample = kwargs.get("mc_sample", 1)
+        self.rho_init = kwargs.get("rho_init", -3)
+        self._init_common((out_features, in_features), (out_features,), weight_prior, bias_prior, kwargs)
+
+    def forward(self, input: torch.Tensor):
+        if self.sampling == "activations":
+            w, b = self.weight, (self.bias if self.use_bias else None)
+            mean = F.linear(input, w.mean, b.mean if b is not None else None)
+            var = F.linear((input ** 2).clamp(min=_CLAMP), (w.std ** 2).clamp(min=_CLAMP),
+                           (b.std ** 2).clamp(min=_CLAMP) if b is not None else None)
+            return self._sample_activations(mean, var) / self.mc_sample
+        if self.sampling == "parameters":
+            out = None
+            for _ in range(self.mc_sample):
+                y = F.linear(input, self.weight.sample(), self.bias.sample() if self.use_bias else None)
+                out = y if out is None else out + y
+            return out / self.mc_sample
+        raise ValueError("Invalid value of sampling")
+
+    def means(self):
+        return torch.cat([self.weight.mean.flatten(), self.bias.mean.flatten()])
+
+    def sigmas(self):
+        return torch.cat([self.weight.std.flatten(), self.bias.std.flatten()])
+
+
+class BBBConv2d(_LocalReparamLayer):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, weight_prior, bias_prior, **kwargs):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride = kwargs.get("stride", 1)
+        self.padding = kwargs.get("padding", 0)
+        self._init_common((out_channels, in_channels, kernel_size, kernel_size), (out_channels,), weight_prior,
+                          bias_prior, kwargs)
+
+    def forward(self, input: torch.Tensor):
+        if self.sampling == "parameters":
+            raise NotImplementedError()
+        if self.sampling != "activations":
+            raise ValueError("Invalid value of sampling")
+        w, b = self.weight, (self.bias if self.use_bias else None)
+        mean = F.conv2d(input, w.mean, b.mean if b is not None else None, stride=self.stride, padding=self.padding)
+        var = F.conv2d((input ** 2).clamp(min=_CLAMP), (w.std ** 2).clamp(min=_CLAMP),
+                       b.std ** 2 if b is not None else None, stride=self.stride, padding=self.padding)
+        return self._sample_activations(mean, var)
+
+
+def make_module_bbb(module: nn.Module, prior, **kwargs) -> int:
+    """Replace every nn.Linear / nn.Conv2d of ``module`` by its mean-field counterpart, keeping the
+    current weights as the means (cf. the reference's ``make_module_bbb``); returns the number of
+    layers replaced."""
+    replaced = 0
+    for name, child in list(module.named_children()):
+        new = None
+        if isinstance(child, nn.Linear):
+            new = BBBLinear(child.in_features, child.out_features, prior, prior, bias=child.bias is not None, **kwargs)
+        elif isinstance(child, nn.Conv2d) and child.groups == 1 and child.dilation == (1, 1) \
+                and child.kernel_size[0] == child.kernel_size[1] and isinstance(child.padding, tuple):
+            new = BBBConv2d(child.in_channels, child.out_channels, child.kernel_size[0], prior, prior,
+                            stride=child.stride, padding=child.padding, bias=child.bias is not None, **kwargs)
+        if new is not None:
+            new = new.to(child.weight.device)
+            with torch.no_grad():
+                new.weight.mean.copy_(child.weight)
+                if child.bias is not None:
+                    new.bias.mean.copy_(child.bias)
+            setattr(module, name, new)
+            replaced += 1
+        else:
+            replaced += make_module_bbb(child, prior, **kwargs)
+    return replaced
