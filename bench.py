@@ -170,6 +170,29 @@ def cpu_baseline(P, G, d, budget_s=25.0):
                       f"torch {torch.__version__} CPU, {cores} threads", "ms_per_step": round(best * 1e3, 2)}
 
 
+def torch_gpu_baseline(P, G, d, dev):
+    """The reference's own op sequence (oracle functions = same ATen calls as svgd.py:86-89 and
+    swag.py:57,112-114) executed by PyTorch-ROCm ON THE SAME GPU: what a user of the reference gets on an
+    MI355X without this library.  Reported next to the HIP numbers; not a target."""
+    from oracle import bde_oracle as O
+    out = {}
+    Pd, Gd = P[:, :d].contiguous(), G[:, :d].contiguous()
+    t = time_loop(lambda: O.cpu_svgd_step(Pd, Gd, 0.0, 1.0, DATASET_SIZE), 5, warm=2)
+    out["svgd_step_ms"] = round(t * 1e3, 3)
+    out["svgd_steps_per_s"] = round(1.0 / t, 2)
+    del Pd, Gd
+    g = torch.Generator(device=dev).manual_seed(5)
+    mean = torch.randn(d, device=dev, generator=g) * 0.05
+    sq = mean * mean + 1e-4
+    devs = torch.randn(d, K_SWAG, device=dev, generator=g) * 1e-3
+    dist_obj = O.swag_build_dist(mean, sq, devs)                   # swag.py:107-114 (cached between updates)
+    t = time_loop(lambda: dist_obj.sample(), 5, warm=2)            # swag.py:57
+    out["swag_sample_ms"] = round(t * 1e3, 3)
+    out["swag_samples_per_s"] = round(1.0 / t, 2)
+    out["what"] = "oracle functions (the reference's ATen op sequence) on CUDA tensors, torch " + torch.__version__
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -314,6 +337,11 @@ def main():
                 log("cpu baseline ...")
                 res["cpu_baseline"] = cpu_baseline(P, G, d)
                 log(f"  {res['cpu_baseline']}")
+                try:
+                    res["gpu_torch_baseline"] = torch_gpu_baseline(P, G, d, dev)
+                    log(f"  {res['gpu_torch_baseline']}")
+                except Exception as e:      # informational only
+                    log(f"  gpu_torch_baseline skipped: {e}")
             del P, G
             torch.cuda.empty_cache()
             if not args.no_extras and d == D_RESNET50:
