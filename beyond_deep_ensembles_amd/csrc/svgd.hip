@@ -76,19 +76,38 @@ __device__ __forceinline__ void gram_load_tile(f32x4 (&v)[kGramU], const float* 
 // Lanes of padded particle rows (prow >= M) read row 0 and are zeroed after the load, so the
 // hot loop has no divergent branches.  The next tile's loads are issued before this tile's
 // DPP/MFMA work (register double buffering).
+//
+// Row map (PACK = 1 only): tile rows 0..7 are particles rowA .. rowA+nA-1, tile rows 8..15 are particles
+// rowB .. rowB+nB-1.  M <= 16 uses (0, min(M,8), 8, M-8); the generic path (M > 16) launches one such
+// tile per PAIR of 8-particle groups, each into its own slice of ws (tile_slot).
+struct GramRows {
+  int rowA, nA, rowB, nB, tile_slot;
+};
+
 template <int PACK>
 __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __restrict__ P, int M, int64_t D,
-                                                              int64_t ld, float* __restrict__ ws) {
+                                                              int64_t ld, float* __restrict__ ws, GramRows rows) {
   constexpr int W4 = (PACK == 2) ? 8 : 4;           // float4 columns one wave-load covers
   constexpr int MP = (PACK == 2) ? 8 : 16;          // padded particle count
   __shared__ float tile[kGramBlock / 64][16][17];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kq = lane >> 4;
-  const int prow = (PACK == 2) ? (r16 & 7) : r16;
   const int c4 = (PACK == 2) ? ((r16 >> 3) * 4 + kq) : kq;
-  const bool valid = prow < M;
-  const float inv_m = 1.0f / static_cast<float>(M);
+  int prow;
+  bool valid;
+  float inv_m;
+  if (PACK == 2) {
+    prow = r16 & 7;
+    valid = prow < M;
+    inv_m = 1.0f / static_cast<float>(M);
+  } else {
+    const bool hi = r16 >= 8;
+    const int r = r16 & 7;
+    valid = r < (hi ? rows.nB : rows.nA);
+    prow = (hi ? rows.rowB : rows.rowA) + r;
+    inv_m = 1.0f / static_cast<float>(rows.nA + rows.nB);
+  }
   const float* rowp = P + static_cast<int64_t>(valid ? prow : 0) * ld;
 
   const int64_t n4 = (D + 3) >> 2;                   // float4 columns (last may be partial)
@@ -132,7 +151,8 @@ __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __re
       s += tile[w][pi][pj];
       if (PACK == 2) s += tile[w][pi + 8][pj + 8];
     }
-    ws[kWsHeaderFloats + static_cast<int64_t>(blockIdx.x) * (MP * MP) + threadIdx.x] = s;
+    const int64_t slot = (PACK == 1) ? static_cast<int64_t>(rows.tile_slot) * kGramMaxBlocks * 256 : 0;
+    ws[kWsHeaderFloats + slot + static_cast<int64_t>(blockIdx.x) * (MP * MP) + threadIdx.x] = s;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     ws[0] = static_cast<float>(gridDim.x);
@@ -355,12 +375,177 @@ __global__ __launch_bounds__(kBlock) void svgd_apply_adam_kernel(float* __restri
   }
 }
 
+// ===================== generic path: 16 < M <= 64 (blocked, several passes) =====================
+// Not a tuned path (the reference's configs use 5 particles); it exists so that any particle_count the
+// reference accepts up to 64 works.  Particles are split into groups of 8; one 16-row Gram tile per PAIR
+// of groups (centred by the mean of the rows in the tile, which is all the distances need), reduced to a
+// d2 [M, M] matrix; statistics as in the fast path; combine in chunks of 16 output rows.
+
+// One workgroup per pair of groups: fp64 fixed-order reduction of that pair's partial tiles -> d2 entries.
+__global__ __launch_bounds__(kStatsBlock) void svgd_pairs_to_d2_kernel(const float* __restrict__ ws, int M,
+                                                                      float* __restrict__ d2mat) {
+  __shared__ double red[kStatsBlock];
+  __shared__ double gmat[256];
+  // pair index -> (ga <= gb)
+  const int ng = (M + 7) / 8;
+  int pair = blockIdx.x, ga = 0;
+  while (pair >= ng - ga) { pair -= ng - ga; ++ga; }
+  const int gb = ga + pair;
+  const int nb = static_cast<int>(ws[0]);
+  const float* part = ws + kWsHeaderFloats + static_cast<int64_t>(blockIdx.x) * kGramMaxBlocks * 256;
+  const int tid = threadIdx.x;
+  {
+    const int e = tid & 255, slice = tid >> 8;          // 4 slices
+    double s = 0.0;
+    for (int b = slice; b < nb; b += 4) s += static_cast<double>(part[static_cast<int64_t>(b) * 256 + e]);
+    red[tid] = s;
+  }
+  __syncthreads();
+  if (tid < 256) gmat[tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+  __syncthreads();
+  if (tid < 256) {
+    const int ti = tid >> 4, tj = tid & 15;
+    const int i = (ti < 8 ? ga * 8 + ti : gb * 8 + ti - 8), j = (tj < 8 ? ga * 8 + tj : gb * 8 + tj - 8);
+    const bool vi = i < M && (ti < 8 || ga != gb), vj = j < M && (tj < 8 || ga != gb);
+    // the diagonal blocks come from the (g, g) pairs, the cross blocks from the (ga < gb) pairs
+    const bool mine = (ga == gb) ? (ti < 8 && tj < 8) : ((ti < 8) != (tj < 8));
+    if (vi && vj && mine) {
+      double d = gmat[ti * 16 + ti] + gmat[tj * 16 + tj] - 2.0 * gmat[ti * 16 + tj];
+      if (d < 0.0 || i == j) d = 0.0;
+      d2mat[i * M + j] = static_cast<float>(d);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kStatsBlock) void svgd_kstats_generic_kernel(const float* __restrict__ d2mat, int M,
+                                                                         float l2_reg, float kernel_grad_scale,
+                                                                         float dataset_size, float sign,
+                                                                         float h_override, float log_m1, int mode,
+                                                                         float* __restrict__ kstat) {
+  __shared__ float d2f[BDE_MAX_PARTICLES * BDE_MAX_PARTICLES];
+  __shared__ float sorted[BDE_MAX_PARTICLES * BDE_MAX_PARTICLES];
+  __shared__ float kmat[BDE_MAX_PARTICLES * BDE_MAX_PARTICLES];
+  __shared__ float rowsum[BDE_MAX_PARTICLES];
+  __shared__ float hs[2];
+  const int tid = threadIdx.x, n = M * M;
+  for (int e = tid; e < n; e += kStatsBlock) d2f[e] = d2mat[e];
+  __syncthreads();
+  for (int e = tid; e < n; e += kStatsBlock) {
+    const float v = d2f[e];
+    int rank = 0;
+    for (int u = 0; u < n; ++u) {
+      const float o = d2f[u];
+      rank += (o < v || (o == v && u < e)) ? 1 : 0;
+    }
+    sorted[rank] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float pos = 0.5f * static_cast<float>(n - 1);
+    const float lo = floorf(pos);
+    const float wgt = pos - lo;
+    const float a = sorted[static_cast<int>(lo)], b = sorted[static_cast<int>(ceilf(pos))];
+    const float med = (fabsf(wgt) < 0.5f) ? a + wgt * (b - a) : b - (b - a) * (1.0f - wgt);
+    float h = __builtin_sqrtf((0.5f * med) / log_m1) + 1e-8f;
+    if (h_override > 0.f) h = h_override;
+    hs[0] = h;
+    hs[1] = med;
+  }
+  __syncthreads();
+  const float h = hs[0];
+  for (int e = tid; e < n; e += kStatsBlock) kmat[e] = expf(-d2f[e] / (2.0f * (h * h)));
+  __syncthreads();
+  if (tid < M) {
+    float s = 0.f;
+    for (int j = 0; j < M; ++j) s += kmat[tid * M + j];
+    rowsum[tid] = s;
+  }
+  __syncthreads();
+  const int oK = 0, oD2 = n, oRow = 2 * n, oMisc = 2 * n + M, oCG = oMisc + 4, oCP = oCG + n;
+  const double h2 = static_cast<double>(h) * static_cast<double>(h);
+  const double s_rep = static_cast<double>(kernel_grad_scale) / (static_cast<double>(dataset_size) * h2);
+  for (int e = tid; e < n; e += kStatsBlock) {
+    const int i = e / M, j = e % M;
+    const double kij = kmat[e];
+    const double rep = ((i == j) ? static_cast<double>(rowsum[i]) : 0.0) - kij;
+    double cg, cp;
+    if (mode == 0) {
+      cg = static_cast<double>(sign) * (-kij);
+      cp = static_cast<double>(sign) * (-kij * (0.5 * static_cast<double>(l2_reg)) + s_rep * rep);
+    } else {
+      cg = 0.0;
+      cp = rep / h2;
+    }
+    kstat[oK + e] = kmat[e];
+    kstat[oD2 + e] = d2f[e];
+    kstat[oCG + j * M + i] = static_cast<float>(cg);
+    kstat[oCP + j * M + i] = static_cast<float>(cp);
+  }
+  if (tid < M) kstat[oRow + tid] = rowsum[tid];
+  if (tid == 0) {
+    kstat[oMisc + 0] = h;
+    kstat[oMisc + 1] = hs[1];
+    kstat[oMisc + 2] = static_cast<float>(s_rep);
+    kstat[oMisc + 3] = static_cast<float>(M);
+  }
+}
+
+// 16 output rows [i0, i0 + mi) per launch, all M input rows streamed through.
+template <bool HAS_G>
+__global__ __launch_bounds__(kBlock) void svgd_combine_generic_kernel(const float* __restrict__ P,
+                                                                     const float* __restrict__ G,
+                                                                     float* __restrict__ out, int M, int i0, int mi,
+                                                                     int64_t D, int64_t ld,
+                                                                     const float* __restrict__ cgT,
+                                                                     const float* __restrict__ cpT) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t n4 = D >> 2;
+  for (int64_t i4 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i4 < n4 + 1; i4 += stride) {
+    const bool tail = i4 == n4;                       // the D % 4 leftover coordinates: one thread, scalar
+    if (tail && (D & 3) == 0) continue;
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < M; ++j) {
+      f32x4 p = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+      if (!tail) {
+        p = ld4_nt(P + j * ld + 4 * i4);
+        if (HAS_G) g = ld4_nt(G + j * ld + 4 * i4);
+      } else {
+        for (int c = 0; c < static_cast<int>(D & 3); ++c) {
+          p[c] = P[j * ld + 4 * i4 + c];
+          if (HAS_G) g[c] = G[j * ld + 4 * i4 + c];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i < mi) {                                 // wave-uniform
+          const float a = HAS_G ? cgT[j * M + i0 + i] : 0.f, b = cpT[j * M + i0 + i];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_fmaf(b, p[c], HAS_G ? __builtin_fmaf(a, g[c], acc[i][c]) : acc[i][c]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i < mi) {
+        if (!tail) {
+          st4_nt(out + (i0 + i) * ld + 4 * i4, acc[i]);
+        } else {
+          for (int c = 0; c < static_cast<int>(D & 3); ++c) out[(i0 + i) * ld + 4 * i4 + c] = acc[i][c];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace bde
 
 using namespace bde;
 
 extern "C" size_t bde_svgd_ws_bytes(int M) {
   if (M < 1 || M > BDE_MAX_PARTICLES) return 0;
+  if (M > BDE_FAST_PARTICLES) return sizeof(float) * (svgd_generic_d2_offset(M) + static_cast<size_t>(M) * M);
   const size_t mp = (M <= 8) ? 8 : 16;
   return sizeof(float) * (kWsHeaderFloats + static_cast<size_t>(kGramMaxBlocks) * mp * mp);
 }
@@ -374,15 +559,32 @@ extern "C" int bde_svgd_gram(const float* P, int M, int64_t D, int64_t ld, void*
   if (!svgd_args_ok(P, M, D, ld) || !ws || !aligned16(ws)) return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n4 = (D + 3) / 4;
+  float* wsf = static_cast<float*>(ws);
   if (M <= 8) {
     const int64_t tiles = (n4 + kGramU * 8 - 1) / (kGramU * 8);
     const int grid = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, kGramMaxBlocks));
-    hipLaunchKernelGGL(svgd_gram_kernel<2>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, static_cast<float*>(ws));
-  } else {
-    const int64_t tiles = (n4 + kGramU * 4 - 1) / (kGramU * 4);
-    const int grid = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, kGramMaxBlocks));
-    hipLaunchKernelGGL(svgd_gram_kernel<1>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, static_cast<float*>(ws));
+    hipLaunchKernelGGL(svgd_gram_kernel<2>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, wsf, GramRows{});
+    return to_err(hipGetLastError());
   }
+  const int64_t tiles = (n4 + kGramU * 4 - 1) / (kGramU * 4);
+  const int grid = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, kGramMaxBlocks));
+  if (M <= BDE_FAST_PARTICLES) {
+    hipLaunchKernelGGL(svgd_gram_kernel<1>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, wsf,
+                       GramRows{0, 8, 8, M - 8, 0});
+    return to_err(hipGetLastError());
+  }
+  // generic: one 16-row tile per pair of 8-particle groups, then the pairs' tiles -> d2 [M, M]
+  const int ng = svgd_groups(M);
+  int slot = 0;
+  for (int ga = 0; ga < ng; ++ga) {
+    for (int gb = ga; gb < ng; ++gb, ++slot) {
+      const int nA = std::min(8, M - ga * 8), nB = (gb == ga) ? 0 : std::min(8, M - gb * 8);
+      hipLaunchKernelGGL(svgd_gram_kernel<1>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, wsf,
+                         GramRows{ga * 8, nA, gb * 8, nB, slot});
+    }
+  }
+  hipLaunchKernelGGL(svgd_pairs_to_d2_kernel, dim3(svgd_pairs(M)), dim3(kStatsBlock), 0, s, wsf, M,
+                     wsf + svgd_generic_d2_offset(M));
   return to_err(hipGetLastError());
 }
 
@@ -390,6 +592,12 @@ extern "C" int bde_svgd_kstats(const void* ws, int M, float l2_reg, float kernel
                                float sign, float h_override, int mode, float* kstat, void* stream) {
   if (!ws || !kstat || M < 1 || M > BDE_MAX_PARTICLES || (mode != 0 && mode != 1)) return BDE_ERR_INVALID;
   const float log_m1 = static_cast<float>(std::log(static_cast<double>(M) + 1.0));   // np.log(M + 1), svgd.py:18
+  if (M > BDE_FAST_PARTICLES) {
+    hipLaunchKernelGGL(svgd_kstats_generic_kernel, dim3(1), dim3(kStatsBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(ws) + svgd_generic_d2_offset(M), M, l2_reg, kernel_grad_scale,
+                       dataset_size, sign, h_override, log_m1, mode, kstat);
+    return to_err(hipGetLastError());
+  }
   hipLaunchKernelGGL(svgd_kstats_kernel, dim3(1), dim3(kStatsBlock), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float*>(ws), M, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, log_m1,
                      mode, kstat);
@@ -401,6 +609,23 @@ extern "C" int bde_svgd_combine(const float* P, const float* G, float* out, int 
   if (!svgd_args_ok(P, M, D, ld) || !out || !kstat || !aligned16(out) || (G && !aligned16(G)) || out == P)
     return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (M > BDE_FAST_PARTICLES) {
+    if (out == G) return BDE_ERR_INVALID;              // chunks of output rows re-read all of G
+    const int n = M * M;
+    const float* cg = kstat + 2 * n + M + 4;
+    const float* cp = cg + n;
+    const int grid = stream_grid((D + 3) / 4 + 1);
+    for (int i0 = 0; i0 < M; i0 += 16) {
+      const int mi = std::min(16, M - i0);
+      if (G)
+        hipLaunchKernelGGL(svgd_combine_generic_kernel<true>, dim3(grid), dim3(kBlock), 0, s, P, G, out, M, i0, mi, D,
+                           ld, cg, cp);
+      else
+        hipLaunchKernelGGL(svgd_combine_generic_kernel<false>, dim3(grid), dim3(kBlock), 0, s, P, G, out, M, i0, mi, D,
+                           ld, cg, cp);
+    }
+    return to_err(hipGetLastError());
+  }
   switch (M) {
 #define BDE_CASE(m) \
   case m:           \

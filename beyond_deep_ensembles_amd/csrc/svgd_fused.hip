@@ -220,7 +220,8 @@ extern "C" int bde_svgd_fused_gram_supported(int M) { return (M >= 1 && M <= 8) 
 extern "C" int bde_svgd_fused_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
                                   const float* kstat, double lr, double momentum, double dampening,
                                   double weight_decay, int nesterov, int first, void* ws_next, void* stream) {
-  if (!svgd_args_ok(P, M, D, ld) || !G || !kstat || !aligned16(G) || (momentum != 0.0 && !momentum_buf))
+  if (!svgd_args_ok(P, M, D, ld) || M > BDE_FAST_PARTICLES || !G || !kstat || !aligned16(G) ||
+      (momentum != 0.0 && !momentum_buf))
     return BDE_ERR_INVALID;
   if (ws_next && (M > 8 || !aligned16(ws_next))) return BDE_ERR_INVALID;
   const SgdParams sk{static_cast<float>(lr), static_cast<float>(momentum), static_cast<float>(1.0 - dampening),
@@ -232,7 +233,8 @@ extern "C" int bde_svgd_fused_sgd(float* P, const float* G, float* momentum_buf,
 extern "C" int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D,
                                    int64_t ld, const float* kstat, double lr, double beta1, double beta2, double eps,
                                    double weight_decay, int64_t step0, void* ws_next, void* stream) {
-  if (!svgd_args_ok(P, M, D, ld) || !G || !kstat || !aligned16(G) || !exp_avg || !exp_avg_sq || step0 < 0)
+  if (!svgd_args_ok(P, M, D, ld) || M > BDE_FAST_PARTICLES || !G || !kstat || !aligned16(G) || !exp_avg ||
+      !exp_avg_sq || step0 < 0)
     return BDE_ERR_INVALID;
   if (ws_next && (M > 8 || !aligned16(ws_next))) return BDE_ERR_INVALID;
   const AdamParams ak{static_cast<float>(beta1), static_cast<float>(beta2), static_cast<float>(1.0 - beta1),

@@ -23,6 +23,14 @@ static inline AdamSteps make_adam_steps(double lr, double beta1, double beta2, i
   return st;
 }
 
+// ---- generic path (16 < M <= 64): particles in groups of 8, one 16-row Gram tile per pair of groups ----
+static inline int svgd_groups(int M) { return (M + 7) / 8; }
+static inline int svgd_pairs(int M) { const int g = svgd_groups(M); return g * (g + 1) / 2; }
+// ws layout for M > 16: [header 16][pairs x kGramMaxBlocks x 256 partial tiles][M*M d2 matrix]
+static inline size_t svgd_generic_d2_offset(int M) {
+  return static_cast<size_t>(kWsHeaderFloats) + static_cast<size_t>(svgd_pairs(M)) * kGramMaxBlocks * 256;
+}
+
 static inline bool svgd_args_ok(const float* P, int M, int64_t D, int64_t ld) {
   return P && M >= 1 && M <= BDE_MAX_PARTICLES && D >= 1 && ld >= D && (ld & 3) == 0 && aligned16(P);
 }

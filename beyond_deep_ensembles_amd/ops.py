@@ -64,7 +64,7 @@ class HipOps:
     def svgd_ws(self, m: int, device) -> torch.Tensor:
         n = self.lib.bde_svgd_ws_bytes(m)
         if n == 0:
-            raise BdeKernelError(f"SVGD supports 1 <= particle_count <= 16, got {m}")
+            raise BdeKernelError(f"SVGD supports 1 <= particle_count <= 64, got {m}")
         return torch.empty(n // 4, dtype=torch.float32, device=device)
 
     def svgd_kstat(self, m: int, device) -> torch.Tensor:

@@ -45,7 +45,7 @@ def rbf(particles: torch.Tensor, h_override=None, _ops=None):
         P = particles.new_zeros((m, layout_ld))
         P[:, :d] = particles
     ws, ks = ops.svgd_ws(m, P.device), ops.svgd_kstat(m, P.device)
-    out = torch.empty_like(P)
+    out = torch.zeros_like(P)
     ops.svgd_gram(P, d, ws)
     ops.svgd_kstats(ws, m, 0.0, 1.0, 1.0, 1.0, ks, h_override=float(h_override) if h_override is not None else 0.0,
                     mode=1)
@@ -114,7 +114,8 @@ class SVGDOptimizer(BayesianOptimizer):
                 raise ValueError(f"particle_count ({particle_count}) must be a multiple of the group size ({self._world})")
             # identical particles on every rank whatever the local RNG state was
             dist.broadcast(self._P, src=dist.get_global_rank(process_group, 0), group=process_group)
-        self._fuse = bool(fuse_base_optimizer)
+        self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
+        self._tmp = None
         self._fused_state = None
         self._reuse_gram = bool(reuse_gram) and self._fuse and self._ops.svgd_fused_gram_supported(particle_count)
         self._gram_valid = False
@@ -165,7 +166,14 @@ class SVGDOptimizer(BayesianOptimizer):
             else:
                 self._gram_valid = False
                 # svgd.py:86-89: -phi overwrites the gradient rows
-                self._ops.svgd_combine(self._P, self._G, self._G, d, self._kstat)
+                if m <= 16:
+                    self._ops.svgd_combine(self._P, self._G, self._G, d, self._kstat)
+                else:
+                    # the blocked path for > 16 particles produces 16 rows per pass and re-reads all of G
+                    if self._tmp is None:
+                        self._tmp = torch.zeros_like(self._G)
+                    self._ops.svgd_combine(self._P, self._G, self._tmp, d, self._kstat)
+                    self._G.copy_(self._tmp)
                 # write the modified gradients TO THE ORIGINAL PARAMETERS and call the optimizer on them (svgd.py:92-103)
                 for particle_idx in range(m):
                     for model_param, pview, gview in zip(self._plist, self._pviews[particle_idx], self._gviews[particle_idx]):

@@ -34,7 +34,9 @@ extern "C" {
 #endif
 
 #define BDE_ERR_INVALID (-1)
-#define BDE_MAX_PARTICLES 16   /* SVGD: M <= 16 (one 16x16 MFMA tile)        */
+#define BDE_MAX_PARTICLES 64   /* SVGD: M <= 64; M <= 16 runs the single-tile fast path,
+                                  17..64 a blocked generic path (several passes)        */
+#define BDE_FAST_PARTICLES 16
 #define BDE_MAX_RANK 256       /* SWAG: deviation_samples K <= 256           */
 #define BDE_MAX_BATCH 32       /* SWAG batched sampling: S <= 32 per call    */
 
@@ -88,7 +90,8 @@ int bde_svgd_kstats(const void* ws, int M, float l2_reg, float kernel_grad_scale
                     float* kstat, void* stream);
 
 /* Stage 3: out[i, :] = sum_j CG[i][j] * G[j, :] + CP[i][j] * P[j, :].
- * G may be NULL (CG ignored).  out may alias G (not P). */
+ * G may be NULL (CG ignored).  out may alias G (not P) for M <= 16; for M > 16 the
+ * rows are produced in chunks of 16 that re-read all of G, so out must not alias G. */
 int bde_svgd_combine(const float* P, const float* G, float* out, int M, int64_t D,
                      int64_t ld, const float* kstat, void* stream);
 

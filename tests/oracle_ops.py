@@ -19,7 +19,7 @@ class OracleOps:
 
     # ------------------------------------------------------------ SVGD --
     def svgd_ws(self, m, device):
-        if not 1 <= m <= 16:
+        if not 1 <= m <= 64:
             raise RuntimeError("M out of range")
         return torch.zeros(16 + 2048 * 256)
 

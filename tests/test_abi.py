@@ -34,7 +34,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(raw, name), f"{name} not exported"
         assert len(_lib.SIGNATURES[name][1]) == nargs, name
     assert lib.bde_version() >= 100 and lib.bde_arch() == b"gfx950"
-    assert lib.bde_svgd_ws_bytes(8) > 0 and lib.bde_svgd_ws_bytes(17) == 0      # M <= 16
+    assert lib.bde_svgd_ws_bytes(8) > 0 and lib.bde_svgd_ws_bytes(65) == 0      # M <= 64
     assert lib.bde_svgd_kstat_floats(8) == 4 * 64 + 8 + 4
 
 

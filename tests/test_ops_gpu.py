@@ -120,14 +120,39 @@ def test_svgd_deterministic_and_ragged_sizes(ops):
         assert err <= max(2 * err_ref, 3e-6 * np.max(np.abs(phi64))), (m, d, err, err_ref)
 
 
+def test_svgd_blocked_path_for_more_than_16_particles(ops):
+    """17..64 particles: pair-of-groups Gram tiles -> d2 -> statistics -> chunked combine."""
+    torch.manual_seed(9)
+    for m, d in [(17, 515), (24, 1003), (32, 4099), (40, 130), (64, 257)]:
+        P = torch.randn(m, d) * 0.05
+        if m == 32:                                   # shared backbone, distinct heads
+            P = (torch.randn(d) * 0.05).repeat(m, 1)
+            P[:, -100:] += torch.randn(m, 100) * 0.02
+        G = torch.randn(m, d) * 0.01
+        a, ks = run_svgd(ops, P, G, 0.01, 1.0, 5000.0)
+        b, _ = run_svgd(ops, P, G, 0.01, 1.0, 5000.0)
+        assert torch.equal(a, b)
+        phi64 = O.svgd_phi(P.double(), G.double(), 0.01, 1.0, 5000.0).numpy()
+        ref32 = O.svgd_phi(P, G, 0.01, 1.0, 5000.0).numpy().astype(np.float64)
+        err_ref = np.max(np.abs(ref32 - phi64))
+        err = np.max(np.abs(-a.numpy() - phi64))
+        assert err <= max(2 * err_ref, 3e-6 * np.max(np.abs(phi64))), (m, d, err, err_ref)
+        k64, _ = O.svgd_rbf(P.double())
+        assert np.max(np.abs(ks[:m * m].reshape(m, m).numpy() - k64.numpy())) <= 5e-6, (m, d)
+        from beyond_deep_ensembles_amd.ops import BdeKernelError
+        Pb, Gb = flat_rows(P), flat_rows(G)
+        with pytest.raises(BdeKernelError):           # in-place is a single-tile-path feature
+            ops.svgd_combine(Pb, Gb, Gb, d, ks.to(DEV))
+
+
 def test_svgd_rejects_bad_arguments(ops):
     from beyond_deep_ensembles_amd.ops import BdeKernelError
-    P = torch.zeros(17, 64, device=DEV)
+    P = torch.zeros(65, 64, device=DEV)
     with pytest.raises(BdeKernelError):
-        ops.svgd_ws(17, DEV)
+        ops.svgd_ws(65, DEV)
     ws, ks = ops.svgd_ws(8, DEV), ops.svgd_kstat(8, DEV)
     with pytest.raises(BdeKernelError):
-        ops.svgd_gram(P, 64, ws)                      # M > 16
+        ops.svgd_gram(P, 64, ws)                      # M > 64
     with pytest.raises(BdeKernelError):
         ops.svgd_gram(torch.zeros(8, 64), 64, ws)     # CPU tensor: no CPU path
     P8 = torch.zeros(8, 64, device=DEV)

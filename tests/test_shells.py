@@ -96,6 +96,39 @@ def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
     assert opt.get_base_optimizer() is base
 
 
+def test_svgd_many_particles(backend):
+    """particle_count > 16 (blocked path; fused options silently fall back to the base optimizer loop)."""
+    ops, dev = backend
+    torch.manual_seed(3)
+    model = nn.Linear(7, 2).to(dev)
+    base = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=20,
+                            dataset_size=50, l2_reg=0.01, fuse_base_optimizer=True, _ops=ops)
+    x, y = torch.randn(10, 7, device=dev), torch.randn(10, 2, device=dev)
+    before = opt.particles.clone()
+    for _ in range(2):
+        loss = opt.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
+    assert torch.isfinite(loss) and torch.isfinite(opt.particles).all()
+    assert not torch.equal(before, opt.particles)
+    # same two steps with the per-tensor reference arithmetic (oracle) on the CPU
+    import oracle.bde_oracle as O
+    P = before.cpu().clone()
+    buf = None
+    xc, yc = x.cpu(), y.cpu()
+    for _ in range(2):
+        G = torch.zeros_like(P)
+        for i in range(20):
+            w, b = P[i, :14].view(2, 7).clone().requires_grad_(), P[i, 14:].clone().requires_grad_()
+            F.mse_loss(F.linear(xc, w, b), yc).backward()
+            G[i] = torch.cat([w.grad.flatten(), b.grad])
+        neg_phi = -O.svgd_phi(P, G, 0.01, 1.0, 50.0)
+        for i in range(20):
+            g = neg_phi[i]
+            buf = g.clone() if buf is None else 0.9 * buf + g
+            P[i] -= 0.1 * buf
+    np.testing.assert_allclose(opt.particles.cpu().numpy(), P.numpy(), rtol=2e-4, atol=2e-6)
+
+
 def test_svgd_state_dict_roundtrip(backend):
     ops, dev = backend
     torch.manual_seed(0)
