@@ -27,10 +27,10 @@ __device__ __forceinline__ float lowrank_noise_b(const float* __restrict__ eps_w
   return z[c & 3];
 }
 
-constexpr int kBatchCH = 8;    // k-steps (2 ring rows each) whose loads are issued back to back
+constexpr int kBatchCH = 10;   // k-steps (2 ring rows each) whose loads are issued back to back
 
 template <bool RNG>
-__global__ __launch_bounds__(kBlock, 2) void swag_sample_batched_kernel(
+__global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
     const float* __restrict__ mean, const float* __restrict__ sq, const float* __restrict__ dev, int K, int64_t ld,
     int head, const float* __restrict__ eps_w, const float* __restrict__ eps_d, uint64_t seed, uint64_t stream0,
     float* __restrict__ out, int64_t ld_out, int S, int64_t D) {
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(kBlock, 2) void swag_sample_batched_kernel(
       f32x4 sd;
 #pragma unroll
       for (int c = 0; c < 4; ++c) sd[c] = __builtin_sqrtf(0.5f * (fmaxf(v[c], 0.0f) + 1e-6f));   // swag.py:112
-#pragma unroll
+      // rolled on purpose: unrolled, the 16 Philox chains cost > 240 VGPRs (2 waves/SIMD, spills at 3)
+#pragma unroll 1
       for (int reg = 0; reg < 16; ++reg) {
         const int s = (reg & 3) + 8 * (reg >> 2) + 4 * half;   // C/D row of the 32x32 tile
         if (s < S) {
@@ -96,8 +97,6 @@ __global__ __launch_bounds__(kBlock, 2) void swag_sample_batched_kernel(
           const f32x4 lr = {acc0[reg], acc1[reg], acc2[reg], acc3[reg]};
           st4_nt(out + static_cast<int64_t>(s) * ld_out + 4 * g4, (m + lr) + sd * z);
         }
-        // keep the 16 Philox chains from being interleaved (which costs > 250 VGPRs and spills)
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
