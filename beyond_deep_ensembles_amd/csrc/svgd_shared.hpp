@@ -10,7 +10,7 @@ constexpr int kGramMaxBlocks = 1024;       // 4 workgroups per CU: best measured
 // Per-particle Adam scalars of the SHARED step counter (advanced once per particle).
 struct AdamSteps {
   float step_size[BDE_MAX_PARTICLES];     // lr / (1 - beta1^t)
-  float bc2_sqrt[BDE_MAX_PARTICLES];      // sqrt(1 - beta2^t)
+  float bc2_sqrt[BDE_MAX_PARTICLES];      // 1 / sqrt(1 - beta2^t)
 };
 
 static inline AdamSteps make_adam_steps(double lr, double beta1, double beta2, int64_t step0) {
@@ -18,7 +18,7 @@ static inline AdamSteps make_adam_steps(double lr, double beta1, double beta2, i
   for (int i = 0; i < BDE_MAX_PARTICLES; ++i) {
     const double t = static_cast<double>(step0 + i + 1);
     st.step_size[i] = static_cast<float>(lr / (1.0 - std::pow(beta1, t)));
-    st.bc2_sqrt[i] = static_cast<float>(std::sqrt(1.0 - std::pow(beta2, t)));
+    st.bc2_sqrt[i] = static_cast<float>(1.0 / std::sqrt(1.0 - std::pow(beta2, t)));
   }
   return st;
 }
@@ -53,12 +53,14 @@ struct AdamParams {
   float beta1, beta2, omb1, omb2, eps, wd;
 };
 __device__ __forceinline__ float adam_apply(float p, float g, float& m, float& v, const AdamParams& k, float step_size,
-                                            float bc2_sqrt) {
+                                            float ibc2_sqrt) {
   if (k.wd != 0.f) g = __builtin_fmaf(k.wd, p, g);
   m = m + (g - m) * k.omb1;                             // exp_avg.lerp_(grad, 1 - beta1)
   v = __builtin_fmaf(k.omb2 * g, g, k.beta2 * v);       // mul_(beta2).addcmul_(g, g, value=1-beta2)
-  const float denom = __builtin_sqrtf(v) / bc2_sqrt + k.eps;
-  return p - step_size * (m / denom);
+  // hardware sqrt / reciprocal (1 ulp each) instead of the IEEE expansions: the M applications per element
+  // form one serial dependency chain (shared m, v), so their latency, not their count, sets the pace
+  const float denom = __builtin_amdgcn_sqrtf(v) * ibc2_sqrt + k.eps;
+  return p - step_size * (m * __builtin_amdgcn_rcpf(denom));
 }
 
 }  // namespace bde

@@ -199,7 +199,7 @@ def test_svgd_fused_optimizers_match_torch_shared_state(ops):
                 step0 += m
             want = torch.stack(rows)
             got = Pb[:, :d].cpu()
-            assert torch.allclose(got, want, rtol=2e-6, atol=2e-7), (kind, it, (got - want).abs().max())
+            assert torch.allclose(got, want, rtol=5e-6, atol=5e-7), (kind, it, (got - want).abs().max())
 
 
 def test_svgd_fused_equals_combine_plus_apply(ops):
