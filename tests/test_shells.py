@@ -655,3 +655,77 @@ def test_load_reference_svgd_checkpoint_and_resume(backend):
     loss = opt.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
     assert abs(float(loss) - nxt["loss"]) <= 2e-5 * abs(nxt["loss"])
     np.testing.assert_allclose(opt.particles.cpu().numpy(), nxt["particles_after"].numpy(), rtol=2e-5, atol=3e-6)
+
+
+# ------------------------------------------------------ integration (CNN) --
+class _SmallCNN(nn.Module):
+    def __init__(self, conv=None, linear=None):
+        super().__init__()
+        self.c1 = conv(3, 8, 3) if conv else nn.Conv2d(3, 8, 3, padding=1)
+        self.bn = nn.BatchNorm2d(8)
+        self.c2 = nn.Conv2d(8, 8, 3, padding=1, bias=False)
+        self.fc = linear(8, 5) if linear else nn.Linear(8, 5)
+
+    def forward(self, x):
+        x = F.relu(self.bn(self.c1(x)))
+        x = F.relu(self.c2(x)).mean(dim=(2, 3))
+        return F.log_softmax(self.fc(x), dim=1)
+
+
+@pytest.mark.parametrize("algo", ["svgd", "svgd_fused", "swag", "ivon", "bbb"])
+def test_cnn_training_loop_like_the_reference_drivers(backend, algo):
+    """The call sequence of the reference's train/eval loops (cifar.py:160-176, ensemble.py:28-44) on a small
+    conv net with BatchNorm: 4-D parameters, a bias-free conv, buffers that are not parameters."""
+    ops, dev = backend
+    torch.manual_seed(0)
+    prior = bde.GaussianPrior(0, 1.0)
+    if algo == "bbb":
+        model = _SmallCNN(conv=lambda i, o, k: bde.BBBConv2d(i, o, k, prior, prior, padding=1, _ops=ops),
+                          linear=lambda i, o: bde.BBBLinear(i, o, prior, prior, _ops=ops)).to(dev)
+    else:
+        model = _SmallCNN().to(dev)
+    params = list(model.parameters())
+    if algo.startswith("svgd"):
+        base = torch.optim.SGD(params, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)
+        opt = bde.SVGDOptimizer(params, lambda: bde.reset_model_params(model), base, particle_count=3, dataset_size=64,
+                                l2_reg=1e-5, fuse_base_optimizer=(algo == "svgd_fused"), reuse_gram=(algo == "svgd_fused"),
+                                _ops=ops)
+    elif algo == "swag":
+        base = torch.optim.SGD(params, lr=0.05, momentum=0.9)
+        opt = bde.SwagOptimizer(params, base, update_interval=2, start_epoch=1, deviation_samples=3, rng="philox", _ops=ops)
+    elif algo == "ivon":
+        opt = bde.iVONOptimizer(params, lr=1e-2, prior_prec=50.0, dataset_size=64, mc_samples=2, damping=1e-3,
+                                rng="philox", _ops=ops)
+        base = opt
+    else:
+        base = torch.optim.Adam(params, lr=1e-3)
+        opt = bde.BBBOptimizer(params, base, prior, dataset_size=64, mc_samples=2, kl_rescaling=0.2, _ops=ops)
+    sched = torch.optim.lr_scheduler.StepLR(opt.get_base_optimizer(), step_size=1, gamma=0.5)
+    ens = bde.DeepEnsemble([(model, opt)])
+    x = torch.randn(64, 3, 8, 8, generator=torch.Generator().manual_seed(1)).to(dev)
+    y = torch.randint(0, 5, (64,), generator=torch.Generator().manual_seed(2)).to(dev)
+    before = flat(params).clone()
+    losses = []
+    for epoch in range(3):
+        model.train()
+        for b in range(4):
+            xb, yb = x[b * 16:(b + 1) * 16], y[b * 16:(b + 1) * 16]
+            loss = opt.step(lambda: F.nll_loss(model(xb), yb), lambda l: l.backward())
+            losses.append(float(loss.detach()))
+        opt.complete_epoch()
+        sched.step()
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] * 1.5
+    assert not torch.equal(before, flat(params))
+    model.eval()
+    with torch.no_grad():
+        out = ens.predict(lambda m: m(x[:8]), 6)
+    assert out.shape == (6, 8, 5) and torch.isfinite(out).all()
+    if algo in ("swag", "ivon", "svgd", "svgd_fused"):
+        assert not torch.equal(out[0], out[1])              # different posterior samples / particles
+    # state_dict round trip through the ensemble container (ensemble.py:17-26)
+    sd = ens.state_dict()
+    assert set(sd) == {"models", "optimizers"} and len(sd["optimizers"]) == 1
+    # training continues after evaluation (SWAG restores its weights, swag.py:38)
+    model.train()
+    loss = opt.step(lambda: F.nll_loss(model(x[:16]), y[:16]), lambda l: l.backward())
+    assert torch.isfinite(loss)
