@@ -38,6 +38,25 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _on_device_of(method):
+    """Run a HipOps method with the device of its first tensor argument current, so that the kernel is
+    enqueued on THAT device's current torch stream (multi-GPU processes)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        dev = None
+        for a in args:
+            if torch.is_tensor(a):
+                dev = a.device
+                break
+        if dev is None or dev.type != "cuda" or dev.index == torch.cuda.current_device():
+            return method(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
 def _check(rc: int, what: str):
     if rc != 0:
         raise BdeKernelError(f"{what} failed with code {rc}" + (" (invalid argument)" if rc == -1 else " (hipError)"))
@@ -70,14 +89,17 @@ class HipOps:
     def svgd_kstat(self, m: int, device) -> torch.Tensor:
         return torch.zeros(self.lib.bde_svgd_kstat_floats(m), dtype=torch.float32, device=device)
 
+    @_on_device_of
     def svgd_gram(self, P, d, ws):
         m = P.shape[0]
         _check(self.lib.bde_svgd_gram(_ptr(P, "P"), m, d, _ld(P), _ptr(ws), _stream()), "bde_svgd_gram")
 
+    @_on_device_of
     def svgd_kstats(self, ws, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override=0.0, mode=0):
         _check(self.lib.bde_svgd_kstats(_ptr(ws), m, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, mode,
                                         _ptr(kstat), _stream()), "bde_svgd_kstats")
 
+    @_on_device_of
     def svgd_combine(self, P, G, out, d, kstat):
         m = P.shape[0]
         if G is not None and _ld(G) != _ld(P) or _ld(out) != _ld(P):
@@ -85,6 +107,7 @@ class HipOps:
         _check(self.lib.bde_svgd_combine(_ptr(P, "P"), _ptr(G, "G"), _ptr(out, "out"), m, d, _ld(P), _ptr(kstat),
                                          _stream()), "bde_svgd_combine")
 
+    @_on_device_of
     def svgd_step(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat):
         """out = sign * phi (svgd.py:86-89); out may alias G."""
         m = P.shape[0]
@@ -94,11 +117,13 @@ class HipOps:
                                       kernel_grad_scale, dataset_size, sign, _ptr(ws), _ptr(kstat), _stream()),
                "bde_svgd_step")
 
+    @_on_device_of
     def svgd_apply_sgd(self, P, grad, buf, d, lr, momentum, dampening, weight_decay, nesterov, first):
         _check(self.lib.bde_svgd_apply_sgd(_ptr(P), _ptr(grad), _ptr(buf), P.shape[0], d, _ld(P), lr, momentum,
                                            dampening, weight_decay, int(nesterov), int(first), _stream()),
                "bde_svgd_apply_sgd")
 
+    @_on_device_of
     def svgd_apply_adam(self, P, grad, exp_avg, exp_avg_sq, d, lr, beta1, beta2, eps, weight_decay, step0):
         _check(self.lib.bde_svgd_apply_adam(_ptr(P), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), P.shape[0], d,
                                             _ld(P), lr, beta1, beta2, eps, weight_decay, int(step0), _stream()),
@@ -107,12 +132,14 @@ class HipOps:
     def svgd_fused_gram_supported(self, m: int) -> bool:
         return bool(self.lib.bde_svgd_fused_gram_supported(m))
 
+    @_on_device_of
     def svgd_fused_sgd(self, P, G, buf, d, kstat, lr, momentum, dampening, weight_decay, nesterov, first, ws_next=None):
         """combine + M shared-state SGD applications in one pass; optionally the next step's Gram partials."""
         _check(self.lib.bde_svgd_fused_sgd(_ptr(P, "P"), _ptr(G, "G"), _ptr(buf), P.shape[0], d, _ld(P), _ptr(kstat),
                                            lr, momentum, dampening, weight_decay, int(nesterov), int(first),
                                            _ptr(ws_next), _stream()), "bde_svgd_fused_sgd")
 
+    @_on_device_of
     def svgd_fused_adam(self, P, G, exp_avg, exp_avg_sq, d, kstat, lr, beta1, beta2, eps, weight_decay, step0,
                         ws_next=None):
         _check(self.lib.bde_svgd_fused_adam(_ptr(P, "P"), _ptr(G, "G"), _ptr(exp_avg), _ptr(exp_avg_sq), P.shape[0], d,
@@ -120,15 +147,18 @@ class HipOps:
                                             _ptr(ws_next), _stream()), "bde_svgd_fused_adam")
 
     # ------------------------------------------------------------ SWAG --
+    @_on_device_of
     def swag_update(self, theta, mean, sq, dev_row, n, d):
         _check(self.lib.bde_swag_update(_ptr(theta, "theta"), _ptr(mean), _ptr(sq), _ptr(dev_row), int(n), d,
                                         _stream()), "bde_swag_update")
 
+    @_on_device_of
     def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0):
         k = dev.shape[0]
         _check(self.lib.bde_swag_sample(_ptr(mean), _ptr(sq), _ptr(dev), k, _ld(dev), head, _ptr(eps_w), _ptr(eps_d),
                                         seed, stream_id, _ptr(out), d, _stream()), "bde_swag_sample")
 
+    @_on_device_of
     def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0):
         k, s = dev.shape[0], out.shape[0]
         if eps_d is not None and _ld(eps_d) != _ld(out):
@@ -147,30 +177,36 @@ class HipOps:
     def reduce_ws(self, device) -> torch.Tensor:
         return torch.empty(self.lib.bde_reduce_ws_bytes() // 4, dtype=torch.float32, device=device)
 
+    @_on_device_of
     def gauss_draw_fwd(self, mean, rho, out, n, eps=None, seed=0, stream_id=0, eps_out=None):
         _check(self.lib.bde_gauss_draw_fwd(_ptr(mean), _ptr(rho), _ptr(eps), seed, stream_id, _ptr(out), _ptr(eps_out),
                                            n, _stream()), "bde_gauss_draw_fwd")
 
+    @_on_device_of
     def gauss_draw_bwd(self, g, rho, gmean, grho, n, eps=None, seed=0, stream_id=0, accumulate=False):
         _check(self.lib.bde_gauss_draw_bwd(_ptr(g), _ptr(rho), _ptr(eps), seed, stream_id, _ptr(gmean), _ptr(grho),
                                            int(accumulate), n, _stream()), "bde_gauss_draw_bwd")
 
+    @_on_device_of
     def gauss_kl(self, mean, rho, prior_mu, prior_sigma, n, ws, kl_out=None, gmean=None, grho=None, grad_scale=1.0,
                  grad_scale_dev=None, accumulate=False):
         _check(self.lib.bde_gauss_kl(_ptr(mean), _ptr(rho), prior_mu, prior_sigma, grad_scale, _ptr(grad_scale_dev),
                                      _ptr(gmean), _ptr(grho), int(accumulate), _ptr(kl_out), _ptr(ws), n, _stream()),
                "bde_gauss_kl")
 
+    @_on_device_of
     def l2(self, p, l2_scale, n, ws, val_out=None, g=None, grad_scale=1.0, grad_scale_dev=None, accumulate=False):
         _check(self.lib.bde_l2(_ptr(p), l2_scale, grad_scale, _ptr(grad_scale_dev), _ptr(g), int(accumulate),
                                _ptr(val_out), _ptr(ws), n, _stream()), "bde_l2")
 
     # ------------------------------------------------------------ iVON --
+    @_on_device_of
     def ivon_sample(self, mean, prec, param, delta_sum, n, n_eff, first, eps=None, seed=0, stream_id=0,
                     deterministic=False):
         _check(self.lib.bde_ivon_sample(_ptr(mean), _ptr(prec), _ptr(eps), seed, stream_id, n_eff, int(deterministic),
                                         int(first), _ptr(param), _ptr(delta_sum), n, _stream()), "bde_ivon_sample")
 
+    @_on_device_of
     def ivon_update(self, mean, momentum, prec, delta_sum, acc_grad, n, *, lam, n_eff, mc, beta1, beta2, t, lr,
                     damping):
         # Python-double scalar expressions exactly as ivorn.py:72-89 forms them
