@@ -289,8 +289,7 @@ __global__ __launch_bounds__(kBlock) void svgd_combine_kernel(const float* __res
     for (int i = 0; i < M; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      // streamed once: non-temporal loads/stores (+4 % measured; P often still hits in the
-      // Infinity Cache behind the Gram pass when traversed in the same forward order)
+      // streamed once: non-temporal loads/stores (+4 % measured)
       const f32x4 p = ld4_nt(P + j * ld + 4 * i4);
       if (HAS_G) {
         const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + j * ld + 4 * i4));

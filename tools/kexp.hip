@@ -91,6 +91,59 @@ __global__ __launch_bounds__(256) void gram_prefetch_kernel(const float* __restr
   }
 }
 
+// V1b: as V1, but only the first `thr4` float4 columns are loaded with allocating loads (to stay in the
+// Infinity Cache for the combine pass); the rest is streamed non-temporally.
+template <int U>
+__global__ __launch_bounds__(256) void gram_prefetch_nt_kernel(const float* __restrict__ P, int M, int64_t D, int64_t ld, float* __restrict__ ws, int64_t thr4) {
+  constexpr int W4 = 8, MP = 8;
+  __shared__ float tile[4][16][17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int prow = r16 & 7;
+  const int c4 = (r16 >> 3) * 4 + kq;
+  const bool valid = prow < M;
+  const float inv_m = 1.0f / (float)M;
+  const float* rowp = P + (int64_t)(valid ? prow : 0) * ld;
+  const int64_t tile4 = (int64_t)U * W4;
+  const int64_t n_tiles = (D / 4) / tile4;
+  const int64_t waves_total = (int64_t)gridDim.x * 4;
+  f32x4acc acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  f32x4 cur[U], nxt[U];
+  auto load = [&](int64_t tt, f32x4 (&v)[U]) {
+    const bool keep = (tt + 1) * tile4 <= thr4;       // wave-uniform
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = keep ? ld4(rowp + 4 * (tt * tile4 + c4 + u * W4)) : ld4_nt(rowp + 4 * (tt * tile4 + c4 + u * W4));
+  };
+  if (t < n_tiles) load(t, cur);
+  for (; t < n_tiles; t += waves_total) {
+    const int64_t tn = t + waves_total;
+    if (tn < n_tiles) load(tn, nxt);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = valid ? cur[u][j] : 0.f;
+        const float s = group_sum<2>(x);
+        const float q = valid ? (x - s * inv_m) : 0.f;
+        if ((j & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q, q, acc0, 0, 0, 0);
+        else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q, q, acc1, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][r16] = acc0[r] + acc1[r];
+  __syncthreads();
+  if (threadIdx.x < MP * MP) {
+    const int pi = threadIdx.x / MP, pj = threadIdx.x % MP;
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w) s += tile[w][pi][pj] + tile[w][pi + 8][pj + 8];
+    ws[kWsHeaderFloats + (int64_t)blockIdx.x * 64 + threadIdx.x] = s;
+  }
+}
+
 // V2: VALU Gram with combine-style loads: each lane holds its column of all 8 rows; 36 pair products
 __global__ __launch_bounds__(256) void gram_valu_kernel(const float* __restrict__ P, int64_t D, int64_t ld, float* __restrict__ ws) {
   constexpr int M = 8;
@@ -235,6 +288,12 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL((combine_m_kernel<8, 0>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
   vs.push_back({"PAIR gram(pref g1024)+combine nt REV", [&] { hipLaunchKernelGGL(gram_prefetch_kernel<4>, dim3(1024), dim3(256), 0, st, P, M, D, ld, ws);
       hipLaunchKernelGGL((combine_m_kernel<8, 3>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
+  for (int64_t thrM : {0, 4, 6, 8, 10, 24}) {
+    const int64_t thr4 = thrM * 1000000 / 4;
+    vs.push_back({"PAIR gram(keep first " + std::to_string(thrM) + "M cols)+combine nt", [&, thr4] {
+        hipLaunchKernelGGL(gram_prefetch_nt_kernel<4>, dim3(1024), dim3(256), 0, st, P, M, D, ld, ws, thr4);
+        hipLaunchKernelGGL((combine_m_kernel<8, 0>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
+  }
   vs.push_back({"PAIR product gram + product combine", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, G, O, M, D, ld, ks, st); }, 4 * B});
   vs.push_back({"PAIR product gram + product combine INPLACE", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, O, O, M, D, ld, ks, st); }, 4 * B});
   vs.push_back({"PAIR product gram+kstats+combine", [&] { bde_svgd_step(P, G, O, M, D, ld, 0.f, 1.f, 129809.f, -1.f, ws, ks, st); }, 4 * B});
