@@ -240,6 +240,39 @@ __global__ __launch_bounds__(256) void combine_m_kernel(const float* __restrict_
   }
 }
 
+#define ST_ASM(NAME, MODS) __device__ __forceinline__ void NAME(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off " MODS :: "v"(p), "v"(v) : "memory"); }
+ST_ASM(st4_sc1, "sc1")
+ST_ASM(st4_sc0sc1, "sc0 sc1")
+ST_ASM(st4_sc0sc1nt, "sc0 sc1 nt")
+ST_ASM(st4_ntonly, "nt")
+template <int M, int SMODE>
+__global__ __launch_bounds__(256) void combine_s_kernel(const float* __restrict__ P, const float* G, float* out, int64_t D, int64_t ld,
+                                                        const float* __restrict__ cgT, const float* __restrict__ cpT) {
+  const int64_t n4 = D >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += stride) {
+    f32x4 acc[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) acc[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const f32x4 p = ld4_nt(P + j * ld + 4 * i4);
+      const f32x4 g = __builtin_nontemporal_load((const f32x4*)(G + j * ld + 4 * i4));
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        const float a = cgT[j * M + i], b = cpT[j * M + i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_fmaf(b, p[c], __builtin_fmaf(a, g[c], acc[i][c]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      float* q = out + i * ld + 4 * i4;
+      if (SMODE == 0) st4_sc1(q, acc[i]); else if (SMODE == 1) st4_sc0sc1(q, acc[i]); else if (SMODE == 2) st4_sc0sc1nt(q, acc[i]); else st4_ntonly(q, acc[i]);
+    }
+  }
+}
+
 struct Variant { std::string name; std::function<void()> fn; double bytes; };
 
 int main(int argc, char** argv) {
@@ -294,6 +327,10 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(gram_prefetch_nt_kernel<4>, dim3(1024), dim3(256), 0, st, P, M, D, ld, ws, thr4);
         hipLaunchKernelGGL((combine_m_kernel<8, 0>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
   }
+  vs.push_back({"PAIR gram + combine st sc1", [&] { bde_svgd_gram(P, M, D, ld, ws, st); hipLaunchKernelGGL((combine_s_kernel<8, 0>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
+  vs.push_back({"PAIR gram + combine st sc0 sc1", [&] { bde_svgd_gram(P, M, D, ld, ws, st); hipLaunchKernelGGL((combine_s_kernel<8, 1>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
+  vs.push_back({"PAIR gram + combine st sc0 sc1 nt", [&] { bde_svgd_gram(P, M, D, ld, ws, st); hipLaunchKernelGGL((combine_s_kernel<8, 2>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
+  vs.push_back({"PAIR gram + combine st nt(asm)", [&] { bde_svgd_gram(P, M, D, ld, ws, st); hipLaunchKernelGGL((combine_s_kernel<8, 3>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
   vs.push_back({"PAIR product gram + product combine", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, G, O, M, D, ld, ks, st); }, 4 * B});
   vs.push_back({"PAIR product gram + product combine INPLACE", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, O, O, M, D, ld, ks, st); }, 4 * B});
   vs.push_back({"PAIR product gram+kstats+combine", [&] { bde_svgd_step(P, G, O, M, D, ld, 0.f, 1.f, 129809.f, -1.f, ws, ks, st); }, 4 * B});
