@@ -542,3 +542,70 @@ def test_invalid_arguments_are_rejected(ops):
     P = torch.zeros(8, 66, device=DEV)
     with pytest.raises(BdeKernelError):
         ops.svgd_gram(P, 60, ops.svgd_ws(8, DEV))                               # ld not a multiple of 4 ... (66 % 4 != 0)
+
+
+def test_randomized_shapes_against_oracle(ops):
+    """Seeded fuzz over (M, D, K, S, head, alignment remainders): every op vs the CPU oracle."""
+    rng = np.random.default_rng(2024)
+    for trial in range(24):
+        m = int(rng.integers(1, 17))
+        d = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 127, 255, 1000, 4097, 8190, 33333]))
+        torch.manual_seed(trial)
+        # --- SVGD
+        P = torch.randn(m, d) * float(rng.choice([0.01, 0.05, 1.0]))
+        if rng.random() < 0.5 and d > 8:                     # shared backbone
+            P = P[:1].repeat(m, 1)
+            P[:, -max(1, d // 7):] += torch.randn(m, max(1, d // 7)) * 0.02
+        G = torch.randn(m, d) * 0.01
+        l2, scale, n = float(rng.choice([0.0, 1e-5, 0.01])), float(rng.choice([0.5, 1.0])), float(rng.choice([10.0, 5e4]))
+        out, ks = run_svgd(ops, P, G, l2, scale, n)
+        phi64 = O.svgd_phi(P.double(), G.double(), l2, scale, n).numpy()
+        ref32 = O.svgd_phi(P, G, l2, scale, n).numpy().astype(np.float64)
+        err_ref = np.max(np.abs(ref32 - phi64))
+        err = np.max(np.abs(-out.numpy() - phi64))
+        assert np.isfinite(err) and err <= max(2 * err_ref, 3e-6 * np.max(np.abs(phi64)) + 1e-12), (trial, m, d, err, err_ref)
+        # --- SWAG update + sample (+ batched)
+        k = int(rng.integers(2, 40))
+        head = int(rng.integers(0, k))
+        s_count = int(rng.integers(1, 33))
+        ld = (d + 63) // 64 * 64
+        theta0 = torch.randn(d) * 0.05
+        st = O.swag_init(theta0, k)
+        mean, sq = padded(st.mean), padded(st.sq_weights)
+        ring = torch.zeros(k, ld, device=DEV)
+        hd = 0
+        for nupd in range(1, int(rng.integers(2, k + 5))):
+            theta = theta0 + torch.randn(d) * 1e-2
+            st.updates = nupd
+            O.swag_moment_update(st, theta)
+            ops.swag_update(padded(theta), mean, sq, ring[hd], nupd, d)
+            hd = (hd + 1) % k
+        assert torch.equal(mean[:d].cpu(), st.mean) and torch.equal(sq[:d].cpu(), st.sq_weights)
+        logical = torch.stack([ring[(hd + c) % k, :d].cpu() for c in range(k)], dim=1)
+        assert torch.equal(logical, st.deviations), (trial, d, k)
+        ew, ed = torch.randn(s_count, k), torch.randn(s_count, d)
+        edb = torch.zeros(s_count, ld, device=DEV)
+        edb[:, :d] = ed.to(DEV)
+        outb = torch.zeros(s_count, ld, device=DEV)
+        ops.swag_sample_batched(mean, sq, ring, hd, outb, d, eps_w=ew.to(DEV), eps_d=edb)
+        o1 = torch.zeros(ld, device=DEV)
+        for s in range(0, s_count, max(1, s_count // 3)):
+            want = O.swag_sample(st.mean, st.sq_weights, st.deviations, ew[s], ed[s])
+            ops.swag_sample(mean, sq, ring, hd, o1, d, eps_w=ew[s].to(DEV), eps_d=edb[s])
+            assert torch.allclose(o1[:d].cpu(), want, rtol=3e-5, atol=3e-6), (trial, d, k, s)
+            assert torch.allclose(outb[s, :d].cpu(), want, rtol=3e-5, atol=3e-6), (trial, d, k, s)
+        # --- Gaussian KL + draw
+        mu, rho, eps = torch.randn(d) * 0.2, torch.randn(d) * 2 - 2, torch.randn(d)
+        psig = float(rng.choice([0.1, 1.0, 7.0]))
+        ws = ops.reduce_ws(DEV)
+        kl, gm, gr = torch.zeros(1, device=DEV), torch.zeros(ld, device=DEV), torch.zeros(ld, device=DEV)
+        ops.gauss_kl(padded(mu), padded(rho), 0.1, psig, d, ws, kl_out=kl, gmean=gm, grho=gr, grad_scale=0.5)
+        want = O.gauss_kl(mu.double(), rho.double(), 0.1, psig).item()
+        assert abs(kl.item() - want) <= 5e-6 * abs(want) + 1e-6, (trial, d)
+        wgm, wgr = O.gauss_kl_grads(mu.double(), rho.double(), 0.1, psig)
+        s64 = O.gauss_std(rho.double())
+        assert np.max(np.abs(gm[:d].cpu().numpy() - 0.5 * wgm.numpy())) <= 3e-6 * (np.max(np.abs(wgm.numpy())) + 1e-3)
+        assert np.max(np.abs(gr[:d].cpu().numpy() - 0.5 * wgr.numpy()) / (0.5 * (1 / s64 + s64 / psig ** 2)).numpy()) <= 5e-6
+        w = torch.zeros(ld, device=DEV)
+        ops.gauss_draw_fwd(padded(mu), padded(rho), w, d, eps=padded(eps))
+        assert torch.allclose(w[:d].cpu(), O.gauss_sample(mu, rho, eps), rtol=3e-6, atol=1e-6)
