@@ -125,7 +125,8 @@ int bde_svgd_apply_adam(float* P, const float* grad, float* exp_avg, float* exp_
  * written: (12*M + 8)*D bytes instead of (24*M + 8)*D.  If ws_next != NULL (M <= 8 only,
  * see bde_svgd_fused_gram_supported) the kernel also leaves the Gram partials of the
  * UPDATED particles in ws_next, in the format bde_svgd_kstats reads, so the next step can
- * skip bde_svgd_gram as long as nothing else modifies P in between. */
+ * skip bde_svgd_gram as long as nothing else modifies P in between.
+ * Single-tile path only: M <= BDE_FAST_PARTICLES. */
 int bde_svgd_fused_gram_supported(int M);
 int bde_svgd_fused_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
                        const float* kstat, double lr, double momentum, double dampening, double weight_decay,
