@@ -729,3 +729,26 @@ def test_cnn_training_loop_like_the_reference_drivers(backend, algo):
     model.train()
     loss = opt.step(lambda: F.nll_loss(model(x[:16]), y[:16]), lambda l: l.backward())
     assert torch.isfinite(loss)
+
+
+def test_svgd_fused_reuse_gram_tracks_unfused_over_many_steps(backend):
+    """30 steps: the one-pass path (fused optimizer + Gram carried from step to step) stays on the trajectory of
+    the three-launch path with the stock torch optimizer (no drift from reusing the previous kernel's Gram)."""
+    ops, dev = backend
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.randn(32, 13, generator=g).to(dev), torch.randn(32, 1, generator=g).to(dev)
+    runs = []
+    for fused in (False, True):
+        torch.manual_seed(12)
+        model = make_mlp().to(dev)
+        base = torch.optim.SGD(model.parameters(), lr=0.02, momentum=0.9, nesterov=True, weight_decay=1e-4)
+        opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=6,
+                                dataset_size=32, l2_reg=1e-4, fuse_base_optimizer=fused, reuse_gram=fused, _ops=ops)
+        sched = torch.optim.lr_scheduler.StepLR(base, step_size=10, gamma=0.5)     # LR schedule reaches the fused kernel
+        for t in range(30):
+            xb, yb = x[(t % 2) * 16:(t % 2 + 1) * 16], y[(t % 2) * 16:(t % 2 + 1) * 16]
+            opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+            sched.step()
+        runs.append(opt.particles.detach().cpu().clone())
+    assert torch.isfinite(runs[1]).all()
+    np.testing.assert_allclose(runs[1].numpy(), runs[0].numpy(), rtol=2e-3, atol=2e-5)
