@@ -19,6 +19,7 @@ Fixture list:
   ivon.npz            iVON trajectories with recorded noise (ivorn.py:41-115)
   ensemble.npz        DeepEnsemble.predict sample split     (ensemble.py:37-40)
   ref_*_checkpoint.pt state_dict()s written by the reference optimizers (wire compatibility)
+  rank1.npz           BBBOptimizer over the reference's Rank1Linear, 2 components, draws recorded
 """
 import math
 import os
@@ -375,6 +376,47 @@ def gen_ensemble():
     np.savez_compressed(os.path.join(OUT, "ensemble.npz"), rows=np.array(rows, dtype=np.int64))
 
 
+# ------------------------------------------------------------------ rank-1 BBB
+def gen_rank1():
+    """BBBOptimizer over the reference's Rank1Linear layers (rank1.py:9-80): two components, the
+    GaussianParameter.sample() draws recorded."""
+    import src.algos.rank1 as ref_rank1
+    out = {}
+    torch.manual_seed(61)
+    prior = ref_bbb.GaussianPrior(0, 1.0)
+    model = nn.Sequential(ref_rank1.Rank1Linear(13, 20, prior, components=2), nn.ReLU(),
+                          ref_rank1.Rank1Linear(20, 1, prior, components=2))
+    x, y = torch.randn(32, 13), torch.randn(32, 1)
+    params = list(model.parameters())
+    names = [n for n, _ in model.named_parameters()]
+    base = torch.optim.Adam(params, lr=5e-3)
+    opt = ref_bbb.BBBOptimizer(params, base, prior, dataset_size=32, mc_samples=1, kl_rescaling=1.0, components=2,
+                               l2_scale=1e-2)
+    tape = NoiseTape(23)
+    old = ref_util.normal_like
+    ref_util.normal_like = tape
+    for n, p in zip(names, params):
+        out[f"init/{n}"] = npy(p)
+    losses, traj = [], []
+    try:
+        for t in range(4):
+            xb, yb = x[(t % 2) * 16:(t % 2 + 1) * 16], y[(t % 2) * 16:(t % 2 + 1) * 16]
+            # one optimizer step = one forward per component, summed (the drivers' closure for rank-1 ensembles)
+            loss = opt.step(lambda: sum(F.mse_loss(model(xb), yb) for _ in range(2)), lambda l: l.backward())
+            losses.append(float(loss))
+            traj.append(flat(params))
+    finally:
+        ref_util.normal_like = old
+    out["names"] = np.array(names)
+    out["x"], out["y"] = npy(x), npy(y)
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["traj"] = npy(torch.stack(traj))
+    out["n_eps"] = np.array(len(tape.tape))
+    for i, e in enumerate(tape.tape):
+        out[f"eps_{i}"] = npy(e)
+    np.savez_compressed(os.path.join(OUT, "rank1.npz"), **out)
+
+
 # ------------------------------------------------------------------ checkpoints
 def gen_checkpoints():
     """state_dict()s written by the REFERENCE optimizers (data: tensors, counters and a pickled
@@ -422,6 +464,7 @@ if __name__ == "__main__":
     gen_ivon()
     gen_ensemble()
     gen_checkpoints()
+    gen_rank1()
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} B")

@@ -752,3 +752,37 @@ def test_svgd_fused_reuse_gram_tracks_unfused_over_many_steps(backend):
         runs.append(opt.particles.detach().cpu().clone())
     assert torch.isfinite(runs[1]).all()
     np.testing.assert_allclose(runs[1].numpy(), runs[0].numpy(), rtol=2e-3, atol=2e-5)
+
+
+def test_rank1_layers_reproduce_reference_trajectory(golden, backend):
+    """bde.Rank1Linear (the caller of GaussianParameter.sample(), rank1.py:51-52) + BBBOptimizer(components=2)
+    against the trajectory of the reference's Rank1Linear + BBBOptimizer, draws replayed."""
+    ops, dev = backend
+    g = golden("rank1.npz")
+    tape = [T(g[f"eps_{i}"]) for i in range(int(g["n_eps"]))]
+    prior = bde.GaussianPrior(0, 1.0)
+    model = nn.Sequential(bde.Rank1Linear(13, 20, prior, components=2, _ops=ops), nn.ReLU(),
+                          bde.Rank1Linear(20, 1, prior, components=2, _ops=ops)).to(dev)
+    for m in model.modules():
+        if isinstance(m, bde.GaussianParameter):
+            m.noise_source = lambda rho: tape.pop(0).to(rho.device)
+    names = [str(n) for n in g["names"]]
+    named = dict(model.named_parameters())
+    assert set(named) == set(names)
+    with torch.no_grad():
+        for n in names:
+            named[n].copy_(T(g[f"init/{n}"]).to(dev))
+    params = [named[n] for n in names]
+    opt = bde.BBBOptimizer(params, torch.optim.Adam(params, lr=5e-3), prior, dataset_size=32, mc_samples=1,
+                           kl_rescaling=1.0, components=2, l2_scale=1e-2, _ops=ops)
+    x, y = T(g["x"]).to(dev), T(g["y"]).to(dev)
+    for t in range(4):
+        xb, yb = x[(t % 2) * 16:(t % 2 + 1) * 16], y[(t % 2) * 16:(t % 2 + 1) * 16]
+        loss = opt.step(lambda: sum(F.mse_loss(model(xb), yb) for _ in range(2)), lambda l: l.backward())
+        assert abs(float(loss.detach()) - g["losses"][t]) <= 1e-5 * abs(g["losses"][t])
+        np.testing.assert_allclose(flat(params).cpu().numpy(), g["traj"][t], rtol=2e-4, atol=2e-5)
+    assert not tape and model[0].component_counter == 0
+    conv = bde.Rank1Conv2D(3, 4, 3, prior, padding=1, components=3, _ops=ops).to(dev)
+    assert conv(torch.randn(2, 3, 6, 6, device=dev)).shape == (2, 4, 6, 6) and conv.component_counter == 1
+    net = nn.Sequential(nn.Conv2d(3, 4, 3), nn.Flatten(), nn.Linear(4, 2)).to(dev)
+    assert bde.make_module_rank1(net, prior, components=2, _ops=ops) == 2
