@@ -24,9 +24,32 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .util import GaussianParameter, normal_like
+from .util import GaussianParameter, normal_like, _philox_stream
 
 _CLAMP = 1e-4
+
+
+class _LocalReparam(torch.autograd.Function):
+    """out = mean + sqrt(var) * eps with the fused HIP epilogue (bde_local_reparam_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, mean, var, eps, seed, stream_id, ops):
+        m, v = mean.contiguous().view(-1), var.contiguous().view(-1)
+        e = None if eps is None else eps.contiguous().view(-1)
+        out = torch.empty_like(m)
+        ops.local_reparam_fwd(m, v, out, m.numel(), eps=e, seed=seed, stream_id=stream_id)
+        ctx.save_for_backward(v, e)
+        ctx.meta = (seed, stream_id, ops, mean.shape)
+        return out.view(mean.shape)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        v, e = ctx.saved_tensors
+        seed, stream_id, ops, shape = ctx.meta
+        g = grad_out.contiguous().view(-1)
+        gvar = torch.empty_like(g)
+        ops.local_reparam_bwd(g, v, gvar, g.numel(), eps=e, seed=seed, stream_id=stream_id)
+        return grad_out, gvar.view(shape), None, None, None, None
 
 
 class _LocalReparamLayer(nn.Module):
@@ -38,6 +61,7 @@ class _LocalReparamLayer(nn.Module):
         self.freeze_on_eval = kwargs.get("freeze_on_eval", True)
         self.kl_on_eval = kwargs.get("kl_on_eval", False)
         self.use_bias = kwargs.get("bias", True)
+        self.fused_epilogue = kwargs.get("fused_epilogue", True)     # one HIP pass for mean + sqrt(var) * eps
         self.weight_prior, self.bias_prior = weight_prior, bias_prior
         gp_kwargs = {k: kwargs[k] for k in ("rng", "seed", "_ops") if k in kwargs}
         self.weight = GaussianParameter(weight_shape, **gp_kwargs)
@@ -67,7 +91,12 @@ class _LocalReparamLayer(nn.Module):
         return normal_like(mean)
 
     def _sample_activations(self, mean: torch.Tensor, var: torch.Tensor) -> torch.Tensor:
-        return mean + torch.sqrt(var) * self._noise(mean)
+        frozen = not self.training and self.freeze_on_eval
+        if frozen or not self.fused_epilogue or mean.dtype != torch.float32:
+            return mean + torch.sqrt(var) * self._noise(mean)       # stock PyTorch (eval: broadcast noise)
+        gp = self.weight
+        eps = None if gp.rng == "philox" and gp.noise_source is None else normal_like(mean)
+        return _LocalReparam.apply(mean, var, eps, gp.seed, next(_philox_stream), gp._get_ops())
 
 
 class BBBLinear(_LocalReparamLayer):

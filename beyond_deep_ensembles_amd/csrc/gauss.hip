@@ -125,6 +125,61 @@ __global__ __launch_bounds__(kBlock) void gauss_draw_bwd_scalar_kernel(const flo
   }
 }
 
+// -------------------------------------------------- local reparameterisation --
+// Epilogue of the mean-field layers (bbb_layers.py:70-80 of the reference): the two GEMMs / convs give the
+// pre-activation mean and variance, then  out = mean + sqrt(var) * eps  (4 ATen launches + autograd nodes
+// there: sqrt, normal_, mul, add).  One pass forward (12 B/element with in-kernel noise), one pass backward:
+//   g_mean = g,   g_var = g * eps / (2 sqrt(var)).
+template <bool RNG>
+__global__ __launch_bounds__(kBlock) void local_reparam_fwd_kernel(const float* __restrict__ mean,
+                                                                  const float* __restrict__ var,
+                                                                  const float* __restrict__ eps, uint64_t seed,
+                                                                  uint64_t stream_id, float* __restrict__ out,
+                                                                  int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 m = ld4_nt(mean + 4 * i), v = ld4_nt(var + 4 * i);
+    const f32x4 e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag) : ld4_nt(eps + 4 * i);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = m[j] + __builtin_sqrtf(v[j]) * e[j];
+    st4_nt(out + 4 * i, o);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t k = (n4 << 2) + threadIdx.x;
+    if (k < n) {
+      const float e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(n4), kDomainDiag)[threadIdx.x & 3] : eps[k];
+      out[k] = mean[k] + __builtin_sqrtf(var[k]) * e;
+    }
+  }
+}
+
+template <bool RNG>
+__global__ __launch_bounds__(kBlock) void local_reparam_bwd_kernel(const float* __restrict__ g,
+                                                                  const float* __restrict__ var,
+                                                                  const float* __restrict__ eps, uint64_t seed,
+                                                                  uint64_t stream_id, float* __restrict__ gvar,
+                                                                  int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 go = ld4_nt(g + 4 * i), v = ld4_nt(var + 4 * i);
+    const f32x4 e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag) : ld4_nt(eps + 4 * i);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (go[j] * e[j]) / (2.0f * __builtin_sqrtf(v[j]));
+    st4_nt(gvar + 4 * i, o);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t k = (n4 << 2) + threadIdx.x;
+    if (k < n) {
+      const float e = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(n4), kDomainDiag)[threadIdx.x & 3] : eps[k];
+      gvar[k] = (g[k] * e) / (2.0f * __builtin_sqrtf(var[k]));
+    }
+  }
+}
+
 // -------------------------------------------------------------------- KL --
 // Per element (bbb.py:20): 0.5 * (2 ln(sp/s) - 1 + (s/sp)^2 + ((mp - m)/sp)^2).
 // One exp, two hardware logs and two hardware reciprocals per element; the divisions by the
@@ -341,5 +396,31 @@ extern "C" int bde_l2(const float* p, float l2_scale, float grad_scale, const fl
   int rc = to_err(hipGetLastError());
   if (rc || !val_out) return rc;
   hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(kBlock), 0, s, part, 0.5f * l2_scale, val_out);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_local_reparam_fwd(const float* mean, const float* var, const float* eps, uint64_t seed,
+                                     uint64_t stream_id, float* out, int64_t n, void* stream) {
+  if (!mean || !var || !out || n <= 0) return BDE_ERR_INVALID;
+  if (!aligned16(mean) || !aligned16(var) || !aligned16(out) || (eps && !aligned16(eps))) return BDE_ERR_INVALID;
+  const int grid = stream_grid((n + 3) / 4);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (eps)
+    hipLaunchKernelGGL(local_reparam_fwd_kernel<false>, dim3(grid), dim3(kBlock), 0, s, mean, var, eps, seed, stream_id, out, n);
+  else
+    hipLaunchKernelGGL(local_reparam_fwd_kernel<true>, dim3(grid), dim3(kBlock), 0, s, mean, var, eps, seed, stream_id, out, n);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_local_reparam_bwd(const float* g, const float* var, const float* eps, uint64_t seed,
+                                     uint64_t stream_id, float* gvar, int64_t n, void* stream) {
+  if (!g || !var || !gvar || n <= 0) return BDE_ERR_INVALID;
+  if (!aligned16(g) || !aligned16(var) || !aligned16(gvar) || (eps && !aligned16(eps))) return BDE_ERR_INVALID;
+  const int grid = stream_grid((n + 3) / 4);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (eps)
+    hipLaunchKernelGGL(local_reparam_bwd_kernel<false>, dim3(grid), dim3(kBlock), 0, s, g, var, eps, seed, stream_id, gvar, n);
+  else
+    hipLaunchKernelGGL(local_reparam_bwd_kernel<true>, dim3(grid), dim3(kBlock), 0, s, g, var, eps, seed, stream_id, gvar, n);
   return to_err(hipGetLastError());
 }

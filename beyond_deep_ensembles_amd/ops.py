@@ -199,6 +199,16 @@ class HipOps:
         _check(self.lib.bde_l2(_ptr(p), l2_scale, grad_scale, _ptr(grad_scale_dev), _ptr(g), int(accumulate),
                                _ptr(val_out), _ptr(ws), n, _stream()), "bde_l2")
 
+    @_on_device_of
+    def local_reparam_fwd(self, mean, var, out, n, eps=None, seed=0, stream_id=0):
+        _check(self.lib.bde_local_reparam_fwd(_ptr(mean), _ptr(var), _ptr(eps), seed, stream_id, _ptr(out), n, _stream()),
+               "bde_local_reparam_fwd")
+
+    @_on_device_of
+    def local_reparam_bwd(self, g, var, gvar, n, eps=None, seed=0, stream_id=0):
+        _check(self.lib.bde_local_reparam_bwd(_ptr(g), _ptr(var), _ptr(eps), seed, stream_id, _ptr(gvar), n, _stream()),
+               "bde_local_reparam_bwd")
+
     # ------------------------------------------------------------ iVON --
     @_on_device_of
     def ivon_sample(self, mean, prec, param, delta_sum, n, n_eff, first, eps=None, seed=0, stream_id=0,

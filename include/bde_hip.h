@@ -209,6 +209,15 @@ int bde_gauss_kl(const float* mean, const float* rho, float prior_mu, float prio
 int bde_l2(const float* p, float l2_scale, float grad_scale, const float* grad_scale_dev, float* g,
            int accumulate, float* val_out, void* ws, int64_t n, void* stream);
 
+/* Epilogue of the local-reparameterisation layers (bbb_layers.py:70-80: activation_mean +
+ * sqrt(activation_var) * eps after the mean and variance GEMMs / convs), fused:
+ *   fwd: out = mean + sqrt(var) * eps          bwd: gvar = g * eps / (2 sqrt(var))   (gmean = g)
+ * eps == NULL: Philox(seed, stream_id) noise, regenerated in the backward call. */
+int bde_local_reparam_fwd(const float* mean, const float* var, const float* eps, uint64_t seed,
+                          uint64_t stream_id, float* out, int64_t n, void* stream);
+int bde_local_reparam_bwd(const float* g, const float* var, const float* eps, uint64_t seed,
+                          uint64_t stream_id, float* gvar, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------ iVON --
  * src/algos/ivorn.py:102-115 (weight-noise draw) and :66-89 (update). */
 

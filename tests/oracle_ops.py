@@ -172,6 +172,16 @@ class OracleOps:
             else:
                 g[:n] = c * l2_scale * p[:n]
 
+    def local_reparam_fwd(self, mean, var, out, n, eps=None, seed=0, stream_id=0):
+        if eps is None:
+            eps = torch.randn(mean.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+        out[:n] = mean[:n] + torch.sqrt(var[:n]) * eps[:n]
+
+    def local_reparam_bwd(self, g, var, gvar, n, eps=None, seed=0, stream_id=0):
+        if eps is None:
+            eps = torch.randn(var.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+        gvar[:n] = (g[:n] * eps[:n]) / (2 * torch.sqrt(var[:n]))
+
     # ------------------------------------------------------------ iVON --
     def ivon_sample(self, mean, prec, param, delta_sum, n, n_eff, first, eps=None, seed=0, stream_id=0,
                     deterministic=False):

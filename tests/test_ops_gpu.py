@@ -609,3 +609,25 @@ def test_randomized_shapes_against_oracle(ops):
         w = torch.zeros(ld, device=DEV)
         ops.gauss_draw_fwd(padded(mu), padded(rho), w, d, eps=padded(eps))
         assert torch.allclose(w[:d].cpu(), O.gauss_sample(mu, rho, eps), rtol=3e-6, atol=1e-6)
+
+
+def test_local_reparam_epilogue(ops):
+    """out = mean + sqrt(var) * eps and its backward vs torch autograd (bbb_layers.py:70-80 epilogue)."""
+    torch.manual_seed(12)
+    for n in (3, 64, 1000003):
+        mean = torch.randn(n, device=DEV, requires_grad=True)
+        var = (torch.rand(n, device=DEV) + 1e-4).requires_grad_()
+        eps, gout = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+        (mean + torch.sqrt(var) * eps).backward(gout)
+        out, gvar = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+        ops.local_reparam_fwd(mean.detach(), var.detach(), out, n, eps=eps)
+        ops.local_reparam_bwd(gout, var.detach(), gvar, n, eps=eps)
+        assert torch.allclose(out, (mean + torch.sqrt(var) * eps).detach(), rtol=1e-6, atol=1e-7)
+        assert torch.allclose(gvar, var.grad, rtol=2e-6, atol=1e-7)
+        # Philox: forward noise regenerated in backward
+        out2, gvar2, e2 = torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.zeros((n + 3) // 4 * 4, device=DEV)
+        ops.local_reparam_fwd(mean.detach(), var.detach(), out2, n, seed=3, stream_id=8)
+        ops.philox_normal(3, 8, eps_d=e2, d=n)
+        assert torch.allclose(out2, (mean + torch.sqrt(var) * e2[:n]).detach(), rtol=1e-6, atol=1e-7)
+        ops.local_reparam_bwd(gout, var.detach(), gvar2, n, seed=3, stream_id=8)
+        assert torch.allclose(gvar2, gout * e2[:n] / (2 * torch.sqrt(var.detach())), rtol=2e-6, atol=1e-7)

@@ -73,6 +73,13 @@ report("gauss_draw_bwd(philox,acc)", timeit(lambda: ops.gauss_draw_bwd(w, rho, g
 rws = ops.reduce_ws(dev); kl = torch.zeros(1, device=dev)
 report("gauss_kl fwd+bwd (write)", timeit(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, D, rws, kl_out=kl, gmean=gm, grho=gr)), 16 * D)
 report("gauss_kl fwd+bwd (acc)", timeit(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, D, rws, kl_out=kl, gmean=gm, grho=gr, accumulate=True)), 24 * D)
+var = torch.rand(ld, device=dev) + 1e-4
+report("local_reparam_fwd(philox)", timeit(lambda: ops.local_reparam_fwd(mean, var, w, D, seed=1, stream_id=0)), 12 * D)
+report("local_reparam_bwd(philox)", timeit(lambda: ops.local_reparam_bwd(w, var, gm, D, seed=1, stream_id=0)), 12 * D)
+def torch_epi():
+    e = torch.empty_like(mean).normal_()
+    return mean + torch.sqrt(var) * e
+report("  same epilogue, 4 torch ops", timeit(torch_epi), 12 * D)
 prec = torch.full((ld,), 100.0 / 129809, device=dev); ds = torch.zeros(ld, device=dev)
 report("ivon_sample(philox)", timeit(lambda: ops.ivon_sample(mean, prec, w, ds, D, 129809.0, first=False, seed=1, stream_id=0)), 20 * D)
 mom = torch.zeros(ld, device=dev)
