@@ -140,6 +140,8 @@ def extras(ops, dev, quick):
     rec("bbb_draw_fwd_resnet50", time_loop(lambda: ops.gauss_draw_fwd(mean, rho, w, d, seed=1, stream_id=0), it), 12 * d)
     rec("bbb_draw_bwd_resnet50", time_loop(lambda: ops.gauss_draw_bwd(w, rho, gm, gr, d, seed=1, stream_id=0, accumulate=True), it), 24 * d)
     rec("bbb_kl_fwd_bwd_resnet50", time_loop(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, d, rws, kl_out=kl, gmean=gm, grho=gr), it), 16 * d)
+    var = torch.rand(ld, device=dev) + 1e-4
+    rec("bbb_local_reparam_epilogue_fwd_resnet50", time_loop(lambda: ops.local_reparam_fwd(mean, var, w, d, seed=1, stream_id=0), it), 12 * d)
     # --- iVON
     prec = torch.full((ld,), 100.0 / DATASET_SIZE, device=dev)
     ds, mom = torch.zeros(ld, device=dev), torch.zeros(ld, device=dev)
