@@ -207,3 +207,52 @@ def test_bbb_ivon_fullsize(ops):
                              lr=1e-3, prior_prec=100.0, dataset_size=129809.0, damping=1e-3, mc_samples=2)
         for got, w in zip((m2, mo2, p2), want):
             assert torch.equal(got[sl].cpu(), w)
+
+
+# ---- the other BASELINE.json configs as parity cases -----------------------------------------------
+@pytest.mark.parametrize("name,d", [("cifar_resnet20", 273_610), ("camelyon_densenet121", 6_955_906)])
+def test_baseline_config_sizes_svgd_and_swag(ops, name, d):
+    """configs[1]/[2] (CIFAR-10 ResNet-20: SVGD 8 particles; SWAG K=20, 30 samples) and configs[4]
+    (Camelyon17 DenseNet-121 MultiSWAG: 5 modes x 30 samples) at their real parameter counts, HIP vs the CPU oracle."""
+    ld = (d + 16 + 63) // 64 * 64
+    g = torch.Generator().manual_seed(3)
+    P = torch.randn(M, d, generator=g) * 0.05
+    G = torch.randn(M, d, generator=g) * 0.01
+    Pb, Gb = torch.zeros(M, ld, device=DEV), torch.zeros(M, ld, device=DEV)
+    Pb[:, :d], Gb[:, :d] = P.to(DEV), G.to(DEV)
+    ws, ks = ops.svgd_ws(M, DEV), ops.svgd_kstat(M, DEV)
+    ops.svgd_step(Pb, Gb, Gb, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks)            # cifar.yaml-like: l2 3e-4, N 50,000
+    phi64 = O.svgd_phi(P.double(), G.double(), 3e-4, 1.0, 50000.0)
+    ref32 = O.svgd_phi(P, G, 3e-4, 1.0, 50000.0)
+    err = (-Gb[:, :d].cpu().double() - phi64).abs().max().item()
+    err_ref = (ref32.double() - phi64).abs().max().item()
+    assert err <= max(2 * err_ref, 3e-6 * phi64.abs().max().item()), (name, err, err_ref)
+    # SWAG: 25 updates, then samples of every "mode" with supplied noise vs the oracle; batched == unbatched
+    modes = 5 if "densenet" in name else 1
+    for mode in range(modes):
+        theta = torch.randn(d, generator=g) * 0.05
+        st = O.swag_init(theta, K)
+        mean, sq = torch.zeros(ld, device=DEV), torch.zeros(ld, device=DEV)
+        mean[:d], sq[:d] = st.mean.to(DEV), st.sq_weights.to(DEV)
+        ring = torch.zeros(K, ld, device=DEV)
+        th = torch.zeros(ld, device=DEV)
+        head = 0
+        for n in range(1, 26 if mode == 0 else 4):
+            theta = theta + torch.randn(d, generator=g) * 1e-3
+            st.updates = n
+            O.swag_moment_update(st, theta)
+            th[:d] = theta.to(DEV)
+            ops.swag_update(th, mean, sq, ring[head], n, d)
+            head = (head + 1) % K
+        assert torch.equal(mean[:d].cpu(), st.mean) and torch.equal(sq[:d].cpu(), st.sq_weights)
+        ew, ed = torch.randn(S, K, generator=g), torch.randn(S, d, generator=g)
+        edb = torch.zeros(S, ld, device=DEV)
+        edb[:, :d] = ed.to(DEV)
+        outb = torch.zeros(S, ld, device=DEV)
+        ops.swag_sample_batched(mean, sq, ring, head, outb, d, eps_w=ew.to(DEV), eps_d=edb)
+        out1 = torch.zeros(ld, device=DEV)
+        for s in (0, S - 1):
+            want = O.swag_sample(st.mean, st.sq_weights, st.deviations, ew[s], ed[s])
+            ops.swag_sample(mean, sq, ring, head, out1, d, eps_w=ew[s].to(DEV), eps_d=edb[s])
+            assert torch.allclose(out1[:d].cpu(), want, rtol=2e-5, atol=2e-6), (name, mode, s)
+            assert torch.allclose(outb[s, :d].cpu(), want, rtol=2e-5, atol=2e-6), (name, mode, s)
