@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbde_hip.so")
@@ -25,22 +25,28 @@ SIGNATURES = {
     "bde_svgd_kstat_floats": (c_size_t, [c_int]),
     "bde_svgd_gram": (c_int, [_P, c_int, c_int64, c_int64, _P, _P]),
     "bde_svgd_kstats": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
-    "bde_svgd_combine": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, _P, _P]),
+    "bde_svgd_gram_finish": (c_int, [_P, c_int, _P, _P]),
+    "bde_svgd_kstats_gmat": (c_int, [_P, c_int, c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
+    "bde_svgd_combine": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_int64, _P, _P]),
     "bde_svgd_step": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_float, c_float, c_float, c_float, _P, _P, _P]),
+    "bde_svgd_small_supported": (c_int, [c_int, c_int64]),
+    "bde_svgd_step_small": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
+                                    c_int, _P, _P, _P]),
     "bde_svgd_apply_sgd": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_double, c_double, c_double, c_double,
                                    c_int, c_int, _P]),
     "bde_svgd_apply_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, c_double, c_double, c_double, c_double,
                                     c_double, c_int64, _P]),
     "bde_svgd_fused_gram_supported": (c_int, [c_int]),
-    "bde_svgd_fused_sgd": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, _P, c_double, c_double, c_double, c_double,
+    "bde_svgd_fused_sgd": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_int64, _P, c_double, c_double, c_double, c_double,
                                    c_int, c_int, _P, _P]),
-    "bde_svgd_fused_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, _P, c_double, c_double, c_double,
+    "bde_svgd_fused_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, c_int64, _P, c_double, c_double, c_double,
                                     c_double, c_double, c_int64, _P, _P]),
     "bde_swag_update": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P]),
     "bde_swag_sample": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_swag_sample_batched": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64,
                                         c_int, c_int64, _P]),
     "bde_philox_normal": (c_int, [c_uint64, c_uint64, _P, c_int, _P, c_int64, _P]),
+    "bde_philox_bits": (c_int, [c_uint64, c_uint64, c_uint32, c_uint64, _P, c_int64, _P]),
     "bde_gauss_draw_fwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, c_int64, _P]),
     "bde_gauss_draw_bwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, c_int, c_int64, _P]),
     "bde_reduce_ws_bytes": (c_size_t, []),

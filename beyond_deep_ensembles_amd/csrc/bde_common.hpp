@@ -81,17 +81,25 @@ __device__ __forceinline__ double block_sum(double v, double* smem) {
 // Counter layout: (lo32(idx), hi32(idx), lo32(stream), hi32(stream) ^ domain),
 // key = seed.  `idx` is the float4 group index of the element, so the normal
 // attached to element e of stream s is a pure function of (seed, s, e).
+// The bijection is the published Philox4x32-10 (Salmon et al., SC'11; the
+// Random123 known-answer vectors are checked in tests/ through bde_philox_bits).
+// Per round: two v_mad_u64_u32 (hi and lo of a 32x32 product in one
+// instruction) and two v_bitop3_b32 (hi ^ c ^ key as ONE gfx950 instruction;
+// the compiler emits two v_xor_b32 for the same expression) -- 40 VALU
+// instructions per 128 random bits instead of 59.
 struct Philox {
   static constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  __device__ __forceinline__ static uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+  }
   __device__ __forceinline__ static uint4 round10(uint4 c, uint2 k) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-      // one 32x32->64 multiply per lane pair of outputs (v_mad_u64_u32) instead of mul_hi + mul_lo
       const uint64_t p0 = static_cast<uint64_t>(M0) * c.x, p1 = static_cast<uint64_t>(M1) * c.z;
       const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
       const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
-      c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-      k.x += W0;
+      c = make_uint4(xor3(hi1, c.y, k.x), lo1, xor3(hi0, c.w, k.y), lo0);
+      k.x += W0;      // the key schedule is wave-uniform: scalar adds
       k.y += W1;
     }
     return c;
@@ -100,26 +108,36 @@ struct Philox {
 
 enum : uint32_t { kDomainDiag = 0x0u, kDomainLowRank = 0x80000000u };
 
-// Four standard normals for float4 group `idx4` of stream `stream_id`.
-__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t stream_id, uint64_t idx4, uint32_t domain) {
+__device__ __forceinline__ uint4 philox_bits4(uint64_t seed, uint64_t stream_id, uint64_t idx4, uint32_t domain) {
   const uint4 c = make_uint4(static_cast<uint32_t>(idx4), static_cast<uint32_t>(idx4 >> 32),
                              static_cast<uint32_t>(stream_id), static_cast<uint32_t>(stream_id >> 32) ^ domain);
   const uint2 k = make_uint2(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
-  const uint4 r = Philox::round10(c, k);
-  // u in (0, 1]: (x + 1) * 2^-32 would round to 1.0f for large x only, never 0.
+  return Philox::round10(c, k);
+}
+
+// Box-Muller on the 24 high bits of each word.  u0, u2 in [2^-24, 1]: never zero or denormal,
+// so the bare hardware v_log_f32 / v_sqrt_f32 (1 ulp; the libm wrappers add ~12 instructions
+// of denormal scaling and Newton fix-up per call) are exact enough and the radius is at most
+// sqrt(2 * 24 ln 2) = 5.77.  v_sin_f32 / v_cos_f32 take their argument in revolutions.
+__device__ __forceinline__ f32x4 box_muller4(uint4 r) {
   const float u0 = (static_cast<float>(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);
   const float u1 = static_cast<float>(r.y >> 8) * (1.0f / 16777216.0f);
   const float u2 = (static_cast<float>(r.z >> 8) + 1.0f) * (1.0f / 16777216.0f);
   const float u3 = static_cast<float>(r.w >> 8) * (1.0f / 16777216.0f);
-  const float r0 = __builtin_sqrtf(-2.0f * __logf(u0));
-  const float r1 = __builtin_sqrtf(-2.0f * __logf(u2));
-  // v_sin_f32 / v_cos_f32 take their argument in revolutions
+  constexpr float kM2Ln2 = -1.3862943611198906f;                 // -2 ln 2: -2 ln(u) = kM2Ln2 * log2(u)
+  const float r0 = __builtin_amdgcn_sqrtf(kM2Ln2 * __builtin_amdgcn_logf(u0));
+  const float r1 = __builtin_amdgcn_sqrtf(kM2Ln2 * __builtin_amdgcn_logf(u2));
   f32x4 z;
   z.x = r0 * __builtin_amdgcn_cosf(u1);
   z.y = r0 * __builtin_amdgcn_sinf(u1);
   z.z = r1 * __builtin_amdgcn_cosf(u3);
   z.w = r1 * __builtin_amdgcn_sinf(u3);
   return z;
+}
+
+// Four standard normals for float4 group `idx4` of stream `stream_id`.
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t stream_id, uint64_t idx4, uint32_t domain) {
+  return box_muller4(philox_bits4(seed, stream_id, idx4, domain));
 }
 
 // softplus(rho) = torch.nn.functional.softplus (beta = 1, threshold = 20; util.py:183) and

@@ -22,67 +22,9 @@
 // fp32 ridge (~20 flop/B) -> HBM-bound; the MFMA is used for the Gram
 // contraction because it leaves the VALU free for the centring, not because
 // the kernel is matrix-bound.
-#include "svgd_shared.hpp"
+#include "svgd_gram.hpp"
 
 namespace bde {
-
-constexpr int kGramBlock = 256;            // 4 waves
-constexpr int kGramU = 4;                  // float4 loads in flight per lane per iteration
-
-using f32x4acc = __attribute__((ext_vector_type(4))) float;
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-
-// Sum over the 8 (PACK 2) or 16 (PACK 1) consecutive lanes that hold one
-// coordinate of all particles; every lane of the group gets the sum.
-template <int PACK>
-__device__ __forceinline__ float group_sum(float x) {
-  float s = x + dpp_mov<0xB1>(x);      // quad_perm [1,0,3,2]
-  s += dpp_mov<0x4E>(s);               // quad_perm [2,3,0,1]
-  s += dpp_mov<0x141>(s);              // row_half_mirror: 8 lanes
-  if (PACK == 1) s += dpp_mov<0x140>(s);   // row_mirror: 16 lanes
-  return s;
-}
-
-// One tile = kGramU float4 columns per lane.  Full tiles take the branch-free path; the ragged
-// last tile masks by index (never by multiplication: the row padding may hold NaNs).
-template <int W4>
-__device__ __forceinline__ void gram_load_tile(f32x4 (&v)[kGramU], const float* __restrict__ rowp, bool valid,
-                                               int64_t t, int64_t tile4, int c4, int64_t n4, int64_t D) {
-  const int64_t base4 = t * tile4 + c4;
-  if ((t + 1) * tile4 * 4 <= D) {                    // wave-uniform: every column full
-#pragma unroll
-    for (int u = 0; u < kGramU; ++u) v[u] = ld4(rowp + 4 * (base4 + u * W4));
-  } else {
-#pragma unroll
-    for (int u = 0; u < kGramU; ++u) {
-      const int64_t col = base4 + u * W4;
-      f32x4 x = {0.f, 0.f, 0.f, 0.f};
-      if (valid && col < n4) {
-        x = ld4(rowp + 4 * col);                     // in bounds: ld >= roundup4(D)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (4 * col + j >= D) x[j] = 0.f;
-      }
-      v[u] = x;
-    }
-  }
-}
-
-// PACK = 2: M <= 8, the 16 tile rows are (particle, d-chunk 0/1); PACK = 1: M <= 16.
-// Lanes of padded particle rows (prow >= M) read row 0 and are zeroed after the load, so the
-// hot loop has no divergent branches.  The next tile's loads are issued before this tile's
-// DPP/MFMA work (register double buffering).
-//
-// Row map (PACK = 1 only): tile rows 0..7 are particles rowA .. rowA+nA-1, tile rows 8..15 are particles
-// rowB .. rowB+nB-1.  M <= 16 uses (0, min(M,8), 8, M-8); the generic path (M > 16) launches one such
-// tile per PAIR of 8-particle groups, each into its own slice of ws (tile_slot).
-struct GramRows {
-  int rowA, nA, rowB, nB, tile_slot;
-};
 
 template <int PACK>
 __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __restrict__ P, int M, int64_t D,
@@ -163,25 +105,13 @@ __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __re
 // ---------------------------------------------------------------- kstats --
 constexpr int kStatsBlock = 1024;
 
-__global__ __launch_bounds__(kStatsBlock) void svgd_kstats_kernel(const float* __restrict__ ws, int M, float l2_reg,
-                                                                 float kernel_grad_scale, float dataset_size,
-                                                                 float sign, float h_override, float log_m1, int mode,
-                                                                 float* __restrict__ kstat) {
-  __shared__ double red[kStatsBlock];
-  __shared__ double gmat[256];
-  __shared__ float d2f[256];
-  __shared__ float sorted[256];
-  __shared__ float kmat[256];
-  __shared__ float rowsum[16];
-  __shared__ float hs[2];
-
+// Fixed-order fp64 reduction of the per-workgroup partial Gram tiles of `ws` into gmat [MP * MP] (LDS).
+__device__ __forceinline__ void reduce_gram_partials(const float* __restrict__ ws, double* red, double* gmat, int& MP_out) {
   const int nb = static_cast<int>(ws[0]);
   const int MP = static_cast<int>(ws[1]);
   const int mp2 = MP * MP;
   const float* part = ws + kWsHeaderFloats;
   const int tid = threadIdx.x;
-
-  // fixed-order fp64 reduction of the per-workgroup partial Gram tiles
   const int nslices = kStatsBlock / mp2;
   {
     // 8 independent accumulators keep 8 loads in flight (a single dependent chain made this
@@ -203,83 +133,50 @@ __global__ __launch_bounds__(kStatsBlock) void svgd_kstats_kernel(const float* _
     gmat[tid] = s;
   }
   __syncthreads();
+  MP_out = MP;
+}
 
-  const int n = M * M;
-  if (tid < n) {
-    const int i = tid / M, j = tid % M;
-    double d = gmat[i * MP + i] + gmat[j * MP + j] - 2.0 * gmat[i * MP + j];   // svgd.py:15
-    if (d < 0.0 || i == j) d = 0.0;
-    d2f[tid] = static_cast<float>(d);
-  }
-  __syncthreads();
-  // rank sort of the M*M distances (diagonal zeros included, svgd.py:18)
-  if (tid < n) {
-    const float v = d2f[tid];
-    int rank = 0;
-    for (int u = 0; u < n; ++u) {
-      const float o = d2f[u];
-      rank += (o < v || (o == v && u < tid)) ? 1 : 0;
-    }
-    sorted[rank] = v;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    // torch.quantile(d2, 0.5), 'linear' interpolation, fp32 like the reference
-    const float pos = 0.5f * static_cast<float>(n - 1);
-    const float lo = floorf(pos);
-    const float wgt = pos - lo;
-    const float a = sorted[static_cast<int>(lo)], b = sorted[static_cast<int>(ceilf(pos))];
-    const float med = (fabsf(wgt) < 0.5f) ? a + wgt * (b - a) : b - (b - a) * (1.0f - wgt);   // at::lerp
-    float h = __builtin_sqrtf((0.5f * med) / log_m1) + 1e-8f;                                 // svgd.py:18
-    if (h_override > 0.f) h = h_override;
-    hs[0] = h;
-    hs[1] = med;
-  }
-  __syncthreads();
-  const float h = hs[0];
-  if (tid < n) kmat[tid] = expf(-d2f[tid] / (2.0f * (h * h)));   // svgd.py:21
-  __syncthreads();
-  if (tid < M) {
-    float s = 0.f;
-    for (int j = 0; j < M; ++j) s += kmat[tid * M + j];
-    rowsum[tid] = s;
-  }
-  __syncthreads();
+__global__ __launch_bounds__(kStatsBlock) void svgd_kstats_kernel(const float* __restrict__ ws, int M, StatParams sp,
+                                                                 float* __restrict__ kstat) {
+  __shared__ double red[kStatsBlock];
+  __shared__ double gmat[256];
+  int MP;
+  reduce_gram_partials(ws, red, gmat, MP);
+  svgd_stats_core(gmat, M, MP, sp, kstat, nullptr, nullptr);
+}
 
-  const int oK = 0, oD2 = n, oRow = 2 * n, oMisc = 2 * n + M, oCG = oMisc + 4, oCP = oCG + n;
-  const double h2 = static_cast<double>(h) * static_cast<double>(h);
-  const double s_rep = static_cast<double>(kernel_grad_scale) / (static_cast<double>(dataset_size) * h2);
-  if (tid < n) {
-    const int i = tid / M, j = tid % M;
-    const double kij = kmat[tid];
-    const double rep = ((i == j) ? static_cast<double>(rowsum[i]) : 0.0) - kij;   // rowsum_i [i==j] - K_ij
-    double cg, cp;
-    if (mode == 0) {
-      // phi_i = sum_j -K_ij (G_j + l2/2 P_j) + s_rep * (rowsum_i P_i - K_ij P_j)   (svgd.py:86-89)
-      cg = static_cast<double>(sign) * (-kij);
-      cp = static_cast<double>(sign) * (-kij * (0.5 * static_cast<double>(l2_reg)) + s_rep * rep);
-    } else {
-      cg = 0.0;
-      cp = rep / h2;                                                              // svgd.py:23,31
-    }
-    kstat[oK + tid] = kmat[tid];
-    kstat[oD2 + tid] = d2f[tid];
-    kstat[oCG + j * M + i] = static_cast<float>(cg);
-    kstat[oCP + j * M + i] = static_cast<float>(cp);
+// Dimension-sharded multi-GPU update: every rank reduces the Gram partials of ITS column slice to an fp64
+// [MP, MP] matrix (gram_finish), the ranks exchange those (MP*MP doubles each), and every rank sums them in
+// rank order and evaluates the statistics (kstats_gmat) -- identical bits on all ranks.
+__global__ __launch_bounds__(kStatsBlock) void svgd_gram_finish_kernel(const float* __restrict__ ws,
+                                                                      double* __restrict__ gmat_out) {
+  __shared__ double red[kStatsBlock];
+  __shared__ double gmat[256];
+  int MP;
+  reduce_gram_partials(ws, red, gmat, MP);
+  if (threadIdx.x < 256) gmat_out[threadIdx.x] = (static_cast<int>(threadIdx.x) < MP * MP) ? gmat[threadIdx.x] : 0.0;
+  if (threadIdx.x == 0) gmat_out[256] = static_cast<double>(MP);
+}
+
+__global__ __launch_bounds__(256) void svgd_kstats_gmat_kernel(const double* __restrict__ gmats, int n_mats,
+                                                              int64_t mat_stride, int M, StatParams sp,
+                                                              float* __restrict__ kstat) {
+  __shared__ double gmat[256];
+  const int MP = static_cast<int>(gmats[256]);
+  if (static_cast<int>(threadIdx.x) < MP * MP) {
+    double s = 0.0;
+    for (int r = 0; r < n_mats; ++r) s += gmats[r * mat_stride + threadIdx.x];
+    gmat[threadIdx.x] = s;
   }
-  if (tid < M) kstat[oRow + tid] = rowsum[tid];
-  if (tid == 0) {
-    kstat[oMisc + 0] = h;
-    kstat[oMisc + 1] = hs[1];
-    kstat[oMisc + 2] = static_cast<float>(s_rep);
-    kstat[oMisc + 3] = static_cast<float>(M);
-  }
+  __syncthreads();
+  svgd_stats_core(gmat, M, MP, sp, kstat, nullptr, nullptr);
 }
 
 // --------------------------------------------------------------- combine --
 template <int M, bool HAS_G>
 __global__ __launch_bounds__(kBlock) void svgd_combine_kernel(const float* __restrict__ P, const float* G, float* out,
-                                                             int64_t D, int64_t ld, const float* __restrict__ cgT,
+                                                             int64_t D, int64_t ld, int64_t ldg,
+                                                             const float* __restrict__ cgT,
                                                              const float* __restrict__ cpT) {
   const int64_t n4 = D >> 2;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -292,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void svgd_combine_kernel(const float* __res
       // streamed once: non-temporal loads/stores (+4 % measured)
       const f32x4 p = ld4_nt(P + j * ld + 4 * i4);
       if (HAS_G) {
-        const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + j * ld + 4 * i4));
+        const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + j * ldg + 4 * i4));
 #pragma unroll
         for (int i = 0; i < M; ++i) {
           const float a = cgT[j * M + i];
@@ -319,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void svgd_combine_kernel(const float* __res
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         const float p = P[j * ld + e];
-        const float g = HAS_G ? G[j * ld + e] : 0.f;
+        const float g = HAS_G ? G[j * ldg + e] : 0.f;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
           if (HAS_G) acc[i] = __builtin_fmaf(cgT[j * M + i], g, acc[i]);
@@ -333,16 +230,16 @@ __global__ __launch_bounds__(kBlock) void svgd_combine_kernel(const float* __res
 }
 
 template <int M>
-static int launch_combine(const float* P, const float* G, float* out, int64_t D, int64_t ld, const float* kstat,
-                          hipStream_t s) {
+static int launch_combine(const float* P, const float* G, float* out, int64_t D, int64_t ld, int64_t ldg,
+                          const float* kstat, hipStream_t s) {
   const int n = M * M;
   const float* cg = kstat + 2 * n + M + 4;
   const float* cp = cg + n;
   const int grid = stream_grid((D + 3) / 4);
   if (G)
-    hipLaunchKernelGGL((svgd_combine_kernel<M, true>), dim3(grid), dim3(kBlock), 0, s, P, G, out, D, ld, cg, cp);
+    hipLaunchKernelGGL((svgd_combine_kernel<M, true>), dim3(grid), dim3(kBlock), 0, s, P, G, out, D, ld, ldg, cg, cp);
   else
-    hipLaunchKernelGGL((svgd_combine_kernel<M, false>), dim3(grid), dim3(kBlock), 0, s, P, G, out, D, ld, cg, cp);
+    hipLaunchKernelGGL((svgd_combine_kernel<M, false>), dim3(grid), dim3(kBlock), 0, s, P, G, out, D, ld, ldg, cg, cp);
   return to_err(hipGetLastError());
 }
 
@@ -598,18 +495,40 @@ extern "C" int bde_svgd_kstats(const void* ws, int M, float l2_reg, float kernel
     return to_err(hipGetLastError());
   }
   hipLaunchKernelGGL(svgd_kstats_kernel, dim3(1), dim3(kStatsBlock), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const float*>(ws), M, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, log_m1,
-                     mode, kstat);
+                     static_cast<const float*>(ws), M,
+                     StatParams{l2_reg, kernel_grad_scale, dataset_size, sign, h_override, log_m1, mode}, kstat);
   return to_err(hipGetLastError());
 }
 
-extern "C" int bde_svgd_combine(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
+extern "C" int bde_svgd_gram_finish(const void* ws, int M, double* gmat_out, void* stream) {
+  if (!ws || !gmat_out || M < 1 || M > BDE_FAST_PARTICLES) return BDE_ERR_INVALID;
+  hipLaunchKernelGGL(svgd_gram_finish_kernel, dim3(1), dim3(kStatsBlock), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(ws), gmat_out);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_svgd_kstats_gmat(const double* gmats, int n_mats, int64_t mat_stride, int M, float l2_reg,
+                                    float kernel_grad_scale, float dataset_size, float sign, float h_override, int mode,
+                                    float* kstat, void* stream) {
+  if (!gmats || n_mats < 1 || mat_stride < BDE_GMAT_DOUBLES || !kstat || M < 1 || M > BDE_FAST_PARTICLES ||
+      (mode != 0 && mode != 1))
+    return BDE_ERR_INVALID;
+  const float log_m1 = static_cast<float>(std::log(static_cast<double>(M) + 1.0));
+  hipLaunchKernelGGL(svgd_kstats_gmat_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), gmats, n_mats,
+                     mat_stride, M, StatParams{l2_reg, kernel_grad_scale, dataset_size, sign, h_override, log_m1, mode},
+                     kstat);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_svgd_combine(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld, int64_t ldg,
                                 const float* kstat, void* stream) {
+  if (ldg == 0) ldg = ld;
   if (!svgd_args_ok(P, M, D, ld) || !out || !kstat || !aligned16(out) || (G && !aligned16(G)) || out == P)
     return BDE_ERR_INVALID;
+  if (G && (ldg < D || (ldg & 3) || (out == G && ldg != ld))) return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M > BDE_FAST_PARTICLES) {
-    if (out == G) return BDE_ERR_INVALID;              // chunks of output rows re-read all of G
+    if (out == G || ldg != ld) return BDE_ERR_INVALID;  // chunks of output rows re-read all of G
     const int n = M * M;
     const float* cg = kstat + 2 * n + M + 4;
     const float* cp = cg + n;
@@ -628,7 +547,7 @@ extern "C" int bde_svgd_combine(const float* P, const float* G, float* out, int 
   switch (M) {
 #define BDE_CASE(m) \
   case m:           \
-    return launch_combine<m>(P, G, out, D, ld, kstat, s);
+    return launch_combine<m>(P, G, out, D, ld, ldg, kstat, s);
     BDE_CASE(1) BDE_CASE(2) BDE_CASE(3) BDE_CASE(4) BDE_CASE(5) BDE_CASE(6) BDE_CASE(7) BDE_CASE(8)
     BDE_CASE(9) BDE_CASE(10) BDE_CASE(11) BDE_CASE(12) BDE_CASE(13) BDE_CASE(14) BDE_CASE(15) BDE_CASE(16)
 #undef BDE_CASE
@@ -640,11 +559,14 @@ extern "C" int bde_svgd_step(const float* P, const float* G, float* out, int M, 
                              float kernel_grad_scale, float dataset_size, float sign, void* ws, float* kstat,
                              void* stream) {
   if (!G) return BDE_ERR_INVALID;
+  if (bde_svgd_small_supported(M, D))
+    return bde_svgd_step_small(P, G, out, M, D, ld, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, ws, kstat,
+                               stream);
   int rc = bde_svgd_gram(P, M, D, ld, ws, stream);
   if (rc) return rc;
   rc = bde_svgd_kstats(ws, M, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, kstat, stream);
   if (rc) return rc;
-  return bde_svgd_combine(P, G, out, M, D, ld, kstat, stream);
+  return bde_svgd_combine(P, G, out, M, D, ld, ld, kstat, stream);
 }
 
 extern "C" int bde_svgd_apply_sgd(float* P, const float* grad, float* momentum_buf, int M, int64_t D, int64_t ld,

@@ -24,7 +24,7 @@ constexpr int kFusedMaxBlocks = kGramMaxBlocks;   // the Gram partials go into t
 template <int M, int OPT /* 0 sgd, 1 adam */, bool GRAM>
 __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ P, const float* __restrict__ G,
                                                            float* __restrict__ s0, float* __restrict__ s1, int64_t D,
-                                                           int64_t ld, const float* __restrict__ cgT,
+                                                           int64_t ld, int64_t ldg, const float* __restrict__ cgT,
                                                            const float* __restrict__ cpT, SgdParams sk, AdamParams ak,
                                                            AdamSteps st, float* __restrict__ ws_next) {
   constexpr int NP = M * (M + 1) / 2;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       p[j] = ld4(P + j * ld + 4 * i4);
-      const f32x4 g = ld4_nt(G + j * ld + 4 * i4);
+      const f32x4 g = ld4_nt(G + j * ldg + 4 * i4);
 #pragma unroll
       for (int i = 0; i < M; ++i) {
         const float a = cgT[j * M + i], b = cpT[j * M + i];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         p[j] = P[j * ld + e];
-        const float g = G[j * ld + e];
+        const float g = G[j * ldg + e];
 #pragma unroll
         for (int i = 0; i < M; ++i) u[i] = __builtin_fmaf(cpT[j * M + i], p[j], __builtin_fmaf(cgT[j * M + i], g, u[i]));
       }
@@ -178,7 +178,8 @@ __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ 
 }
 
 template <int M, int OPT>
-static int launch_fused(float* P, const float* G, float* s0, float* s1, int64_t D, int64_t ld, const float* kstat,
+static int launch_fused(float* P, const float* G, float* s0, float* s1, int64_t D, int64_t ld, int64_t ldg,
+                        const float* kstat,
                         const SgdParams& sk, const AdamParams& ak, const AdamSteps& st, float* ws_next, hipStream_t s) {
   const int n = M * M;
   const float* cg = kstat + 2 * n + M + 4;
@@ -186,24 +187,24 @@ static int launch_fused(float* P, const float* G, float* s0, float* s1, int64_t 
   const int grid = stream_grid((D + 3) / 4, kBlock, kFusedMaxBlocks);
   if constexpr (M <= 8) {
     if (ws_next) {
-      hipLaunchKernelGGL((svgd_fused_kernel<M, OPT, true>), dim3(grid), dim3(kBlock), 0, s, P, G, s0, s1, D, ld, cg, cp,
-                         sk, ak, st, ws_next);
+      hipLaunchKernelGGL((svgd_fused_kernel<M, OPT, true>), dim3(grid), dim3(kBlock), 0, s, P, G, s0, s1, D, ld, ldg, cg,
+                         cp, sk, ak, st, ws_next);
       return to_err(hipGetLastError());
     }
   }
-  hipLaunchKernelGGL((svgd_fused_kernel<M, OPT, false>), dim3(grid), dim3(kBlock), 0, s, P, G, s0, s1, D, ld, cg, cp, sk,
-                     ak, st, static_cast<float*>(nullptr));
+  hipLaunchKernelGGL((svgd_fused_kernel<M, OPT, false>), dim3(grid), dim3(kBlock), 0, s, P, G, s0, s1, D, ld, ldg, cg, cp,
+                     sk, ak, st, static_cast<float*>(nullptr));
   return to_err(hipGetLastError());
 }
 
 template <int OPT>
-static int dispatch_fused(int M, float* P, const float* G, float* s0, float* s1, int64_t D, int64_t ld,
+static int dispatch_fused(int M, float* P, const float* G, float* s0, float* s1, int64_t D, int64_t ld, int64_t ldg,
                           const float* kstat, const SgdParams& sk, const AdamParams& ak, const AdamSteps& st,
                           float* ws_next, hipStream_t s) {
   switch (M) {
 #define BDE_CASE(m) \
   case m:           \
-    return launch_fused<m, OPT>(P, G, s0, s1, D, ld, kstat, sk, ak, st, ws_next, s);
+    return launch_fused<m, OPT>(P, G, s0, s1, D, ld, ldg, kstat, sk, ak, st, ws_next, s);
     BDE_CASE(1) BDE_CASE(2) BDE_CASE(3) BDE_CASE(4) BDE_CASE(5) BDE_CASE(6) BDE_CASE(7) BDE_CASE(8)
     BDE_CASE(9) BDE_CASE(10) BDE_CASE(11) BDE_CASE(12) BDE_CASE(13) BDE_CASE(14) BDE_CASE(15) BDE_CASE(16)
 #undef BDE_CASE
@@ -218,28 +219,32 @@ using namespace bde;
 extern "C" int bde_svgd_fused_gram_supported(int M) { return (M >= 1 && M <= 8) ? 1 : 0; }
 
 extern "C" int bde_svgd_fused_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
-                                  const float* kstat, double lr, double momentum, double dampening,
+                                  int64_t ldg, const float* kstat, double lr, double momentum, double dampening,
                                   double weight_decay, int nesterov, int first, void* ws_next, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || M > BDE_FAST_PARTICLES || !G || !kstat || !aligned16(G) ||
       (momentum != 0.0 && !momentum_buf))
     return BDE_ERR_INVALID;
+  if (ldg == 0) ldg = ld;
+  if (ldg < D || (ldg & 3)) return BDE_ERR_INVALID;
   if (ws_next && (M > 8 || !aligned16(ws_next))) return BDE_ERR_INVALID;
   const SgdParams sk{static_cast<float>(lr), static_cast<float>(momentum), static_cast<float>(1.0 - dampening),
                      static_cast<float>(weight_decay), nesterov, first};
-  return dispatch_fused<0>(M, P, G, momentum_buf, nullptr, D, ld, kstat, sk, AdamParams{}, AdamSteps{},
+  return dispatch_fused<0>(M, P, G, momentum_buf, nullptr, D, ld, ldg, kstat, sk, AdamParams{}, AdamSteps{},
                            static_cast<float*>(ws_next), static_cast<hipStream_t>(stream));
 }
 
 extern "C" int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D,
-                                   int64_t ld, const float* kstat, double lr, double beta1, double beta2, double eps,
+                                   int64_t ld, int64_t ldg, const float* kstat, double lr, double beta1, double beta2, double eps,
                                    double weight_decay, int64_t step0, void* ws_next, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || M > BDE_FAST_PARTICLES || !G || !kstat || !aligned16(G) || !exp_avg ||
       !exp_avg_sq || step0 < 0)
     return BDE_ERR_INVALID;
+  if (ldg == 0) ldg = ld;
+  if (ldg < D || (ldg & 3)) return BDE_ERR_INVALID;
   if (ws_next && (M > 8 || !aligned16(ws_next))) return BDE_ERR_INVALID;
   const AdamParams ak{static_cast<float>(beta1), static_cast<float>(beta2), static_cast<float>(1.0 - beta1),
                       static_cast<float>(1.0 - beta2), static_cast<float>(eps), static_cast<float>(weight_decay)};
-  return dispatch_fused<1>(M, P, G, exp_avg, exp_avg_sq, D, ld, kstat, SgdParams{}, ak,
+  return dispatch_fused<1>(M, P, G, exp_avg, exp_avg_sq, D, ld, ldg, kstat, SgdParams{}, ak,
                            make_adam_steps(lr, beta1, beta2, step0), static_cast<float*>(ws_next),
                            static_cast<hipStream_t>(stream));
 }

@@ -135,6 +135,18 @@ __global__ __launch_bounds__(kBlock) void philox_normal_kernel(uint64_t seed, ui
   }
 }
 
+__global__ __launch_bounds__(kBlock) void philox_bits_kernel(uint64_t seed, uint64_t stream_id, uint32_t domain,
+                                                            uint64_t idx0, uint32_t* __restrict__ out, int64_t n_groups) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
+    const uint4 r = philox_bits4(seed, stream_id, idx0 + static_cast<uint64_t>(g), domain);
+    out[4 * g + 0] = r.x;
+    out[4 * g + 1] = r.y;
+    out[4 * g + 2] = r.z;
+    out[4 * g + 3] = r.w;
+  }
+}
+
 }  // namespace bde
 
 using namespace bde;
@@ -173,5 +185,13 @@ extern "C" int bde_philox_normal(uint64_t seed, uint64_t stream_id, float* eps_w
   const int grid = stream_grid(eps_d ? (D + 3) / 4 : K);
   hipLaunchKernelGGL(philox_normal_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), seed,
                      stream_id, eps_w, K, eps_d, D);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_philox_bits(uint64_t seed, uint64_t stream_id, uint32_t domain, uint64_t idx0, uint32_t* out,
+                               int64_t n_groups, void* stream) {
+  if (!out || n_groups < 1) return BDE_ERR_INVALID;
+  hipLaunchKernelGGL(philox_bits_kernel, dim3(stream_grid(n_groups)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     seed, stream_id, domain, idx0, out, n_groups);
   return to_err(hipGetLastError());
 }

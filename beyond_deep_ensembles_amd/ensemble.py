@@ -23,16 +23,26 @@ def split_samples(samples: int, members: int) -> List[int]:
 
 
 def fan_out(samples: int, members: int, rank: int, world_size: int) -> List[Tuple[int, int, int]]:
-    """The (unit index, member, sample-within-member) triples this rank owns:
-    units are numbered in the reference's output order and dealt round-robin."""
+    """The (unit index, member, sample-within-member) triples this rank owns.  Units are numbered in the
+    reference's output order (member 0's samples, then member 1's, ...) and every rank takes ONE contiguous
+    range of them, so a rank touches at most two neighbouring members when there are at least as many units per
+    member as per rank (MultiSWAG 5 x 30 over 8 GPUs: 18-19 units per rank): it needs only those members'
+    statistics in HBM, and each of its member blocks is one pass of the batched sampler."""
+    lo = samples * rank // world_size
+    hi = samples * (rank + 1) // world_size
     units = []
     u = 0
     for member, count in enumerate(split_samples(samples, members)):
         for s in range(count):
-            if u % world_size == rank:
+            if lo <= u < hi:
                 units.append((u, member, s))
             u += 1
     return units
+
+
+def members_needed(samples: int, members: int, rank: int, world_size: int) -> List[int]:
+    """Indices of the ensemble members whose posterior this rank samples from (see ``fan_out``)."""
+    return sorted({member for _, member, _ in fan_out(samples, members, rank, world_size)})
 
 
 class DeepEnsemble(nn.Module):
@@ -42,19 +52,25 @@ class DeepEnsemble(nn.Module):
 
     def __init__(self, models_and_optimizers):
         super().__init__()
-        self.models = nn.ModuleList(list(map(lambda p: p[0], models_and_optimizers)))
-        self.optimizers = list(map(lambda p: p[1], models_and_optimizers))
+        pairs = list(models_and_optimizers)
+        # the models are registered sub-modules (their weights appear in parameters() / state_dict()); the
+        # optimizers are plain attributes, kept in the same order (ensemble.py:12-15)
+        self.models = nn.ModuleList([model for model, _ in pairs])
+        self.optimizers = [optimizer for _, optimizer in pairs]
 
+    @property
+    def models_and_optimizers(self):
+        return list(zip(self.models, self.optimizers))
+
+    # checkpoint layout of the reference (ensemble.py:17-26): {"models": ModuleList state, "optimizers": [state, ...]}
     def state_dict(self, prefix='', keep_vars=False):
-        return {
-            "models": self.models.state_dict(prefix=prefix, keep_vars=keep_vars),
-            "optimizers": list(map(lambda o: o.state_dict(), self.optimizers)),
-        }
+        optimizer_states = [optimizer.state_dict() for optimizer in self.optimizers]
+        return {"models": self.models.state_dict(prefix=prefix, keep_vars=keep_vars), "optimizers": optimizer_states}
 
     def load_state_dict(self, state_dict, strict=True):
         self.models.load_state_dict(state_dict["models"], strict=strict)
-        for optimizer, optimizer_state in zip(self.optimizers, state_dict["optimizers"]):
-            optimizer.load_state_dict(optimizer_state)
+        for optimizer, saved in zip(self.optimizers, state_dict["optimizers"]):
+            optimizer.load_state_dict(saved)
 
     def predict(self, predict_closure, samples, multisample=False, *, rank=0, world_size=1):
         '''
@@ -62,30 +78,27 @@ class DeepEnsemble(nn.Module):
             and makes a single prediction with it; sample_parameters() is called here (ensemble.py:28-44).
 
             With world_size > 1 only this rank's share of the (member, sample) units is evaluated; the
-            result holds them in unit order (see fan_out()).
+            result holds them in unit order (see fan_out()).  Every member's sampler ends where the
+            single-process call would leave it, on every rank, whatever the world size.
         '''
         if len(self.models) == 1 and getattr(self.models[0], "supports_multisample", False) and multisample:
             return predict_closure(self.models[0], n_samples=samples)
 
+        counts = split_samples(samples, len(self.models))
+        mine = fan_out(samples, len(self.models), rank, world_size)
         output = []
-        if world_size == 1:
-            for (model, optimizer), model_samples in zip(self.models_and_optimizers,
-                                                         split_samples(samples, len(self.models))):
+        for member, ((model, optimizer), count) in enumerate(zip(self.models_and_optimizers, counts)):
+            own = [s for _, mem, s in mine if mem == member]           # a contiguous range of this member's samples
+            start = _sampler_position(optimizer)
+            if own:
+                _seek_sampler(optimizer, start, own[0])
                 prefetch = getattr(optimizer, "prefetch_samples", None)
                 if prefetch is not None:
-                    prefetch(model_samples)      # SWAG, rng="philox": all of this member's samples in one pass
-                for _ in range(model_samples):
+                    prefetch(len(own))           # SWAG, rng="philox": this block's samples in one batched MFMA pass
+                for _ in own:
                     optimizer.sample_parameters()
                     output.append(predict_closure(model))
-        else:
-            pairs = self.models_and_optimizers
-            for _, member, s in fan_out(samples, len(self.models), rank, world_size):
-                model, optimizer = pairs[member]
-                # per-(member, sample) RNG stream so the result is independent of the GPU count
-                if hasattr(optimizer, "_sample_counter"):
-                    optimizer._sample_counter = s
-                optimizer.sample_parameters()
-                output.append(predict_closure(model))
+            _seek_sampler(optimizer, start, count)                     # where the single-process loop ends
         return torch.stack(output)
 
     def predict_distributed(self, predict_closure, samples, process_group=None):
@@ -122,6 +135,25 @@ class DeepEnsemble(nn.Module):
                 out[u] = gathered[r * most + j]
         return out
 
-    @property
-    def models_and_optimizers(self):
-        return list(zip(self.models, self.optimizers))
+
+def _sampler_position(optimizer):
+    """Where the optimizer's sample sequence stands: the Philox stream counter of a SWAG optimizer, the
+    round-robin particle index of an SVGD optimizer (svgd.py:107-112); None for samplers without a position."""
+    if hasattr(optimizer, "_sample_counter"):
+        return optimizer._sample_counter
+    state = getattr(optimizer, "state", None)
+    if state is not None and "__current_particle" in state:
+        return state["__current_particle"]
+    return None
+
+
+def _seek_sampler(optimizer, start, offset):
+    """Position the sampler ``offset`` draws after ``start``."""
+    if start is None:
+        return
+    if hasattr(optimizer, "_sample_counter"):
+        optimizer._sample_counter = start + offset
+        if getattr(optimizer, "_prefetched", None) is not None:
+            optimizer._prefetched = None
+    else:
+        optimizer.state["__current_particle"] = (start + offset) % optimizer.state["__particle_count"]

@@ -84,7 +84,7 @@ class HipOps:
         n = self.lib.bde_svgd_ws_bytes(m)
         if n == 0:
             raise BdeKernelError(f"SVGD supports 1 <= particle_count <= 64, got {m}")
-        return torch.empty(n // 4, dtype=torch.float32, device=device)
+        return torch.zeros(n // 4, dtype=torch.float32, device=device)    # the header must start out zero
 
     def svgd_kstat(self, m: int, device) -> torch.Tensor:
         return torch.zeros(self.lib.bde_svgd_kstat_floats(m), dtype=torch.float32, device=device)
@@ -99,13 +99,33 @@ class HipOps:
         _check(self.lib.bde_svgd_kstats(_ptr(ws), m, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, mode,
                                         _ptr(kstat), _stream()), "bde_svgd_kstats")
 
+    GMAT_DOUBLES = 257
+
+    @_on_device_of
+    def svgd_gram_finish(self, ws, m, gmat_out):
+        """Partials of ``ws`` -> fp64 Gram block ``gmat_out [257]`` (dimension-sharded exchange)."""
+        if gmat_out.dtype != torch.float64 or not gmat_out.is_cuda or gmat_out.numel() < self.GMAT_DOUBLES:
+            raise BdeKernelError("gmat_out: expected a CUDA float64 tensor with >= 257 elements")
+        _check(self.lib.bde_svgd_gram_finish(_ptr(ws), m, gmat_out.data_ptr(), _stream()), "bde_svgd_gram_finish")
+
+    @_on_device_of
+    def svgd_kstats_gmat(self, gmats, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override=0.0, mode=0):
+        """Statistics from the ranks' Gram blocks ``gmats [n, >= 257]`` (float64), summed in row order."""
+        if gmats.dtype != torch.float64 or not gmats.is_cuda or gmats.dim() != 2 or gmats.stride(1) != 1:
+            raise BdeKernelError("gmats: expected a CUDA float64 [n, >= 257] tensor")
+        _check(self.lib.bde_svgd_kstats_gmat(gmats.data_ptr(), gmats.shape[0], gmats.stride(0), m, l2_reg,
+                                             kernel_grad_scale, dataset_size, sign, h_override, mode, _ptr(kstat),
+                                             _stream()), "bde_svgd_kstats_gmat")
+
     @_on_device_of
     def svgd_combine(self, P, G, out, d, kstat):
+        """out = CG @ G + CP @ P over the first d columns; P / out may be column-offset views of the flat buffers
+        (same row stride), G may have its own row stride (a staging buffer of the multi-GPU exchange)."""
         m = P.shape[0]
-        if G is not None and _ld(G) != _ld(P) or _ld(out) != _ld(P):
-            raise BdeKernelError("P, G, out must share one leading dimension")
-        _check(self.lib.bde_svgd_combine(_ptr(P, "P"), _ptr(G, "G"), _ptr(out, "out"), m, d, _ld(P), _ptr(kstat),
-                                         _stream()), "bde_svgd_combine")
+        if _ld(out) != _ld(P):
+            raise BdeKernelError("P and out must share one leading dimension")
+        _check(self.lib.bde_svgd_combine(_ptr(P, "P"), _ptr(G, "G"), _ptr(out, "out"), m, d, _ld(P),
+                                         _ld(G) if G is not None else 0, _ptr(kstat), _stream()), "bde_svgd_combine")
 
     @_on_device_of
     def svgd_step(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat):
@@ -116,6 +136,20 @@ class HipOps:
         _check(self.lib.bde_svgd_step(_ptr(P, "P"), _ptr(G, "G"), _ptr(out, "out"), m, d, _ld(P), l2_reg,
                                       kernel_grad_scale, dataset_size, sign, _ptr(ws), _ptr(kstat), _stream()),
                "bde_svgd_step")
+
+    def svgd_small_supported(self, m: int, d: int) -> bool:
+        return bool(self.lib.bde_svgd_small_supported(m, d))
+
+    @_on_device_of
+    def svgd_step_small(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat, h_override=0.0,
+                        mode=0):
+        """The whole update in one persistent launch (small models); mode 1 = rbf's grad_kernel (G may be None)."""
+        m = P.shape[0]
+        if (G is not None and _ld(G) != _ld(P)) or _ld(out) != _ld(P):
+            raise BdeKernelError("P, G, out must share one leading dimension")
+        _check(self.lib.bde_svgd_step_small(_ptr(P, "P"), _ptr(G, "G"), _ptr(out, "out"), m, d, _ld(P), l2_reg,
+                                            kernel_grad_scale, dataset_size, sign, h_override, mode, _ptr(ws),
+                                            _ptr(kstat), _stream()), "bde_svgd_step_small")
 
     @_on_device_of
     def svgd_apply_sgd(self, P, grad, buf, d, lr, momentum, dampening, weight_decay, nesterov, first):
@@ -135,7 +169,7 @@ class HipOps:
     @_on_device_of
     def svgd_fused_sgd(self, P, G, buf, d, kstat, lr, momentum, dampening, weight_decay, nesterov, first, ws_next=None):
         """combine + M shared-state SGD applications in one pass; optionally the next step's Gram partials."""
-        _check(self.lib.bde_svgd_fused_sgd(_ptr(P, "P"), _ptr(G, "G"), _ptr(buf), P.shape[0], d, _ld(P), _ptr(kstat),
+        _check(self.lib.bde_svgd_fused_sgd(_ptr(P, "P"), _ptr(G, "G"), _ptr(buf), P.shape[0], d, _ld(P), _ld(G), _ptr(kstat),
                                            lr, momentum, dampening, weight_decay, int(nesterov), int(first),
                                            _ptr(ws_next), _stream()), "bde_svgd_fused_sgd")
 
@@ -143,7 +177,7 @@ class HipOps:
     def svgd_fused_adam(self, P, G, exp_avg, exp_avg_sq, d, kstat, lr, beta1, beta2, eps, weight_decay, step0,
                         ws_next=None):
         _check(self.lib.bde_svgd_fused_adam(_ptr(P, "P"), _ptr(G, "G"), _ptr(exp_avg), _ptr(exp_avg_sq), P.shape[0], d,
-                                            _ld(P), _ptr(kstat), lr, beta1, beta2, eps, weight_decay, int(step0),
+                                            _ld(P), _ld(G), _ptr(kstat), lr, beta1, beta2, eps, weight_decay, int(step0),
                                             _ptr(ws_next), _stream()), "bde_svgd_fused_adam")
 
     # ------------------------------------------------------------ SWAG --
@@ -172,6 +206,14 @@ class HipOps:
         n = 0 if eps_d is None else (d if d is not None else eps_d.numel())
         _check(self.lib.bde_philox_normal(seed, stream_id, _ptr(eps_w), k, _ptr(eps_d), n, _stream()),
                "bde_philox_normal")
+
+    def philox_bits(self, seed, stream_id, n_groups, device, domain=0, idx0=0) -> torch.Tensor:
+        """Raw Philox4x32-10 words [n_groups, 4] (int64 holding uint32 values) -- the known-answer hook."""
+        out = torch.empty(n_groups * 4, dtype=torch.int32, device=device)
+        with torch.cuda.device(out.device):
+            _check(self.lib.bde_philox_bits(seed, stream_id, domain, idx0, out.data_ptr(), n_groups, _stream()),
+                   "bde_philox_bits")
+        return (out.to(torch.int64) & 0xFFFFFFFF).view(n_groups, 4)
 
     # ----------------------------------------------------------- Gauss --
     def reduce_ws(self, device) -> torch.Tensor:

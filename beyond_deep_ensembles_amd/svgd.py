@@ -12,24 +12,37 @@ the data lives and who does the arithmetic:
 * during the M forward/backward passes ``param.grad`` is a view of row i of
   ``G``, so autograd accumulates straight into the flat buffer (no
   ``_store_grads`` clones, svgd.py:129-133);
-* the posterior update (svgd.py:86-89) is three HIP launches
-  (``bde_svgd_step``: MFMA Gram, bandwidth/kernel statistics, streaming
-  combine) that leave ``-phi`` in ``G``, whose rows then ARE the gradients the
-  shared base optimizer consumes (svgd.py:92-103; no per-tensor clones).
+* the posterior update (svgd.py:86-89) is three HIP launches (MFMA Gram,
+  bandwidth/kernel statistics, streaming combine) -- ONE persistent launch for
+  small models -- that leave ``-phi`` in ``G``, whose rows then ARE the
+  gradients the shared base optimizer consumes (svgd.py:92-103), or, with
+  ``fuse_base_optimizer``, one pass that also applies the optimizer.
 
-Multi-GPU (not in the reference): with ``process_group`` each rank runs the
-forward/backward passes of its own M/W particles; the gradient rows are
-exchanged with ONE RCCL all-gather (xGMI) into the replicated ``G``, then
-every rank applies the same deterministic update to its replica of ``P``.
+Multi-GPU (not in the reference): with ``process_group``
+each rank runs the forward/backward passes of its own M/W particles, then
+
+* ``exchange="allgather"`` (default): the gradient rows are exchanged with an
+  RCCL all-gather (xGMI) into a replicated ``G`` and every rank applies the same
+  deterministic update to its replica of ``P``.  ``exchange_chunks=C`` splits
+  the exchange into C column chunks so that the update of chunk c runs while
+  chunk c+1 is still on the wire;
+* ``exchange="alltoall"``: dimension-sharded.  Every rank owns a column slice
+  of ALL particles (and of the shared optimizer state); the gradient rows are
+  re-partitioned by an all-to-all, the Gram blocks of the slices are exchanged
+  (a few hundred doubles), each rank updates its slice with the fused kernel,
+  and a second all-to-all returns the updated slices to the particles' owners:
+  2/W of the all-gather's bytes per link and 1/W of the update per rank.
 """
 from __future__ import annotations
 
+import warnings
 from typing import List, Optional
 
 import numpy as np
 import torch
 
-from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, _default_ops, _opt_state
+from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, repoint, _default_ops, _opt_state
+from .ops import pad4
 
 
 def rbf(particles: torch.Tensor, h_override=None, _ops=None):
@@ -46,10 +59,13 @@ def rbf(particles: torch.Tensor, h_override=None, _ops=None):
         P[:, :d] = particles
     ws, ks = ops.svgd_ws(m, P.device), ops.svgd_kstat(m, P.device)
     out = torch.zeros_like(P)
-    ops.svgd_gram(P, d, ws)
-    ops.svgd_kstats(ws, m, 0.0, 1.0, 1.0, 1.0, ks, h_override=float(h_override) if h_override is not None else 0.0,
-                    mode=1)
-    ops.svgd_combine(P, None, out, d, ks)
+    h = float(h_override) if h_override is not None else 0.0
+    if ops.svgd_small_supported(m, d):
+        ops.svgd_step_small(P, None, out, d, 0.0, 1.0, 1.0, 1.0, ws, ks, h_override=h, mode=1)   # one launch
+    else:
+        ops.svgd_gram(P, d, ws)
+        ops.svgd_kstats(ws, m, 0.0, 1.0, 1.0, 1.0, ks, h_override=h, mode=1)
+        ops.svgd_combine(P, None, out, d, ks)
     return ks[:m * m].view(m, m).clone(), out[:, :d]
 
 
@@ -63,6 +79,9 @@ class SVGDOptimizer(BayesianOptimizer):
 
         Extra keyword-only arguments (not in the reference):
           process_group       shard the particles' forward/backward passes over the ranks of this group
+          exchange            "allgather" (replicated particles, gradient rows gathered) or "alltoall"
+                              (dimension-sharded particles and optimizer state; needs fuse_base_optimizer)
+          exchange_chunks     "allgather" only: pipeline the gather and the update over this many column chunks
           fuse_base_optimizer apply a torch.optim.SGD / Adam base optimizer inside the update kernel (one pass over
                               P and G that writes the updated particles; -phi is never materialised)
           reuse_gram          with fuse_base_optimizer: the fused kernel also emits the Gram partials of the updated
@@ -71,15 +90,17 @@ class SVGDOptimizer(BayesianOptimizer):
     '''
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
-                 kernel_grad_scale=1.0, *, process_group=None, fuse_base_optimizer=False, reuse_gram=False, _ops=None):
-        super().__init__(map(lambda p: {"params": p}, params), {})
+                 kernel_grad_scale=1.0, *, process_group=None, exchange="allgather", exchange_chunks=1,
+                 fuse_base_optimizer=False, reuse_gram=False, _ops=None):
+        # one param group per tensor, like the reference (svgd.py:50): groups distinguish tensors, not particles
+        super().__init__([{"params": p} for p in params], {})
         self._ops = _ops or _default_ops()
-        self.state["__base_optimizer"] = base_optimizer
-        self.state["__l2_reg"] = l2_reg
-        self.state["__dataset_size"] = dataset_size
-        self.state["__current_particle"] = 0
-        self.state["__particle_count"] = particle_count
-        self.state["__kernel_grad_scale"] = kernel_grad_scale
+        for key, value in (("__base_optimizer", base_optimizer), ("__l2_reg", l2_reg), ("__dataset_size", dataset_size),
+                           ("__current_particle", 0), ("__particle_count", particle_count),
+                           ("__kernel_grad_scale", kernel_grad_scale)):
+            self.state[key] = value
+        if exchange not in ("allgather", "alltoall"):
+            raise ValueError("exchange must be 'allgather' or 'alltoall'")
 
         plist = list(self._params())
         check_params(plist, self._ops)
@@ -90,23 +111,26 @@ class SVGDOptimizer(BayesianOptimizer):
         # flat particle / gradient storage; padding stays zero
         self._P = torch.zeros((m, ld), dtype=torch.float32, device=dev)
         self._G = torch.zeros((m, ld), dtype=torch.float32, device=dev)
-        self._pviews: List[List[torch.Tensor]] = [self._layout.views(self._P[i]) for i in range(m)]
-        self._gviews: List[List[torch.Tensor]] = [self._layout.views(self._G[i]) for i in range(m)]
+        self._pviews: List[Optional[List[torch.Tensor]]] = [self._layout.views(self._P[i]) for i in range(m)]
+        self._gviews: List[Optional[List[torch.Tensor]]] = [self._layout.views(self._G[i]) for i in range(m)]
         self._ws = self._ops.svgd_ws(m, dev)
         self._kstat = self._ops.svgd_kstat(m, dev)
 
-        # particle 0 = the current weights, particles 1.. = after reset_params_closure() (svgd.py:54-59)
-        for particle_idx in range(particle_count):
+        # particle 0 = the current weights, every further particle = the weights after one more
+        # reset_params_closure() (svgd.py:54-59)
+        for particle_idx in range(m):
+            if particle_idx > 0:
+                reset_params_closure()
             with torch.no_grad():
                 torch._foreach_copy_(self._pviews[particle_idx], [p.detach() for p in plist])
             for param, view in zip(plist, self._pviews[particle_idx]):
                 self.state[param][f"particle_{particle_idx}"] = view
-            if particle_idx < particle_count - 1:
-                reset_params_closure()
 
         # ---- multi-GPU sharding of the particles (new) ----
         self._pg = process_group
         self._world, self._rank = 1, 0
+        self._exchange = "allgather"
+        self._chunks = None
         if process_group is not None:
             import torch.distributed as dist
             self._world, self._rank = dist.get_world_size(process_group), dist.get_rank(process_group)
@@ -114,16 +138,32 @@ class SVGDOptimizer(BayesianOptimizer):
                 raise ValueError(f"particle_count ({particle_count}) must be a multiple of the group size ({self._world})")
             # identical particles on every rank whatever the local RNG state was
             dist.broadcast(self._P, src=dist.get_global_rank(process_group, 0), group=process_group)
+            if self._world > 1:
+                self._exchange = exchange
+        if fuse_base_optimizer and particle_count > 16:
+            warnings.warn("fuse_base_optimizer needs particle_count <= 16 (single-tile kernels); running unfused")
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
+        self._fused_decision = None
         self._tmp = None
         self._fused_state = None
         self._reuse_gram = bool(reuse_gram) and self._fuse and self._ops.svgd_fused_gram_supported(particle_count)
         self._gram_valid = False
+        if self._exchange == "allgather" and self._world > 1 and int(exchange_chunks) > 1:
+            clen = pad4((ld + int(exchange_chunks) - 1) // int(exchange_chunks))
+            self._chunks = [(c0, min(ld, c0 + clen)) for c0 in range(0, ld, clen)]
+            self._stage = [torch.zeros((m, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in self._chunks]
+        if self._exchange == "alltoall":
+            self._init_dimension_sharding()
 
     # ------------------------------------------------------------------
     def _local_particles(self) -> range:
         per = self.state["__particle_count"] // self._world
         return range(self._rank * per, (self._rank + 1) * per)
+
+    def _grad_row(self, particle_idx: int) -> torch.Tensor:
+        if self._exchange == "alltoall":
+            return self._Gown[particle_idx - self._local_particles().start]
+        return self._G[particle_idx]
 
     def step(self, forward_closure, backward_closure, grad_scaler=None):
         OptState = _opt_state()
@@ -135,10 +175,8 @@ class SVGDOptimizer(BayesianOptimizer):
             # _use_particle (svgd.py:120-127) and base_optimizer.zero_grad() (svgd.py:70) in one pass over the
             # tensors: the gradient row is zeroed and param.grad pointed at it, so backward() accumulates
             # into the flat buffer
-            self._G[particle_idx].zero_()
-            for param, pview, gview in zip(self._plist, self._pviews[particle_idx], self._gviews[particle_idx]):
-                param.data = pview
-                param.grad = gview
+            self._grad_row(particle_idx).zero_()
+            repoint(self._plist, self._pviews[particle_idx], self._gviews[particle_idx])
 
             loss = forward_closure()
             total_loss += loss.detach()
@@ -148,46 +186,70 @@ class SVGDOptimizer(BayesianOptimizer):
             adopt_grads(self._plist, self._gviews[particle_idx])      # _store_grads (svgd.py:129-133)
 
         with torch.no_grad():
-            pending = self._start_gradient_exchange(total_loss) if self._world > 1 else None
             fused = self._fuse and (grad_scaler is None or not grad_scaler.is_enabled())
-            # The Gram pass and the kernel statistics need only the (replicated) particles: they run while the
-            # gradient all-gather is in flight.  (Skipped when the previous fused kernel already left the Gram.)
+            if self._fused_decision is None:
+                self._fused_decision = fused
+            elif self._fused_decision != fused:
+                raise RuntimeError("fuse_base_optimizer: the GradScaler was enabled/disabled mid-run; the fused path keeps "
+                                   "the shared optimizer state in its own flat buffers, so the choice must not change")
+            if self._exchange == "alltoall":
+                total_loss = self._step_dimension_sharded(total_loss, base)
+            elif self._chunks is not None:
+                total_loss = self._step_pipelined(total_loss, base, fused, grad_scaler)
+            else:
+                total_loss = self._step_replicated(total_loss, base, fused, grad_scaler)
+        return total_loss / m
+
+    # ---- replicated particles: one gather (or none), then the update ----------------------------------------
+    def _stat_args(self):
+        return (float(self.state["__l2_reg"]), float(self.state["__kernel_grad_scale"]),
+                float(self.state["__dataset_size"]), -1.0)
+
+    def _step_replicated(self, total_loss, base, fused, grad_scaler):
+        m, d = self.state["__particle_count"], self._layout.d
+        pending = self._start_gradient_exchange(total_loss) if self._world > 1 else None
+        # The Gram pass and the kernel statistics need only the (replicated) particles: they run while the
+        # gradient all-gather is in flight.  (Skipped when the previous fused kernel already left the Gram.)
+        single_launch = pending is None and not fused and self._ops.svgd_small_supported(m, d)
+        if not single_launch:
             if not (fused and self._reuse_gram and self._gram_valid):
                 self._ops.svgd_gram(self._P, d, self._ws)
-            self._ops.svgd_kstats(self._ws, m, float(self.state["__l2_reg"]), float(self.state["__kernel_grad_scale"]),
-                                  float(self.state["__dataset_size"]), -1.0, self._kstat)
-            if pending is not None:
-                total_loss = self._finish_gradient_exchange(pending)
-            if fused:
-                # ONE pass: -phi in registers, M shared-state optimizer applications, updated particles out
-                self._fused_apply(base)
-                self._gram_valid = self._reuse_gram
-                self._use_particle(m - 1)    # the reference leaves the model aliased to the last particle
+            self._ops.svgd_kstats(self._ws, m, *self._stat_args(), self._kstat)
+        if pending is not None:
+            total_loss = self._finish_gradient_exchange(pending)
+        if fused:
+            # ONE pass: -phi in registers, M shared-state optimizer applications, updated particles out
+            self._fused_apply(base, [(self._P, self._G, d, 0)], ws_next=self._ws if self._reuse_gram else None)
+            self._gram_valid = self._reuse_gram
+            self._use_particle(m - 1)    # the reference leaves the model aliased to the last particle
+        else:
+            self._gram_valid = False
+            # svgd.py:86-89: -phi overwrites the gradient rows
+            if single_launch:
+                # small model on one GPU: Gram, statistics and combine in ONE persistent launch
+                self._ops.svgd_step(self._P, self._G, self._G, d, *self._stat_args(), self._ws, self._kstat)
+            elif m <= 16:
+                self._ops.svgd_combine(self._P, self._G, self._G, d, self._kstat)
             else:
-                self._gram_valid = False
-                # svgd.py:86-89: -phi overwrites the gradient rows
-                if m <= 16:
-                    self._ops.svgd_combine(self._P, self._G, self._G, d, self._kstat)
-                else:
-                    # the blocked path for > 16 particles produces 16 rows per pass and re-reads all of G
-                    if self._tmp is None:
-                        self._tmp = torch.zeros_like(self._G)
-                    self._ops.svgd_combine(self._P, self._G, self._tmp, d, self._kstat)
-                    self._G.copy_(self._tmp)
-                # write the modified gradients TO THE ORIGINAL PARAMETERS and call the optimizer on them (svgd.py:92-103)
-                for particle_idx in range(m):
-                    for model_param, pview, gview in zip(self._plist, self._pviews[particle_idx], self._gviews[particle_idx]):
-                        model_param.grad = gview
-                        model_param.data = pview
-                    if grad_scaler is not None:
-                        self._set_grad_scaler_state(grad_scaler, OptState.UNSCALED, base)
-                        grad_scaler.step(base)
-                    else:
-                        base.step()
+                # the blocked path for > 16 particles produces 16 rows per pass and re-reads all of G
+                if self._tmp is None:
+                    self._tmp = torch.zeros_like(self._G)
+                self._ops.svgd_combine(self._P, self._G, self._tmp, d, self._kstat)
+                self._G.copy_(self._tmp)
+            self._apply_base_optimizer(base, grad_scaler)
+        return total_loss
 
-        return total_loss / self.state["__particle_count"]
+    def _apply_base_optimizer(self, base, grad_scaler):
+        """svgd.py:92-103: hand row i of -phi to the base optimizer as the gradient of particle i, for every i."""
+        OptState = _opt_state()
+        for particle_idx in range(self.state["__particle_count"]):
+            repoint(self._plist, self._pviews[particle_idx], self._gviews[particle_idx])
+            if grad_scaler is not None:
+                self._set_grad_scaler_state(grad_scaler, OptState.UNSCALED, base)
+                grad_scaler.step(base)
+            else:
+                base.step()
 
-    # ------------------------------------------------------------------
     def _start_gradient_exchange(self, local_loss_sum: torch.Tensor):
         """ONE all-gather of the gradient rows (RCCL over xGMI on the GPU box), asynchronous.
         The particle's loss rides in the spare floats behind the D gradients of its row, so no
@@ -210,59 +272,251 @@ class SVGDOptimizer(BayesianOptimizer):
         self._G[:, d] = 0
         return total
 
-    def _fused_apply(self, base) -> None:
-        """-phi and the M sequential base-optimizer applications with shared state in ONE
-        kernel (bde_svgd_fused_sgd / bde_svgd_fused_adam); hyper-parameters are read from the
-        base optimizer's param_groups every step, so LR schedulers keep working."""
+    # ---- replicated particles, pipelined: gather chunk c+1 while chunk c is being updated --------------------
+    def _step_pipelined(self, total_loss, base, fused, grad_scaler):
+        import torch.distributed as dist
+        m, d = self.state["__particle_count"], self._layout.d
+        per = m // self._world
+        lo = self._rank * per
+        self._G[lo:lo + per, d] = total_loss / per
+        works = []
+        for (c0, c1), stage in zip(self._chunks, self._stage):
+            # a row chunk is contiguous; several own rows are packed first (1/W of the data)
+            send = self._G[lo, c0:c1] if per == 1 else self._G[lo:lo + per, c0:c1].contiguous().view(-1)
+            works.append(dist.all_gather_into_tensor(stage.view(-1), send, group=self._pg, async_op=True))
+        self._ops.svgd_gram(self._P, d, self._ws)            # needs the particles only: hidden behind the exchange
+        self._ops.svgd_kstats(self._ws, m, *self._stat_args(), self._kstat)
+        self._gram_valid = False
+        for (c0, c1), stage, work in zip(self._chunks, self._stage, works):
+            work.wait()                                       # the compute stream waits for THIS chunk only
+            if c0 <= d < c1:
+                total_loss = stage[:, d - c0].sum()
+            dc = min(d, c1) - c0
+            if dc <= 0:
+                continue
+            if fused:
+                self._fused_apply(base, [(self._P[:, c0:c1], stage, dc, c0)], ws_next=None, advance=False)
+            else:
+                self._ops.svgd_combine(self._P[:, c0:c1], stage, self._G[:, c0:c1], dc, self._kstat)
+        self._G[lo:lo + per, d] = 0
+        if fused:
+            self._fused_advance()
+            self._use_particle(m - 1)
+        else:
+            self._apply_base_optimizer(base, grad_scaler)
+        return total_loss
+
+    # ---- dimension-sharded particles (exchange="alltoall") ---------------------------------------------------
+    def _init_dimension_sharding(self):
+        """Split the (broadcast, identical) particle matrix: this rank keeps the full rows of its own particles
+        (for forward/backward) and its column slice of ALL particles (for the update)."""
+        if not self._fuse:
+            raise ValueError("exchange='alltoall' keeps the shared base-optimizer state sharded by columns and therefore "
+                             "needs fuse_base_optimizer=True (torch.optim.SGD or Adam) and particle_count <= 16")
+        m, d, ld, dev = self.state["__particle_count"], self._layout.d, self._layout.ld, self._P.device
+        w, r = self._world, self._rank
+        per = m // w
+        lo = r * per
+        sl = pad4((ld + w - 1) // w)
+        self._sl, self._ldw = sl, sl * w
+        full = torch.zeros((m, self._ldw), dtype=torch.float32, device=dev)
+        full[:, :ld] = self._P
+        self._Pown = full[lo:lo + per].clone()
+        self._Gown = torch.zeros_like(self._Pown)
+        self._Ps = full[:, r * sl:(r + 1) * sl].clone()
+        self._Gs = torch.zeros_like(self._Ps)
+        self._slice_d = max(0, min(d, (r + 1) * sl) - r * sl)          # valid columns of this rank's slice
+        self._msg = torch.zeros(self._ops.GMAT_DOUBLES + 1, dtype=torch.float64, device=dev)
+        self._msgs = torch.zeros((w, self._ops.GMAT_DOUBLES + 1), dtype=torch.float64, device=dev)
+        self._reuse_gram = False
+        del self._P, self._G, full
+        self._P = self._G = None
+        for i in range(m):
+            if lo <= i < lo + per:
+                self._pviews[i] = self._layout.views(self._Pown[i - lo])
+                self._gviews[i] = self._layout.views(self._Gown[i - lo])
+                for param, view in zip(self._plist, self._pviews[i]):
+                    self.state[param][f"particle_{i}"] = view
+            else:
+                self._pviews[i] = self._gviews[i] = None
+                for param in self._plist:
+                    self.state[param].pop(f"particle_{i}", None)
+        self._use_particle(lo)
+
+    def _all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
+        """out[s] <- rank s's inp[this rank]; both [W, per, sl] contiguous.  RCCL: one all_to_all_single.  Backends
+        without a device all-to-all (gloo in the one-GPU test harness) gather everything and select."""
+        import torch.distributed as dist
+        if dist.get_backend(self._pg) == "nccl":
+            return dist.all_to_all_single(out.view(-1), inp.view(-1), group=self._pg, async_op=True)
+        everything = torch.empty((self._world,) + tuple(inp.shape), dtype=inp.dtype, device=inp.device)
+        dist.all_gather_into_tensor(everything.view(-1), inp.reshape(-1).clone(), group=self._pg)
+        out.copy_(everything[:, self._rank])
+        return None
+
+    def _step_dimension_sharded(self, local_loss_sum, base):
+        import torch.distributed as dist
+        m, w, r, sl = self.state["__particle_count"], self._world, self._rank, self._sl
+        per = m // w
+        # (1) the slice's Gram block + this rank's loss: one tiny all-gather, issued first
+        if self._slice_d > 0:
+            self._ops.svgd_gram(self._Ps, self._slice_d, self._ws)
+            self._ops.svgd_gram_finish(self._ws, m, self._msg)
+        else:
+            self._msg.zero_()
+            self._msg[256] = 8.0 if m <= 8 else 16.0
+        self._msg[-1] = local_loss_sum.double()
+        stats = dist.all_gather_into_tensor(self._msgs.view(-1), self._msg, group=self._pg, async_op=True)
+        # (2) gradient rows -> gradient slices
+        if per == 1:
+            send = self._Gown.view(w, 1, sl)
+        else:
+            send = self._Gown.view(per, w, sl).transpose(0, 1).contiguous()
+        grads = self._all_to_all(self._Gs.view(w, per, sl), send)
+        stats.wait()
+        self._ops.svgd_kstats_gmat(self._msgs, m, *self._stat_args(), self._kstat)
+        total_loss = self._msgs[:, -1].sum().float()
+        if grads is not None:
+            grads.wait()
+        # (3) the fused update of this rank's slice of all particles (shared optimizer state sharded the same way)
+        if self._slice_d > 0:
+            self._fused_apply(base, [(self._Ps, self._Gs, self._slice_d, 0)], ws_next=None)
+        else:
+            self._fused_apply(base, [], ws_next=None)
+        # (4) updated slices -> the particles' owners
+        if per == 1:
+            back = self._all_to_all(self._Pown.view(w, 1, sl), self._Ps.view(w, 1, sl))
+            if back is not None:
+                back.wait()
+        else:
+            tmp = torch.empty((w, per, sl), dtype=torch.float32, device=self._Ps.device)
+            back = self._all_to_all(tmp, self._Ps.view(w, per, sl))
+            if back is not None:
+                back.wait()
+            self._Pown.view(per, w, sl).copy_(tmp.transpose(0, 1))
+        self._use_particle(r * per + per - 1)
+        return total_loss
+
+    # ---- fused shared-state optimizer -----------------------------------------------------------------------
+    def _fused_hyper(self, base):
         groups = base.param_groups
         g0 = groups[0]
         keys = [k for k in g0 if k != "params"]
         for g in groups[1:]:
             if any(g[k] != g0[k] for k in keys):
                 raise RuntimeError("fuse_base_optimizer needs identical hyper-parameters in all param groups")
-        d, ld = self._layout.d, self._layout.ld
-        dev = self._P.device
+        return g0
+
+    def _fused_buffers(self, base, kind):
+        """The SHARED optimizer state as flat buffers (one element per parameter / per slice column).  Replicated
+        layouts alias it into ``base.state[param]`` (``momentum_buffer`` / ``exp_avg`` / ``exp_avg_sq`` views and
+        ``step``), so ``base.state_dict()`` is complete and a run can be resumed unfused or in the reference."""
+        if self._fused_state is not None:
+            return self._fused_state
+        dev = self._params_device()
+        loaded, self._fused_loaded = getattr(self, "_fused_loaded", None), None
+        sharded = self._exchange == "alltoall"
+        n = self._sl if sharded else self._layout.ld
+        if kind == "sgd":
+            st = {"kind": "sgd", "buf": torch.zeros(n, device=dev), "first": True}
+            names = {"buf": "momentum_buffer"}
+        else:
+            st = {"kind": "adam", "exp_avg": torch.zeros(n, device=dev), "exp_avg_sq": torch.zeros(n, device=dev),
+                  "step": 0}
+            names = {"exp_avg": "exp_avg", "exp_avg_sq": "exp_avg_sq"}
+        if loaded is not None and loaded.get("kind") == kind:
+            # a checkpoint written by the fused path: its flat buffers are the state
+            for key in names:
+                if torch.is_tensor(loaded.get(key)) and loaded[key].numel() == n:
+                    st[key].copy_(loaded[key].to(dev))
+            for key in ("first", "step"):
+                if key in loaded:
+                    st[key] = loaded[key]
+        elif not sharded:
+            # adopt whatever state the base optimizer already has (a resumed unfused / reference run) ...
+            views = {key: self._layout.views(st[key]) for key in names}
+            seen = False
+            for i, p in enumerate(self._plist):
+                old = base.state.get(p, {})
+                for key, name in names.items():
+                    if torch.is_tensor(old.get(name)):
+                        views[key][i].copy_(old[name].to(dev))
+                        seen = True
+                if kind == "adam" and "step" in old:
+                    st["step"] = int(old["step"])
+            if kind == "sgd" and seen:
+                st["first"] = False
+        if not sharded:
+            # ... and publish the flat buffers as that state
+            views = {key: self._layout.views(st[key]) for key in names}
+            if kind == "adam":
+                st["step_tensor"] = torch.tensor(float(st["step"]))
+            for i, p in enumerate(self._plist):
+                entry = base.state[p]
+                for key, name in names.items():
+                    entry[name] = views[key][i]
+                if kind == "adam":
+                    entry["step"] = st["step_tensor"]
+        self._fused_state = self.state["__fused"] = st
+        return st
+
+    def _fused_apply(self, base, pieces, ws_next=None, advance=True) -> None:
+        """-phi and the M sequential base-optimizer applications with shared state in ONE kernel per piece
+        (bde_svgd_fused_sgd / bde_svgd_fused_adam); ``pieces`` = (P, G, valid columns, column offset into the state
+        buffers).  Hyper-parameters are read from the base optimizer's param_groups every step, so LR schedulers
+        keep working."""
+        g0 = self._fused_hyper(base)
         if isinstance(base, torch.optim.SGD):
             if g0.get("maximize", False):
                 raise RuntimeError("fuse_base_optimizer: maximize=True is not supported")
-            if self._fused_state is None:
-                self._fused_state = self.state["__fused"] = {"kind": "sgd", "buf": torch.zeros(ld, device=dev), "first": True}
-            st = self._fused_state
-            self._ops.svgd_fused_sgd(self._P, self._G, st["buf"], d, self._kstat, g0["lr"], g0["momentum"],
-                                     g0["dampening"], g0["weight_decay"], g0["nesterov"], st["first"],
-                                     ws_next=self._ws if self._reuse_gram else None)
-            st["first"] = False
+            st = self._fused_buffers(base, "sgd")
+            for P, G, d, c0 in pieces:
+                self._ops.svgd_fused_sgd(P, G, st["buf"][c0:], d, self._kstat, g0["lr"], g0["momentum"], g0["dampening"],
+                                         g0["weight_decay"], g0["nesterov"], st["first"], ws_next=ws_next)
         elif type(base) is torch.optim.Adam:
             if g0.get("amsgrad", False) or g0.get("maximize", False):
                 raise RuntimeError("fuse_base_optimizer: amsgrad / maximize are not supported")
-            if self._fused_state is None:
-                self._fused_state = self.state["__fused"] = {"kind": "adam", "exp_avg": torch.zeros(ld, device=dev),
-                                                             "exp_avg_sq": torch.zeros(ld, device=dev), "step": 0}
-            st = self._fused_state
-            lr = g0["lr"]
-            self._ops.svgd_fused_adam(self._P, self._G, st["exp_avg"], st["exp_avg_sq"], d, self._kstat, float(lr),
-                                      g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"],
-                                      ws_next=self._ws if self._reuse_gram else None)
-            st["step"] += self.state["__particle_count"]
+            st = self._fused_buffers(base, "adam")
+            for P, G, d, c0 in pieces:
+                self._ops.svgd_fused_adam(P, G, st["exp_avg"][c0:], st["exp_avg_sq"][c0:], d, self._kstat, float(g0["lr"]),
+                                          g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"],
+                                          ws_next=ws_next)
         else:
             raise RuntimeError(f"fuse_base_optimizer supports torch.optim.SGD and torch.optim.Adam, got {type(base)}")
+        if advance:
+            self._fused_advance()
+
+    def _fused_advance(self):
+        """One SVGD step = particle_count applications of the shared optimizer."""
+        st = self._fused_state
+        if st["kind"] == "sgd":
+            st["first"] = False
+        else:
+            st["step"] += self.state["__particle_count"]
+            if "step_tensor" in st:
+                st["step_tensor"].fill_(float(st["step"]))
 
     # ------------------------------------------------------------------
     def sample_parameters(self):
-        '''Cycles through the particles (svgd.py:107-112)'''
-        self._use_particle(self.state["__current_particle"])
-        self.state["__current_particle"] = (self.state["__current_particle"] + 1) % self.state["__particle_count"]
+        '''Point the model at the next particle, round robin (svgd.py:107-112).  With dimension-sharded
+        particles only this rank's own particles are available, so the cycle runs over those.'''
+        count = self.state["__particle_count"]
+        current = self.state["__current_particle"]
+        if self._exchange == "alltoall":
+            local = self._local_particles()
+            self._use_particle(local.start + current % len(local))
+        else:
+            self._use_particle(current)
+        self.state["__current_particle"] = (current + 1) % count
 
     def _params_for_particle(self, particle_idx):
-        particle = f"particle_{particle_idx}"
-        for group in self.param_groups:
-            for param in group["params"]:
-                yield self.state[param][particle]
+        '''Particle i's tensors in parameter order (svgd.py:114-118).'''
+        key = f"particle_{particle_idx}"
+        return (self.state[param][key] for param in self._params())
 
     def _use_particle(self, particle_idx):
         '''Does *not* clone: updates of the model parameters are updates of the particle (svgd.py:120-127)'''
-        for param, view in zip(self._plist, self._pviews[particle_idx]):
-            param.data = view
+        repoint(self._plist, self._pviews[particle_idx], None)
 
     def get_base_optimizer(self):
         return self.state["__base_optimizer"]
@@ -270,8 +524,16 @@ class SVGDOptimizer(BayesianOptimizer):
     # ---- flat access (bench / multi-GPU tests / checkpoints) -----------
     @property
     def particles(self) -> torch.Tensor:
-        """[M, D] view of the flat particle buffer."""
-        return self._P[:, :self._layout.d]
+        """[M, D] view of the flat particle buffer.  With exchange="alltoall" the slices are gathered first
+        (a collective: every rank of the group must read this property)."""
+        d = self._layout.d
+        if self._exchange != "alltoall":
+            return self._P[:, :d]
+        import torch.distributed as dist
+        m, w, sl = self.state["__particle_count"], self._world, self._sl
+        slices = torch.empty((w, m, sl), dtype=torch.float32, device=self._Ps.device)
+        dist.all_gather_into_tensor(slices.view(-1), self._Ps.reshape(-1).clone(), group=self._pg)
+        return slices.permute(1, 0, 2).reshape(m, w * sl)[:, :d]
 
     @property
     def kernel_stats(self) -> dict:
@@ -284,16 +546,24 @@ class SVGDOptimizer(BayesianOptimizer):
         """Call after modifying the particles outside this optimizer when reuse_gram=True."""
         self._gram_valid = False
 
+    def state_dict(self):
+        if self._exchange == "alltoall":
+            raise NotImplementedError("exchange='alltoall': the particles are sharded over the ranks; gather them with "
+                                      ".particles (a collective) and save that")
+        return super().state_dict()
+
     def load_state_dict(self, state_dict):
         """Accepts the reference's layout (per-tensor ``particle_i`` entries): the
         values are copied into the flat buffer and the state re-aliased to it."""
+        if self._exchange == "alltoall":
+            raise NotImplementedError("exchange='alltoall': load the checkpoint before sharding (construct with "
+                                      "exchange='allgather', load, then rebuild)")
         super().load_state_dict(state_dict)
         self._gram_valid = False
-        self._fused_state = self.state.get("__fused")          # shared optimizer state of the fused path
-        if self._fused_state is not None:
-            for k, v in self._fused_state.items():
-                if torch.is_tensor(v):
-                    self._fused_state[k] = v.to(self._P.device)
+        # shared optimizer state of the fused path: re-adopted (and re-published into base.state) at the next step
+        self._fused_loaded = self.state.pop("__fused", None)
+        self._fused_state = None
+        self._fused_decision = None
         m = self.state["__particle_count"]
         with torch.no_grad():
             for i in range(m):

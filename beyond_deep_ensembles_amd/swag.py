@@ -43,6 +43,9 @@ class SwagOptimizer(BayesianOptimizer):
         self._ops = _ops or _default_ops()
         if rng not in ("torch", "philox"):
             raise ValueError("rng must be 'torch' or 'philox'")
+        if not 1 <= int(deviation_samples) <= 256:
+            raise ValueError(f"deviation_samples must be in [1, 256] (BDE_MAX_RANK of the sampling kernels), got "
+                             f"{deviation_samples}")
 
         self.start_epoch = start_epoch
         self.update_interval = math.floor(update_interval)
@@ -238,11 +241,14 @@ class SwagOptimizer(BayesianOptimizer):
         st["__sq_weights"] = self.sq_vector().detach().cpu()
         st["__deviations"] = self.deviations_dk().detach().cpu()
         st.pop("__dev_head", None)
+        st["__sample_counter"] = self._sample_counter     # Philox stream position (extra key; the reference ignores it)
         return sd
 
     def load_state_dict(self, state_dict: dict):
         super().load_state_dict(state_dict)
         dev, d, ld, k = self._params_device(), self._layout.d, self._layout.ld, self.deviation_samples
+        self._prefetched = None                          # rows drawn from the old posterior must not be served
+        self._sample_counter = int(self.state.pop("__sample_counter", 0))
 
         def flat(v):
             out = torch.zeros(ld, dtype=torch.float32, device=dev)

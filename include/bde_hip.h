@@ -37,6 +37,7 @@ extern "C" {
 #define BDE_MAX_PARTICLES 64   /* SVGD: M <= 64; M <= 16 runs the single-tile fast path,
                                   17..64 a blocked generic path (several passes)        */
 #define BDE_FAST_PARTICLES 16
+#define BDE_GMAT_DOUBLES 257    /* bde_svgd_gram_finish: 16 x 16 Gram matrix (row-major, padded) + its padded M */
 #define BDE_MAX_RANK 256       /* SWAG: deviation_samples K <= 256           */
 #define BDE_MAX_BATCH 32       /* SWAG batched sampling: S <= 32 per call    */
 
@@ -60,7 +61,9 @@ const char* bde_arch(void);
  *             out; out may alias G).
  */
 
-/* Bytes of scratch `ws` needed by the SVGD entry points for M particles. */
+/* Bytes of scratch `ws` needed by the SVGD entry points for M particles.  The first 256 bytes are a
+ * header; it must be ZERO-FILLED once after allocation (it holds the arrive / depart counters of the
+ * single-launch path, which every launch leaves at zero again).  One `ws` serves one stream at a time. */
 size_t bde_svgd_ws_bytes(int M);
 
 /* Number of floats of the `kstat` result block for M particles.  Layout:
@@ -89,16 +92,40 @@ int bde_svgd_kstats(const void* ws, int M, float l2_reg, float kernel_grad_scale
                     float dataset_size, float sign, float h_override, int mode,
                     float* kstat, void* stream);
 
-/* Stage 3: out[i, :] = sum_j CG[i][j] * G[j, :] + CP[i][j] * P[j, :].
- * G may be NULL (CG ignored).  out may alias G (not P) for M <= 16; for M > 16 the
- * rows are produced in chunks of 16 that re-read all of G, so out must not alias G. */
-int bde_svgd_combine(const float* P, const float* G, float* out, int M, int64_t D,
-                     int64_t ld, const float* kstat, void* stream);
+/* Dimension-sharded multi-GPU update (every rank owns a column slice of all M particles): after
+ * bde_svgd_gram over the slice, gram_finish reduces the partials to gmat_out [BDE_GMAT_DOUBLES] (fp64, fixed
+ * order); the ranks exchange those blocks (one tiny all-gather); kstats_gmat sums `n_mats` blocks (stride
+ * `mat_stride` doubles) in order and evaluates the same statistics as bde_svgd_kstats.  M <= 16. */
+int bde_svgd_gram_finish(const void* ws, int M, double* gmat_out, void* stream);
+int bde_svgd_kstats_gmat(const double* gmats, int n_mats, int64_t mat_stride, int M, float l2_reg,
+                         float kernel_grad_scale, float dataset_size, float sign, float h_override, int mode,
+                         float* kstat, void* stream);
 
-/* All three stages back to back on `stream` (one SVGD posterior update). */
+/* Stage 3: out[i, :] = sum_j CG[i][j] * G[j, :] + CP[i][j] * P[j, :].
+ * P and out have leading dimension ld, G has ldg (0 = ld): with P / out offset to a column chunk and G a
+ * staging buffer the multi-GPU exchange gathers into, the update runs chunk by chunk behind the collective.
+ * G may be NULL (CG ignored).  out may alias G (not P) for M <= 16 when ldg == ld; for M > 16 the
+ * rows are produced in chunks of 16 that re-read all of G, so out must not alias G (and ldg must equal ld). */
+int bde_svgd_combine(const float* P, const float* G, float* out, int M, int64_t D,
+                     int64_t ld, int64_t ldg, const float* kstat, void* stream);
+
+/* One SVGD posterior update (svgd.py:86-89) on `stream`: the single-launch path when
+ * bde_svgd_small_supported(M, D), otherwise the three stages back to back. */
 int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
                   float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
                   void* ws, float* kstat, void* stream);
+
+/* Small models (M <= 8 and D <= 524,288, e.g. the CIFAR ResNet-20 of the reference: D = 273,610): the whole
+ * update in ONE persistent launch -- per-workgroup Gram partials, an in-kernel hand-off through an agent-scope
+ * counter, the kernel statistics evaluated redundantly by every workgroup, and the combine of the columns each
+ * workgroup already holds in registers.  12*M*D bytes of HBM traffic, no launch boundaries.  Same results as the
+ * three-stage path up to the order of the partial sums.  mode / h_override as in bde_svgd_kstats (mode 1: G may
+ * be NULL, out = grad_kernel).  Needs all its (<= 256) workgroups co-resident: use on a device with >= 256 CUs
+ * that is not oversubscribed by other persistent kernels. */
+int bde_svgd_small_supported(int M, int64_t D);
+int bde_svgd_step_small(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
+                        float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
+                        float h_override, int mode, void* ws, float* kstat, void* stream);
 
 /* Shared-state base-optimizer apply for the M particles, in particle order
  * (svgd.py:92-103 with ONE torch.optim.SGD / Adam whose state is keyed on the
@@ -126,13 +153,13 @@ int bde_svgd_apply_adam(float* P, const float* grad, float* exp_avg, float* exp_
  * see bde_svgd_fused_gram_supported) the kernel also leaves the Gram partials of the
  * UPDATED particles in ws_next, in the format bde_svgd_kstats reads, so the next step can
  * skip bde_svgd_gram as long as nothing else modifies P in between.
- * Single-tile path only: M <= BDE_FAST_PARTICLES. */
+ * Single-tile path only: M <= BDE_FAST_PARTICLES.  ldg = leading dimension of G (0 = ld), as in bde_svgd_combine. */
 int bde_svgd_fused_gram_supported(int M);
-int bde_svgd_fused_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
+int bde_svgd_fused_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld, int64_t ldg,
                        const float* kstat, double lr, double momentum, double dampening, double weight_decay,
                        int nesterov, int first, void* ws_next, void* stream);
 int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D, int64_t ld,
-                        const float* kstat, double lr, double beta1, double beta2, double eps,
+                        int64_t ldg, const float* kstat, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int64_t step0, void* ws_next, void* stream);
 
 /* ------------------------------------------------------------------ SWAG --
@@ -172,6 +199,14 @@ int bde_swag_sample_batched(const float* mean, const float* sq, const float* dev
  * callers that want the noise): eps_w [K] and/or eps_d [D] (either may be NULL). */
 int bde_philox_normal(uint64_t seed, uint64_t stream_id, float* eps_w, int K, float* eps_d, int64_t D,
                       void* stream);
+
+/* The raw Philox4x32-10 words behind every in-kernel noise draw: for g in [0, n_groups)
+ * out[4g .. 4g+3] = Philox4x32-10(counter = (lo32(idx0+g), hi32(idx0+g), lo32(stream_id),
+ * hi32(stream_id) ^ domain), key = (lo32(seed), hi32(seed))).  Lets the tests pin the
+ * generator against the published Random123 known-answer vectors (domain 0 = the diagonal /
+ * element noise, 0x80000000 = the low-rank weights of the SWAG sampler). */
+int bde_philox_bits(uint64_t seed, uint64_t stream_id, uint32_t domain, uint64_t idx0, uint32_t* out,
+                    int64_t n_groups, void* stream);
 
 /* ------------------------------------------------- mean-field Gaussian (BBB) --
  * src/algos/util.py:151-183 (GaussianParameter) and bbb.py:18-21 (KL). */

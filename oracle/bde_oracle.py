@@ -37,52 +37,76 @@ import torch
 # --------------------------------------------------------------------------
 
 
-def svgd_rbf(particles: torch.Tensor, h_override=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Pairwise RBF kernel with the median heuristic and its repulsive gradient.
+def svgd_sq_dists(particles: torch.Tensor) -> torch.Tensor:
+    """``d2 [M, M]``: squared Euclidean distances between the rows, formed as the reference forms them
+    (``src/algos/svgd.py:15``): the p=2 ``cdist`` (a square root of the summed squares) squared again."""
+    return torch.cdist(particles, particles, p=2) ** 2
 
-    Follows ``src/algos/svgd.py:14-32`` (``rbf``):
-      * ``d2 = cdist(P, P, p=2) ** 2``  (line 15; i.e. (sqrt(sum diff^2))^2)
-      * ``h = sqrt(0.5 * quantile(d2, 0.5) / ln(M + 1)) + 1e-8``  (line 18; the
-        quantile runs over all M*M entries, the M zero diagonal entries
-        included, with linear interpolation)
-      * ``K = exp(-d2 / (2 h^2))``  (line 21)
-      * ``gradK = rowsum(K)[:, None] * P - K @ P`` then ``/= h^2``  (lines 23, 31)
-    Returns ``(K [M, M], gradK [M, D])``.
-    """
-    distances = torch.cdist(particles, particles, p=2) ** 2
-    if h_override is None:
-        h = torch.sqrt(0.5 * torch.quantile(distances, 0.5) / np.log(particles.shape[0] + 1)) + 1e-8
-    else:
-        h = h_override
-    kernel = torch.exp(-distances / (2 * h ** 2))
-    grad_kernel = kernel.sum(dim=1).unsqueeze(-1) * particles - torch.matmul(kernel, particles)
-    grad_kernel /= h ** 2
-    return kernel, grad_kernel
+
+def svgd_bandwidth_from_sq_dists(d2: torch.Tensor) -> torch.Tensor:
+    """Median heuristic (``src/algos/svgd.py:18``): ``h = sqrt(0.5 * median / ln(M + 1)) + 1e-8`` where the
+    "median" is ``torch.quantile(d2, 0.5)`` over ALL M*M entries -- the M zeros of the diagonal included,
+    linear interpolation between the two middle order statistics."""
+    m = d2.shape[0]
+    return torch.sqrt(0.5 * torch.quantile(d2, 0.5) / np.log(m + 1)) + 1e-8
+
+
+def svgd_kernel_from_sq_dists(d2: torch.Tensor, h) -> torch.Tensor:
+    """``K = exp(-d2 / (2 h^2))`` (``src/algos/svgd.py:21``)."""
+    return torch.exp(-d2 / (2 * h ** 2))
+
+
+def svgd_repulsion(kernel: torch.Tensor, particles: torch.Tensor, h) -> torch.Tensor:
+    """``gradK_i = (sum_j K_ij) x_i - sum_j K_ij x_j``, then divided by ``h^2`` (``src/algos/svgd.py:23,31``).
+    Acts column by column on ``particles``, so it can be evaluated on a column slice with the full-width ``K``."""
+    out = kernel.sum(dim=1).unsqueeze(-1) * particles - torch.matmul(kernel, particles)
+    out /= h ** 2
+    return out
+
+
+def svgd_rbf(particles: torch.Tensor, h_override=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``rbf(particles, h_override)`` of ``src/algos/svgd.py:14-32``: returns ``(K [M, M], gradK [M, D])``.
+    Composition of the four pieces above, in the reference's order (distances, bandwidth unless overridden,
+    kernel, repulsive gradient)."""
+    d2 = svgd_sq_dists(particles)
+    h = svgd_bandwidth_from_sq_dists(d2) if h_override is None else h_override
+    kernel = svgd_kernel_from_sq_dists(d2, h)
+    return kernel, svgd_repulsion(kernel, particles, h)
 
 
 def svgd_bandwidth(particles: torch.Tensor) -> torch.Tensor:
     """The median-heuristic bandwidth ``h`` alone (``src/algos/svgd.py:15,18``)."""
-    distances = torch.cdist(particles, particles, p=2) ** 2
-    return torch.sqrt(0.5 * torch.quantile(distances, 0.5) / np.log(particles.shape[0] + 1)) + 1e-8
+    return svgd_bandwidth_from_sq_dists(svgd_sq_dists(particles))
+
+
+def svgd_direction(kernel: torch.Tensor, repulsion: torch.Tensor, particles: torch.Tensor, grads: torch.Tensor,
+                   l2_reg: float, kernel_grad_scale: float, dataset_size: float) -> torch.Tensor:
+    """``phi`` from a given kernel matrix and repulsive gradient (``src/algos/svgd.py:86,89``):
+    the Gaussian-prior term ``l2_reg / 2 * theta`` is added to the gradients (Q2), then
+    ``phi = K @ (-grads) + kernel_grad_scale * gradK / dataset_size`` -- no 1/M (Q1).  ``grads`` is left alone
+    (the reference modifies its own stacked copy)."""
+    with_prior = grads.clone()
+    with_prior += l2_reg / 2 * particles
+    return torch.matmul(kernel, -with_prior) + kernel_grad_scale * repulsion / dataset_size
 
 
 def svgd_phi(particles: torch.Tensor, grads: torch.Tensor, l2_reg: float,
              kernel_grad_scale: float, dataset_size: float) -> torch.Tensor:
-    """The SVGD direction ``phi [M, D]`` of one step.
+    """The SVGD direction ``phi [M, D]`` of one step (``src/algos/svgd.py:86-89``).  The reference then hands
+    row i of ``-phi`` to the base optimizer as the gradient of particle i (``svgd.py:92-103``)."""
+    kernel, repulsion = svgd_rbf(particles)
+    return svgd_direction(kernel, repulsion, particles, grads, l2_reg, kernel_grad_scale, dataset_size)
 
-    Follows ``src/algos/svgd.py:86-89``:
-      * ``G += l2_reg / 2 * P``  (line 86; prior gradient is l2_reg/2 * theta)
-      * ``K, gradK = rbf(P)``  (line 87)
-      * ``phi = K @ (-G) + kernel_grad_scale * gradK / dataset_size``  (line 89;
-        there is no 1/M factor)
-    ``grads`` is not modified (the reference modifies its own stacked copy).
-    The reference then hands ``-phi`` row i to the base optimizer as the
-    gradient of particle i (``svgd.py:92-103``).
-    """
-    gradient_vecs = grads.clone()
-    gradient_vecs += l2_reg / 2 * particles
-    kernel, grad_kernel = svgd_rbf(particles)
-    return torch.matmul(kernel, -gradient_vecs) + kernel_grad_scale * grad_kernel / dataset_size
+
+def svgd_phi_cols(particle_cols: torch.Tensor, grad_cols: torch.Tensor, d2: torch.Tensor, l2_reg: float,
+                  kernel_grad_scale: float, dataset_size: float, h_override=None) -> torch.Tensor:
+    """``phi`` restricted to a column slice, given the FULL-width squared distances ``d2 [M, M]``: what one rank
+    of the dimension-sharded multi-GPU update computes.  Same formulas as above; only
+    the distances come from outside (they are sums over all columns)."""
+    h = svgd_bandwidth_from_sq_dists(d2) if h_override is None else h_override
+    kernel = svgd_kernel_from_sq_dists(d2, h)
+    return svgd_direction(kernel, svgd_repulsion(kernel, particle_cols, h), particle_cols, grad_cols, l2_reg,
+                          kernel_grad_scale, dataset_size)
 
 
 def svgd_apply_shared_optimizer(rows: List[List[torch.Tensor]], neg_phi_rows: List[List[torch.Tensor]],

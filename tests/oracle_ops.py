@@ -8,6 +8,12 @@ import math
 import torch
 
 from oracle import bde_oracle as O
+from oracle import philox as PH
+
+
+def _philox(seed, stream_id, n, domain=PH.DOMAIN_DIAG):
+    """The in-kernel noise of rng="philox" (csrc/bde_common.hpp), evaluated by the numpy checker."""
+    return torch.from_numpy(PH.normals(int(seed), int(stream_id), int(n), domain)).float()
 
 
 def pad4(n, mult=64):
@@ -36,21 +42,59 @@ class OracleOps:
         kstat[m * m:2 * m * m] = (torch.cdist(p, p) ** 2).reshape(-1)
         kstat[2 * m * m + m] = O.svgd_bandwidth(p)
 
+    def svgd_small_supported(self, m, d):
+        return m <= 8 and d <= 524288
+
+    def svgd_step_small(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat, h_override=0.0,
+                        mode=0):
+        self.svgd_gram(P, d, ws)
+        self.svgd_kstats(ws, P.shape[0], l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override, mode)
+        self.svgd_combine(P, G, out, d, kstat)
+
     def svgd_gram(self, P, d, ws):
         self._gram_P = P[:, :d].clone()
 
-    def svgd_kstats(self, ws, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override=0.0, mode=0):
-        p = self._gram_P
-        kernel, gradk = O.svgd_rbf(p, h_override if h_override > 0 else None)
+    def _set_stats(self, d2, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override, mode):
+        h = O.svgd_bandwidth_from_sq_dists(d2) if not h_override > 0 else h_override
+        kernel = O.svgd_kernel_from_sq_dists(d2, h)
         kstat[:m * m] = kernel.reshape(-1)
-        self._pending = (mode, kernel, gradk, l2_reg, kernel_grad_scale, dataset_size, sign)
+        kstat[m * m:2 * m * m] = d2.reshape(-1)
+        kstat[2 * m * m + m] = h
+        self._pending = (mode, kernel, h, l2_reg, kernel_grad_scale, dataset_size, sign)
+
+    def svgd_kstats(self, ws, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override=0.0, mode=0):
+        self._set_stats(O.svgd_sq_dists(self._gram_P), m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat,
+                        h_override, mode)
+
+    GMAT_DOUBLES = 257
+
+    def svgd_gram_finish(self, ws, m, gmat_out):
+        """Centred Gram matrix of the column slice handed to svgd_gram, fp64, in the padded block layout."""
+        p = self._gram_P.double()
+        q = p - p.mean(dim=0, keepdim=True)
+        mp = 8 if m <= 8 else 16
+        block = torch.zeros(mp, mp, dtype=torch.float64)
+        block[:m, :m] = q @ q.t()
+        gmat_out.zero_()
+        gmat_out[:mp * mp] = block.reshape(-1)
+        gmat_out[256] = mp
+
+    def svgd_kstats_gmat(self, gmats, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override=0.0, mode=0):
+        mp = int(gmats[0, 256])
+        g = gmats[:, :mp * mp].sum(dim=0).view(mp, mp)[:m, :m]
+        diag = torch.diagonal(g)
+        d2 = (diag[:, None] + diag[None, :] - 2 * g).clamp_min(0.0)
+        d2.fill_diagonal_(0.0)
+        self._set_stats(d2.float(), m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override, mode)
 
     def svgd_combine(self, P, G, out, d, kstat):
-        mode, kernel, gradk, l2_reg, scale, n, sign = self._pending
+        mode, kernel, h, l2_reg, scale, n, sign = self._pending
+        p = P[:, :d].clone()
+        repulsion = O.svgd_repulsion(kernel, p, h)
         if mode == 1:
-            out[:, :d] = gradk
+            out[:, :d] = repulsion
         else:
-            out[:, :d] = sign * O.svgd_phi(P[:, :d].clone(), G[:, :d].clone(), l2_reg, scale, n)
+            out[:, :d] = sign * O.svgd_direction(kernel, repulsion, p, G[:, :d].clone(), l2_reg, scale, n)
 
     def svgd_apply_sgd(self, P, grad, buf, d, lr, momentum, dampening, weight_decay, nesterov, first):
         b = buf[:d]
@@ -82,11 +126,13 @@ class OracleOps:
         return m <= 8
 
     def _neg_phi_from_pending(self, P, G, d):
-        mode, kernel, gradk, l2_reg, scale, n, sign = self._pending
+        mode, kernel, h, l2_reg, scale, n, sign = self._pending
         assert mode == 0 and sign == -1.0
-        # the kernel statistics were formed from the particles handed to svgd_gram / the previous fused call
-        assert torch.equal(self._gram_P, P[:, :d]), "stale Gram: particles changed since the statistics were formed"
-        return sign * O.svgd_phi(P[:, :d].clone(), G[:, :d].clone(), l2_reg, scale, n)
+        p = P[:, :d].clone()
+        if self._gram_P.shape == p.shape:
+            # the kernel statistics were formed from the particles handed to svgd_gram / the previous fused call
+            assert torch.equal(self._gram_P, p), "stale Gram: particles changed since the statistics were formed"
+        return sign * O.svgd_direction(kernel, O.svgd_repulsion(kernel, p, h), p, G[:, :d].clone(), l2_reg, scale, n)
 
     def svgd_fused_sgd(self, P, G, buf, d, kstat, lr, momentum, dampening, weight_decay, nesterov, first, ws_next=None):
         tmp = torch.zeros_like(P)
@@ -117,8 +163,7 @@ class OracleOps:
     def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0):
         k = dev.shape[0]
         if eps_w is None:
-            g = torch.Generator().manual_seed(seed * 1000003 + stream_id)
-            eps_w, eps_d = torch.randn(k, generator=g), torch.randn(d, generator=g)
+            eps_w, eps_d = _philox(seed, stream_id, k, PH.DOMAIN_LOWRANK), _philox(seed, stream_id, d)
         out[:d] = O.swag_sample(mean[:d], sq[:d], self._logical(dev, head, d), eps_w, eps_d[:d])
 
     def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0):
@@ -132,14 +177,14 @@ class OracleOps:
 
     def gauss_draw_fwd(self, mean, rho, out, n, eps=None, seed=0, stream_id=0, eps_out=None):
         if eps is None:
-            eps = torch.randn(mean.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+            eps = _philox(seed, stream_id, n)
             if eps_out is not None:
-                eps_out.copy_(eps)
+                eps_out[:n] = eps
         out[:n] = O.gauss_sample(mean[:n], rho[:n], eps[:n])
 
     def gauss_draw_bwd(self, g, rho, gmean, grho, n, eps=None, seed=0, stream_id=0, accumulate=False):
         if eps is None:
-            eps = torch.randn(rho.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+            eps = _philox(seed, stream_id, n)
         gm, gr = O.gauss_sample_backward(g[:n], rho[:n], eps[:n])
         if accumulate:
             gmean[:n] += gm
@@ -174,12 +219,12 @@ class OracleOps:
 
     def local_reparam_fwd(self, mean, var, out, n, eps=None, seed=0, stream_id=0):
         if eps is None:
-            eps = torch.randn(mean.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+            eps = _philox(seed, stream_id, n)
         out[:n] = mean[:n] + torch.sqrt(var[:n]) * eps[:n]
 
     def local_reparam_bwd(self, g, var, gvar, n, eps=None, seed=0, stream_id=0):
         if eps is None:
-            eps = torch.randn(var.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+            eps = _philox(seed, stream_id, n)
         gvar[:n] = (g[:n] * eps[:n]) / (2 * torch.sqrt(var[:n]))
 
     # ------------------------------------------------------------ iVON --
@@ -189,7 +234,7 @@ class OracleOps:
             delta = torch.zeros(n)
         else:
             if eps is None:
-                eps = torch.randn(mean.numel(), generator=torch.Generator().manual_seed(seed * 1000003 + stream_id))
+                eps = _philox(seed, stream_id, n)
             delta = O.ivon_sample(mean[:n], prec[:n], n_eff, eps[:n])
         param[:n] = mean[:n] + delta
         if first:

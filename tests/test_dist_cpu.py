@@ -22,13 +22,16 @@ def _free_port():
     return port
 
 
-def _make(seed, m, ops, pg=None, fuse=False):
+def _make(seed, m, ops, pg=None, fuse=False, base="sgd", **kw):
     import beyond_deep_ensembles_amd as bde
     torch.manual_seed(seed)
     model = nn.Sequential(nn.Linear(13, 20), nn.Tanh(), nn.Linear(20, 1))
-    base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    if base == "sgd":
+        base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    else:
+        base = torch.optim.Adam(model.parameters(), lr=0.01)
     opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=m,
-                            dataset_size=64, l2_reg=0.01, process_group=pg, fuse_base_optimizer=fuse, _ops=ops)
+                            dataset_size=64, l2_reg=0.01, process_group=pg, fuse_base_optimizer=fuse, _ops=ops, **kw)
     return model, opt
 
 
@@ -42,7 +45,7 @@ def _run_steps(model, opt, steps=3):
     return losses
 
 
-def _svgd_worker(rank, world, port, m, fuse, out_dir):
+def _svgd_worker(rank, world, port, m, fuse, kw, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,7 +53,7 @@ def _svgd_worker(rank, world, port, m, fuse, out_dir):
         from tests.oracle_ops import OracleOps
         torch.set_num_threads(1)
         # different local RNG state per rank: the constructor must still agree on the particles (broadcast)
-        model, opt = _make(100 + rank, m, OracleOps(), pg=dist.group.WORLD, fuse=fuse)
+        model, opt = _make(100 + rank, m, OracleOps(), pg=dist.group.WORLD, fuse=fuse, **dict(kw))
         fwd_calls = [0]
         orig = model.forward
 
@@ -65,12 +68,19 @@ def _svgd_worker(rank, world, port, m, fuse, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("m,fuse", [(4, False), (2, True)])
-def test_svgd_sharded_equals_single_process(tmp_path, m, fuse):
+@pytest.mark.parametrize("m,fuse,kw", [
+    (4, False, {}), (2, True, {}),
+    (4, False, {"exchange_chunks": 3}), (4, True, {"exchange_chunks": 2}), (2, True, {"exchange_chunks": 4, "base": "adam"}),
+    (4, True, {"exchange": "alltoall"}), (2, True, {"exchange": "alltoall"}), (4, True, {"exchange": "alltoall", "base": "adam"}),
+], ids=["allgather", "allgather_fused", "pipelined", "pipelined_fused", "pipelined_fused_adam", "alltoall_2per",
+        "alltoall_1per", "alltoall_adam"])
+def test_svgd_sharded_equals_single_process(tmp_path, m, fuse, kw):
+    """One exchange of gradient rows (all-gather, chunk-pipelined all-gather, or the dimension-sharded all-to-all
+    pair) + the deterministic update reproduces the single-process trajectory, with identical particles on all ranks."""
     from tests.oracle_ops import OracleOps
     world = 2
     port = _free_port()
-    mp.spawn(_svgd_worker, args=(world, port, m, fuse, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_svgd_worker, args=(world, port, m, fuse, tuple(kw.items()), str(tmp_path)), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     # replicas stay bit-identical across ranks
     np.testing.assert_array_equal(r0["particles"], r1["particles"])
@@ -79,7 +89,7 @@ def test_svgd_sharded_equals_single_process(tmp_path, m, fuse):
     assert int(r0["fwd"]) == 3 * m // world and int(r1["fwd"]) == 3 * m // world
     # single-process run from rank 0's initial state
     torch.set_num_threads(1)
-    model, opt = _make(100, m, OracleOps(), fuse=fuse)
+    model, opt = _make(100, m, OracleOps(), fuse=fuse, base=kw.get("base", "sgd"))
     losses = _run_steps(model, opt)
     np.testing.assert_allclose(r0["particles"], opt.particles.numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=1e-6)

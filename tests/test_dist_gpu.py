@@ -1,0 +1,198 @@
+"""The multi-GPU paths with the REAL kernels (HipOps) under a process group, on whatever the box has:
+
+* always: two fresh child ranks sharing ``cuda:0`` over gloo (CUDA tensors through the collective) --
+  ``SVGDOptimizer(process_group=...)`` fused / unfused / chunk-pipelined / dimension-sharded reproduces the
+  single-process HIP trajectory with bit-identical replicas across ranks, and
+  ``DeepEnsemble.predict_distributed`` reproduces the single-process output order;
+* when ``torch.cuda.device_count() >= 2``: the same over nccl (= RCCL), one device per rank.
+
+The children are new processes started by ``torch.multiprocessing.spawn`` (the pytest process is never
+re-exec'd); reference: ``src/algos/svgd.py:65-105``, ``ensemble.py:28-44``.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_svgd(seed, m, dev, pg=None, **kw):
+    import beyond_deep_ensembles_amd as bde
+    torch.manual_seed(seed)
+    model = nn.Sequential(nn.Linear(13, 40), nn.Tanh(), nn.Linear(40, 1)).to(dev)
+    base_kind = kw.pop("base", "sgd")
+    if base_kind == "sgd":
+        base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)
+    else:
+        base = torch.optim.Adam(model.parameters(), lr=1e-2)
+    opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=m,
+                            dataset_size=64, l2_reg=0.01, process_group=pg, **kw)
+    return model, opt
+
+
+def _run_steps(model, opt, dev, steps=4):
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(64, 13, generator=g).to(dev), torch.randn(64, 1, generator=g).to(dev)
+    losses = []
+    for t in range(steps):
+        xb, yb = x[t * 16:(t + 1) * 16], y[t * 16:(t + 1) * 16]
+        losses.append(float(opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())))
+    return losses
+
+
+def _init(rank, world, port, backend):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev_index = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist, dev
+
+
+def _svgd_worker(rank, world, port, backend, m, kw, out_dir):
+    dist, dev = _init(rank, world, port, backend)
+    try:
+        from beyond_deep_ensembles_amd.ops import HipOps
+        # a different local RNG state per rank: the constructor must still agree on the particles (broadcast)
+        model, opt = _make_svgd(100 + rank, m, dev, pg=dist.group.WORLD, **dict(kw))
+        assert isinstance(opt._ops, HipOps)
+        calls = [0]
+        orig = model.forward
+
+        def counting_forward(*a, **k):
+            calls[0] += 1
+            return orig(*a, **k)
+        model.forward = counting_forward
+        losses = _run_steps(model, opt, dev)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=opt.particles.cpu().numpy(),
+                 losses=np.array(losses), fwd=np.array(calls[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+SVGD_CASES = [
+    ("unfused", 4, {}),
+    ("fused_sgd_reuse", 4, {"fuse_base_optimizer": True, "reuse_gram": True}),
+    ("fused_adam", 2, {"fuse_base_optimizer": True, "base": "adam"}),
+    ("pipelined", 4, {"exchange_chunks": 3}),
+    ("pipelined_fused", 4, {"exchange_chunks": 2, "fuse_base_optimizer": True}),
+    ("alltoall_2per", 4, {"exchange": "alltoall", "fuse_base_optimizer": True}),
+    ("alltoall_1per_adam", 2, {"exchange": "alltoall", "fuse_base_optimizer": True, "base": "adam"}),
+]
+
+
+def _check_svgd(tmp_path, backend, name, m, kw):
+    world = 2
+    mp.spawn(_svgd_worker, args=(world, _free_port(), backend, m, tuple(kw.items()), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["particles"], r1["particles"])          # replicas stay bit-identical
+    np.testing.assert_array_equal(r0["losses"], r1["losses"])
+    assert int(r0["fwd"]) == 4 * m // world and int(r1["fwd"]) == 4 * m // world
+    # the single-process HIP run from rank 0's initial state (no process group; same kernels)
+    single_kw = {k: v for k, v in kw.items() if k not in ("exchange", "exchange_chunks")}
+    model, opt = _make_svgd(100, m, torch.device("cuda", 0), **single_kw)
+    losses = _run_steps(model, opt, torch.device("cuda", 0))
+    np.testing.assert_allclose(r0["particles"], opt.particles.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=2e-5)
+
+
+@pytest.mark.parametrize("name,m,kw", SVGD_CASES, ids=[c[0] for c in SVGD_CASES])
+def test_svgd_sharded_hip_two_ranks_one_device(tmp_path, name, m, kw):
+    _check_svgd(tmp_path, "gloo", name, m, kw)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
+@pytest.mark.parametrize("name,m,kw", SVGD_CASES, ids=[c[0] for c in SVGD_CASES])
+def test_svgd_sharded_hip_rccl(tmp_path, name, m, kw):
+    _check_svgd(tmp_path, "nccl", name, m, kw)
+
+
+# ------------------------------------------------------------------ MultiX fan-out --
+def _members(dev, kind="swag"):
+    import beyond_deep_ensembles_amd as bde
+    out = []
+    for i in range(3):
+        torch.manual_seed(10 + i)
+        model = nn.Linear(6, 2).to(dev)
+        x = torch.randn(8, 6, generator=torch.Generator().manual_seed(3)).to(dev)
+        if kind == "swag":
+            opt = bde.SwagOptimizer(model.parameters(), torch.optim.SGD(model.parameters(), lr=0.1), update_interval=1,
+                                    deviation_samples=4, rng="philox", seed=10 + i)
+            for _ in range(6):
+                opt.step(lambda: model(x).pow(2).mean(), lambda l: l.backward())
+        else:
+            base = torch.optim.SGD(model.parameters(), lr=0.1)
+            opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=4,
+                                    dataset_size=8)
+            opt.step(lambda: model(x).pow(2).mean(), lambda l: l.backward())
+        out.append((model, opt))
+    return out
+
+
+def _predict_worker(rank, world, port, backend, kind, out_dir):
+    dist, dev = _init(rank, world, port, backend)
+    try:
+        import beyond_deep_ensembles_amd as bde
+        ens = bde.DeepEnsemble(_members(dev, kind))
+        x = torch.randn(4, 6, generator=torch.Generator().manual_seed(1)).to(dev)
+        calls = {"batched": 0}
+        for _, opt in ens.models_and_optimizers:
+            if hasattr(opt._ops, "swag_sample_batched"):
+                orig = opt._ops.swag_sample_batched
+
+                def counted(*a, _orig=orig, **k):
+                    calls["batched"] += 1
+                    return _orig(*a, **k)
+                opt._ops.swag_sample_batched = counted
+        out = ens.predict_distributed(lambda m: m(x).detach(), 13, dist.group.WORLD)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"pred{rank}.npz"), out=out.cpu().numpy(), batched=np.array(calls["batched"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["swag", "svgd"])
+def test_predict_distributed_hip_two_ranks_one_device(tmp_path, kind):
+    import beyond_deep_ensembles_amd as bde
+    world = 2
+    mp.spawn(_predict_worker, args=(world, _free_port(), "gloo", kind, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "pred0.npz"), np.load(tmp_path / "pred1.npz")
+    np.testing.assert_array_equal(a["out"], b["out"])
+    assert a["out"].shape[0] == 13
+    dev = torch.device("cuda", 0)
+    ens = bde.DeepEnsemble(_members(dev, kind))
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(1)).to(dev)
+    want = ens.predict(lambda m: m(x).detach(), 13).cpu().numpy()            # the reference's single-process order
+    np.testing.assert_allclose(a["out"], want, rtol=1e-6, atol=1e-7)
+    if kind == "swag":
+        # the fan-out branch draws each member block with the batched MFMA sampler
+        assert int(a["batched"]) >= 1 and int(b["batched"]) >= 1
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
+def test_predict_distributed_hip_rccl(tmp_path):
+    world = 2
+    mp.spawn(_predict_worker, args=(world, _free_port(), "nccl", "swag", str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "pred0.npz"), np.load(tmp_path / "pred1.npz")
+    np.testing.assert_array_equal(a["out"], b["out"])

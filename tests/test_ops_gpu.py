@@ -63,6 +63,19 @@ def run_svgd(ops, P, G, l2, scale, n, sign=-1.0):
     return out[:, :d].cpu(), ks.cpu()
 
 
+def run_svgd_staged(ops, P, G, l2, scale, n, sign=-1.0):
+    """The three-launch path (gram -> kstats -> combine) whatever the size."""
+    m, d = P.shape
+    Pb, Gb = flat_rows(P), flat_rows(G)
+    out = torch.zeros_like(Gb)
+    ws, ks = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV)
+    ops.svgd_gram(Pb, d, ws)
+    ops.svgd_kstats(ws, m, l2, scale, n, sign, ks)
+    ops.svgd_combine(Pb, Gb, out, d, ks)
+    torch.cuda.synchronize()
+    return out[:, :d].cpu(), ks.cpu()
+
+
 def test_svgd_step_golden(ops, golden):
     g = golden("svgd_phi.npz")
     for i, (m, d, l2, scale, n, shared) in enumerate(g["cases"]):
@@ -78,8 +91,16 @@ def test_svgd_step_golden(ops, golden):
         K = ks[:m * m].reshape(m, m).numpy()
         errK_ref = np.max(np.abs(g[f"K_{i}"].astype(np.float64) - g[f"K64_{i}"]))
         assert np.max(np.abs(K - g[f"K64_{i}"])) <= max(2 * errK_ref, 3e-6), (i, m, d)
+        # bandwidth: anchored on the fp64 evaluation of svgd.py:15-18 (for shared-backbone particles the
+        # reference's own fp32 value is the less accurate one, so it only sets the allowance)
         h = float(ks[2 * m * m + m])
-        assert abs(h - float(g[f"h_{i}"])) <= max(2e-6 * h, 1e-12) or shared, (i, h, float(g[f"h_{i}"]))
+        h64 = float(O.svgd_bandwidth(P.double()))
+        assert abs(h - h64) <= max(2 * abs(float(g[f"h_{i}"]) - h64), 2e-6 * h64), (i, h, h64, float(g[f"h_{i}"]))
+        # both launch structures (single persistent launch for small models, three stages) meet the same bar
+        out3, ks3 = run_svgd_staged(ops, P, G, float(l2), float(scale), float(n))
+        err3 = np.max(np.abs(-out3.numpy().astype(np.float64) - phi64))
+        assert err3 <= max(2 * err_ref, 3e-6 * scale_mag), (i, m, d, err3, err_ref)
+        assert abs(float(ks3[2 * m * m + m]) - h64) <= max(2 * abs(float(g[f"h_{i}"]) - h64), 2e-6 * h64)
 
 
 def test_svgd_inplace_and_rbf_mode(ops, golden):
@@ -118,6 +139,52 @@ def test_svgd_deterministic_and_ragged_sizes(ops):
         err_ref = np.max(np.abs(ref32 - phi64))
         err = np.max(np.abs(-a.numpy() - phi64))
         assert err <= max(2 * err_ref, 3e-6 * np.max(np.abs(phi64))), (m, d, err, err_ref)
+
+
+def test_svgd_single_launch_path(ops):
+    """bde_svgd_step_small (one persistent launch: Gram partials -> in-kernel hand-off -> redundant statistics ->
+    combine) against the three-stage path and the fp64 anchor: sizes around its tile / workgroup / eligibility
+    boundaries, the CIFAR ResNet-20 size of BASELINE configs 2-3, in place, and many launches on one workspace
+    (the arrive / depart counters must come back to zero every time)."""
+    torch.manual_seed(3)
+    assert ops.svgd_small_supported(8, 273_610) and ops.svgd_small_supported(8, 524_288)
+    assert not ops.svgd_small_supported(8, 524_289) and not ops.svgd_small_supported(9, 1000)
+    cases = [(8, 273_610), (5, 273_610), (8, 524_288), (8, 524_285), (1, 4096), (2, 127), (3, 128), (7, 129),
+             (8, 32 * 128 * 3 + 5), (8, 256 * 128), (8, 256 * 128 + 1), (6, 256 * 128 * 2 - 3), (4, 70_001)]
+    for m, d in cases:
+        P = torch.randn(1, d) * 0.05 + torch.randn(m, d) * (0.002 if d % 2 else 0.05)     # shared-backbone-like and independent
+        G = torch.randn(m, d) * 0.01
+        a, ka = run_svgd(ops, P, G, 3e-4, 1.0, 50000.0)
+        b, kb = run_svgd_staged(ops, P, G, 3e-4, 1.0, 50000.0)
+        phi64 = O.svgd_phi(P.double(), G.double(), 3e-4, 1.0, 50000.0).numpy()
+        ref32 = O.svgd_phi(P, G, 3e-4, 1.0, 50000.0).numpy().astype(np.float64)
+        err_ref = np.max(np.abs(ref32 - phi64))
+        tol = max(2 * err_ref, 3e-6 * np.max(np.abs(phi64)))
+        assert np.max(np.abs(-a.numpy() - phi64)) <= tol, (m, d)
+        assert np.max(np.abs(-b.numpy() - phi64)) <= tol, (m, d)
+        assert torch.allclose(ka[:m * m], kb[:m * m], rtol=0, atol=2e-6), (m, d)        # K
+        assert torch.allclose(a, b, rtol=0, atol=float(tol)), (m, d)
+    # in place + repeated launches on ONE workspace, then the counters are zero again
+    m, d = 8, 273_610
+    P, G = torch.randn(m, d) * 0.05, torch.randn(m, d) * 0.01
+    Pb, G0 = flat_rows(P), flat_rows(G)
+    ws, ks = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV)
+    ref = torch.zeros_like(G0)
+    ops.svgd_step_small(Pb, G0, ref, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks)
+    for _ in range(200):
+        Gb = G0.clone()
+        ops.svgd_step_small(Pb, Gb, Gb, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks)
+    torch.cuda.synchronize()
+    assert torch.equal(Gb[:, :d], ref[:, :d])
+    assert int(ws[32:34].view(torch.int32).abs().sum()) == 0
+    # rbf mode (grad_kernel) through the same launch
+    out = torch.zeros_like(Pb)
+    ops.svgd_step_small(Pb, None, out, d, 0.0, 1.0, 1.0, 1.0, ws, ks, mode=1)
+    k64, gk64 = O.svgd_rbf(P.double())
+    k32, gk32 = O.svgd_rbf(P)
+    err_ref = (gk32.double() - gk64).abs().max().item()
+    assert (out[:, :d].cpu().double() - gk64).abs().max().item() <= max(2 * err_ref, 3e-6 * gk64.abs().max().item())
+    # (hipGraph capture of this launch: test_svgd_step_is_graph_capturable, whose size takes this path)
 
 
 def test_svgd_blocked_path_for_more_than_16_particles(ops):

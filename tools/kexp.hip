@@ -308,7 +308,7 @@ int main(int argc, char** argv) {
   vs.push_back({"gram mfma prefetch U2 g2048", [&] { hipLaunchKernelGGL(gram_prefetch_kernel<2>, dim3(2048), dim3(256), 0, st, P, M, D, ld, ws); }, B});
   for (int g : {1024, 2048})
     vs.push_back({"gram valu g" + std::to_string(g), [&, g] { hipLaunchKernelGGL(gram_valu_kernel, dim3(g), dim3(256), 0, st, P, D, ld, ws); }, B});
-  vs.push_back({"combine product", [&] { bde_svgd_combine(P, G, O, M, D, ld, ks, st); }, 3 * B});
+  vs.push_back({"combine product", [&] { bde_svgd_combine(P, G, O, M, D, ld, ld, ks, st); }, 3 * B});
   for (int g : {1024, 1280, 1536, 2048, 2560, 4096})
     vs.push_back({"combine plain g" + std::to_string(g), [&, g] { hipLaunchKernelGGL((combine_v_kernel<8, false>), dim3(g), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 3 * B});
   for (int g : {1280, 2048})
@@ -331,8 +331,8 @@ int main(int argc, char** argv) {
   vs.push_back({"PAIR gram + combine st sc0 sc1", [&] { bde_svgd_gram(P, M, D, ld, ws, st); hipLaunchKernelGGL((combine_s_kernel<8, 1>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
   vs.push_back({"PAIR gram + combine st sc0 sc1 nt", [&] { bde_svgd_gram(P, M, D, ld, ws, st); hipLaunchKernelGGL((combine_s_kernel<8, 2>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
   vs.push_back({"PAIR gram + combine st nt(asm)", [&] { bde_svgd_gram(P, M, D, ld, ws, st); hipLaunchKernelGGL((combine_s_kernel<8, 3>), dim3(2048), dim3(256), 0, st, P, G, O, D, ld, cg, cp); }, 4 * B});
-  vs.push_back({"PAIR product gram + product combine", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, G, O, M, D, ld, ks, st); }, 4 * B});
-  vs.push_back({"PAIR product gram + product combine INPLACE", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, O, O, M, D, ld, ks, st); }, 4 * B});
+  vs.push_back({"PAIR product gram + product combine", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, G, O, M, D, ld, ld, ks, st); }, 4 * B});
+  vs.push_back({"PAIR product gram + product combine INPLACE", [&] { bde_svgd_gram(P, M, D, ld, ws, st); bde_svgd_combine(P, O, O, M, D, ld, ld, ks, st); }, 4 * B});
   vs.push_back({"PAIR product gram+kstats+combine", [&] { bde_svgd_step(P, G, O, M, D, ld, 0.f, 1.f, 129809.f, -1.f, ws, ks, st); }, 4 * B});
   const int rounds = 7, inner = 5;
   std::vector<std::vector<float>> times(vs.size());
