@@ -11,9 +11,16 @@ reference's iWildCam ResNet-50), from P and G resident in
 HBM to -phi: three launches (MFMA Gram, kernel statistics, streaming combine),
 16*M*D algorithmic bytes.  Model forward/backward is not part of the path.
 
-N > 1: the 8 particles are sharded M/N per rank; a step is then ONE RCCL
-all-gather of the ranks' gradient rows (xGMI) followed by the update on the
-replicated particles -- total work fixed ("strong").
+N > 1: the 8 particles are sharded M/N per rank and a step is the product's own
+multi-GPU posterior update (SVGDOptimizer._posterior_update, fused SGD base
+optimizer): gradient exchange over RCCL/xGMI + update, total work fixed
+("strong").  --exchange picks the exchange: "alltoall" (dimension-sharded,
+default), "pipelined" (chunked all-gather overlapped with the update) or
+"allgather" (one all-gather, then the update).
+
+Timing: after W warm-up steps, --blocks (default 5) blocks of EXACTLY K steps,
+each bracketed by barrier + synchronize and reduced with MAX over ranks;
+ms_per_step is the MEDIAN block (all blocks are reported).
 
 One JSON line on stdout (rank 0); progress goes to stderr.
 """
@@ -139,7 +146,9 @@ def extras(ops, dev, quick):
     rws, kl = ops.reduce_ws(dev), torch.zeros(1, device=dev)
     rec("bbb_draw_fwd_resnet50", time_loop(lambda: ops.gauss_draw_fwd(mean, rho, w, d, seed=1, stream_id=0), it), 12 * d)
     rec("bbb_draw_bwd_resnet50", time_loop(lambda: ops.gauss_draw_bwd(w, rho, gm, gr, d, seed=1, stream_id=0, accumulate=True), it), 24 * d)
-    rec("bbb_kl_fwd_bwd_resnet50", time_loop(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, d, rws, kl_out=kl, gmean=gm, grho=gr), it), 16 * d)
+    # the KL row is the ACCUMULATE form (mu, rho read; gmu, grho read-modify-write) = 24 B/param
+    rec("bbb_kl_fwd_bwd_resnet50", time_loop(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, d, rws, kl_out=kl, gmean=gm, grho=gr, accumulate=True), it), 24 * d)
+    rec("bbb_kl_fwd_bwd_overwrite_resnet50", time_loop(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, d, rws, kl_out=kl, gmean=gm, grho=gr), it), 16 * d)
     var = torch.rand(ld, device=dev) + 1e-4
     rec("bbb_local_reparam_epilogue_fwd_resnet50", time_loop(lambda: ops.local_reparam_fwd(mean, var, w, d, seed=1, stream_id=0), it), 12 * d)
     # --- iVON
@@ -195,12 +204,88 @@ def torch_gpu_baseline(P, G, d, dev):
     return out
 
 
+def shell_step_ms(dev, steps=6):
+    """End-to-end SVGDOptimizer.step() with trivial closures over 161 parameter tensors totalling ResNet-50 size
+    (fused SGD base optimizer, Gram reuse): host logic of the shell + kernels, minus the closures' own cost."""
+    import beyond_deep_ensembles_amd as bde
+    n_tensors, d = 161, D_RESNET50
+    sizes = [d // n_tensors] * (n_tensors - 1)
+    sizes.append(d - sum(sizes))
+    params = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in sizes]
+    consts = [torch.randn(s, device=dev) * 0.01 for s in sizes]
+    base = torch.optim.SGD(params, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=3e-4)
+
+    def reset():
+        with torch.no_grad():
+            for p in params[-2:]:
+                p.normal_(0, 0.05)
+    opt = bde.SVGDOptimizer(params, reset, base, particle_count=M, dataset_size=DATASET_SIZE, fuse_base_optimizer=True,
+                            reuse_gram=True)
+
+    def fwd():
+        return torch.stack([p.sum() for p in torch._foreach_mul(params, consts)]).sum()
+
+    def bwd(loss):
+        loss.backward()
+    for _ in range(2):
+        opt.step(fwd, bwd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for _i in range(M):
+            for p in params:
+                p.grad = None
+            fwd().backward()
+    torch.cuda.synchronize()
+    t_closure = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        opt.step(fwd, bwd)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / steps
+    return {"step_ms": round(t_step * 1e3, 3), "closures_ms": round(t_closure * 1e3, 3),
+            "shell_plus_kernels_ms": round((t_step - t_closure) * 1e3, 3), "tensors": n_tensors, "particles": M,
+            "what": "SVGDOptimizer(fuse_base_optimizer=True, reuse_gram=True).step with trivial closures; "
+                    "closures_ms = the same M forward/backward closures alone"}
+
+
+def timed_blocks(step, steps, blocks, dist, dev):
+    """`blocks` blocks of exactly `steps` steps, each bracketed by barrier + synchronize; MAX over ranks per block."""
+    out = []
+    for _ in range(blocks):
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        out.append(elapsed / steps * 1e3)
+    return out
+
+
+def median(v):
+    s = sorted(v)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps; the median is reported")
     ap.add_argument("--dim", type=int, default=D_RESNET50)
+    ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "pipelined", "allgather"],
+                    help="N > 1: gradient exchange of the SVGD update")
+    ap.add_argument("--chunks", type=int, default=8, help="column chunks of the pipelined all-gather")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -230,59 +315,128 @@ def main():
     from beyond_deep_ensembles_amd.ops import HipOps
     ops = HipOps()                                 # raises if libbde_hip.so is missing: no fallback
     d = args.dim
-    P, G = make_svgd_inputs(d, dev, 1234)          # replicated particles: same seed on every rank
     per = M // world
-    if world > 1:                                  # own gradient rows differ per rank
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        G[rank * per:(rank + 1) * per, :d] = torch.randn(per, d, device=dev, generator=g) * 0.01
-    out = torch.empty_like(G)
-    ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
-    own = G[rank * per:(rank + 1) * per].reshape(-1)
-    if world > 1 and dist.get_backend() != "nccl":
-        own = own.clone()                              # gloo wants disjoint input/output
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    exchange_used, exchange_note = "none", None
+    phases = None
 
-    def step(i=None):
-        work = None
-        if world > 1:
-            # RCCL over xGMI: the particles' gradient rows.  The Gram pass and the kernel statistics only
-            # need the (replicated) particles, so they run while the collective is in flight.
-            work = dist.all_gather_into_tensor(G.view(-1), own, async_op=True)
-        ops.svgd_gram(P, d, ws)
-        ops.svgd_kstats(ws, M, 0.0, 1.0, DATASET_SIZE, -1.0, ks)
-        if work is not None:
-            work.wait()
-        if i is not None:
-            ev[i][0].record()
-        ops.svgd_combine(P, G, out, d, ks)
-        if i is not None:
-            ev[i][1].record()
+    if world == 1:
+        P, G = make_svgd_inputs(d, dev, 1234)
+        out = torch.empty_like(G)
+        ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+        def step(i=None):
+            ops.svgd_gram(P, d, ws)
+            ops.svgd_kstats(ws, M, 0.0, 1.0, DATASET_SIZE, -1.0, ks)
+            if i is not None:
+                ev[i][0].record()
+            ops.svgd_combine(P, G, out, d, ks)
+            if i is not None:
+                ev[i][1].record()
+    else:
+        # the product's multi-GPU update, driven exactly as SVGDOptimizer.step drives it after the backward passes
+        import beyond_deep_ensembles_amd as bde
+        P0, G0 = make_svgd_inputs(d, dev, 1234)                     # same seed: identical particles on every rank
+        theta = torch.nn.Parameter(P0[0, :d].clone())
+        rows = [P0[i, :d].clone() for i in range(M)]
+        del P0
+        it = iter(range(1, M))
+
+        def reset():
+            with torch.no_grad():
+                theta.copy_(rows[next(it)])
+        base = torch.optim.SGD([theta], lr=1e-12, momentum=0.9, nesterov=True, weight_decay=3e-4)
+
+        def build(kind):
+            nonlocal it
+            it = iter(range(1, M))
+            with torch.no_grad():
+                theta.data = rows[0].clone()
+            kw = {"alltoall": dict(exchange="alltoall"), "pipelined": dict(exchange_chunks=args.chunks), "allgather": {}}[kind]
+            return bde.SVGDOptimizer([theta], reset, base, particle_count=M, dataset_size=DATASET_SIZE,
+                                     process_group=dist.group.WORLD, fuse_base_optimizer=True, **kw)
+        try:
+            opt = build(args.exchange)
+            exchange_used = args.exchange
+            opt._posterior_update(torch.zeros((), device=dev))       # first contact with the collective
+            torch.cuda.synchronize()
+        except Exception as e:                                         # reported, never silent
+            exchange_note = f"{args.exchange} failed ({type(e).__name__}: {e}); fell back to allgather"
+            log(exchange_note)
+            opt = build("allgather")
+            exchange_used = "allgather"
+        # own gradient rows differ per rank
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        grow = opt._Gown if exchange_used == "alltoall" else opt._G[rank * per:(rank + 1) * per]
+        grow[:, :d] = torch.randn(per, d, device=dev, generator=g) * 0.01
+        del rows, G0
+        loss0 = torch.zeros((), device=dev)
+        ev = None
+
+        def step(i=None):
+            opt._posterior_update(loss0)
 
     for _ in range(args.warmup):
         step()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    combine_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    assert torch.isfinite(out[:, :d]).all()
+    blocks_ms = timed_blocks(step, args.steps, max(1, args.blocks), dist, dev)
+    ms_per_step = median(blocks_ms)
+    combine_ms = None
+    if world == 1:
+        combine_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps     # HIP events of the last block
+        assert torch.isfinite(out[:, :d]).all()
+    else:
+        assert torch.isfinite(opt.particles).all()
+        # where the time goes: the same update with (a) the kernels and (b) the collectives switched off
+        import contextlib
+
+        class _NoKernels:
+            """SVGD kernel calls become no-ops (allocation / capability queries pass through)."""
+            _keep = ("svgd_ws", "svgd_kstat", "svgd_small_supported", "svgd_fused_gram_supported")
+
+            def __init__(self, real):
+                self._real = real
+
+            def __getattr__(self, name):
+                attr = getattr(self._real, name)
+                if name.startswith("svgd_") and name not in self._keep and callable(attr):
+                    return lambda *a, **k: None
+                return attr
+
+        class _Done:
+            def wait(self):
+                return True
+
+        @contextlib.contextmanager
+        def no_collectives():
+            saved = (dist.all_gather_into_tensor, dist.all_to_all_single)
+            fake = lambda *a, async_op=False, **k: _Done() if async_op else None
+            dist.all_gather_into_tensor, dist.all_to_all_single = fake, fake
+            try:
+                yield
+            finally:
+                dist.all_gather_into_tensor, dist.all_to_all_single = saved
+        real_ops = opt._ops
+        opt._ops = _NoKernels(real_ops)
+        exchange_only = median(timed_blocks(step, args.steps, 1, dist, dev))
+        opt._ops = real_ops
+        with no_collectives():
+            update_only = median(timed_blocks(step, args.steps, 1, dist, dev))
+        hidden = exchange_only + update_only - ms_per_step
+        phases = {"mode": exchange_used, "exchange_ms": round(exchange_only, 4), "update_ms": round(update_only, 4),
+                  "step_ms": round(ms_per_step, 4),
+                  "overlap": round(max(0.0, hidden) / max(1e-9, min(exchange_only, update_only)), 3),
+                  "what": "exchange_ms = the step with the SVGD kernels switched off (collectives + host logic), "
+                          "update_ms = the step with the collectives switched off (kernels + host logic), "
+                          "overlap = (exchange + update - step) / min(exchange, update)"}
 
     # ---- SWAG posterior samples/s (the second half of BASELINE's metric): every rank samples independently
     # (MultiSWAG fan-out, DeepEnsemble.predict(rank=, world_size=)); aggregate = sum over ranks ("weak").
     swag = None
     if d == D_RESNET50:
-        del out
+        if world == 1:
+            del out
+        else:
+            del opt, grow
         torch.cuda.empty_cache()
         ld = pad_ld(d)
         gsw = torch.Generator(device=dev).manual_seed(99 + rank)
@@ -300,40 +454,56 @@ def main():
             dist.all_reduce(rates, op=dist.ReduceOp.SUM)
         swag = {"samples_per_s": round(float(rates[0]), 1), "samples_per_s_batched_S30": round(float(rates[1]), 1),
                 "K": K_SWAG, "D": d, "scaling": "weak (independent posterior samples on every GPU)",
-                "per_sample_hbm_frac_rank0": round(4 * d * (K_SWAG + 3) / t_single / 1e9 / HBM_PEAK_GBS, 4)}
+                "per_sample_hbm_frac_rank0": round(4 * d * (K_SWAG + 3) / t_single / 1e9 / HBM_PEAK_GBS, 4),
+                "batched_hbm_frac_rank0": round(4 * d * (K_SWAG + 2 + S_SWAG) / t_batch / 1e9 / HBM_PEAK_GBS, 4)}
         del mean, sq, ring, o1, ob
         out = None
 
     if rank == 0:
-        alg_bytes = 12 * M * d                       # dominant kernel: combine reads P and G, writes out
-        achieved = alg_bytes / (combine_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath) and d == D_RESNET50:
-            try:
-                traffic = json.load(open(tpath)).get("svgd_combine_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
         res = {
             "metric": "svgd_steps_per_s", "value": round(1e3 / ms_per_step, 2), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timing": {"blocks": len(blocks_ms), "steps_per_block": args.steps, "statistic": "median block",
+                       "ms_per_step_blocks": [round(x, 4) for x in blocks_ms],
+                       "ms_per_step_min": round(min(blocks_ms), 4), "ms_per_step_max": round(max(blocks_ms), 4)},
             "config": {"workload": "SVGD posterior update (svgd.py:83-89): 8 particles x ResNet-50-sized flat weights "
                                    "(iWildCam config, BASELINE configs[3] shape on N GPUs / its 1-GPU form at N=1); "
-                                   "gram + kernel stats + combine, P and G resident in HBM",
+                                   + ("gram + kernel stats + combine, P and G resident in HBM" if world == 1 else
+                                      "gradient exchange + kernel stats + fused update (-phi and 8 shared-state SGD "
+                                      "applications) + return of the updated particles to their owners"),
                        "particles": M, "D": d, "ld": pad_ld(d), "l2_reg": 0.0, "kernel_grad_scale": 1.0,
                        "dataset_size": DATASET_SIZE, "particles_per_rank": per,
-                       "exchange": "none" if world == 1 else "rccl all_gather of gradient rows",
-                       "algorithmic_bytes_per_step": 16 * M * d},
-            "step_hbm_frac": round(16 * M * d / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "roofline": {"kernel": "svgd_combine_kernel<8,true>", "bound": "hbm", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": round(combine_ms, 4)},
+                       "exchange": exchange_used, "exchange_note": exchange_note,
+                       "algorithmic_bytes_per_step": 16 * M * d if world == 1 else (12 * M + 8) * d},
+            "step_hbm_frac": round((16 * M * d if world == 1 else (12 * M + 8) * d / world) / (ms_per_step * 1e-3) / 1e9
+                                   / HBM_PEAK_GBS, 4),
         }
+        if world == 1:
+            alg_bytes = 12 * M * d                       # dominant kernel: combine reads P and G, writes out
+            achieved = alg_bytes / (combine_ms * 1e-3) / 1e9
+            traffic, traffic_source = None, None
+            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            if os.path.exists(tpath) and d == D_RESNET50:
+                try:
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("svgd_combine_kernel_bytes_per_launch")
+                    traffic_source = "profiles/roofline_traffic.json: " + tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 on gfx950)") \
+                        + " -- a recorded PMC measurement of this kernel at this size, not re-measured in this run"
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"kernel": "svgd_combine_kernel<8,true>", "bound": "hbm", "achieved": round(achieved, 1),
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                               "traffic": traffic, "traffic_source": traffic_source,
+                               "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(combine_ms, 4),
+                               "avg_launch_source": "HIP events around the kernel on its stream, last timed block"}
+        else:
+            res["roofline"] = None
+            res["exchange"] = phases
         if swag is not None:
             res["swag"] = swag
-        log(f"svgd_step: {ms_per_step:.4f} ms/step = {res['value']} steps/s; combine {combine_ms:.4f} ms = {achieved:.0f} GB/s; swag {swag}")
+        log(f"svgd_step: {ms_per_step:.4f} ms/step (blocks {[round(x, 4) for x in blocks_ms]}) = {res['value']} steps/s; "
+            f"combine {combine_ms} ms; swag {swag}")
         if world == 1:
             if not args.no_cpu_baseline:
                 log("cpu baseline ...")
@@ -349,6 +519,11 @@ def main():
             if not args.no_extras and d == D_RESNET50:
                 log("extras ...")
                 res["extra"] = extras(ops, dev, quick=False)
+                try:
+                    res["extra"]["svgd_shell_step_ms"] = shell_step_ms(dev)
+                    log(f"  svgd_shell_step_ms {res['extra']['svgd_shell_step_ms']}")
+                except Exception as e:
+                    log(f"  svgd_shell_step_ms skipped: {e}")
         print(json.dumps(res), flush=True)
     if dist:
         dist.barrier()

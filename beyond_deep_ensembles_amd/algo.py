@@ -78,31 +78,42 @@ def repoint(params: Sequence[torch.nn.Parameter], datas: Optional[Sequence[torch
             p.grad = g
 
 
+def clear_grads(params: Sequence[torch.nn.Parameter]) -> None:
+    """``param.grad = None`` for every parameter (``zero_grad(set_to_none=True)``).  With no gradient installed
+    autograd simply keeps the tensor a backward pass produces; with one installed it launches an in-place add PER
+    TENSOR (161 extra launches per backward at ResNet-50's tensor count), which is why the shells clear the
+    gradients before every backward pass and move the results into the flat buffers with ONE multi-tensor op."""
+    from . import _host
+    native = _host.load()
+    if native is not None:
+        native.clear_grads(params)
+        return
+    for p in params:
+        p.grad = None
+
+
 def adopt_grads(params: Sequence[torch.nn.Parameter], views: Sequence[torch.Tensor], add: bool = False) -> None:
-    """After a backward pass make sure the gradients sit in ``views`` (rows of
-    the flat gradient buffer).  Autograd accumulates in place into an existing
-    ``.grad`` (we point it at the view beforehand), so normally this is only a
-    pointer comparison per tensor; if the closure replaced ``.grad`` the values
-    are copied over (``add=False``) or added on top of what the view already
-    holds (``add=True``) with one multi-tensor op."""
+    """After a backward pass move the gradients into ``views`` (rows of the flat gradient buffer) and make them
+    the parameters' ``.grad``: copied (``add=False``; a missing gradient zeroes its view) or added on top of what
+    the view already holds (``add=True``), with one multi-tensor op for the whole list.  Gradients that already
+    live in their view (in-place accumulation) are left alone."""
     src, dst = [], []
     for p, v in zip(params, views):
         g = p.grad
-        if g is v:            # in-place accumulation keeps the very tensor object we installed (the common case)
+        if g is v:
             continue
         if g is None:
             if not add:
                 v.zero_()
-            p.grad = v
         elif g.data_ptr() != v.data_ptr():
             src.append(g)
             dst.append(v)
-            p.grad = v
     if src:
         if add:
             torch._foreach_add_(dst, src)
         else:
             torch._foreach_copy_(dst, src)
+    repoint(params, None, views)
 
 
 class BayesianOptimizer(Optimizer):

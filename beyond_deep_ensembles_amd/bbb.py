@@ -18,7 +18,7 @@ from typing import List
 
 import torch
 
-from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, _default_ops
+from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, clear_grads, _default_ops
 from .util import GaussianParameter
 
 
@@ -81,10 +81,13 @@ class _Group:
         params = group["params"]
         fused_ok = isinstance(self.prior, GaussianPrior) and not torch.is_tensor(self.prior.mu) \
             and not torch.is_tensor(self.prior.sigma)
+        frozen_plain = []
         for p in params:
             mod = getattr(p, "_bde_gaussian", None)
+            # the fused kernel writes gradients for mean AND rho, so both must be trainable; a frozen half keeps the
+            # pair on the reference's autograd path, where it simply receives no gradient
             if hasattr(p, "get_parameter_kl") and fused_ok and isinstance(mod, GaussianParameter) \
-                    and any(mod.rho is q for q in params):
+                    and any(mod.rho is q for q in params) and p.requires_grad and mod.rho.requires_grad:
                 means.append(p)
                 rhos.append(mod.rho)
                 claimed.add(id(p))
@@ -95,8 +98,10 @@ class _Group:
             if hasattr(p, "get_parameter_kl"):
                 generic.append(p)                   # autograd path of the reference (bbb.py:73-74)
             elif not getattr(p, "_is_gaussian_mean", False) and not getattr(p, "_is_gaussian_rho", False):
-                plain.append(p)                     # l2 term (bbb.py:75-76)
+                # l2 term (bbb.py:75-76); a frozen tensor contributes its value but never gets a gradient
+                (plain if p.requires_grad else frozen_plain).append(p)
         self.means, self.rhos, self.plain, self.generic = means, rhos, plain, generic
+        self.frozen_plain = frozen_plain
         self.gl = FlatLayout(means) if means else None
         self.pl = FlatLayout(plain) if plain else None
 
@@ -136,12 +141,34 @@ class BBBOptimizer(BayesianOptimizer):
         check_params(list(self._params()), self._ops)
         dev = self._params_device()
         self._groups: List[_Group] = [_Group(g, self._ops, dev) for g in self.param_groups]
+        self._uncovered = None
         self._rws = self._ops.reduce_ws(dev)
         self._kl_parts = torch.zeros(2 * len(self._groups), dtype=torch.float32, device=dev)
 
+    def _not_in_flat_buffers(self):
+        """Every parameter base_optimizer.zero_grad() (bbb.py:60) would clear whose gradient the KL kernels do
+        NOT overwrite: parameters on the autograd path (MixturePrior / tensor-valued priors / frozen halves, and
+        their rho partners), frozen tensors, and parameters only the base optimizer knows."""
+        if self._uncovered is None:
+            covered = set()
+            for fg in self._groups:
+                covered.update(id(p) for p in fg.means + fg.rhos + fg.plain)
+            seen, rest = set(), []
+            base = self.state["__base_optimizer"]
+            for group in list(self.param_groups) + list(base.param_groups):
+                for p in group["params"]:
+                    if id(p) not in covered and id(p) not in seen:
+                        seen.add(id(p))
+                        rest.append(p)
+            self._uncovered = rest
+        return self._uncovered
+
     def step(self, forward_closure, backward_closure, grad_scaler=None):
-        # base_optimizer.zero_grad() (bbb.py:60) is folded into the KL kernels below: they OVERWRITE the flat
-        # gradient buffers with pi * dKL, so nothing has to be zeroed first.
+        # base_optimizer.zero_grad() (bbb.py:60): for the flat groups it is folded into the KL kernels below, which
+        # OVERWRITE the flat gradient buffers with pi * dKL; every other parameter is cleared here (set to None, the
+        # zero_grad default), so nothing accumulates from step to step.
+        for p in self._not_in_flat_buffers():
+            p.grad = None
         pi = self.kl_rescaling / self.dataset_size
         scale_dev = None
         if grad_scaler is not None and grad_scaler.is_enabled():
@@ -160,18 +187,16 @@ class BBBOptimizer(BayesianOptimizer):
         total_kl_loss = torch.tensor(0.0, device=self._params_device())
         with torch.no_grad():
             for gi, (group, fg) in enumerate(zip(self.param_groups, self._groups)):
-                for p in fg.generic:
-                    p.grad = None
                 if fg.means:
                     kl = self._kl_parts[2 * gi:2 * gi + 1]
                     self._ops.gauss_kl(fg.mu, fg.rho, float(fg.prior.mu), float(fg.prior.sigma), fg.gl.d, self._rws,
                                        kl_out=kl, gmean=fg.gmu, grho=fg.grho, grad_scale=pi, grad_scale_dev=scale_dev,
                                        accumulate=False)
                     total_kl_loss = total_kl_loss + kl[0]
-                    for p, v in zip(fg.means, fg.gmu_views):
-                        p.grad = v
-                    for p, v in zip(fg.rhos, fg.grho_views):
-                        p.grad = v
+                    # the data-loss gradients of backward() come as fresh tensors and are added onto the KL
+                    # gradients with one multi-tensor op (adopt_grads below), not one in-place add per tensor
+                    clear_grads(fg.means)
+                    clear_grads(fg.rhos)
                 if fg.plain:
                     l2_scale = float(group["l2_scale"])
                     if l2_scale != 0.0:
@@ -181,12 +206,14 @@ class BBBOptimizer(BayesianOptimizer):
                         total_kl_loss = total_kl_loss + val[0]
                     else:
                         fg.gp.zero_()
-                    for p, v in zip(fg.plain, fg.gp_views):
-                        p.grad = v
+                    clear_grads(fg.plain)
         # priors without a fused kernel keep the reference's autograd path
         for group, fg in zip(self.param_groups, self._groups):
             for p in fg.generic:
                 total_kl_loss = total_kl_loss + p.get_parameter_kl(group["prior"])
+            if group["l2_scale"] != 0:
+                for p in fg.frozen_plain:
+                    total_kl_loss = total_kl_loss + group["l2_scale"] / 2 * p.pow(2).sum()
 
         # don't divide the kl loss by the mc sample count as it has been collected only once (bbb.py:78-80)
         loss = pi * total_kl_loss + total_data_loss / (self.mc_samples * self.components)

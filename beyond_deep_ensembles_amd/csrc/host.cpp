@@ -1,0 +1,46 @@
+// Native host helper of the optimizer shells: the per-tensor pointer-aliasing loops in C++.
+//
+// The reference re-points `param.data` (and hands over `param.grad`) tensor by tensor in Python
+// (src/algos/svgd.py:93-96,120-127; swag.py:58,81; ivorn.py:111).  With ResNet-50's 161 tensors an
+// SVGD step does that 2 * 8 * 161 times -- ~4 ms of interpreter time around 0.5 ms of kernels.  Here
+// the same loop runs over the already-unpacked tensor lists.  No arithmetic, no device work: plumbing.
+#include <torch/extension.h>
+
+#include <vector>
+
+namespace {
+
+// param[i].data = datas[i] (if given); param[i].grad = grads[i] (if given; None clears).
+void repoint(const std::vector<at::Tensor>& params, const c10::optional<std::vector<at::Tensor>>& datas,
+             const c10::optional<std::vector<at::Tensor>>& grads) {
+  const size_t n = params.size();
+  if (datas.has_value()) {
+    TORCH_CHECK(datas->size() == n, "repoint: ", n, " parameters but ", datas->size(), " data tensors");
+    for (size_t i = 0; i < n; ++i) {
+      at::Tensor p = params[i];
+      p.set_data((*datas)[i]);
+    }
+  }
+  if (grads.has_value()) {
+    TORCH_CHECK(grads->size() == n, "repoint: ", n, " parameters but ", grads->size(), " gradient tensors");
+    for (size_t i = 0; i < n; ++i) {
+      at::Tensor p = params[i];
+      p.mutable_grad() = (*grads)[i];
+    }
+  }
+}
+
+void clear_grads(const std::vector<at::Tensor>& params) {
+  for (const at::Tensor& t : params) {
+    at::Tensor p = t;
+    p.mutable_grad() = at::Tensor();
+  }
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("repoint", &repoint, "param.data / param.grad = views, for whole parameter lists", py::arg("params"),
+        py::arg("datas"), py::arg("grads"));
+  m.def("clear_grads", &clear_grads, "param.grad = None for a whole parameter list");
+}

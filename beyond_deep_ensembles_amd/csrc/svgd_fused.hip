@@ -19,6 +19,14 @@
 
 namespace bde {
 
+// how the in-place particle stream is loaded / stored (A/B switch for tools/kexp6.hip)
+#ifndef BDE_FUSED_PLD
+#define BDE_FUSED_PLD ld4
+#endif
+#ifndef BDE_FUSED_PST
+#define BDE_FUSED_PST st4
+#endif
+
 constexpr int kFusedMaxBlocks = kGramMaxBlocks;   // the Gram partials go into the same ws slots
 
 template <int M, int OPT /* 0 sgd, 1 adam */, bool GRAM>
@@ -40,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ 
     for (int i = 0; i < M; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      p[j] = ld4(P + j * ld + 4 * i4);
+      p[j] = BDE_FUSED_PLD(P + j * ld + 4 * i4);
       const f32x4 g = ld4_nt(G + j * ldg + 4 * i4);
 #pragma unroll
       for (int i = 0; i < M; ++i) {
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ 
         }
         a0[c] = b;
       }
-      st4(P + i * ld + 4 * i4, p[i]);
+      BDE_FUSED_PST(P + i * ld + 4 * i4, p[i]);
     }
     if (OPT == 0) {
       if (sk.momentum != 0.f) st4(s0 + 4 * i4, a0);

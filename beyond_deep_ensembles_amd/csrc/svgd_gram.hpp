@@ -29,13 +29,15 @@ __device__ __forceinline__ float group_sum(float x) {
 
 // One tile = kGramU float4 columns per lane.  Full tiles take the branch-free path; the ragged
 // last tile masks by index (never by multiplication: the row padding may hold NaNs).
-template <int W4>
+// NT: the particles are streamed once per pass by the three-stage path -> non-temporal loads (6.56 vs 5.93 TB/s
+// measured, profiles/r02_probes.txt); the single-launch path re-reads them from L2 and loads them normally.
+template <int W4, bool NT = true>
 __device__ __forceinline__ void gram_load_tile(f32x4 (&v)[kGramU], const float* __restrict__ rowp, bool valid,
                                                int64_t t, int64_t tile4, int c4, int64_t n4, int64_t D) {
   const int64_t base4 = t * tile4 + c4;
   if ((t + 1) * tile4 * 4 <= D) {                    // wave-uniform: every column full
 #pragma unroll
-    for (int u = 0; u < kGramU; ++u) v[u] = ld4(rowp + 4 * (base4 + u * W4));
+    for (int u = 0; u < kGramU; ++u) v[u] = NT ? ld4_nt(rowp + 4 * (base4 + u * W4)) : ld4(rowp + 4 * (base4 + u * W4));
   } else {
 #pragma unroll
     for (int u = 0; u < kGramU; ++u) {

@@ -4,11 +4,17 @@
 
 namespace bde {
 
-// ws header (256 B, so that the partial tiles behind it start on a 128-byte line): ws[0] = #partial tiles,
-// ws[1] = padded M (8 or 16); words 32 / 33 (their own 128-byte line) are the arrive / depart counters of the
-// single-launch path (svgd_small.hip) -- they must be ZERO before the first launch and every launch leaves them zero.
-constexpr int kWsHeaderFloats = 64;
-constexpr int kWsArriveWord = 32, kWsDepartWord = 33;
+// ws header (1 KB, so that the partial tiles behind it start on a 128-byte line): ws[0] = #partial tiles,
+// ws[1] = padded M (8 or 16).  The rest are the hand-off words of the single-launch path (svgd_small.hip), each
+// group on 128-byte lines of its own: 8 sharded arrive counters (word 32 + 32 s), the top counter (word 32 + 32*8),
+// 8 go flags (word 32 + 32 * (9 + s)) and the depart counter.  They must be ZERO before the first launch and every
+// launch leaves them zero.
+constexpr int kWsHeaderFloats = 32 * 20;
+constexpr int kWsShards = 8;
+constexpr int kWsArriveWord = 32;                         // + 32 * shard
+constexpr int kWsTopWord = 32 + 32 * kWsShards;
+constexpr int kWsGoWord = 32 + 32 * (kWsShards + 1);      // + 32 * shard
+constexpr int kWsDepartWord = 32 + 32 * (2 * kWsShards + 1);
 constexpr int kGramMaxBlocks = 1024;       // 4 workgroups per CU: best measured (tools/kexp.hip)
 
 // Per-particle Adam scalars of the SHARED step counter (advanced once per particle).
@@ -30,7 +36,7 @@ static inline AdamSteps make_adam_steps(double lr, double beta1, double beta2, i
 // ---- generic path (16 < M <= 64): particles in groups of 8, one 16-row Gram tile per pair of groups ----
 static inline int svgd_groups(int M) { return (M + 7) / 8; }
 static inline int svgd_pairs(int M) { const int g = svgd_groups(M); return g * (g + 1) / 2; }
-// ws layout for M > 16: [header 64][pairs x kGramMaxBlocks x 256 partial tiles][M*M d2 matrix]
+// ws layout for M > 16: [header][pairs x kGramMaxBlocks x 256 partial tiles][M*M d2 matrix]
 static inline size_t svgd_generic_d2_offset(int M) {
   return static_cast<size_t>(kWsHeaderFloats) + static_cast<size_t>(svgd_pairs(M)) * kGramMaxBlocks * 256;
 }

@@ -9,11 +9,14 @@
 //   phase 1  every workgroup owns <= 512 consecutive float4 columns of P: centred Gram partial
 //            of its slice on the f32 MFMA (same tiles as svgd_gram_kernel<2>), published with
 //            write-through (sc1) stores;
-//   hand-off one agent-scope atomic add per workgroup on an arrive counter, one lane polling it
-//            with sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + drained
-//            vmcnt + counter add on the producer, sc1 poll + workgroup barrier + sc1 loads on the
-//            consumer) -- while it waits, the workgroup's P and G columns for phase 2 are already
-//            in flight into registers (P from the XCD's L2, where phase 1 just put it);
+//   hand-off one agent-scope atomic add per workgroup on one of 8 SHARDED arrive counters (a single
+//            counter serialises 256 adds at ~12 ns each and is hammered by 256 pollers on top); the
+//            last arriver of a shard adds to a top counter, the last of those raises the 8 go flags;
+//            one lane per workgroup polls its shard's flag with sc1 loads (MI355X_MICROARCH.md,
+//            inter-workgroup visibility: sc1 stores + drained vmcnt + counter add on the producer,
+//            sc1 poll + workgroup barrier + sc1 loads on the consumer) -- while it waits, the
+//            workgroup's P and G columns for phase 2 are already in flight into registers (P from
+//            the XCD's L2, where phase 1 just put it);
 //   phase 2  EVERY workgroup reduces all partials in the same fixed order (fp64) and evaluates the
 //            kernel statistics redundantly (a few hundred scalar operations), keeps the 2 M^2
 //            coefficients in LDS, and combines its own columns.
@@ -25,6 +28,14 @@
 #include "svgd_gram.hpp"
 
 namespace bde {
+
+// development aid (tools/kexp6.hip): per-workgroup phase timestamps, 100 MHz wall clock
+#ifdef BDE_SMALL_TIMING
+__device__ unsigned long long g_small_ts[256 * 16];
+#define BDE_TS(k) if (threadIdx.x == 0) g_small_ts[blockIdx.x * 16 + (k)] = wall_clock64();
+#else
+#define BDE_TS(k)
+#endif
 
 constexpr int kSmallBlock = 256;
 constexpr int kSmallMaxTilesPerWG = 16;            // 16 tiles x 32 float4 columns = 512 columns = 2 per thread
@@ -53,10 +64,15 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwg = gridDim.x;
-  unsigned* arrive = reinterpret_cast<unsigned*>(ws) + kWsArriveWord;
-  unsigned* depart = reinterpret_cast<unsigned*>(ws) + kWsDepartWord;
+  unsigned* words = reinterpret_cast<unsigned*>(ws);
+  const int shard = blockIdx.x & (kWsShards - 1);
+  unsigned* arrive = words + kWsArriveWord + 32 * shard;
+  unsigned* top = words + kWsTopWord;
+  unsigned* go = words + kWsGoWord + 32 * shard;
+  unsigned* depart = words + kWsDepartWord;
   float* part = ws + kWsHeaderFloats;
 
+  BDE_TS(0)
   // ---------------- phase 1: centred Gram partial of this workgroup's columns ----------------
   const int r16 = lane & 15, kq = lane >> 4;
   const int c4 = (r16 >> 3) * 4 + kq;
@@ -77,7 +93,7 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
 #pragma unroll
     for (int k = 0; k < TW; ++k) {
       const int64_t t = t0 + wave + 4 * k;
-      if (t < t1) gram_load_tile<8>(v[k], rowp, valid, t, kSmallTile4, c4, n4c, D);
+      if (t < t1) gram_load_tile<8, false>(v[k], rowp, valid, t, kSmallTile4, c4, n4c, D);
     }
 #pragma unroll
     for (int k = 0; k < TW; ++k) {
@@ -102,6 +118,7 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
 #pragma unroll
   for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][r16] = acc0[r] + acc1[r];
   __syncthreads();
+  BDE_TS(1)
   if (tid < MP2) {                                                 // one wave, one store instruction per 128-B line
     const int pi = tid / MP, pj = tid % MP;
     float s = 0.f;
@@ -111,7 +128,22 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the write-through stores have left this CU
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  BDE_TS(2)
+  if (tid == 0) {
+    const unsigned in_shard = static_cast<unsigned>((nwg - shard + kWsShards - 1) / kWsShards);
+    const unsigned shards = static_cast<unsigned>(nwg < kWsShards ? nwg : kWsShards);
+    if (__hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1u) {
+      // last of this shard: its counter can go back to zero, and the shard reports to the top counter
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u) {
+        // last of all: every partial tile is published
+        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned sh = 0; sh < shards; ++sh)
+          __hip_atomic_store(words + kWsGoWord + 32 * sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  BDE_TS(3)
 
   // ---------------- phase 2 operands: requested now, consumed after the hand-off ----------------
   const int64_t n4 = D >> 2;                                       // full float4 columns
@@ -135,9 +167,9 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
 
   // ---------------- hand-off ----------------
   if (tid == 0) {
-    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<unsigned>(nwg))
-      __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
   }
+  BDE_TS(4)
   __syncthreads();
 
   // fixed-order fp64 reduction of ALL partial tiles (every workgroup computes the same bits)
@@ -158,13 +190,16 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
   __syncthreads();
   if (tid < MP2) gmat[tid] = (red[tid] + red[MP2 + tid]) + (red[2 * MP2 + tid] + red[3 * MP2 + tid]);
   __syncthreads();
+  BDE_TS(5)
   svgd_stats_core(gmat, M, MP, sp, blockIdx.x == 0 ? kstat : nullptr, cgT, cpT);
 
-  // the arrive counter is no longer read by this workgroup: the last one to get here resets both counters
+  BDE_TS(6)
+  // every workgroup has passed its go flag once all have added here: the last one lowers the flags again
   if (tid == 0) {
     const unsigned left = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (left == static_cast<unsigned>(nwg) - 1u) {
-      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int sh = 0; sh < kWsShards; ++sh)
+        __hip_atomic_store(words + kWsGoWord + 32 * sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (blockIdx.x == 0) {
@@ -205,6 +240,7 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
     if (hasA) st4_nt(out + i * ld + 4 * cA, oA[i]);
     if (hasB) st4_nt(out + i * ld + 4 * cB, oB[i]);
   }
+  BDE_TS(7)
   // the D % 4 leftover coordinates (last workgroup)
   if (blockIdx.x == nwg - 1) {
     const int64_t e = (n4 << 2) + tid;

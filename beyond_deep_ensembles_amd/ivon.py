@@ -20,7 +20,7 @@ from typing import Callable, List, Optional
 
 import torch
 
-from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, _default_ops, _opt_state
+from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, clear_grads, repoint, _default_ops, _opt_state
 from .util import normal_like
 
 
@@ -97,13 +97,10 @@ class iVONOptimizer(BayesianOptimizer):
 
             self.sample_parameters()
             with torch.enable_grad():
-                if scaler_on:
-                    # unscale_() acts on the gradients of ONE sample, so they cannot share the accumulator
-                    for fg in self._groups:
-                        for p in fg.params:
-                            p.grad = None
-                else:
-                    self._point_grads()          # zero_grad() once, then autograd accumulates the MC sum in place
+                # no gradient installed: backward() hands over fresh tensors (no per-tensor in-place add launches);
+                # _store_gradients moves / adds them into the flat accumulator with one multi-tensor op
+                for fg in self._groups:
+                    clear_grads(fg.params)
                 loss = forward_closure()
                 backward_closure(loss)
 
@@ -135,15 +132,6 @@ class iVONOptimizer(BayesianOptimizer):
     def _reset_state(self):
         for fg in self._groups:
             fg.have_delta = False
-            fg.grad_zeroed = False
-
-    def _point_grads(self):
-        for fg in self._groups:
-            if not getattr(fg, "grad_zeroed", False):
-                fg.grad.zero_()
-                fg.grad_zeroed = True
-            for p, v in zip(fg.params, fg.grad_views):
-                p.grad = v
 
     def sample_parameters(self):
         with torch.no_grad():
@@ -198,12 +186,6 @@ class iVONOptimizer(BayesianOptimizer):
                 fg.have_delta = False
 
     def _store_gradients(self, scaler_on=False, first=True):
+        """ivorn.py:120-127: the first MC sample's gradients become the accumulator, the others are added."""
         for fg in self._groups:
-            if scaler_on:
-                grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in fg.params]
-                if first:
-                    torch._foreach_copy_(fg.grad_views, grads)
-                else:
-                    torch._foreach_add_(fg.grad_views, grads)
-            else:
-                adopt_grads(fg.params, fg.grad_views, add=True)
+            adopt_grads(fg.params, fg.grad_views, add=not first)

@@ -41,8 +41,12 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, repoint, _default_ops, _opt_state
+from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, clear_grads, repoint, _default_ops, _opt_state
 from .ops import pad4
+
+
+import os as _os
+_INPLACE_GRADS = bool(_os.environ.get("BDE_SVGD_INPLACE_GRADS"))
 
 
 def rbf(particles: torch.Tensor, h_override=None, _ops=None):
@@ -172,11 +176,15 @@ class SVGDOptimizer(BayesianOptimizer):
         total_loss = torch.tensor(0.0, device=self._params_device())
         for particle_idx in self._local_particles():
             self._set_grad_scaler_state(grad_scaler, OptState.READY, base)
-            # _use_particle (svgd.py:120-127) and base_optimizer.zero_grad() (svgd.py:70) in one pass over the
-            # tensors: the gradient row is zeroed and param.grad pointed at it, so backward() accumulates
-            # into the flat buffer
-            self._grad_row(particle_idx).zero_()
-            repoint(self._plist, self._pviews[particle_idx], self._gviews[particle_idx])
+            # _use_particle (svgd.py:120-127) and base_optimizer.zero_grad() (svgd.py:70)
+            if _INPLACE_GRADS:
+                # round-1 hand-over, kept for A/B timing (tools/shell_bench.py): the gradient row is zeroed and
+                # param.grad pointed at it, so backward() accumulates in place -- one add launch PER TENSOR
+                self._grad_row(particle_idx).zero_()
+                repoint(self._plist, self._pviews[particle_idx], self._gviews[particle_idx])
+            else:
+                repoint(self._plist, self._pviews[particle_idx], None)
+                clear_grads(self._plist)
 
             loss = forward_closure()
             total_loss += loss.detach()
@@ -185,6 +193,14 @@ class SVGDOptimizer(BayesianOptimizer):
                 return None
             adopt_grads(self._plist, self._gviews[particle_idx])      # _store_grads (svgd.py:129-133)
 
+        return self._posterior_update(total_loss, grad_scaler)
+
+    def _posterior_update(self, total_loss, grad_scaler=None):
+        """Everything after the forward/backward passes (svgd.py:82-105): gradient exchange (multi-GPU), kernel
+        statistics, -phi and the base-optimizer applications.  ``total_loss`` = sum of this rank's particle losses;
+        returns the mean loss over all particles.  (bench.py times exactly this.)"""
+        base = self.state["__base_optimizer"]
+        m = self.state["__particle_count"]
         with torch.no_grad():
             fused = self._fuse and (grad_scaler is None or not grad_scaler.is_enabled())
             if self._fused_decision is None:

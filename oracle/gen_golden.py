@@ -16,6 +16,7 @@ Fixture list:
   swag_schedule.npz   update-gate counter traces            (swag.py:91-97)
   swag_stats.npz      moments / deviation columns / samples (swag.py:98-114, 53-58)
   bbb.npz             GaussianParameter draw, KL, one BBBOptimizer trajectory
+  bbb2.npz            BBBOptimizer with MixturePrior; with frozen parameters; over the reference's BBBConv2d CNN
   ivon.npz            iVON trajectories with recorded noise (ivorn.py:41-115)
   ensemble.npz        DeepEnsemble.predict sample split     (ensemble.py:37-40)
   ref_*_checkpoint.pt state_dict()s written by the reference optimizers (wire compatibility)
@@ -306,6 +307,120 @@ def gen_bbb():
     np.savez_compressed(os.path.join(OUT, "bbb.npz"), **out)
 
 
+def _record_bbb_run(out, tag, model, extra, opt, x, y, tape, steps=3, loss_extra=True):
+    """Run `steps` BBBOptimizer steps of the reference with the noise recorded; store inputs, initial
+    parameters (by name), losses, the flat parameter trajectory and the noise tape under `tag`."""
+    params = list(model.parameters()) + ([extra] if extra is not None else [])
+    names = [n for n, _ in model.named_parameters()] + (["extra"] if extra is not None else [])
+    init = {n: npy(p) for n, p in zip(names, params)}
+    old_u, old_l = ref_util.normal_like, ref_bbb_layers.normal_like
+    ref_util.normal_like = tape
+    ref_bbb_layers.normal_like = tape
+    losses, trajs = [], []
+    n_batches = x.shape[0] // 16
+    try:
+        for t in range(steps):
+            xb, yb = x[(t % n_batches) * 16:(t % n_batches + 1) * 16], y[(t % n_batches) * 16:(t % n_batches + 1) * 16]
+            if extra is not None:
+                loss = opt.step(lambda: F.mse_loss(model(xb), yb) + extra.sum() * 0.01, lambda l: l.backward())
+            else:
+                loss = opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+            losses.append(float(loss))
+            trajs.append(flat(params))
+    finally:
+        ref_util.normal_like, ref_bbb_layers.normal_like = old_u, old_l
+    out[f"{tag}_x"], out[f"{tag}_y"] = npy(x), npy(y)
+    for n in names:
+        out[f"{tag}_init/{n}"] = init[n]
+    out[f"{tag}_names"] = np.array(names)
+    out[f"{tag}_losses"] = np.array(losses, dtype=np.float64)
+    out[f"{tag}_traj"] = npy(torch.stack(trajs))
+    out[f"{tag}_n_eps"] = np.array(len(tape.tape))
+    for i, e in enumerate(tape.tape):
+        out[f"{tag}_eps_{i}"] = npy(e)
+    return params
+
+
+def gen_bbb2():
+    """Round-2 additions (bbb2.npz), all produced by the reference's own classes:
+      d  BBBOptimizer with a MixturePrior (bbb.py:23-37): the optimizer-level zero_grad (bbb.py:60) matters here,
+         the rho gradients come only from the data term;
+      e  frozen (requires_grad=False) Gaussian mean and plain parameter with weight decay on the base optimizer
+         (they must not move: their .grad stays None, bbb.py:60 + torch's optimizers skip None grads);
+      f  the reference's BBBConv2d + BBBLinear (bbb_layers.py:105-159, 10-90) on a small CNN, Adam."""
+    out = {}
+    # ---- d: MixturePrior
+    torch.manual_seed(31)
+    prior = ref_bbb.MixturePrior(0.5, 1.0, 0.05)
+    model = nn.Sequential(RefSampledLinear(13, 20), nn.ReLU(), RefSampledLinear(20, 1))
+    extra = nn.Parameter(torch.randn(4) * 0.1)
+    x, y = torch.randn(48, 13), torch.randn(48, 1)
+    params = list(model.parameters()) + [extra]
+    base = torch.optim.SGD(params, lr=0.05, momentum=0.9)
+    opt = ref_bbb.BBBOptimizer(params, base, prior, dataset_size=48, mc_samples=2, kl_rescaling=0.5, l2_scale=0.3)
+    _record_bbb_run(out, "d", model, extra, opt, x, y, NoiseTape(11), steps=4)
+
+    # ---- e: frozen parameters
+    torch.manual_seed(32)
+    prior = ref_bbb.GaussianPrior(0, 1.0)
+    model = nn.Sequential(RefSampledLinear(13, 20), nn.ReLU(), RefSampledLinear(20, 1))
+    model[0].bias.mean.requires_grad_(False)           # a frozen Gaussian mean (its rho stays trainable)
+    model[2].weight.rho.requires_grad_(False)          # a frozen rho (its mean stays trainable)
+    extra = nn.Parameter(torch.randn(4) * 0.1)
+    frozen_plain = nn.Parameter(torch.randn(6) * 0.5, requires_grad=False)
+    x, y = torch.randn(48, 13), torch.randn(48, 1)
+    params = list(model.parameters()) + [extra, frozen_plain]
+    base = torch.optim.SGD(params, lr=0.05, momentum=0.9, weight_decay=0.1)
+    opt = ref_bbb.BBBOptimizer(params, base, prior, dataset_size=48, mc_samples=1, kl_rescaling=1.0, l2_scale=1.0)
+    names = [n for n, _ in model.named_parameters()] + ["extra", "frozen_plain"]
+    init = {n: npy(p) for n, p in zip(names, params)}
+    tape = NoiseTape(12)
+    old_u = ref_util.normal_like
+    ref_util.normal_like = tape
+    losses, trajs = [], []
+    try:
+        for t in range(3):
+            xb, yb = x[t * 16:(t + 1) * 16], y[t * 16:(t + 1) * 16]
+            loss = opt.step(lambda: F.mse_loss(model(xb), yb) + extra.sum() * 0.01, lambda l: l.backward())
+            losses.append(float(loss))
+            trajs.append(flat(params))
+    finally:
+        ref_util.normal_like = old_u
+    out["e_x"], out["e_y"] = npy(x), npy(y)
+    for n in names:
+        out[f"e_init/{n}"] = init[n]
+    out["e_names"] = np.array(names)
+    out["e_losses"] = np.array(losses, dtype=np.float64)
+    out["e_traj"] = npy(torch.stack(trajs))
+    out["e_n_eps"] = np.array(len(tape.tape))
+    for i, e in enumerate(tape.tape):
+        out[f"e_eps_{i}"] = npy(e)
+
+    # ---- f: BBBConv2d + BBBLinear CNN
+    torch.manual_seed(33)
+    prior = ref_bbb.GaussianPrior(0, 1.0)
+
+    class RefCNN(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = ref_bbb_layers.BBBConv2d(3, 4, 3, prior, prior, padding=1)
+            self.conv2 = ref_bbb_layers.BBBConv2d(4, 4, 3, prior, prior, stride=2, bias=False)
+            self.fc = ref_bbb_layers.BBBLinear(4, 2, prior, prior)
+
+        def forward(self, x):
+            x = F.relu(self.conv(x))
+            x = F.relu(self.conv2(x)).mean(dim=(2, 3))
+            return self.fc(x)
+
+    model = RefCNN()
+    x, y = torch.randn(32, 3, 7, 7), torch.randn(32, 2)
+    params = list(model.parameters())
+    base = torch.optim.Adam(params, lr=1e-2)
+    opt = ref_bbb.BBBOptimizer(params, base, prior, dataset_size=32, mc_samples=2, kl_rescaling=0.2)
+    _record_bbb_run(out, "f", model, None, opt, x, y, NoiseTape(13), steps=3)
+    np.savez_compressed(os.path.join(OUT, "bbb2.npz"), **out)
+
+
 # ------------------------------------------------------------------ iVON
 def gen_ivon():
     out = {}
@@ -452,7 +567,11 @@ def gen_checkpoints():
     torch.save({"particles_after": after, "loss": float(loss)}, os.path.join(OUT, "ref_svgd_checkpoint_next.pt"))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1:
+    for _name in sys.argv[1:]:
+        globals()["gen_" + _name]()
+    print("regenerated:", sys.argv[1:])
+elif __name__ == "__main__":
     gen_svgd_phi()
     gen_svgd_traj("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4),
                   m=5, l2_reg=0.01, scale=1.0)
@@ -461,6 +580,7 @@ if __name__ == "__main__":
     gen_swag_schedule()
     gen_swag_stats()
     gen_bbb()
+    gen_bbb2()
     gen_ivon()
     gen_ensemble()
     gen_checkpoints()

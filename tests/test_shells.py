@@ -786,3 +786,105 @@ def test_rank1_layers_reproduce_reference_trajectory(golden, backend):
     assert conv(torch.randn(2, 3, 6, 6, device=dev)).shape == (2, 4, 6, 6) and conv.component_counter == 1
     net = nn.Sequential(nn.Conv2d(3, 4, 3), nn.Flatten(), nn.Linear(4, 2)).to(dev)
     assert bde.make_module_rank1(net, prior, components=2, _ops=ops) == 2
+
+
+# ------------------------------------------- BBB round-2 fixtures (bbb2.npz) --
+def _load_named(g, tag, named, dev):
+    names = [str(n) for n in g[f"{tag}_names"]]
+    with torch.no_grad():
+        for n in names:
+            named[n].copy_(T(g[f"{tag}_init/{n}"]).to(dev))
+    return [named[n] for n in names]
+
+
+def test_bbb_mixture_prior_trajectory(golden, backend):
+    """BBBOptimizer with the reference's MixturePrior (bbb.py:23-37): the means take the autograd path, and the
+    optimizer-level zero_grad (bbb.py:60) must clear the rho gradients every step -- they only receive the data
+    term, so a missed clear shows up as a drifting trajectory (4 steps, SGD with momentum)."""
+    ops, dev = backend
+    from beyond_deep_ensembles_amd.bbb import MixturePrior
+    g = golden("bbb2.npz")
+    tape = [T(g[f"d_eps_{i}"]) for i in range(int(g["d_n_eps"]))]
+    model = nn.Sequential(SampledLinear(13, 20, tape, ops), nn.ReLU(), SampledLinear(20, 1, tape, ops)).to(dev)
+    extra = nn.Parameter(torch.zeros(4, device=dev))
+    named = dict(model.named_parameters())
+    named["extra"] = extra
+    params = _load_named(g, "d", named, dev)
+    prior = MixturePrior(0.5, 1.0, 0.05)
+    opt = bde.BBBOptimizer(params, torch.optim.SGD(params, lr=0.05, momentum=0.9), prior, dataset_size=48, mc_samples=2,
+                           kl_rescaling=0.5, l2_scale=0.3, _ops=ops)
+    x, y = T(g["d_x"]).to(dev), T(g["d_y"]).to(dev)
+    for t in range(4):
+        xb, yb = x[(t % 3) * 16:(t % 3 + 1) * 16], y[(t % 3) * 16:(t % 3 + 1) * 16]
+        loss = opt.step(lambda: F.mse_loss(model(xb), yb) + extra.sum() * 0.01, lambda l: l.backward())
+        want = g["d_losses"][t]
+        assert abs(float(loss) - want) <= 1e-5 * abs(want), (t, float(loss), want)
+        np.testing.assert_allclose(flat(params).cpu().numpy(), g["d_traj"][t], rtol=1e-4, atol=2e-5)
+    assert not tape
+
+
+def test_bbb_frozen_parameters_do_not_move(golden, backend):
+    """requires_grad=False parameters handed to BBBOptimizer (a Gaussian mean, a rho, a plain tensor): in the
+    reference their .grad stays None, so the base optimizer -- weight decay included -- skips them; the trainable
+    rest follows the reference's trajectory."""
+    ops, dev = backend
+    g = golden("bbb2.npz")
+    tape = [T(g[f"e_eps_{i}"]) for i in range(int(g["e_n_eps"]))]
+    model = nn.Sequential(SampledLinear(13, 20, tape, ops), nn.ReLU(), SampledLinear(20, 1, tape, ops)).to(dev)
+    model[0].bias.mean.requires_grad_(False)
+    model[2].weight.rho.requires_grad_(False)
+    extra = nn.Parameter(torch.zeros(4, device=dev))
+    frozen_plain = nn.Parameter(torch.zeros(6, device=dev), requires_grad=False)
+    named = dict(model.named_parameters())
+    named["extra"], named["frozen_plain"] = extra, frozen_plain
+    params = _load_named(g, "e", named, dev)
+    before = {n: named[n].detach().clone() for n in ("0.bias.mean", "2.weight.rho", "frozen_plain")}
+    prior = bde.GaussianPrior(0, 1.0)
+    base = torch.optim.SGD(params, lr=0.05, momentum=0.9, weight_decay=0.1)
+    opt = bde.BBBOptimizer(params, base, prior, dataset_size=48, mc_samples=1, kl_rescaling=1.0, l2_scale=1.0, _ops=ops)
+    x, y = T(g["e_x"]).to(dev), T(g["e_y"]).to(dev)
+    for t in range(3):
+        xb, yb = x[t * 16:(t + 1) * 16], y[t * 16:(t + 1) * 16]
+        loss = opt.step(lambda: F.mse_loss(model(xb), yb) + extra.sum() * 0.01, lambda l: l.backward())
+        want = g["e_losses"][t]
+        assert abs(float(loss) - want) <= 1e-5 * abs(want), (t, float(loss), want)
+        np.testing.assert_allclose(flat(params).cpu().numpy(), g["e_traj"][t], rtol=1e-4, atol=2e-5)
+        for n, v in before.items():
+            assert torch.equal(named[n].detach(), v), n
+            assert named[n].grad is None, n
+
+
+class _BdeCNN(nn.Module):
+    def __init__(self, prior, ops):
+        super().__init__()
+        self.conv = bde.BBBConv2d(3, 4, 3, prior, prior, padding=1, _ops=ops)
+        self.conv2 = bde.BBBConv2d(4, 4, 3, prior, prior, stride=2, bias=False, _ops=ops)
+        self.fc = bde.BBBLinear(4, 2, prior, prior, _ops=ops)
+
+    def forward(self, x):
+        x = F.relu(self.conv(x))
+        x = F.relu(self.conv2(x)).mean(dim=(2, 3))
+        return self.fc(x)
+
+
+def test_bbb_conv_layers_reproduce_reference_cnn_trajectory(golden, backend, monkeypatch):
+    """bde.BBBConv2d (padding / stride / bias-free) + bde.BBBLinear under BBBOptimizer against the trajectory of the
+    REFERENCE's BBBConv2d + BBBLinear + BBBOptimizer on the same small CNN (bbb_layers.py:105-159), noise replayed."""
+    ops, dev = backend
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    g = golden("bbb2.npz")
+    tape = [T(g[f"f_eps_{i}"]) for i in range(int(g["f_n_eps"]))]
+    monkeypatch.setattr(L, "normal_like", lambda t: tape.pop(0).to(t.device))
+    prior = bde.GaussianPrior(0, 1.0)
+    model = _BdeCNN(prior, ops).to(dev)
+    params = _load_named(g, "f", dict(model.named_parameters()), dev)
+    opt = bde.BBBOptimizer(params, torch.optim.Adam(params, lr=1e-2), prior, dataset_size=32, mc_samples=2,
+                           kl_rescaling=0.2, _ops=ops)
+    x, y = T(g["f_x"]).to(dev), T(g["f_y"]).to(dev)
+    for t in range(3):
+        xb, yb = x[(t % 2) * 16:(t % 2 + 1) * 16], y[(t % 2) * 16:(t % 2 + 1) * 16]
+        loss = opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+        want = g["f_losses"][t]
+        assert abs(float(loss.detach()) - want) <= 1e-5 * abs(want), (t, float(loss), want)
+        np.testing.assert_allclose(flat(params).cpu().numpy(), g["f_traj"][t], rtol=2e-4, atol=3e-5)
+    assert not tape
