@@ -32,6 +32,10 @@ SIGNATURES = {
     "bde_svgd_small_supported": (c_int, [c_int, c_int64]),
     "bde_svgd_step_small": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
                                     c_int, _P, _P, _P]),
+    "bde_svgd_step_small_sgd": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_float, c_float, c_float, c_double, c_double,
+                                        c_double, c_double, c_int, c_int, _P, _P, _P]),
+    "bde_svgd_step_small_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, c_float, c_float, c_float, c_double,
+                                         c_double, c_double, c_double, c_double, c_int64, _P, _P, _P]),
     "bde_svgd_apply_sgd": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_double, c_double, c_double, c_double,
                                    c_int, c_int, _P]),
     "bde_svgd_apply_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, c_double, c_double, c_double, c_double,

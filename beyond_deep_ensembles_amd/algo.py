@@ -97,17 +97,24 @@ def adopt_grads(params: Sequence[torch.nn.Parameter], views: Sequence[torch.Tens
     the parameters' ``.grad``: copied (``add=False``; a missing gradient zeroes its view) or added on top of what
     the view already holds (``add=True``), with one multi-tensor op for the whole list.  Gradients that already
     live in their view (in-place accumulation) are left alone."""
-    src, dst = [], []
+    from . import _host
+    native = _host.load()
+    if native is not None:
+        native.adopt_grads(params, views, bool(add))
+        return
+    src, dst, missing = [], [], []
     for p, v in zip(params, views):
         g = p.grad
         if g is v:
             continue
         if g is None:
             if not add:
-                v.zero_()
+                missing.append(v)
         elif g.data_ptr() != v.data_ptr():
             src.append(g)
             dst.append(v)
+    if missing:
+        torch._foreach_zero_(missing)
     if src:
         if add:
             torch._foreach_add_(dst, src)

@@ -118,8 +118,23 @@ class _Group:
         if means:
             self.mu, self.gmu, self.gmu_views = flatten(self.gl, means)
             self.rho, self.grho, self.grho_views = flatten(self.gl, rhos)
+            # GaussianParameter.sample() (rng="philox") draws the whole group in one launch through this object
+            self._draw, self._consumed = None, []
+            for i, p in enumerate(means):
+                p._bde_gaussian._flat_group = self
+                p._bde_gaussian._flat_index = i
         if plain:
             self.p, self.gp, self.gp_views = flatten(self.pl, plain)
+
+    def flat_sample(self, index, ops, seed):
+        """Tensor `index` of the current group-wide draw; a new draw (ONE launch for all tensors of the group) starts
+        whenever a tensor is asked for a second time, i.e. at the first sample() of the next forward pass."""
+        from .util import _FlatGaussDraw, _philox_stream
+        if self._draw is None or self._consumed[index]:
+            self._draw = _FlatGaussDraw.apply(self, ops, seed, next(_philox_stream), *self.means, *self.rhos)
+            self._consumed = [False] * len(self.means)
+        self._consumed[index] = True
+        return self._draw[index]
 
 
 class BBBOptimizer(BayesianOptimizer):

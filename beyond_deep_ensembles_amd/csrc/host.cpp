@@ -30,6 +30,38 @@ void repoint(const std::vector<at::Tensor>& params, const c10::optional<std::vec
   }
 }
 
+// After a backward pass: move the gradients autograd produced into `views` (rows of the flat gradient buffer)
+// with ONE multi-tensor copy (or add), zero the views of parameters that received none, and make the views the
+// parameters' .grad.  Same semantics as algo.adopt_grads.
+void adopt_grads(const std::vector<at::Tensor>& params, const std::vector<at::Tensor>& views, bool add) {
+  const size_t n = params.size();
+  TORCH_CHECK(views.size() == n, "adopt_grads: ", n, " parameters but ", views.size(), " views");
+  std::vector<at::Tensor> src, dst, missing;
+  src.reserve(n);
+  dst.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
+    const at::Tensor& g = params[i].grad();
+    if (!g.defined()) {
+      if (!add) missing.push_back(views[i]);
+    } else if (g.data_ptr() != views[i].data_ptr()) {
+      src.push_back(g);
+      dst.push_back(views[i]);
+    }
+  }
+  {
+    at::NoGradGuard no_grad;
+    if (!missing.empty()) at::_foreach_zero_(missing);
+    if (!src.empty()) {
+      if (add) at::_foreach_add_(dst, src);
+      else at::_foreach_copy_(dst, src);
+    }
+  }
+  for (size_t i = 0; i < n; ++i) {
+    at::Tensor p = params[i];
+    p.mutable_grad() = views[i];
+  }
+}
+
 void clear_grads(const std::vector<at::Tensor>& params) {
   for (const at::Tensor& t : params) {
     at::Tensor p = t;
@@ -43,4 +75,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("repoint", &repoint, "param.data / param.grad = views, for whole parameter lists", py::arg("params"),
         py::arg("datas"), py::arg("grads"));
   m.def("clear_grads", &clear_grads, "param.grad = None for a whole parameter list");
+  m.def("adopt_grads", &adopt_grads, "gradients -> flat views (multi-tensor copy/add), views become .grad", py::arg("params"),
+        py::arg("views"), py::arg("add"));
 }

@@ -5,16 +5,13 @@
 namespace bde {
 
 // ws header (1 KB, so that the partial tiles behind it start on a 128-byte line): ws[0] = #partial tiles,
-// ws[1] = padded M (8 or 16).  The rest are the hand-off words of the single-launch path (svgd_small.hip), each
-// group on 128-byte lines of its own: 8 sharded arrive counters (word 32 + 32 s), the top counter (word 32 + 32*8),
-// 8 go flags (word 32 + 32 * (9 + s)) and the depart counter.  They must be ZERO before the first launch and every
-// launch leaves them zero.
-constexpr int kWsHeaderFloats = 32 * 20;
+// ws[1] = padded M (8 or 16).  The rest are the hand-off words of the single-launch path (svgd_small.hip), each on
+// a 128-byte line of its own: 8 sharded arrive counters (word 32 + 32 s) and the depart counter.  They must be ZERO
+// before the first launch and every launch leaves them zero.
+constexpr int kWsHeaderFloats = 32 * 12;
 constexpr int kWsShards = 8;
 constexpr int kWsArriveWord = 32;                         // + 32 * shard
-constexpr int kWsTopWord = 32 + 32 * kWsShards;
-constexpr int kWsGoWord = 32 + 32 * (kWsShards + 1);      // + 32 * shard
-constexpr int kWsDepartWord = 32 + 32 * (2 * kWsShards + 1);
+constexpr int kWsDepartWord = 32 + 32 * kWsShards;
 constexpr int kGramMaxBlocks = 1024;       // 4 workgroups per CU: best measured (tools/kexp.hip)
 
 // Per-particle Adam scalars of the SHARED step counter (advanced once per particle).

@@ -9,14 +9,14 @@
 //   phase 1  every workgroup owns <= 512 consecutive float4 columns of P: centred Gram partial
 //            of its slice on the f32 MFMA (same tiles as svgd_gram_kernel<2>), published with
 //            write-through (sc1) stores;
-//   hand-off one agent-scope atomic add per workgroup on one of 8 SHARDED arrive counters (a single
-//            counter serialises 256 adds at ~12 ns each and is hammered by 256 pollers on top); the
-//            last arriver of a shard adds to a top counter, the last of those raises the 8 go flags;
-//            one lane per workgroup polls its shard's flag with sc1 loads (MI355X_MICROARCH.md,
-//            inter-workgroup visibility: sc1 stores + drained vmcnt + counter add on the producer,
-//            sc1 poll + workgroup barrier + sc1 loads on the consumer) -- while it waits, the
-//            workgroup's P and G columns for phase 2 are already in flight into registers (P from
-//            the XCD's L2, where phase 1 just put it);
+//   hand-off one fire-and-forget agent-scope atomic add per workgroup on one of 8 SHARDED arrive
+//            counters (a single counter serialises 256 adds at ~12 ns each); one wave per workgroup
+//            polls all 8 counters with ONE 8-lane sc1 load per poll until they sum to the grid size
+//            (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + drained vmcnt + counter
+//            add on the producer, sc1 poll + workgroup barrier + sc1 loads on the consumer) -- two
+//            dependent memory round trips instead of the four of a counter tree.  While it waits,
+//            the workgroup's P and G columns for phase 2 are already in flight into registers (P
+//            from the XCD's L2, where phase 1 just put it);
 //   phase 2  EVERY workgroup reduces all partials in the same fixed order (fp64) and evaluates the
 //            kernel statistics redundantly (a few hundred scalar operations), keeps the 2 M^2
 //            coefficients in LDS, and combines its own columns.
@@ -24,7 +24,8 @@
 // P is read once from HBM (4 M D), G once (4 M D), out written once (4 M D): 12 M D bytes, no
 // second pass over P.  The counters are reset by the last workgroup to leave, so the caller only
 // has to hand in a workspace that was zeroed once.  All workgroups must be co-resident (they are:
-// <= 256 workgroups of 256 threads, <= 1 per CU worth of registers/LDS each on a 256-CU device).
+// <= 256 workgroups of 512 threads, one per CU on a 256-CU device).  Measured timeline at D = 273,610
+// (tools/kexp6.hip, profiles/r02_small_step_timeline.txt).
 #include "svgd_gram.hpp"
 
 namespace bde {
@@ -37,8 +38,9 @@ __device__ unsigned long long g_small_ts[256 * 16];
 #define BDE_TS(k)
 #endif
 
-constexpr int kSmallBlock = 256;
-constexpr int kSmallMaxTilesPerWG = 16;            // 16 tiles x 32 float4 columns = 512 columns = 2 per thread
+constexpr int kSmallBlock = 512;                   // 8 waves: the Gram tiles of a workgroup are spread over more MFMA pipes
+constexpr int kSmallWaves = kSmallBlock / 64;
+constexpr int kSmallMaxTilesPerWG = 16;            // 16 tiles x 32 float4 columns = 512 columns = 1 per thread
 constexpr int kSmallTile4 = kGramU * 8;            // float4 columns per Gram tile (PACK = 2)
 constexpr int kSmallMaxGrid = 256;
 
@@ -49,14 +51,85 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int M, bool HAS_G>
-__global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const float* __restrict__ P, const float* G,
-                                                                        float* out, int64_t D, int64_t ld,
-                                                                        int tiles_per_wg, StatParams sp,
-                                                                        float* __restrict__ ws,
-                                                                        float* __restrict__ kstat) {
+// The kernel statistics of svgd_stats_core for M <= 8 (M * M <= 64 entries), evaluated by ONE wave with
+// cross-lane shuffles instead of LDS round trips and workgroup barriers (2.0 us -> well under 1 us on the
+// critical path of the single-launch kernel).  Same arithmetic, same results.  Lane e < M * M owns entry
+// (i, j) = (e / M, e % M).  All 64 lanes of the wave must call it.
+__device__ __forceinline__ void svgd_stats_wave(const double* gmat, int M, const StatParams sp,
+                                                float* __restrict__ kstat, float* lds_cg, float* lds_cp) {
+  const int lane = threadIdx.x & 63;
+  const int n = M * M;
+  const bool act = lane < n;
+  const int i = act ? lane / M : 0, j = act ? lane % M : 0;
+  float d2 = 0.f;
+  if (act) {
+    double d = gmat[i * 8 + i] + gmat[j * 8 + j] - 2.0 * gmat[i * 8 + j];   // svgd.py:15
+    if (d < 0.0 || i == j) d = 0.0;
+    d2 = static_cast<float>(d);
+  }
+  // rank of this entry among the M * M distances (diagonal zeros included, ties by index: svgd.py:18)
+  int rank = 0;
+  for (int u = 0; u < n; ++u) {
+    const float o = __shfl(d2, u, 64);
+    rank += (o < d2 || (o == d2 && u < lane)) ? 1 : 0;
+  }
+  // torch.quantile(d2, 0.5), 'linear' interpolation, fp32 like the reference
+  const float pos = 0.5f * static_cast<float>(n - 1);
+  const float lo = floorf(pos);
+  const float wgt = pos - lo;
+  const int r_lo = static_cast<int>(lo), r_hi = static_cast<int>(ceilf(pos));
+  const unsigned long long m_lo = __ballot(act && rank == r_lo), m_hi = __ballot(act && rank == r_hi);
+  const float a = __shfl(d2, __builtin_ctzll(m_lo), 64), b = __shfl(d2, __builtin_ctzll(m_hi), 64);
+  const float med = (fabsf(wgt) < 0.5f) ? a + wgt * (b - a) : b - (b - a) * (1.0f - wgt);   // at::lerp
+  float h = __builtin_sqrtf((0.5f * med) / sp.log_m1) + 1e-8f;                              // svgd.py:18
+  if (sp.h_override > 0.f) h = sp.h_override;
+  const float k = act ? expf(-d2 / (2.0f * (h * h))) : 0.f;                                // svgd.py:21
+  float rowsum = 0.f;                                                                      // sum_j K[i][j], j ascending
+  for (int jj = 0; jj < M; ++jj) rowsum += __shfl(k, i * M + jj, 64);
+  const double h2 = static_cast<double>(h) * static_cast<double>(h);
+  const double s_rep = static_cast<double>(sp.kernel_grad_scale) / (static_cast<double>(sp.dataset_size) * h2);
+  if (act) {
+    const double kij = k;
+    const double rep = ((i == j) ? static_cast<double>(rowsum) : 0.0) - kij;
+    double cg, cp;
+    if (sp.mode == 0) {
+      cg = static_cast<double>(sp.sign) * (-kij);
+      cp = static_cast<double>(sp.sign) * (-kij * (0.5 * static_cast<double>(sp.l2_reg)) + s_rep * rep);
+    } else {
+      cg = 0.0;
+      cp = rep / h2;
+    }
+    lds_cg[j * M + i] = static_cast<float>(cg);
+    lds_cp[j * M + i] = static_cast<float>(cp);
+    if (kstat) {
+      const int oK = 0, oD2 = n, oRow = 2 * n, oMisc = 2 * n + M, oCG = oMisc + 4, oCP = oCG + n;
+      kstat[oK + lane] = k;
+      kstat[oD2 + lane] = d2;
+      kstat[oCG + j * M + i] = static_cast<float>(cg);
+      kstat[oCP + j * M + i] = static_cast<float>(cp);
+      if (j == 0) kstat[oRow + i] = rowsum;
+      if (lane == 0) {
+        kstat[oMisc + 0] = h;
+        kstat[oMisc + 1] = med;
+        kstat[oMisc + 2] = static_cast<float>(s_rep);
+        kstat[oMisc + 3] = static_cast<float>(M);
+      }
+    }
+  }
+}
+
+// OPT = 0: out = sign * phi (or grad_kernel in mode 1).  OPT = 1 / 2: the shared-state SGD / Adam applications of
+// svgd.py:92-103 follow in registers (svgd_fused.hip's loop) and the updated particles are written back over P
+// (`out` must be P; s0 / s1 are the optimizer state) -- the FULL SVGDOptimizer.step minus forward/backward in one
+// launch, (12 M + 8) D bytes.
+template <int M, bool HAS_G, int OPT>
+__global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const float* P, const float* G, float* out,
+                                                                        int64_t D, int64_t ld, int tiles_per_wg,
+                                                                        StatParams sp, float* __restrict__ ws,
+                                                                        float* __restrict__ kstat, float* s0, float* s1,
+                                                                        SgdParams sk, AdamParams ak, AdamSteps ast) {
   constexpr int MP = 8, MP2 = 64;
-  __shared__ float tile[kSmallBlock / 64][16][17];
+  __shared__ float tile[kSmallWaves][16][17];
   __shared__ double red[kSmallBlock];
   __shared__ double gmat[MP2];
   __shared__ __attribute__((aligned(16))) float cgT[MP2];
@@ -65,10 +138,6 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwg = gridDim.x;
   unsigned* words = reinterpret_cast<unsigned*>(ws);
-  const int shard = blockIdx.x & (kWsShards - 1);
-  unsigned* arrive = words + kWsArriveWord + 32 * shard;
-  unsigned* top = words + kWsTopWord;
-  unsigned* go = words + kWsGoWord + 32 * shard;
   unsigned* depart = words + kWsDepartWord;
   float* part = ws + kWsHeaderFloats;
 
@@ -88,16 +157,16 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
   f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   {
     // all of this wave's tiles are requested before the first DPP/MFMA chain waits on them
-    constexpr int TW = kSmallMaxTilesPerWG / (kSmallBlock / 64);   // tiles per wave, at most
+    constexpr int TW = kSmallMaxTilesPerWG / kSmallWaves;          // tiles per wave, at most
     f32x4 v[TW][kGramU];
 #pragma unroll
     for (int k = 0; k < TW; ++k) {
-      const int64_t t = t0 + wave + 4 * k;
+      const int64_t t = t0 + wave + kSmallWaves * k;
       if (t < t1) gram_load_tile<8, false>(v[k], rowp, valid, t, kSmallTile4, c4, n4c, D);
     }
 #pragma unroll
     for (int k = 0; k < TW; ++k) {
-      const int64_t t = t0 + wave + 4 * k;
+      const int64_t t = t0 + wave + kSmallWaves * k;
       if (t < t1) {                                                // wave-uniform
 #pragma unroll
         for (int u = 0; u < kGramU; ++u) {
@@ -123,95 +192,87 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
     const int pi = tid / MP, pj = tid % MP;
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < kSmallBlock / 64; ++w) s += tile[w][pi][pj] + tile[w][pi + 8][pj + 8];
+    for (int w = 0; w < kSmallWaves; ++w) s += tile[w][pi][pj] + tile[w][pi + 8][pj + 8];
     st_sc1(part + static_cast<int64_t>(blockIdx.x) * MP2 + tid, s);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the write-through stores have left this CU
-  __syncthreads();
-  BDE_TS(2)
-  if (tid == 0) {
-    const unsigned in_shard = static_cast<unsigned>((nwg - shard + kWsShards - 1) / kWsShards);
-    const unsigned shards = static_cast<unsigned>(nwg < kWsShards ? nwg : kWsShards);
-    if (__hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1u) {
-      // last of this shard: its counter can go back to zero, and the shard reports to the top counter
-      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u) {
-        // last of all: every partial tile is published
-        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (unsigned sh = 0; sh < shards; ++sh)
-          __hip_atomic_store(words + kWsGoWord + 32 * sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the write-through stores have left this CU
+    BDE_TS(2)
+    // arrive: one agent-scope add on this workgroup's shard counter, fire and forget
+    if (tid == 0)
+      __hip_atomic_fetch_add(words + kWsArriveWord + 32 * (blockIdx.x & (kWsShards - 1)), 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
   }
   BDE_TS(3)
 
   // ---------------- phase 2 operands: requested now, consumed after the hand-off ----------------
   const int64_t n4 = D >> 2;                                       // full float4 columns
-  const int64_t col0 = t0 * kSmallTile4;
-  const int64_t cA = col0 + tid, cB = col0 + kSmallBlock + tid;
+  const int64_t cA = t0 * kSmallTile4 + tid;
   const int64_t colEnd = (t1 * kSmallTile4 < n4) ? t1 * kSmallTile4 : n4;
-  const bool hasA = cA < colEnd, hasB = cB < colEnd;
-  f32x4 pA[M], gA[M], pB[M], gB[M];
+  const bool hasA = cA < colEnd;
+  f32x4 pA[M], gA[M];
 #pragma unroll
   for (int j = 0; j < M; ++j) {
-    pA[j] = gA[j] = pB[j] = gB[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    pA[j] = gA[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (hasA) {
       pA[j] = ld4(P + j * ld + 4 * cA);
       if (HAS_G) gA[j] = ld4_nt(G + j * ld + 4 * cA);
     }
-    if (hasB) {
-      pB[j] = ld4(P + j * ld + 4 * cB);
-      if (HAS_G) gB[j] = ld4_nt(G + j * ld + 4 * cB);
-    }
+  }
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  if (OPT != 0 && hasA) {
+    if (OPT == 2 || (sk.momentum != 0.f && !sk.first)) a0 = ld4(s0 + 4 * cA);
+    if (OPT == 2) a1 = ld4(s1 + 4 * cA);
   }
 
-  // ---------------- hand-off ----------------
-  if (tid == 0) {
-    while (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+  // ---------------- hand-off: wave 0 polls the 8 shard counters (one 8-lane load per poll) ----------------
+  if (wave == 0) {
+    const unsigned* ctr = words + kWsArriveWord + 32 * (lane & (kWsShards - 1));
+    unsigned total;
+    do {
+      const unsigned c = (lane < kWsShards) ? __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      total = 0;
+#pragma unroll
+      for (int sh = 0; sh < kWsShards; ++sh) total += __builtin_amdgcn_readlane(c, sh);
+      if (total < static_cast<unsigned>(nwg)) __builtin_amdgcn_s_sleep(4);
+    } while (total < static_cast<unsigned>(nwg));
   }
   BDE_TS(4)
   __syncthreads();
 
-  // fixed-order fp64 reduction of ALL partial tiles (every workgroup computes the same bits)
+  // fixed-order fp64 reduction of ALL partial tiles (every workgroup computes the same bits); every load of
+  // a thread is in flight before the first add
   {
-    const int e = tid & (MP2 - 1), slice = tid >> 6;               // 4 slices
-    double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int b = slice;
-    for (; b + 28 < nwg; b += 32) {
-      float x[8];
+    constexpr int NL = kSmallMaxGrid / kSmallWaves;                // partials per thread, at most (32)
+    const int e = tid & (MP2 - 1), slice = tid >> 6;               // 8 slices
+    float x[NL];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = ld_sc1(part + static_cast<int64_t>(b + 4 * u) * MP2 + e);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s8[u] += static_cast<double>(x[u]);
+    for (int u = 0; u < NL; ++u) {
+      const int b = slice + kSmallWaves * u;
+      x[u] = (b < nwg) ? ld_sc1(part + static_cast<int64_t>(b) * MP2 + e) : 0.f;
     }
-    for (int u = 0; b < nwg; b += 4, ++u) s8[u] += static_cast<double>(ld_sc1(part + static_cast<int64_t>(b) * MP2 + e));
-    red[tid] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < NL; ++u) s += static_cast<double>(x[u]);
+    red[tid] = s;
   }
   __syncthreads();
-  if (tid < MP2) gmat[tid] = (red[tid] + red[MP2 + tid]) + (red[2 * MP2 + tid] + red[3 * MP2 + tid]);
-  __syncthreads();
+  if (wave == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kSmallWaves; ++sl) s += red[sl * MP2 + lane];
+    gmat[lane] = s;
+  }
   BDE_TS(5)
-  svgd_stats_core(gmat, M, MP, sp, blockIdx.x == 0 ? kstat : nullptr, cgT, cpT);
-
-  BDE_TS(6)
-  // every workgroup has passed its go flag once all have added here: the last one lowers the flags again
-  if (tid == 0) {
-    const unsigned left = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == static_cast<unsigned>(nwg) - 1u) {
-      for (int sh = 0; sh < kWsShards; ++sh)
-        __hip_atomic_store(words + kWsGoWord + 32 * sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (blockIdx.x == 0) {
-      ws[0] = static_cast<float>(nwg);
-      ws[1] = static_cast<float>(MP);
-    }
+  if (wave == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");         // gmat written above is read across lanes below
+    svgd_stats_wave(gmat, M, sp, blockIdx.x == 0 ? kstat : nullptr, cgT, cpT);
   }
+  __syncthreads();
+  BDE_TS(6)
 
   // ---------------- phase 2: out = CG . G + CP . P for this workgroup's columns ----------------
-  f32x4 oA[M], oB[M];
+  f32x4 oA[M];
 #pragma unroll
-  for (int i = 0; i < M; ++i) oA[i] = oB[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < M; ++i) oA[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < M; ++j) {
     if (HAS_G) {
@@ -219,26 +280,42 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
       for (int i = 0; i < M; ++i) {
         const float a = cgT[j * M + i];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          oA[i][c] = __builtin_fmaf(a, gA[j][c], oA[i][c]);
-          oB[i][c] = __builtin_fmaf(a, gB[j][c], oB[i][c]);
-        }
+        for (int c = 0; c < 4; ++c) oA[i][c] = __builtin_fmaf(a, gA[j][c], oA[i][c]);
       }
     }
 #pragma unroll
     for (int i = 0; i < M; ++i) {
       const float b = cpT[j * M + i];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        oA[i][c] = __builtin_fmaf(b, pA[j][c], oA[i][c]);
-        oB[i][c] = __builtin_fmaf(b, pB[j][c], oB[i][c]);
-      }
+      for (int c = 0; c < 4; ++c) oA[i][c] = __builtin_fmaf(b, pA[j][c], oA[i][c]);
     }
   }
+  if (hasA) {
+    if (OPT == 0) {
 #pragma unroll
-  for (int i = 0; i < M; ++i) {
-    if (hasA) st4_nt(out + i * ld + 4 * cA, oA[i]);
-    if (hasB) st4_nt(out + i * ld + 4 * cB, oB[i]);
+      for (int i = 0; i < M; ++i) st4_nt(out + i * ld + 4 * cA, oA[i]);
+    } else {
+      // oA[i] = -phi_i is the gradient the reference hands to the base optimizer (svgd.py:95); the particles are
+      // walked in order with the SHARED optimizer state in registers
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float b = a0[c];
+          if (OPT == 1) {
+            pA[i][c] = sgd_apply(pA[i][c], oA[i][c], b, sk, i == 0);
+          } else {
+            float v = a1[c];
+            pA[i][c] = adam_apply(pA[i][c], oA[i][c], b, v, ak, ast.step_size[i], ast.bc2_sqrt[i]);
+            a1[c] = v;
+          }
+          a0[c] = b;
+        }
+        st4(out + i * ld + 4 * cA, pA[i]);
+      }
+      if (OPT == 2 || sk.momentum != 0.f) st4(s0 + 4 * cA, a0);
+      if (OPT == 2) st4(s1 + 4 * cA, a1);
+    }
   }
   BDE_TS(7)
   // the D % 4 leftover coordinates (last workgroup)
@@ -258,22 +335,76 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
           acc[i] = __builtin_fmaf(cpT[j * M + i], p, acc[i]);
         }
       }
+      if (OPT == 0) {
 #pragma unroll
-      for (int i = 0; i < M; ++i) out[i * ld + e] = acc[i];
+        for (int i = 0; i < M; ++i) out[i * ld + e] = acc[i];
+      } else {
+        float b = 0.f, v = 0.f;
+        if (OPT == 2 || (sk.momentum != 0.f && !sk.first)) b = s0[e];
+        if (OPT == 2) v = s1[e];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          const float p = P[i * ld + e];
+          out[i * ld + e] = (OPT == 1) ? sgd_apply(p, acc[i], b, sk, i == 0)
+                                       : adam_apply(p, acc[i], b, v, ak, ast.step_size[i], ast.bc2_sqrt[i]);
+        }
+        if (OPT == 2 || sk.momentum != 0.f) s0[e] = b;
+        if (OPT == 2) s1[e] = v;
+      }
+    }
+  }
+  // depart (off the critical path): every workgroup has seen the full count once all have added here; the last
+  // one to leave zeroes the counters for the next launch
+  if (tid == 0) {
+    if (blockIdx.x == 0) {
+      ws[0] = static_cast<float>(nwg);
+      ws[1] = static_cast<float>(MP);
+    }
+    const unsigned left = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == static_cast<unsigned>(nwg) - 1u) {
+      for (int sh = 0; sh < kWsShards; ++sh)
+        __hip_atomic_store(words + kWsArriveWord + 32 * sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
+struct SmallOpt {
+  int kind = 0;                    // 0 none, 1 sgd, 2 adam
+  float* s0 = nullptr;
+  float* s1 = nullptr;
+  SgdParams sk{};
+  AdamParams ak{};
+  AdamSteps ast{};
+};
+
 template <int M>
 static int launch_small(const float* P, const float* G, float* out, int64_t D, int64_t ld, int grid, int tpw,
-                        const StatParams& sp, float* ws, float* kstat, hipStream_t s) {
-  if (G)
-    hipLaunchKernelGGL((svgd_step_small_kernel<M, true>), dim3(grid), dim3(kSmallBlock), 0, s, P, G, out, D, ld, tpw, sp,
-                       ws, kstat);
-  else
-    hipLaunchKernelGGL((svgd_step_small_kernel<M, false>), dim3(grid), dim3(kSmallBlock), 0, s, P, G, out, D, ld, tpw,
-                       sp, ws, kstat);
+                        const StatParams& sp, float* ws, float* kstat, const SmallOpt& o, hipStream_t s) {
+#define BDE_SMALL_LAUNCH(HG, OPT)                                                                                    \
+  hipLaunchKernelGGL((svgd_step_small_kernel<M, HG, OPT>), dim3(grid), dim3(kSmallBlock), 0, s, P, G, out, D, ld, tpw, \
+                     sp, ws, kstat, o.s0, o.s1, o.sk, o.ak, o.ast)
+  if (o.kind == 1) BDE_SMALL_LAUNCH(true, 1);
+  else if (o.kind == 2) BDE_SMALL_LAUNCH(true, 2);
+  else if (G) BDE_SMALL_LAUNCH(true, 0);
+  else BDE_SMALL_LAUNCH(false, 0);
+#undef BDE_SMALL_LAUNCH
   return to_err(hipGetLastError());
+}
+
+static int small_dispatch(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld, const StatParams& sp,
+                          float* ws, float* kstat, const SmallOpt& o, hipStream_t s) {
+  const int64_t n_tiles = (((D + 3) >> 2) + kSmallTile4 - 1) / kSmallTile4;
+  const int tpw = static_cast<int>((n_tiles + kSmallMaxGrid - 1) / kSmallMaxGrid);
+  const int grid = static_cast<int>((n_tiles + tpw - 1) / tpw);
+  switch (M) {
+#define BDE_CASE(m) \
+  case m:           \
+    return launch_small<m>(P, G, out, D, ld, grid, tpw, sp, ws, kstat, o, s);
+    BDE_CASE(1) BDE_CASE(2) BDE_CASE(3) BDE_CASE(4) BDE_CASE(5) BDE_CASE(6) BDE_CASE(7) BDE_CASE(8)
+#undef BDE_CASE
+  }
+  return BDE_ERR_INVALID;
 }
 
 }  // namespace bde
@@ -286,6 +417,12 @@ extern "C" int bde_svgd_small_supported(int M, int64_t D) {
   return n_tiles <= static_cast<int64_t>(kSmallMaxGrid) * kSmallMaxTilesPerWG;
 }
 
+static StatParams small_stat_params(int M, float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
+                                    float h_override, int mode) {
+  return StatParams{l2_reg, kernel_grad_scale, dataset_size, sign, h_override,
+                    static_cast<float>(std::log(static_cast<double>(M) + 1.0)), mode};
+}
+
 extern "C" int bde_svgd_step_small(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
                                    float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
                                    float h_override, int mode, void* ws, float* kstat, void* stream) {
@@ -293,19 +430,41 @@ extern "C" int bde_svgd_step_small(const float* P, const float* G, float* out, i
       out == P || (mode != 0 && mode != 1) || (mode == 0 && !G))
     return BDE_ERR_INVALID;
   if (!bde_svgd_small_supported(M, D)) return BDE_ERR_INVALID;
-  const int64_t n_tiles = (((D + 3) >> 2) + kSmallTile4 - 1) / kSmallTile4;
-  const int tpw = static_cast<int>((n_tiles + kSmallMaxGrid - 1) / kSmallMaxGrid);
-  const int grid = static_cast<int>((n_tiles + tpw - 1) / tpw);
-  const StatParams sp{l2_reg, kernel_grad_scale, dataset_size, sign, h_override,
-                      static_cast<float>(std::log(static_cast<double>(M) + 1.0)), mode};
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  float* wsf = static_cast<float*>(ws);
-  switch (M) {
-#define BDE_CASE(m) \
-  case m:           \
-    return launch_small<m>(P, mode == 0 ? G : nullptr, out, D, ld, grid, tpw, sp, wsf, kstat, s);
-    BDE_CASE(1) BDE_CASE(2) BDE_CASE(3) BDE_CASE(4) BDE_CASE(5) BDE_CASE(6) BDE_CASE(7) BDE_CASE(8)
-#undef BDE_CASE
-  }
-  return BDE_ERR_INVALID;
+  return small_dispatch(P, mode == 0 ? G : nullptr, out, M, D, ld,
+                        small_stat_params(M, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, mode),
+                        static_cast<float*>(ws), kstat, SmallOpt{}, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int bde_svgd_step_small_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
+                                       float l2_reg, float kernel_grad_scale, float dataset_size, double lr,
+                                       double momentum, double dampening, double weight_decay, int nesterov, int first,
+                                       void* ws, float* kstat, void* stream) {
+  if (!svgd_args_ok(P, M, D, ld) || !G || !aligned16(G) || !ws || !aligned16(ws) || !kstat ||
+      (momentum != 0.0 && (!momentum_buf || !aligned16(momentum_buf))) || !bde_svgd_small_supported(M, D))
+    return BDE_ERR_INVALID;
+  SmallOpt o;
+  o.kind = 1;
+  o.s0 = momentum_buf;
+  o.sk = SgdParams{static_cast<float>(lr), static_cast<float>(momentum), static_cast<float>(1.0 - dampening),
+                   static_cast<float>(weight_decay), nesterov, first};
+  return small_dispatch(P, G, P, M, D, ld, small_stat_params(M, l2_reg, kernel_grad_scale, dataset_size, -1.f, 0.f, 0),
+                        static_cast<float*>(ws), kstat, o, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int bde_svgd_step_small_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D,
+                                        int64_t ld, float l2_reg, float kernel_grad_scale, float dataset_size, double lr,
+                                        double beta1, double beta2, double eps, double weight_decay, int64_t step0,
+                                        void* ws, float* kstat, void* stream) {
+  if (!svgd_args_ok(P, M, D, ld) || !G || !aligned16(G) || !ws || !aligned16(ws) || !kstat || !exp_avg || !exp_avg_sq ||
+      !aligned16(exp_avg) || !aligned16(exp_avg_sq) || step0 < 0 || !bde_svgd_small_supported(M, D))
+    return BDE_ERR_INVALID;
+  SmallOpt o;
+  o.kind = 2;
+  o.s0 = exp_avg;
+  o.s1 = exp_avg_sq;
+  o.ak = AdamParams{static_cast<float>(beta1), static_cast<float>(beta2), static_cast<float>(1.0 - beta1),
+                    static_cast<float>(1.0 - beta2), static_cast<float>(eps), static_cast<float>(weight_decay)};
+  o.ast = make_adam_steps(lr, beta1, beta2, step0);
+  return small_dispatch(P, G, P, M, D, ld, small_stat_params(M, l2_reg, kernel_grad_scale, dataset_size, -1.f, 0.f, 0),
+                        static_cast<float*>(ws), kstat, o, static_cast<hipStream_t>(stream));
 }

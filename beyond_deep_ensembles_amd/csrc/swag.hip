@@ -83,38 +83,36 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
   const int64_t n4 = D >> 2;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   // Two float4 columns (one grid-stride apart) per thread and 5 ring rows per batch: 10 independent 16-byte
-  // loads in flight per lane.  Measured on MI355X (tools/kexp5.hip, profiles/r02_probes.txt): 6.29 TB/s against
-  // 5.96 for one column x 10 rows and 5.4-5.9 for contiguous per-workgroup chunks; a kernel that only reads the
+  // loads in flight per lane.  Measured on MI355X (tools/kexp5.hip, profiles/r02_probes.txt): 6.2-6.3 TB/s against
+  // 6.0 for one column x 10 rows and 5.4-5.9 for contiguous per-workgroup chunks; a kernel that only reads the
   // same K + 2 rows and writes one reaches 5.75.
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
-    const int64_t i1 = i + stride;
-    const bool has1 = i1 < n4;
-    const float* col0 = dev + 4 * i;
-    const float* col1 = dev + 4 * (has1 ? i1 : i);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 2;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride * U) {
+    f32x4 acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 5
     for (int r = 0; r < K; ++r) {
       const float wr = w[r];
-      const f32x4 d0 = ld4_nt(col0 + static_cast<int64_t>(r) * ld);
-      f32x4 d1 = {0.f, 0.f, 0.f, 0.f};
-      if (has1) d1 = ld4_nt(col1 + static_cast<int64_t>(r) * ld);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc0[j] = __builtin_fmaf(d0[j], wr, acc0[j]);
-        acc1[j] = __builtin_fmaf(d1[j], wr, acc1[j]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t c = i + u * stride;
+        if (c < n4) {
+          const f32x4 d = ld4_nt(dev + static_cast<int64_t>(r) * ld + 4 * c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[u][j] = __builtin_fmaf(d[j], wr, acc[u][j]);
+        }
       }
     }
-    {
-      const f32x4 m = ld4_nt(mean + 4 * i);
-      const f32x4 s = ld4_nt(sq + 4 * i);
-      const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag) : ld4_nt(eps_d + 4 * i);
-      st4_nt(out + 4 * i, (m + acc0) + diag_std(m, s) * z);
-    }
-    if (has1) {
-      const f32x4 m = ld4_nt(mean + 4 * i1);
-      const f32x4 s = ld4_nt(sq + 4 * i1);
-      const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(i1), kDomainDiag) : ld4_nt(eps_d + 4 * i1);
-      st4_nt(out + 4 * i1, (m + acc1) + diag_std(m, s) * z);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t c = i + u * stride;
+      if (c < n4) {
+        const f32x4 m = ld4_nt(mean + 4 * c);
+        const f32x4 s = ld4_nt(sq + 4 * c);
+        const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(c), kDomainDiag) : ld4_nt(eps_d + 4 * c);
+        st4_nt(out + 4 * c, (m + acc[u]) + diag_std(m, s) * z);
+      }
     }
   }
   if (blockIdx.x == 0) {

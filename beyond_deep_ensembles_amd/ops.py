@@ -152,6 +152,27 @@ class HipOps:
                                             _ptr(kstat), _stream()), "bde_svgd_step_small")
 
     @_on_device_of
+    def svgd_step_small_sgd(self, P, G, buf, d, l2_reg, kernel_grad_scale, dataset_size, ws, kstat, lr, momentum,
+                            dampening, weight_decay, nesterov, first):
+        """Whole step (statistics, -phi, M shared-state SGD applications, particles updated in place): one launch."""
+        if _ld(G) != _ld(P):
+            raise BdeKernelError("P and G must share one leading dimension")
+        _check(self.lib.bde_svgd_step_small_sgd(_ptr(P, "P"), _ptr(G, "G"), _ptr(buf), P.shape[0], d, _ld(P), l2_reg,
+                                                kernel_grad_scale, dataset_size, lr, momentum, dampening, weight_decay,
+                                                int(nesterov), int(first), _ptr(ws), _ptr(kstat), _stream()),
+               "bde_svgd_step_small_sgd")
+
+    @_on_device_of
+    def svgd_step_small_adam(self, P, G, exp_avg, exp_avg_sq, d, l2_reg, kernel_grad_scale, dataset_size, ws, kstat, lr,
+                             beta1, beta2, eps, weight_decay, step0):
+        if _ld(G) != _ld(P):
+            raise BdeKernelError("P and G must share one leading dimension")
+        _check(self.lib.bde_svgd_step_small_adam(_ptr(P, "P"), _ptr(G, "G"), _ptr(exp_avg), _ptr(exp_avg_sq), P.shape[0],
+                                                 d, _ld(P), l2_reg, kernel_grad_scale, dataset_size, lr, beta1, beta2, eps,
+                                                 weight_decay, int(step0), _ptr(ws), _ptr(kstat), _stream()),
+               "bde_svgd_step_small_adam")
+
+    @_on_device_of
     def svgd_apply_sgd(self, P, grad, buf, d, lr, momentum, dampening, weight_decay, nesterov, first):
         _check(self.lib.bde_svgd_apply_sgd(_ptr(P), _ptr(grad), _ptr(buf), P.shape[0], d, _ld(P), lr, momentum,
                                            dampening, weight_decay, int(nesterov), int(first), _stream()),

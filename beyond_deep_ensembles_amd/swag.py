@@ -88,18 +88,19 @@ class SwagOptimizer(BayesianOptimizer):
 
     # ------------------------------------------------------------------
     def step(self, forward_closure, backward_closure, grad_scaler=None):
-        self._prefetched = None
+        """One ordinary training step of the wrapped optimizer, then the moment-collection gate (swag.py:37-51).
+        Training always continues from the training weights: if the model still carries a posterior sample from an
+        evaluation, the parameters are pointed back first."""
+        base = self.state["__base_optimizer"]
+        self._prefetched = None                     # samples drawn ahead belong to the posterior before this step
         self._restore_original_params()
-        self.state["__base_optimizer"].zero_grad()
-
+        base.zero_grad()
         loss = forward_closure()
         backward_closure(loss)
-
-        if grad_scaler is not None:
-            grad_scaler.step(self.state["__base_optimizer"])
+        if grad_scaler is None:
+            base.step()
         else:
-            self.state["__base_optimizer"].step()
-
+            grad_scaler.step(base)                  # unscales, skips the step on inf/nan gradients
         self._swag_update()
         return loss
 

@@ -63,6 +63,36 @@ class _GaussDraw(torch.autograd.Function):
         return gmean.view(shape), grho.view(shape), None, None, None, None
 
 
+class _FlatGaussDraw(torch.autograd.Function):
+    """ALL Gaussian parameters of a BBBOptimizer param group drawn by ONE launch over the group's flat
+    mean / rho buffers (bde_gauss_draw_fwd, in-kernel Philox noise), and their gradients by one multi-tensor
+    copy + ONE launch (bde_gauss_draw_bwd) -- instead of a launch pair per tensor (util.py:170-171 runs ~4 ATen
+    launches per tensor per draw).  Inputs / outputs are the per-tensor views, so autograd sees ordinary tensors."""
+
+    @staticmethod
+    def forward(ctx, group, ops, seed, stream_id, *mean_and_rho):
+        d, ld = group.gl.d, group.gl.ld
+        w = torch.empty(ld, dtype=torch.float32, device=group.mu.device)
+        ops.gauss_draw_fwd(group.mu, group.rho, w, d, eps=None, seed=seed, stream_id=stream_id)
+        ctx.meta = (group, ops, seed, stream_id)
+        return tuple(group.gl.views(w))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        group, ops, seed, stream_id = ctx.meta
+        d, ld = group.gl.d, group.gl.ld
+        dev = group.mu.device
+        g = torch.zeros(ld, dtype=torch.float32, device=dev) if any(x is None for x in grads) \
+            else torch.empty(ld, dtype=torch.float32, device=dev)
+        pairs = [(v, x) for v, x in zip(group.gl.views(g), grads) if x is not None]
+        if pairs:
+            torch._foreach_copy_([v for v, _ in pairs], [x for _, x in pairs])
+        gmean = torch.empty(ld, dtype=torch.float32, device=dev)
+        grho = torch.empty(ld, dtype=torch.float32, device=dev)
+        ops.gauss_draw_bwd(g, group.rho, gmean, grho, d, eps=None, seed=seed, stream_id=stream_id, accumulate=False)
+        return (None, None, None, None) + tuple(group.gl.views(gmean)) + tuple(group.gl.views(grho))
+
+
 class GaussianParameter(nn.Module):
     '''
         A mean-field Gaussian parameter (drop-in for src/algos/util.py:151-183).
@@ -96,6 +126,10 @@ class GaussianParameter(nn.Module):
 
     def sample(self) -> torch.Tensor:
         # util.py:170-171: mean + normal_like(std) * std
+        group = getattr(self, "_flat_group", None)
+        if group is not None and self.rng == "philox" and self.noise_source is None:
+            # owned by a BBBOptimizer: the whole group is drawn at once, this tensor takes its view
+            return group.flat_sample(self._flat_index, self._get_ops(), self.seed)
         if self.noise_source is not None:
             eps = self.noise_source(self.rho)
         elif self.rng == "torch":

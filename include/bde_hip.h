@@ -127,6 +127,18 @@ int bde_svgd_step_small(const float* P, const float* G, float* out, int M, int64
                         float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
                         float h_override, int mode, void* ws, float* kstat, void* stream);
 
+/* The same launch continued through the M shared-state base-optimizer applications (svgd.py:92-103, semantics of
+ * bde_svgd_fused_sgd / bde_svgd_fused_adam): the updated particles are written back over P -- the whole
+ * SVGDOptimizer.step minus forward/backward in ONE launch for small models, (12*M + 8)*D bytes (SGD). */
+int bde_svgd_step_small_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
+                            float l2_reg, float kernel_grad_scale, float dataset_size, double lr, double momentum,
+                            double dampening, double weight_decay, int nesterov, int first, void* ws, float* kstat,
+                            void* stream);
+int bde_svgd_step_small_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D, int64_t ld,
+                             float l2_reg, float kernel_grad_scale, float dataset_size, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, int64_t step0, void* ws, float* kstat,
+                             void* stream);
+
 /* Shared-state base-optimizer apply for the M particles, in particle order
  * (svgd.py:92-103 with ONE torch.optim.SGD / Adam whose state is keyed on the
  * model's parameters and therefore shared by all particles).

@@ -4,9 +4,9 @@ golden vectors captured from the imported reference.
 
 Tolerances (fp32):
   * SWAG moment update, iVON update: separately rounded IEEE ops in the
-    reference's order -> compared bit for bit (array_equal).  iVON draw: IEEE
-    exact on the device, but torch's CPU sqrt is 1 ulp off on long vectors, so
-    the draw is checked to 1e-6 of the noise magnitude.
+    reference's order -> compared bit for bit (array_equal).  iVON draw:
+    anchored on the fp64 evaluation of ivorn.py:108 -- ours may deviate from
+    it by at most twice the reference's own fp32 deviation (floor 1 ulp).
   * SVGD: the anchor is the fp64 evaluation of the reference formula
     (tests/golden phi64).  The reference's own fp32 result deviates from it by
     err_ref; ours must stay within max(2*err_ref, 3e-6 * scale).
@@ -176,7 +176,7 @@ def test_svgd_single_launch_path(ops):
         ops.svgd_step_small(Pb, Gb, Gb, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks)
     torch.cuda.synchronize()
     assert torch.equal(Gb[:, :d], ref[:, :d])
-    assert int(ws[32:640].view(torch.int32).abs().sum()) == 0           # all hand-off words are back to zero
+    assert int(ws[32:384].view(torch.int32).abs().sum()) == 0           # all hand-off words are back to zero
     # rbf mode (grad_kernel) through the same launch
     out = torch.zeros_like(Pb)
     ops.svgd_step_small(Pb, None, out, d, 0.0, 1.0, 1.0, 1.0, ws, ks, mode=1)
@@ -515,12 +515,20 @@ def test_ivon_golden_bit_exact(ops, golden):
         for t in range(3):
             for k in range(mc):
                 ops.ivon_sample(mean, prec, param, dsum, d, n_eff, first=(k == 0), eps=padded(eps[t * mc + k]))
-            # the draw is IEEE-exact here; torch's CPU sqrt (MKL VML) is 1 ulp off for long vectors,
-            # so the draw is compared within a few ulp of the noise magnitude, the update bit for bit
+            # The draw (ivorn.py:108) is anchored on its fp64 evaluation: the sum of the mc draws
+            # eps / sqrt(N * clamp(prec, 1e-4)) from the same fp32 inputs.  The reference's fp32 result deviates from
+            # that by err_ref (torch's CPU sqrt / reciprocal); ours may deviate by at most twice as much (floor: 1 ulp
+            # of the largest draw).  The update below is compared bit for bit.
             want_ds = g[f"delta_sum_{ci}"][t]
-            tol = 1e-6 * np.abs(want_ds).max()
-            assert np.max(np.abs(dsum[:d].cpu().numpy() - want_ds)) <= tol
-            assert np.max(np.abs(param[:d].cpu().numpy() - g[f"after_{ci}"][t])) <= tol
+            prec64 = prec[:d].cpu().double().clamp(min=1e-4)
+            ds64 = sum(eps[t * mc + k].double() / torch.sqrt(n_eff * prec64) for k in range(mc)).numpy()
+            err_ref = np.max(np.abs(want_ds.astype(np.float64) - ds64))
+            err = np.max(np.abs(dsum[:d].cpu().numpy().astype(np.float64) - ds64))
+            assert err <= max(2 * err_ref, 1.2e-7 * np.abs(ds64).max()), (ci, t, err, err_ref)
+            last64 = mean[:d].cpu().double().numpy() + (eps[t * mc + mc - 1].double() / torch.sqrt(n_eff * prec64)).numpy()
+            err_ref_p = np.max(np.abs(g[f"after_{ci}"][t].astype(np.float64) - last64))
+            err_p = np.max(np.abs(param[:d].cpu().numpy().astype(np.float64) - last64))
+            assert err_p <= max(2 * err_ref_p, 1.2e-7 * np.abs(last64).max()), (ci, t, err_p, err_ref_p)
             dsum[:d] = T(want_ds).to(DEV)
             ops.ivon_update(mean, mom, prec, dsum, padded(T(g[f"acc_grad_{ci}"][t])), d,
                             lam=float(temp) * 50.0 / n_eff, n_eff=n_eff, mc=mc, beta1=0.9, beta2=0.999, t=t + 1,

@@ -1,7 +1,16 @@
 #!/usr/bin/env python3
-"""End-to-end cost of SVGDOptimizer.step() minus a real model: 161 parameter tensors totalling
-ResNet-50 size, trivial closures (loss = sum of <p, c>), so what is timed is the shell's host logic
-(re-pointing views, zeroing rows, autograd hand-over) + the kernels + the base optimizer."""
+"""Host-side cost of SVGDOptimizer.step(): 161 parameter tensors totalling ResNet-50 size, M = 8 particles.
+
+Two closure sets, so that what is timed is the shell itself (re-pointing the views, gradient hand-over, kernel
+launches, base optimizer), not a model:
+  null     forward returns a constant, backward does nothing: step time = shell + kernels, nothing to subtract;
+  flatdot  loss = <flat particle row, c> through ONE autograd node with 161 inputs whose backward hands out views
+           of one fresh flat gradient (what a real model's backward produces: fresh, stealable tensors); the
+           closures' own cost is measured separately and subtracted.
+
+BDE_SVGD_INPLACE_GRADS=1 selects the round-1 gradient hand-over (param.grad pre-pointed at the flat row, autograd
+accumulates in place: one add launch per tensor per backward); BDE_NO_HOST_HELPER=1 runs the per-tensor loops in
+Python.  Output of both settings is kept under profiles/."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,11 +22,24 @@ n_tensors, D = 161, 23_880_950
 sizes = [D // n_tensors] * (n_tensors - 1)
 sizes.append(D - sum(sizes))
 M = 8
+print(f"settings: BDE_SVGD_INPLACE_GRADS={os.environ.get('BDE_SVGD_INPLACE_GRADS', '')!r} "
+      f"BDE_NO_HOST_HELPER={os.environ.get('BDE_NO_HOST_HELPER', '')!r}; {n_tensors} tensors, D = {D}, M = {M}", flush=True)
 
 
-def run(fuse, reuse, base_kind, steps=10):
+class FlatDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, row, c, sizes, *params):
+        ctx.c, ctx.sizes = c, sizes
+        return torch.dot(row, c)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        fresh = ctx.c * grad_out                       # one kernel; its views are fresh tensors autograd can keep
+        return (None, None, None) + tuple(torch.split(fresh, ctx.sizes))
+
+
+def run(fuse, reuse, base_kind, closures, steps=10):
     params = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in sizes]
-    consts = [torch.randn(s, device=dev) * 0.01 for s in sizes]
     base = torch.optim.SGD(params, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=3e-4) if base_kind == "sgd" \
         else torch.optim.Adam(params, lr=1e-3)
 
@@ -26,29 +48,41 @@ def run(fuse, reuse, base_kind, steps=10):
             for p in params[-2:]:
                 p.normal_(0, 0.05)
     opt = bde.SVGDOptimizer(params, reset, base, particle_count=M, dataset_size=129809, fuse_base_optimizer=fuse, reuse_gram=reuse)
-    fwd = lambda: sum(torch._foreach_mul(params, consts)[i].sum() for i in range(0, n_tensors, 40))  # touches a few tensors
-    def fwd_all():
-        prods = torch._foreach_mul(params, consts)
-        return torch.stack([p.sum() for p in prods]).sum()
+    c = torch.randn(D, device=dev) * 0.01
+    zero = torch.zeros((), device=dev)
+    ld = opt._layout.ld
+
+    def current_row():
+        idx = (params[0].data_ptr() - opt._P.data_ptr()) // (4 * ld)
+        return opt._P[idx, :D]
+    if closures == "null":
+        fwd, bwd = (lambda: zero), (lambda l: None)
+    else:
+        fwd, bwd = (lambda: FlatDot.apply(current_row(), c, sizes, *params)), (lambda l: l.backward())
     for _ in range(2):
-        opt.step(fwd_all, lambda l: l.backward())
+        opt.step(fwd, bwd)
     torch.cuda.synchronize()
-    # closure cost alone
+    t_closure = 0.0
+    if closures != "null":
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for i in range(M):
+                for p in params:
+                    p.grad = None
+                bwd(fwd())
+        torch.cuda.synchronize()
+        t_closure = (time.perf_counter() - t0) / steps
     t0 = time.perf_counter()
     for _ in range(steps):
-        for i in range(M):
-            for p in params: p.grad = None
-            fwd_all().backward()
-    torch.cuda.synchronize()
-    t_closure = (time.perf_counter() - t0) / steps
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        opt.step(fwd_all, lambda l: l.backward())
+        opt.step(fwd, bwd)
     torch.cuda.synchronize()
     t_step = (time.perf_counter() - t0) / steps
-    print(f"fuse={fuse!s:5} reuse={reuse!s:5} base={base_kind:4}: step {t_step*1e3:8.2f} ms, of which M x fwd/bwd closures {t_closure*1e3:8.2f} ms "
-          f"-> shell + kernels + optimizer {1e3*(t_step - t_closure):8.2f} ms", flush=True)
+    print(f"closures={closures:7} fuse={fuse!s:5} reuse={reuse!s:5} base={base_kind:4}: step {t_step*1e3:8.2f} ms, closures alone "
+          f"{t_closure*1e3:7.2f} ms -> shell + kernels + optimizer {1e3*(t_step - t_closure):8.2f} ms", flush=True)
+    del opt, params, base, c
+    torch.cuda.empty_cache()
 
 
-for args in [(False, False, "sgd"), (True, False, "sgd"), (True, True, "sgd"), (False, False, "adam"), (True, True, "adam")]:
-    run(*args)
+for closures in ("null", "flatdot"):
+    for args in [(False, False, "sgd"), (True, False, "sgd"), (True, True, "sgd"), (False, False, "adam"), (True, True, "adam")]:
+        run(*args, closures)
