@@ -68,10 +68,12 @@ __device__ __forceinline__ void svgd_stats_wave(const double* gmat, int M, const
     d2 = static_cast<float>(d);
   }
   // rank of this entry among the M * M distances (diagonal zeros included, ties by index: svgd.py:18)
+  // (v_readlane with a constant lane: 64 scalar broadcasts, no LDS round trips)
   int rank = 0;
-  for (int u = 0; u < n; ++u) {
-    const float o = __shfl(d2, u, 64);
-    rank += (o < d2 || (o == d2 && u < lane)) ? 1 : 0;
+#pragma unroll
+  for (int u = 0; u < 64; ++u) {
+    const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), u));
+    rank += (u < n && (o < d2 || (o == d2 && u < lane))) ? 1 : 0;
   }
   // torch.quantile(d2, 0.5), 'linear' interpolation, fp32 like the reference
   const float pos = 0.5f * static_cast<float>(n - 1);
@@ -79,13 +81,18 @@ __device__ __forceinline__ void svgd_stats_wave(const double* gmat, int M, const
   const float wgt = pos - lo;
   const int r_lo = static_cast<int>(lo), r_hi = static_cast<int>(ceilf(pos));
   const unsigned long long m_lo = __ballot(act && rank == r_lo), m_hi = __ballot(act && rank == r_hi);
-  const float a = __shfl(d2, __builtin_ctzll(m_lo), 64), b = __shfl(d2, __builtin_ctzll(m_hi), 64);
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), __builtin_ctzll(m_lo)));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), __builtin_ctzll(m_hi)));
   const float med = (fabsf(wgt) < 0.5f) ? a + wgt * (b - a) : b - (b - a) * (1.0f - wgt);   // at::lerp
   float h = __builtin_sqrtf((0.5f * med) / sp.log_m1) + 1e-8f;                              // svgd.py:18
   if (sp.h_override > 0.f) h = sp.h_override;
   const float k = act ? expf(-d2 / (2.0f * (h * h))) : 0.f;                                // svgd.py:21
   float rowsum = 0.f;                                                                      // sum_j K[i][j], j ascending
-  for (int jj = 0; jj < M; ++jj) rowsum += __shfl(k, i * M + jj, 64);
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const float kj = __shfl(k, i * M + (jj < M ? jj : 0), 64);
+    if (jj < M) rowsum += kj;
+  }
   const double h2 = static_cast<double>(h) * static_cast<double>(h);
   const double s_rep = static_cast<double>(sp.kernel_grad_scale) / (static_cast<double>(sp.dataset_size) * h2);
   if (act) {
@@ -244,14 +251,16 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
     constexpr int NL = kSmallMaxGrid / kSmallWaves;                // partials per thread, at most (32)
     const int e = tid & (MP2 - 1), slice = tid >> 6;               // 8 slices
     float x[NL];
+    // unconditional loads (a predicated load gets a basic block and an s_waitcnt of its own: 8 us instead of 1):
+    // slots past the grid re-read the last partial and are dropped by the select below
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
       const int b = slice + kSmallWaves * u;
-      x[u] = (b < nwg) ? ld_sc1(part + static_cast<int64_t>(b) * MP2 + e) : 0.f;
+      x[u] = ld_sc1(part + static_cast<int64_t>(b < nwg ? b : nwg - 1) * MP2 + e);
     }
     double s = 0.0;
 #pragma unroll
-    for (int u = 0; u < NL; ++u) s += static_cast<double>(x[u]);
+    for (int u = 0; u < NL; ++u) s += (slice + kSmallWaves * u < nwg) ? static_cast<double>(x[u]) : 0.0;
     red[tid] = s;
   }
   __syncthreads();

@@ -91,11 +91,13 @@ class SVGDOptimizer(BayesianOptimizer):
           reuse_gram          with fuse_base_optimizer: the fused kernel also emits the Gram partials of the updated
                               particles, so the next step skips the Gram pass.  Only valid while nothing but this
                               optimizer modifies the particles between two steps (call invalidate_gram() otherwise).
+          single_launch       None (default): small models on one GPU run the whole update as ONE persistent launch
+                              (bde_svgd_step_small*); False forces the staged kernels
     '''
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
                  kernel_grad_scale=1.0, *, process_group=None, exchange="allgather", exchange_chunks=1,
-                 fuse_base_optimizer=False, reuse_gram=False, _ops=None):
+                 fuse_base_optimizer=False, reuse_gram=False, single_launch=None, _ops=None):
         # one param group per tensor, like the reference (svgd.py:50): groups distinguish tensors, not particles
         super().__init__([{"params": p} for p in params], {})
         self._ops = _ops or _default_ops()
@@ -146,6 +148,7 @@ class SVGDOptimizer(BayesianOptimizer):
                 self._exchange = exchange
         if fuse_base_optimizer and particle_count > 16:
             warnings.warn("fuse_base_optimizer needs particle_count <= 16 (single-tile kernels); running unfused")
+        self._single_launch = single_launch
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
         self._fused_decision = None
         self._tmp = None
@@ -226,7 +229,13 @@ class SVGDOptimizer(BayesianOptimizer):
         pending = self._start_gradient_exchange(total_loss) if self._world > 1 else None
         # The Gram pass and the kernel statistics need only the (replicated) particles: they run while the
         # gradient all-gather is in flight.  (Skipped when the previous fused kernel already left the Gram.)
-        single_launch = pending is None and not fused and self._ops.svgd_small_supported(m, d)
+        single_launch = pending is None and self._single_launch is not False and self._ops.svgd_small_supported(m, d)
+        if fused and single_launch:
+            # small model on one GPU: statistics, -phi and the M shared-state optimizer applications in ONE launch
+            self._fused_apply(base, [(self._P, self._G, d, 0)], single_launch=True)
+            self._gram_valid = False
+            self._use_particle(m - 1)
+            return total_loss
         if not single_launch:
             if not (fused and self._reuse_gram and self._gram_valid):
                 self._ops.svgd_gram(self._P, d, self._ws)
@@ -476,7 +485,7 @@ class SVGDOptimizer(BayesianOptimizer):
         self._fused_state = self.state["__fused"] = st
         return st
 
-    def _fused_apply(self, base, pieces, ws_next=None, advance=True) -> None:
+    def _fused_apply(self, base, pieces, ws_next=None, advance=True, single_launch=False) -> None:
         """-phi and the M sequential base-optimizer applications with shared state in ONE kernel per piece
         (bde_svgd_fused_sgd / bde_svgd_fused_adam); ``pieces`` = (P, G, valid columns, column offset into the state
         buffers).  Hyper-parameters are read from the base optimizer's param_groups every step, so LR schedulers
@@ -487,6 +496,12 @@ class SVGDOptimizer(BayesianOptimizer):
                 raise RuntimeError("fuse_base_optimizer: maximize=True is not supported")
             st = self._fused_buffers(base, "sgd")
             for P, G, d, c0 in pieces:
+                if single_launch:
+                    l2, scale, n, _ = self._stat_args()
+                    self._ops.svgd_step_small_sgd(P, G, st["buf"], d, l2, scale, n, self._ws, self._kstat, g0["lr"],
+                                                  g0["momentum"], g0["dampening"], g0["weight_decay"], g0["nesterov"],
+                                                  st["first"])
+                    continue
                 self._ops.svgd_fused_sgd(P, G, st["buf"][c0:], d, self._kstat, g0["lr"], g0["momentum"], g0["dampening"],
                                          g0["weight_decay"], g0["nesterov"], st["first"], ws_next=ws_next)
         elif type(base) is torch.optim.Adam:
@@ -494,6 +509,12 @@ class SVGDOptimizer(BayesianOptimizer):
                 raise RuntimeError("fuse_base_optimizer: amsgrad / maximize are not supported")
             st = self._fused_buffers(base, "adam")
             for P, G, d, c0 in pieces:
+                if single_launch:
+                    l2, scale, n, _ = self._stat_args()
+                    self._ops.svgd_step_small_adam(P, G, st["exp_avg"], st["exp_avg_sq"], d, l2, scale, n, self._ws,
+                                                   self._kstat, float(g0["lr"]), g0["betas"][0], g0["betas"][1], g0["eps"],
+                                                   g0["weight_decay"], st["step"])
+                    continue
                 self._ops.svgd_fused_adam(P, G, st["exp_avg"][c0:], st["exp_avg_sq"][c0:], d, self._kstat, float(g0["lr"]),
                                           g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"],
                                           ws_next=ws_next)

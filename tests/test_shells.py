@@ -56,6 +56,10 @@ def flat(ts):
     ("adam_wd", lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2), "reuse_gram"),
     ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "reuse_gram"),
     ("adam", lambda ps: torch.optim.Adam(ps, lr=1e-3), "reuse_gram"),
+    # the staged kernels (gram -> kstats -> combine / fused) instead of the single persistent launch small models take
+    ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "staged"),
+    ("adam_wd", lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2), "staged_fused"),
+    ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "staged_reuse_gram"),
 ])
 def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
     ops, dev = backend
@@ -74,7 +78,10 @@ def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
     base = make_opt(model.parameters())
     opt = bde.SVGDOptimizer(model.parameters(), reset, base, particle_count=m, dataset_size=64,
                             l2_reg=float(g["l2_reg"]), kernel_grad_scale=float(g["scale"]),
-                            fuse_base_optimizer=bool(fuse), reuse_gram=(fuse == "reuse_gram"), _ops=ops)
+                            fuse_base_optimizer=fuse not in (False, "staged"),
+                            reuse_gram=fuse in ("reuse_gram", "staged_reuse_gram"),
+                            single_launch=False if str(fuse).startswith("staged") else None, _ops=ops)
+    fuse = fuse not in (False, "staged")
     assert torch.equal(opt.particles.cpu(), init.cpu())
     for i in range(m):      # reference state keys (svgd.py:57)
         assert f"particle_{i}" in opt.state[params[0]]

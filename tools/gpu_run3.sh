@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r2c; mkdir -p $O
+O=gpurun_out/r2d; mkdir -p $O
 export PYTHONDONTWRITEBYTECODE=1
 timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_dist_gpu.py > $O/pytest_main.log 2>&1; echo "pytest_main rc=$?"
 timeout 600 python -m pytest tests/test_dist_gpu.py -q > $O/pytest_dist.log 2>&1; echo "pytest_dist rc=$?"
