@@ -60,10 +60,10 @@ __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __re
   f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   f32x4 cur[kGramU], nxt[kGramU];
   int64_t t = static_cast<int64_t>(blockIdx.x) * (kGramBlock / 64) + wave;
-  if (t < n_tiles) gram_load_tile<W4>(cur, rowp, valid, t, tile4, c4, n4, D);
+  if (t < n_tiles) gram_load_tile<W4, BDE_GRAM_NT>(cur, rowp, valid, BDE_GRAM_TILE(t), tile4, c4, n4, D);
   for (; t < n_tiles; t += waves_total) {
     const int64_t tn = t + waves_total;
-    if (tn < n_tiles) gram_load_tile<W4>(nxt, rowp, valid, tn, tile4, c4, n4, D);
+    if (tn < n_tiles) gram_load_tile<W4, BDE_GRAM_NT>(nxt, rowp, valid, BDE_GRAM_TILE(tn), tile4, c4, n4, D);
 #pragma unroll
     for (int u = 0; u < kGramU; ++u) {
 #pragma unroll

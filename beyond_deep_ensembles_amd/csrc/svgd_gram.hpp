@@ -6,6 +6,21 @@
 
 namespace bde {
 
+// A/B switches (tools/kexp6.hip): how the three-stage Gram pass loads the particles and in which direction it
+// walks them.  Measured (profiles/r02_gram_ab.txt): non-temporal loads make the Gram pass itself 9 % faster but the
+// combine pass behind it slower by more, so the default is plain loads.
+#ifndef BDE_GRAM_NT
+#define BDE_GRAM_NT false
+#endif
+#ifndef BDE_GRAM_REVERSE
+#define BDE_GRAM_REVERSE 0
+#endif
+#if BDE_GRAM_REVERSE
+#define BDE_GRAM_TILE(t) (n_tiles - 1 - (t))
+#else
+#define BDE_GRAM_TILE(t) (t)
+#endif
+
 constexpr int kGramBlock = 256;            // 4 waves
 constexpr int kGramU = 4;                  // float4 loads in flight per lane per iteration
 
@@ -29,9 +44,9 @@ __device__ __forceinline__ float group_sum(float x) {
 
 // One tile = kGramU float4 columns per lane.  Full tiles take the branch-free path; the ragged
 // last tile masks by index (never by multiplication: the row padding may hold NaNs).
-// NT: the particles are streamed once per pass by the three-stage path -> non-temporal loads (6.56 vs 5.93 TB/s
-// measured, profiles/r02_probes.txt); the single-launch path re-reads them from L2 and loads them normally.
-template <int W4, bool NT = true>
+// NT: non-temporal loads (the Gram pass alone then streams at 6.5 instead of 5.9 TB/s, profiles/r02_probes.txt --
+// but see BDE_GRAM_NT above); the single-launch path re-reads the particles from L2 and always loads them normally.
+template <int W4, bool NT = false>
 __device__ __forceinline__ void gram_load_tile(f32x4 (&v)[kGramU], const float* __restrict__ rowp, bool valid,
                                                int64_t t, int64_t tile4, int c4, int64_t n4, int64_t D) {
   const int64_t base4 = t * tile4 + c4;

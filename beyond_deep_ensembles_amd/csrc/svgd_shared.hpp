@@ -4,14 +4,15 @@
 
 namespace bde {
 
-// ws header (1 KB, so that the partial tiles behind it start on a 128-byte line): ws[0] = #partial tiles,
+// ws header (1.5 KB, so that the partial tiles behind it start on a 128-byte line): ws[0] = #partial tiles,
 // ws[1] = padded M (8 or 16).  The rest are the hand-off words of the single-launch path (svgd_small.hip), each on
-// a 128-byte line of its own: 8 sharded arrive counters (word 32 + 32 s) and the depart counter.  They must be ZERO
-// before the first launch and every launch leaves them zero.
+// a 128-byte line of its own: 8 sharded arrive counters (word 32 + 32 s) that only ever count up, and the target
+// word (their sum once the previous launch on this workspace had fully arrived).  The header must be ZERO-filled
+// once after allocation; nothing is ever reset (uint32 wrap-around is handled by comparing differences).
 constexpr int kWsHeaderFloats = 32 * 12;
 constexpr int kWsShards = 8;
 constexpr int kWsArriveWord = 32;                         // + 32 * shard
-constexpr int kWsDepartWord = 32 + 32 * kWsShards;
+constexpr int kWsTargetWord = 32 + 32 * kWsShards;
 constexpr int kGramMaxBlocks = 1024;       // 4 workgroups per CU: best measured (tools/kexp.hip)
 
 // Per-particle Adam scalars of the SHARED step counter (advanced once per particle).

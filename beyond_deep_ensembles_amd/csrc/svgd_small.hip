@@ -22,8 +22,9 @@
 //            coefficients in LDS, and combines its own columns.
 //
 // P is read once from HBM (4 M D), G once (4 M D), out written once (4 M D): 12 M D bytes, no
-// second pass over P.  The counters are reset by the last workgroup to leave, so the caller only
-// has to hand in a workspace that was zeroed once.  All workgroups must be co-resident (they are:
+// second pass over P.  The counters only count up (each launch waits for "previous total + grid
+// size", kept in the workspace), so nothing is reset and the caller only has to hand in a
+// workspace that was zeroed once.  All workgroups must be co-resident (they are:
 // <= 256 workgroups of 512 threads, one per CU on a 256-CU device).  Measured timeline at D = 273,610
 // (tools/kexp6.hip, profiles/r02_small_step_timeline.txt).
 #include "svgd_gram.hpp"
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
                                                                         SgdParams sk, AdamParams ak, AdamSteps ast) {
   constexpr int MP = 8, MP2 = 64;
   __shared__ float tile[kSmallWaves][16][17];
-  __shared__ double red[kSmallBlock];
+  __shared__ double red[(kSmallBlock / (MP2 / 2)) * MP2];           // [16 slices][64]
   __shared__ double gmat[MP2];
   __shared__ __attribute__((aligned(16))) float cgT[MP2];
   __shared__ __attribute__((aligned(16))) float cpT[MP2];
@@ -145,10 +146,12 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwg = gridDim.x;
   unsigned* words = reinterpret_cast<unsigned*>(ws);
-  unsigned* depart = words + kWsDepartWord;
   float* part = ws + kWsHeaderFloats;
 
   BDE_TS(0)
+  // arrivals counted so far on this workspace (all launches before this one); requested first, needed at the poll
+  unsigned arrived_before = 0;
+  if (wave == 0) arrived_before = __hip_atomic_load(words + kWsTargetWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---------------- phase 1: centred Gram partial of this workgroup's columns ----------------
   const int r16 = lane & 15, kq = lane >> 4;
   const int c4 = (r16 >> 3) * 4 + kq;
@@ -233,41 +236,54 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
   // ---------------- hand-off: wave 0 polls the 8 shard counters (one 8-lane load per poll) ----------------
   if (wave == 0) {
     const unsigned* ctr = words + kWsArriveWord + 32 * (lane & (kWsShards - 1));
+    const unsigned want = arrived_before + static_cast<unsigned>(nwg);
     unsigned total;
+    bool all_here;
     do {
       const unsigned c = (lane < kWsShards) ? __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       total = 0;
 #pragma unroll
       for (int sh = 0; sh < kWsShards; ++sh) total += __builtin_amdgcn_readlane(c, sh);
-      if (total < static_cast<unsigned>(nwg)) __builtin_amdgcn_s_sleep(4);
-    } while (total < static_cast<unsigned>(nwg));
+      all_here = static_cast<int>(total - want) >= 0;              // difference: immune to uint32 wrap-around
+      if (!all_here) __builtin_amdgcn_s_sleep(4);
+    } while (!all_here);
+    // every workgroup read the old target before it arrived, so it can move on now
+    if (blockIdx.x == 0 && lane == 0)
+      __hip_atomic_store(words + kWsTargetWord, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   BDE_TS(4)
   __syncthreads();
 
-  // fixed-order fp64 reduction of ALL partial tiles (every workgroup computes the same bits); every load of
-  // a thread is in flight before the first add
+  // fixed-order fp64 reduction of ALL partial tiles (every workgroup computes the same bits): 8-byte sc1 loads, all
+  // of a thread's loads in flight before the first add, unconditional (a predicated load gets a basic block and an
+  // s_waitcnt of its own: 8 us instead of 1) -- slots past the grid re-read the last partial and are dropped
   {
-    constexpr int NL = kSmallMaxGrid / kSmallWaves;                // partials per thread, at most (32)
-    const int e = tid & (MP2 - 1), slice = tid >> 6;               // 8 slices
-    float x[NL];
-    // unconditional loads (a predicated load gets a basic block and an s_waitcnt of its own: 8 us instead of 1):
-    // slots past the grid re-read the last partial and are dropped by the select below
+    constexpr int PAIRS = MP2 / 2;                                 // 32 float pairs per partial tile
+    constexpr int SLICES = kSmallBlock / PAIRS;                    // 16
+    constexpr int NL = kSmallMaxGrid / SLICES;                     // partials per thread, at most (16)
+    const int q = tid & (PAIRS - 1), slice = tid / PAIRS;
+    unsigned long long x[NL];
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-      const int b = slice + kSmallWaves * u;
-      x[u] = ld_sc1(part + static_cast<int64_t>(b < nwg ? b : nwg - 1) * MP2 + e);
+      const int b = slice + SLICES * u;
+      x[u] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + static_cast<int64_t>(b < nwg ? b : nwg - 1) * MP2) + q,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    double s = 0.0;
+    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int u = 0; u < NL; ++u) s += (slice + kSmallWaves * u < nwg) ? static_cast<double>(x[u]) : 0.0;
-    red[tid] = s;
+    for (int u = 0; u < NL; ++u) {
+      const bool in = slice + SLICES * u < nwg;
+      s0 += in ? static_cast<double>(__uint_as_float(static_cast<unsigned>(x[u]))) : 0.0;
+      s1 += in ? static_cast<double>(__uint_as_float(static_cast<unsigned>(x[u] >> 32))) : 0.0;
+    }
+    red[slice * MP2 + 2 * q] = s0;
+    red[slice * MP2 + 2 * q + 1] = s1;
   }
   __syncthreads();
   if (wave == 0) {
     double s = 0.0;
 #pragma unroll
-    for (int sl = 0; sl < kSmallWaves; ++sl) s += red[sl * MP2 + lane];
+    for (int sl = 0; sl < kSmallBlock / (MP2 / 2); ++sl) s += red[sl * MP2 + lane];
     gmat[lane] = s;
   }
   BDE_TS(5)
@@ -362,19 +378,9 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
       }
     }
   }
-  // depart (off the critical path): every workgroup has seen the full count once all have added here; the last
-  // one to leave zeroes the counters for the next launch
-  if (tid == 0) {
-    if (blockIdx.x == 0) {
-      ws[0] = static_cast<float>(nwg);
-      ws[1] = static_cast<float>(MP);
-    }
-    const unsigned left = __hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (left == static_cast<unsigned>(nwg) - 1u) {
-      for (int sh = 0; sh < kWsShards; ++sh)
-        __hip_atomic_store(words + kWsArriveWord + 32 * sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (blockIdx.x == 0 && tid == 0) {
+    ws[0] = static_cast<float>(nwg);
+    ws[1] = static_cast<float>(MP);
   }
 }
 

@@ -61,9 +61,9 @@ const char* bde_arch(void);
  *             out; out may alias G).
  */
 
-/* Bytes of scratch `ws` needed by the SVGD entry points for M particles.  The first 256 bytes are a
- * header; it must be ZERO-FILLED once after allocation (it holds the arrive / depart counters of the
- * single-launch path, which every launch leaves at zero again).  One `ws` serves one stream at a time. */
+/* Bytes of scratch `ws` needed by the SVGD entry points for M particles.  The first 1.5 KB are a
+ * header; it must be ZERO-FILLED once after allocation (it holds the hand-off counters of the
+ * single-launch path, which only ever count up).  One `ws` serves one stream at a time. */
 size_t bde_svgd_ws_bytes(int M);
 
 /* Number of floats of the `kstat` result block for M particles.  Layout:

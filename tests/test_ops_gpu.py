@@ -145,7 +145,7 @@ def test_svgd_single_launch_path(ops):
     """bde_svgd_step_small (one persistent launch: Gram partials -> in-kernel hand-off -> redundant statistics ->
     combine) against the three-stage path and the fp64 anchor: sizes around its tile / workgroup / eligibility
     boundaries, the CIFAR ResNet-20 size of BASELINE configs 2-3, in place, and many launches on one workspace
-    (the arrive / depart counters must come back to zero every time)."""
+    (the hand-off counters only count up: every launch waits for "previous total + its grid size")."""
     torch.manual_seed(3)
     assert ops.svgd_small_supported(8, 273_610) and ops.svgd_small_supported(8, 524_288)
     assert not ops.svgd_small_supported(8, 524_289) and not ops.svgd_small_supported(9, 1000)
@@ -176,7 +176,10 @@ def test_svgd_single_launch_path(ops):
         ops.svgd_step_small(Pb, Gb, Gb, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks)
     torch.cuda.synchronize()
     assert torch.equal(Gb[:, :d], ref[:, :d])
-    assert int(ws[32:384].view(torch.int32).abs().sum()) == 0           # all hand-off words are back to zero
+    # the hand-off words only count up: after 202 launches of a 238-workgroup grid the 8 shard counters sum to
+    # the target word
+    words = ws[:384].view(torch.int32).cpu()
+    assert int(words[32:32 + 32 * 8:32].sum()) == int(words[32 + 32 * 8]) and int(words[32 + 32 * 8]) > 0           # all hand-off words are back to zero
     # rbf mode (grad_kernel) through the same launch
     out = torch.zeros_like(Pb)
     ops.svgd_step_small(Pb, None, out, d, 0.0, 1.0, 1.0, 1.0, ws, ks, mode=1)
@@ -304,6 +307,40 @@ def test_svgd_fused_equals_combine_plus_apply(ops):
                     ops.svgd_fused_adam(Pb, Gb, s0b, s1b, d, ks, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m, ws_next=wsn)
                 np.testing.assert_allclose(Pb[:, :d].cpu().numpy(), Pa[:, :d].cpu().numpy(), rtol=3e-6, atol=3e-7)
                 np.testing.assert_allclose(s0b[:d].cpu().numpy(), s0a[:d].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_svgd_single_launch_fused_step(ops):
+    """bde_svgd_step_small_sgd / _adam (the whole SVGDOptimizer.step minus forward/backward in ONE launch) ==
+    bde_svgd_step_small followed by bde_svgd_apply_* (svgd.py:86-103), over several steps with carried state, at
+    ragged sizes and the CIFAR ResNet-20 size."""
+    torch.manual_seed(15)
+    for m, d in [(8, 273_610), (5, 4099), (3, 17), (8, 256 * 128 + 3), (1, 1000)]:
+        P0 = torch.randn(1, d) * 0.05 + torch.randn(m, d) * 0.01
+        G0 = torch.randn(m, d) * 0.01
+        for kind in ("sgd", "sgd_plain", "adam"):
+            Pa, Pb, Gb = flat_rows(P0), flat_rows(P0), flat_rows(G0)
+            Pa[:, d:] = 0
+            Pb[:, d:] = 0
+            tmp = torch.zeros_like(Gb)
+            ws, ks, ksb = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV), ops.svgd_kstat(m, DEV)
+            s0a, s1a, s0b, s1b = (torch.zeros(Pa.shape[1], device=DEV) for _ in range(4))
+            for it in range(3):
+                Gb[:, :d] = (G0 * (1 + it)).to(DEV)
+                ops.svgd_step_small(Pa, Gb, tmp, d, 0.01, 1.0, 500.0, -1.0, ws, ks)
+                if kind == "sgd":
+                    ops.svgd_apply_sgd(Pa, tmp, s0a, d, 0.05, 0.9, 0.0, 3e-4, True, it == 0)
+                    ops.svgd_step_small_sgd(Pb, Gb, s0b, d, 0.01, 1.0, 500.0, ws, ksb, 0.05, 0.9, 0.0, 3e-4, True, it == 0)
+                elif kind == "sgd_plain":              # no momentum: the state buffer is never touched
+                    ops.svgd_apply_sgd(Pa, tmp, s0a, d, 0.05, 0.0, 0.0, 0.0, False, it == 0)
+                    ops.svgd_step_small_sgd(Pb, Gb, s0b, d, 0.01, 1.0, 500.0, ws, ksb, 0.05, 0.0, 0.0, 0.0, False, it == 0)
+                else:
+                    ops.svgd_apply_adam(Pa, tmp, s0a, s1a, d, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m)
+                    ops.svgd_step_small_adam(Pb, Gb, s0b, s1b, d, 0.01, 1.0, 500.0, ws, ksb, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m)
+                assert torch.equal(ks[:m * m], ksb[:m * m]), (m, d, kind, it)          # same statistics, same bits
+                np.testing.assert_allclose(Pb[:, :d].cpu().numpy(), Pa[:, :d].cpu().numpy(), rtol=3e-6, atol=3e-7)
+                np.testing.assert_allclose(s0b[:d].cpu().numpy(), s0a[:d].cpu().numpy(), rtol=1e-5, atol=1e-7)
+                np.testing.assert_allclose(s1b[:d].cpu().numpy(), s1a[:d].cpu().numpy(), rtol=1e-5, atol=1e-9)
+            assert torch.equal(Pb[:, d:], torch.zeros_like(Pb[:, d:]))                  # padding untouched
 
 
 # ------------------------------------------------------------------ SWAG --
