@@ -20,7 +20,7 @@
 namespace bde {
 
 // The in-place particle stream is loaded and stored non-temporally like the gradient stream: 0.482 ms vs 0.500 ms
-// per full step with plain accesses (tools/kexp6.hip A/B, profiles/r02_fused_ab.txt).
+// per full step with plain accesses (tools/kexp6.hip A/B, profiles/r02_small_step_timeline_v1_and_fused_ab.txt).
 #ifndef BDE_FUSED_PLD
 #define BDE_FUSED_PLD ld4_nt
 #endif

@@ -7,7 +7,7 @@
 namespace bde {
 
 // A/B switches (tools/kexp6.hip): how the three-stage Gram pass loads the particles and in which direction it
-// walks them.  Measured (profiles/r02_gram_ab.txt): non-temporal loads make the Gram pass itself 9 % faster but the
+// walks them.  Measured (profiles/r02_small_step_timeline_v3_and_gram_ab.txt): non-temporal loads make the Gram pass itself 9 % faster but the
 // combine pass behind it slower by more, so the default is plain loads.
 #ifndef BDE_GRAM_NT
 #define BDE_GRAM_NT false
@@ -44,7 +44,7 @@ __device__ __forceinline__ float group_sum(float x) {
 
 // One tile = kGramU float4 columns per lane.  Full tiles take the branch-free path; the ragged
 // last tile masks by index (never by multiplication: the row padding may hold NaNs).
-// NT: non-temporal loads (the Gram pass alone then streams at 6.5 instead of 5.9 TB/s, profiles/r02_probes.txt --
+// NT: non-temporal loads (the Gram pass alone then streams at 6.5 instead of 5.9 TB/s, profiles/r02_probes_and_variants_before.txt --
 // but see BDE_GRAM_NT above); the single-launch path re-reads the particles from L2 and always loads them normally.
 template <int W4, bool NT = false>
 __device__ __forceinline__ void gram_load_tile(f32x4 (&v)[kGramU], const float* __restrict__ rowp, bool valid,

@@ -26,7 +26,7 @@
 // size", kept in the workspace), so nothing is reset and the caller only has to hand in a
 // workspace that was zeroed once.  All workgroups must be co-resident (they are:
 // <= 256 workgroups of 512 threads, one per CU on a 256-CU device).  Measured timeline at D = 273,610
-// (tools/kexp6.hip, profiles/r02_small_step_timeline.txt).
+// (tools/kexp6.hip, profiles/r02_small_step_timeline_v3_and_gram_ab.txt).
 #include "svgd_gram.hpp"
 
 namespace bde {

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
   const int64_t n4 = D >> 2;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   // Two float4 columns (one grid-stride apart) per thread and 5 ring rows per batch: 10 independent 16-byte
-  // loads in flight per lane.  Measured on MI355X (tools/kexp5.hip, profiles/r02_probes.txt): 6.2-6.3 TB/s against
+  // loads in flight per lane.  Measured on MI355X (tools/kexp5.hip, profiles/r02_probes_and_variants_before.txt): 6.2-6.3 TB/s against
   // 6.0 for one column x 10 rows and 5.4-5.9 for contiguous per-workgroup chunks; a kernel that only reads the
   // same K + 2 rows and writes one reaches 5.75.
   constexpr int U = 2;

@@ -14,7 +14,16 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $grp -d $O/pmc_$tag -o p -- python3 bench.py --gpus 1 --steps 3 --warmup 1 --blocks 1 --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err; echo "pmc $tag rc=$?"
 done
+echo "--- sizes before pruning"; du -sh $O/* | sort -h | tail -12; find $O -type f -size +1M | head -20
+f=$(find $O/pmc_FETCH_SIZE -name "*counter_collection*" | head -1); echo "counter file: $f"; head -2 "$f" | cut -c1-600
 python3 tools/pmc_summary.py $O/pmc_summary.json $O/pmc_*/ ; echo "summary rc=$?"
+# keep the summaries: stats CSVs, the JSON lines, the PMC summary; drop raw traces / per-dispatch tables / databases
+mkdir -p $O/keep
+for t in trace_full trace_main; do for f in $(find $O/$t -name "*kernel_stats.csv"); do cp $f $O/keep/${t}_kernel_stats.csv; done; done
+cp $O/*.json $O/keep/ 2>/dev/null
+for e in $O/*.err; do tail -5 $e > $O/keep/$(basename $e).tail; done
+rm -rf $O/trace_full $O/trace_main $O/pmc_*/ $O/*.err
+ls -la $O/keep
 # plain run for comparison (no profiler attached)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_plain.json 2> $O/bench_plain.err; echo "plain rc=$?"
 find $O -name "*kernel_stats.csv" | head; ls $O
