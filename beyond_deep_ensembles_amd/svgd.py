@@ -475,13 +475,21 @@ class SVGDOptimizer(BayesianOptimizer):
             # ... and publish the flat buffers as that state
             views = {key: self._layout.views(st[key]) for key in names}
             if kind == "adam":
-                st["step_tensor"] = torch.tensor(float(st["step"]))
+                # torch's Adam keeps one step tensor per parameter; they are refreshed from the shared counter
+                # whenever the base optimizer's state_dict is taken
+                st["step_tensors"] = [torch.tensor(float(st["step"])) for _ in self._plist]
+
+                def refresh_steps(_optimizer, st=st):
+                    for t in st["step_tensors"]:
+                        t.fill_(float(st["step"]))
+                if hasattr(base, "register_state_dict_pre_hook"):
+                    base.register_state_dict_pre_hook(refresh_steps)
             for i, p in enumerate(self._plist):
                 entry = base.state[p]
                 for key, name in names.items():
                     entry[name] = views[key][i]
                 if kind == "adam":
-                    entry["step"] = st["step_tensor"]
+                    entry["step"] = st["step_tensors"][i]
         self._fused_state = self.state["__fused"] = st
         return st
 
@@ -530,8 +538,6 @@ class SVGDOptimizer(BayesianOptimizer):
             st["first"] = False
         else:
             st["step"] += self.state["__particle_count"]
-            if "step_tensor" in st:
-                st["step_tensor"].fill_(float(st["step"]))
 
     # ------------------------------------------------------------------
     def sample_parameters(self):

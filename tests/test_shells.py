@@ -995,3 +995,48 @@ def test_bbb_group_draw_is_one_launch_per_forward(backend):
         assert torch.allclose(p.grad.cpu(), m.grad, rtol=1e-4, atol=1e-6)
     for p, r in zip(group.rhos, rs):
         assert torch.allclose(p.grad.cpu(), r.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
+def test_svgd_fused_state_lives_in_the_base_optimizer(backend, kind):
+    """fuse_base_optimizer keeps the SHARED momentum / Adam moments in flat buffers -- and publishes them as
+    base_optimizer.state[param] views, so base.state_dict() is complete and a run continued WITHOUT the fused path
+    (or in the reference) carries on from the same state: fused 3 steps == fused 2 steps + 1 unfused step."""
+    ops, dev = backend
+    x = torch.randn(16, 13, generator=torch.Generator().manual_seed(8)).to(dev)
+    y = torch.randn(16, 1, generator=torch.Generator().manual_seed(9)).to(dev)
+
+    def make(fuse, seed=3):
+        torch.manual_seed(seed)
+        model = make_mlp().to(dev)
+        base = (torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True) if kind == "sgd"
+                else torch.optim.Adam(model.parameters(), lr=1e-2))
+        opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=3,
+                                dataset_size=64, l2_reg=0.01, fuse_base_optimizer=fuse, single_launch=False, _ops=ops)
+        return model, base, opt
+
+    def step(model, opt):
+        return opt.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
+
+    model_a, base_a, opt_a = make(True)
+    for _ in range(3):
+        step(model_a, opt_a)
+    model_b, base_b, opt_b = make(True)
+    for _ in range(2):
+        step(model_b, opt_b)
+    params_b = list(model_b.parameters())
+    sd = base_b.state_dict()                                   # complete: one entry per parameter
+    assert len(sd["state"]) == len(params_b)
+    key = "momentum_buffer" if kind == "sgd" else "exp_avg"
+    assert all(key in e for e in sd["state"].values())
+    if kind == "adam":
+        assert all(float(e["step"]) == 6.0 for e in sd["state"].values())     # 2 steps x 3 particles (Q5)
+    # continue unfused on the SAME base optimizer and particles
+    opt_c = bde.SVGDOptimizer(params_b, lambda: None, base_b, particle_count=3, dataset_size=64, l2_reg=0.01,
+                              single_launch=False, _ops=ops)
+    with torch.no_grad():
+        opt_c._P.copy_(opt_b._P)
+    if kind == "adam":
+        base_b.load_state_dict(sd)                             # per-parameter step counters as torch expects them
+    step(model_b, opt_c)
+    np.testing.assert_allclose(opt_c.particles.cpu().numpy(), opt_a.particles.cpu().numpy(), rtol=2e-5, atol=2e-6)
