@@ -56,6 +56,7 @@ SIGNATURES = {
     "bde_reduce_ws_bytes": (c_size_t, []),
     "bde_gauss_kl": (c_int, [_P, _P, c_float, c_float, c_float, _P, _P, _P, c_int, _P, _P, c_int64, _P]),
     "bde_l2": (c_int, [_P, c_float, c_float, _P, _P, c_int, _P, _P, c_int64, _P]),
+    "bde_mixture_nll": (c_int, [_P, c_float, c_float, c_float, c_float, _P, _P, c_int, _P, _P, c_int64, _P]),
     "bde_local_reparam_fwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_local_reparam_bwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_ivon_sample": (c_int, [_P, _P, _P, c_uint64, c_uint64, c_float, c_int, c_int, _P, _P, c_int64, _P]),

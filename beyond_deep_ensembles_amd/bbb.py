@@ -10,7 +10,8 @@ backward) is ONE fused kernel that returns the KL value and writes
 ``pi * dKL/dmean`` and ``pi * dKL/drho`` straight into the flat gradient
 buffers before ``backward_closure`` accumulates the data-loss gradients on top.
 Plain parameters get the same treatment for the ``l2_scale / 2 * ||p||^2`` term.
-Priors other than ``GaussianPrior`` keep the reference's autograd path.
+``MixturePrior`` has its own fused kernel (value + gradient wrt the means); tensor-valued priors and frozen
+parameters keep the reference's autograd path.
 """
 from __future__ import annotations
 
@@ -79,8 +80,12 @@ class _Group:
         means, rhos, plain, generic = [], [], [], []
         claimed = set()
         params = group["params"]
-        fused_ok = isinstance(self.prior, GaussianPrior) and not torch.is_tensor(self.prior.mu) \
+        gauss_ok = isinstance(self.prior, GaussianPrior) and not torch.is_tensor(self.prior.mu) \
             and not torch.is_tensor(self.prior.sigma)
+        mixture_ok = isinstance(self.prior, MixturePrior) and not torch.is_tensor(self.prior.sigma1) \
+            and not torch.is_tensor(self.prior.sigma2) and 0.0 < float(self.prior.pi) < 1.0
+        self.kind = "gauss" if gauss_ok else ("mixture" if mixture_ok else None)
+        fused_ok = self.kind is not None
         frozen_plain = []
         for p in params:
             mod = getattr(p, "_bde_gaussian", None)
@@ -204,9 +209,16 @@ class BBBOptimizer(BayesianOptimizer):
             for gi, (group, fg) in enumerate(zip(self.param_groups, self._groups)):
                 if fg.means:
                     kl = self._kl_parts[2 * gi:2 * gi + 1]
-                    self._ops.gauss_kl(fg.mu, fg.rho, float(fg.prior.mu), float(fg.prior.sigma), fg.gl.d, self._rws,
-                                       kl_out=kl, gmean=fg.gmu, grho=fg.grho, grad_scale=pi, grad_scale_dev=scale_dev,
-                                       accumulate=False)
+                    if fg.kind == "gauss":
+                        self._ops.gauss_kl(fg.mu, fg.rho, float(fg.prior.mu), float(fg.prior.sigma), fg.gl.d, self._rws,
+                                           kl_out=kl, gmean=fg.gmu, grho=fg.grho, grad_scale=pi,
+                                           grad_scale_dev=scale_dev, accumulate=False)
+                    else:
+                        # MixturePrior (bbb.py:31-37): a function of the means only; the rho gradients start at zero
+                        self._ops.mixture_nll(fg.mu, float(fg.prior.pi), float(fg.prior.sigma1), float(fg.prior.sigma2),
+                                              fg.gl.d, self._rws, val_out=kl, gmean=fg.gmu, grad_scale=pi,
+                                              grad_scale_dev=scale_dev, accumulate=False)
+                        fg.grho.zero_()
                     total_kl_loss = total_kl_loss + kl[0]
                     # the data-loss gradients of backward() come as fresh tensors and are added onto the KL
                     # gradients with one multi-tensor op (adopt_grads below), not one in-place add per tensor

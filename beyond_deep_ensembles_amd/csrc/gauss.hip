@@ -253,6 +253,76 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------ mixture prior --
+// MixturePrior.kl_divergence (bbb.py:23-37): -sum log p(mean) with
+//   p = pi N(0, s1) + (1 - pi) N(0, s2),  each component's log-density clamped to [-23, 0] before the logaddexp.
+// It depends on the means only (rho gets no gradient from it).  Value and gradient in one pass: 4 B/param read,
+// 4 or 8 B/param for the gradient (overwrite / accumulate).  Arithmetic in torch's order: Normal.log_prob =
+// -(x^2) / (2 var) - log(scale) - log(sqrt(2 pi)) with IEEE divides; logaddexp = max + log1p(exp(-|a - b|)).
+struct MixConsts {
+  float two_var1, two_var2, log_s1, log_s2, log_w1, log_w2, c;
+};
+__device__ __forceinline__ float mixture_elem(float x, const MixConsts& k, bool want_grad, float& g) {
+  constexpr float kHalfLog2Pi = 0.91893853320467274178f;          // log(sqrt(2 pi))
+  const float x2 = x * x;
+  const float lp1 = ((-x2) / k.two_var1 - k.log_s1) - kHalfLog2Pi;
+  const float lp2 = ((-x2) / k.two_var2 - k.log_s2) - kHalfLog2Pi;
+  const float a = k.log_w1 + fminf(fmaxf(lp1, -23.0f), 0.0f);
+  const float b = k.log_w2 + fminf(fmaxf(lp2, -23.0f), 0.0f);
+  const float m = fmaxf(a, b);
+  const float out = m + log1pf(expf(-fabsf(a - b)));
+  if (want_grad) {
+    // d out / d a = exp(a - out); the clamp passes gradients inside [-23, 0] (bounds included); d lp / d x = -2 x / (2 var)
+    const float wa = (lp1 >= -23.0f && lp1 <= 0.0f) ? expf(a - out) : 0.0f;
+    const float wb = (lp2 >= -23.0f && lp2 <= 0.0f) ? expf(b - out) : 0.0f;
+    const float dlogp = wa * ((-2.0f * x) / k.two_var1) + wb * ((-2.0f * x) / k.two_var2);
+    g = k.c * (-dlogp);                                           // the "KL" is MINUS the log-density
+  }
+  return -out;
+}
+
+template <bool GRAD, bool ACC>
+__global__ __launch_bounds__(kBlock) void mixture_nll_kernel(const float* __restrict__ mean, MixConsts k,
+                                                            const float* __restrict__ grad_scale_dev,
+                                                            float* __restrict__ gmean, double* __restrict__ partials,
+                                                            int64_t n) {
+  __shared__ double smem[kBlock / 64];
+  k.c = k.c * (grad_scale_dev ? grad_scale_dev[0] : 1.0f);
+  const int64_t n4 = n >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  float local = 0.f;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 m = ld4_nt(mean + 4 * i);
+    f32x4 gm;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f;
+      part += mixture_elem(m[j], k, GRAD, a);
+      gm[j] = a;
+    }
+    local += part;
+    if (GRAD) {
+      if (ACC) gm = gm + ld4(gmean + 4 * i);
+      st4(gmean + 4 * i, gm);
+    }
+  }
+  double acc = static_cast<double>(local);
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < n) {
+      float g = 0.f;
+      acc += static_cast<double>(mixture_elem(mean[e], k, GRAD, g));
+      if (GRAD) gmean[e] = ACC ? gmean[e] + g : g;
+    }
+  }
+  const double tot = block_sum(acc, smem);
+  if (threadIdx.x == 0) {
+    partials[kReduceHeader + blockIdx.x] = tot;
+    if (blockIdx.x == 0) partials[0] = static_cast<double>(gridDim.x);
+  }
+}
+
 template <bool GRAD, bool ACC>
 __global__ __launch_bounds__(kBlock) void l2_kernel(const float* __restrict__ p, float l2_scale, float grad_scale,
                                                    const float* __restrict__ grad_scale_dev, float* __restrict__ g,
@@ -378,6 +448,30 @@ extern "C" int bde_gauss_kl(const float* mean, const float* rho, float prior_mu,
   int rc = to_err(hipGetLastError());
   if (rc || !kl_out) return rc;
   hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(kBlock), 0, s, part, 1.0f, kl_out);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_mixture_nll(const float* mean, float pi, float sigma1, float sigma2, float grad_scale,
+                               const float* grad_scale_dev, float* gmean, int accumulate, float* val_out, void* ws,
+                               int64_t n, void* stream) {
+  if (!mean || !ws || n <= 0 || !(sigma1 > 0.f) || !(sigma2 > 0.f) || !(pi > 0.f) || !(pi < 1.f)) return BDE_ERR_INVALID;
+  if (!aligned16(mean) || (gmean && !aligned16(gmean))) return BDE_ERR_INVALID;
+  // torch forms var = scale ** 2 and log(scale), log(pi), log(1 - pi) on float32 tensors
+  const float var1 = sigma1 * sigma1, var2 = sigma2 * sigma2;
+  const float one_minus_pi = 1.0f - pi;
+  const MixConsts k{2.0f * var1, 2.0f * var2, logf(sigma1), logf(sigma2), logf(pi), logf(one_minus_pi), grad_scale};
+  const int grid = stream_grid((n + 3) / 4, kBlock, kReduceMaxBlocks);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* part = static_cast<double*>(ws);
+#define BDE_LAUNCH(G, A) \
+  hipLaunchKernelGGL((mixture_nll_kernel<G, A>), dim3(grid), dim3(kBlock), 0, s, mean, k, grad_scale_dev, gmean, part, n)
+  if (!gmean) BDE_LAUNCH(false, false);
+  else if (accumulate) BDE_LAUNCH(true, true);
+  else BDE_LAUNCH(true, false);
+#undef BDE_LAUNCH
+  int rc = to_err(hipGetLastError());
+  if (rc || !val_out) return rc;
+  hipLaunchKernelGGL(reduce_finish_kernel, dim3(1), dim3(kBlock), 0, s, part, 1.0f, val_out);
   return to_err(hipGetLastError());
 }
 

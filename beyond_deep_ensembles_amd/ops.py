@@ -263,6 +263,13 @@ class HipOps:
                                _ptr(val_out), _ptr(ws), n, _stream()), "bde_l2")
 
     @_on_device_of
+    def mixture_nll(self, mean, pi, sigma1, sigma2, n, ws, val_out=None, gmean=None, grad_scale=1.0, grad_scale_dev=None,
+                    accumulate=False):
+        """MixturePrior "KL" (bbb.py:31-37): -sum log p(mean) and its gradient wrt the means, one pass."""
+        _check(self.lib.bde_mixture_nll(_ptr(mean), pi, sigma1, sigma2, grad_scale, _ptr(grad_scale_dev), _ptr(gmean),
+                                        int(accumulate), _ptr(val_out), _ptr(ws), n, _stream()), "bde_mixture_nll")
+
+    @_on_device_of
     def local_reparam_fwd(self, mean, var, out, n, eps=None, seed=0, stream_id=0):
         _check(self.lib.bde_local_reparam_fwd(_ptr(mean), _ptr(var), _ptr(eps), seed, stream_id, _ptr(out), n, _stream()),
                "bde_local_reparam_fwd")

@@ -256,6 +256,14 @@ int bde_gauss_kl(const float* mean, const float* rho, float prior_mu, float prio
 int bde_l2(const float* p, float l2_scale, float grad_scale, const float* grad_scale_dev, float* g,
            int accumulate, float* val_out, void* ws, int64_t n, void* stream);
 
+/* MixturePrior.kl_divergence (bbb.py:23-37): -sum over the means of log(pi N(x; 0, sigma1) + (1 - pi) N(x; 0, sigma2))
+ * with each component's log-density clamped to [-23, 0], and its gradient wrt the means
+ * (gmean = or += grad_scale * [grad_scale_dev[0]] * d/dmean; rho receives no gradient from this prior).
+ * val_out / gmean may be NULL. */
+int bde_mixture_nll(const float* mean, float pi, float sigma1, float sigma2, float grad_scale,
+                    const float* grad_scale_dev, float* gmean, int accumulate, float* val_out, void* ws,
+                    int64_t n, void* stream);
+
 /* Epilogue of the local-reparameterisation layers (bbb_layers.py:70-80: activation_mean +
  * sqrt(activation_var) * eps after the mean and variance GEMMs / convs), fused:
  *   fwd: out = mean + sqrt(var) * eps          bwd: gvar = g * eps / (2 sqrt(var))   (gmean = g)

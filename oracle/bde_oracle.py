@@ -267,6 +267,25 @@ def gauss_kl_grads(mean: torch.Tensor, rho: torch.Tensor, prior_mu: float, prior
     return g_mean, g_rho
 
 
+def mixture_nll(mean: torch.Tensor, pi: float, sigma1: float, sigma2: float) -> torch.Tensor:
+    """``MixturePrior.kl_divergence`` (``src/algos/bbb.py:23-37``): minus the summed log-density of the means under
+    ``pi N(0, sigma1) + (1 - pi) N(0, sigma2)``, each component's ``Normal.log_prob`` clamped to [-23, 0] before the
+    ``logaddexp`` (lines 31-33).  Differentiable: autograd of this expression is the gradient oracle."""
+    weight = torch.tensor(pi)
+    parts = []
+    for w, sigma in ((weight, sigma1), (1 - weight, sigma2)):
+        log_density = torch.distributions.Normal(0, sigma).log_prob(mean)
+        parts.append(torch.log(w) + torch.clamp(log_density, -23, 0))
+    return -torch.logaddexp(parts[0], parts[1]).sum()
+
+
+def mixture_nll_grad(mean: torch.Tensor, pi: float, sigma1: float, sigma2: float) -> torch.Tensor:
+    with torch.enable_grad():
+        m = mean.detach().clone().requires_grad_(True)
+        mixture_nll(m, pi, sigma1, sigma2).backward()
+    return m.grad
+
+
 def bbb_loss(total_kl: torch.Tensor, total_data_loss: torch.Tensor, kl_rescaling: float,
              dataset_size: float, mc_samples: int, components: int) -> torch.Tensor:
     """``src/algos/bbb.py:78-80``: ``pi = kl_rescaling / dataset_size``;

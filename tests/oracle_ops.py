@@ -229,6 +229,18 @@ class OracleOps:
             else:
                 g[:n] = c * l2_scale * p[:n]
 
+    def mixture_nll(self, mean, pi, sigma1, sigma2, n, ws, val_out=None, gmean=None, grad_scale=1.0, grad_scale_dev=None,
+                    accumulate=False):
+        c = grad_scale * (float(grad_scale_dev) if grad_scale_dev is not None else 1.0)
+        if val_out is not None:
+            val_out[0] = O.mixture_nll(mean[:n], pi, sigma1, sigma2)
+        if gmean is not None:
+            g = c * O.mixture_nll_grad(mean[:n], pi, sigma1, sigma2)
+            if accumulate:
+                gmean[:n] += g
+            else:
+                gmean[:n] = g
+
     def local_reparam_fwd(self, mean, var, out, n, eps=None, seed=0, stream_id=0):
         if eps is None:
             eps = _philox(seed, stream_id, n)

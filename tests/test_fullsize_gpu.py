@@ -124,9 +124,15 @@ def test_swag_fullsize(ops):
     head = 0
     run_sum, run_sq = theta[:D].double().clone(), (theta[:D].double()) ** 2
     last = {}
+    # the CPU oracle replays the same 25 updates on two slices (first 2^20 and last 1003 parameters)
+    slices = (slice(0, 1 << 20), slice(D - 1003, D))
+    oracle_states = [O.swag_init(theta[sl].cpu(), K) for sl in slices]
     for n in range(1, 26):                                                   # 25 updates: every ring row written
         theta[:D] += torch.randn(D, device=DEV, generator=g) * 1e-3
         ops.swag_update(theta, mean, sq, ring[head], n, D)
+        for st, sl in zip(oracle_states, slices):
+            st.updates = n
+            O.swag_moment_update(st, theta[sl].cpu())
         run_sum += theta[:D].double()
         run_sq += theta[:D].double() ** 2
         last[head] = (n, theta[:D].clone(), mean[:D].clone())
@@ -139,6 +145,11 @@ def test_swag_fullsize(ops):
         assert torch.equal(ring[r, :D], th - mn), (r, n)
     # logical column K-1 (newest) is physical row head-1
     assert last[(head - 1) % K][0] == 25
+    # ... and against the oracle (the reference's fp32 op order, swag.py:98-104): moments and all K columns BIT-EXACT
+    order0 = [(head + c) % K for c in range(K)]
+    for st, sl in zip(oracle_states, slices):
+        assert torch.equal(mean[sl].cpu(), st.mean) and torch.equal(sq[sl].cpu(), st.sq_weights)
+        assert torch.equal(ring[order0][:, sl].t().cpu(), st.deviations)
     # sampling: eps = 0 returns the mean; linear in the noise; batched == unbatched; fp64 closed form
     zeros_w, zeros_d = torch.zeros(K, device=DEV), torch.zeros(LD, device=DEV)
     out0, out1, out2, out12 = (torch.empty(LD, device=DEV) for _ in range(4))
@@ -157,6 +168,10 @@ def test_swag_fullsize(ops):
     sd32 = (0.5 * (torch.relu(sq[:D] - mean[:D] ** 2) + 1e-6)).sqrt()
     want = mean[:D].double() + lowrank + sd32.double() * e1d[:D].double()
     assert (out1[:D].double() - want).abs().max().item() <= 2e-7
+    # the oracle's sample (swag.py:57,112-114: LowRankMultivariateNormal arithmetic) on the slices, same noise
+    for st, sl in zip(oracle_states, slices):
+        ref = O.swag_sample(st.mean, st.sq_weights, st.deviations, e1w.cpu(), e1d[sl].cpu())
+        assert (out1[sl].cpu() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
     # S = 30 in one pass (MFMA) == 30 single samples, Philox noise (stream = sample index)
     outb = torch.empty(S, LD, device=DEV)
     ops.swag_sample_batched(mean, sq, ring, head, outb, D, seed=5, stream_id0=100)
@@ -183,12 +198,20 @@ def test_bbb_ivon_fullsize(ops):
     assert (gm[:D].double() - m64).abs().max().item() <= 1e-6
     want_gr = (-1 / s64 + s64) * torch.sigmoid(rho[:D].double())
     assert ((gr[:D].double() - want_gr).abs() / (1 / s64 + s64)).max().item() <= 3e-6
+    # the oracle (autograd of bbb.py:20 / util.py:171 in fp32) on the first 2^20 and the last 1003 parameters
+    for sl in (slice(0, 1 << 20), slice(D - 1003, D)):
+        ogm, ogr = O.gauss_kl_grads(mean[sl].cpu(), rho[sl].cpu(), 0.0, 1.0)
+        assert (gm[sl].cpu() - ogm).abs().max().item() <= 1e-6
+        assert ((gr[sl].cpu() - ogr).abs() / (1 / s64[sl].cpu().float() + s64[sl].cpu().float())).max().item() <= 3e-6
     # draw: Philox forward == supplied-noise forward; backward regenerates the same noise
     w1, w2, eps = (torch.empty(LD, device=DEV) for _ in range(3))
     ops.gauss_draw_fwd(mean, rho, w1, D, seed=3, stream_id=9, eps_out=eps)
     ops.gauss_draw_fwd(mean, rho, w2, D, eps=eps)
     assert torch.equal(w1[:D], w2[:D])
     assert (w1[:D].double() - (m64 + s64 * eps[:D].double())).abs().max().item() <= 1e-6
+    for sl in (slice(0, 1 << 20), slice(D - 1003, D)):
+        ref = O.gauss_sample(mean[sl].cpu(), rho[sl].cpu(), eps[sl].cpu())
+        assert (w1[sl].cpu() - ref).abs().max().item() <= 1e-6
     assert abs(eps[:D].mean().item()) < 1e-3 and abs(eps[:D].var().item() - 1) < 1e-3
     # iVON update vs the fp64 closed form (ivorn.py:79-89)
     prec = torch.full((LD,), 100.0 / 129809.0, device=DEV)

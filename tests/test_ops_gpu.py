@@ -510,6 +510,28 @@ def test_gauss_kl_large_and_l2(ops):
     np.testing.assert_allclose(g[:n].cpu().numpy(), (0.5 * 0.3 * mean).numpy(), rtol=1e-6, atol=1e-12)
 
 
+def test_mixture_prior_kernel(ops):
+    """bde_mixture_nll against autograd of the reference expression (bbb.py:31-37) evaluated by the oracle: value
+    and gradient, both clamp regimes (|x| small: density clamped at 0 from above; |x| large: clamped at -23)."""
+    torch.manual_seed(12)
+    ws = ops.reduce_ws(DEV)
+    for (pi, s1, s2), n in [((0.5, 1.0, 0.05), 100003), ((0.25, 2.0, 0.002), 4099), ((0.9, 0.5, 0.5), 17)]:
+        x = torch.cat([torch.randn(n // 2) * 0.1, torch.randn(n - n // 2) * 3.0])
+        x[:5] = torch.tensor([0.0, 1e-4, -7.0, 30.0, -0.3])
+        want = O.mixture_nll(x.double(), pi, s1, s2).item()
+        want32 = O.mixture_nll(x, pi, s1, s2).item()
+        g32 = O.mixture_nll_grad(x, pi, s1, s2)
+        xb = padded(x)
+        val, gm = torch.zeros(1, device=DEV), torch.zeros_like(xb)
+        ops.mixture_nll(xb, pi, s1, s2, n, ws, val_out=val, gmean=gm, grad_scale=0.5)
+        assert abs(val.item() - want) <= max(2 * abs(want32 - want), 3e-6 * abs(want)), (pi, s1, s2)
+        scale = g32.abs().max().item()
+        assert (gm[:n].cpu() - 0.5 * g32).abs().max().item() <= 3e-6 * scale, (pi, s1, s2)
+        gm2 = gm.clone()
+        ops.mixture_nll(xb, pi, s1, s2, n, ws, gmean=gm2, grad_scale=0.5, accumulate=True)
+        assert torch.allclose(gm2[:n], 2 * gm[:n], rtol=1e-6, atol=1e-7 * scale)
+
+
 def test_gauss_draw_philox(ops):
     n = 100003
     mean, rho = torch.randn(n) * 0.1, torch.randn(n) - 3
