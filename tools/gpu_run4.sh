@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r2e; mkdir -p $O
+O=gpurun_out/r2f; mkdir -p $O
 export PYTHONDONTWRITEBYTECODE=1
 timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_dist_gpu.py > $O/pytest_main.log 2>&1; echo "pytest_main rc=$?"
 for v in timing base gnt grev gntrev base gnt; do timeout 300 tools/bin/kexp6_$v; done > $O/kexp6.log 2>&1; echo "kexp6 rc=$?"
