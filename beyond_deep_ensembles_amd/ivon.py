@@ -6,9 +6,10 @@ sample_parameters / get_base_optimizer behaviour and per-parameter state keys
 into flat per-group buffers).  What changes: the weight-noise draw
 (ivorn.py:102-115, ~6 ATen launches per tensor per MC sample) is one kernel,
 the update block (ivorn.py:76-89, ~14 launches per tensor) is one fused kernel
-(32 B/param), and the MC gradients accumulate in place in the flat gradient
-buffer (``param.grad`` is a view of it and is simply not zeroed between MC
-samples), which replaces ``_store_gradients`` (ivorn.py:120-127).
+(32 B/param), and the MC gradients are summed into the flat gradient buffer with
+one multi-tensor op per MC sample (``param.grad`` is cleared before every
+backward pass so autograd hands over fresh tensors), which replaces
+``_store_gradients`` (ivorn.py:120-127).
 
 Noise: ``rng="torch"`` (default) draws one ``normal_like`` per tensor in
 parameter order, i.e. consumes the reference's random stream;
@@ -158,8 +159,7 @@ class iVONOptimizer(BayesianOptimizer):
                                       deterministic=bool(group["deterministic"]))
                 fg.have_delta = True
                 self._draw_counter += 1
-                for p, v in zip(fg.params, fg.theta_views):
-                    p.data = v
+                repoint(fg.params, fg.theta_views, None)
 
     def get_base_optimizer(self):
         return self

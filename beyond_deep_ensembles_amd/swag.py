@@ -29,7 +29,7 @@ from typing import Callable, List, Optional, Tuple
 
 import torch
 
-from .algo import BayesianOptimizer, FlatLayout, check_params, _default_ops
+from .algo import BayesianOptimizer, FlatLayout, check_params, repoint, _default_ops
 
 
 class SwagOptimizer(BayesianOptimizer):
@@ -130,8 +130,7 @@ class SwagOptimizer(BayesianOptimizer):
         self.state["__params_dirty"] = True
         if self._prefetched is not None:
             rows, nxt = self._prefetched
-            for param, view in zip(self._plist, self._layout.views(rows[nxt])):
-                param.data = view
+            repoint(self._plist, self._layout.views(rows[nxt]), None)
             self._sample_counter += 1
             self._prefetched = [rows, nxt + 1] if nxt + 1 < rows.shape[0] else None
             return
@@ -152,8 +151,7 @@ class SwagOptimizer(BayesianOptimizer):
                                   seed=self.seed, stream_id=self._sample_counter)
         self._sample_counter += 1
         # vector_to_parameters (swag.py:58): the parameters become views of the sampled vector
-        for param, view in zip(self._plist, self._sample_views):
-            param.data = view
+        repoint(self._plist, self._sample_views, None)
 
     def complete_epoch(self):
         self.state["__epoch"] += 1
@@ -172,8 +170,7 @@ class SwagOptimizer(BayesianOptimizer):
 
     def _restore_original_params(self):
         if self.state["__params_dirty"]:
-            for param, view in zip(self._plist, self._theta_views):
-                param.data = view                      # swag.py:81 clones; here the weights were never overwritten
+            repoint(self._plist, self._theta_views, None)    # swag.py:81 clones; here the weights were never overwritten
             self.state["__params_dirty"] = False
 
     def _save_original_params(self):
