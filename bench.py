@@ -239,6 +239,77 @@ def shell_step_ms(dev, steps=10):
                     "of the shell + kernels + fused SGD for 8 particles x 161 tensors"}
 
 
+def config_extras(dev):
+    """The other BASELINE.json configs through the PRODUCT shells (null closures: what is timed is the optimizer's
+    own work -- kernels + host logic -- per step / per posterior sample):
+      configs[1]  CIFAR ResNet-20 SVGD, 8 particles: SVGDOptimizer.step, SGD-nesterov base (cifar.yaml), unfused and fused;
+      configs[2]  CIFAR ResNet-20 SWAG, K = 20, 30 posterior samples: DeepEnsemble.predict through the batched sampler;
+      configs[4]  Camelyon DenseNet-121 MultiSWAG, 5 modes x 30 samples: DeepEnsemble.predict, this GPU's share at N = 1."""
+    import beyond_deep_ensembles_amd as bde
+    out = {}
+    zero = torch.zeros((), device=dev)
+
+    def tensors(d, n):
+        sizes = [d // n] * (n - 1)
+        sizes.append(d - sum(sizes))
+        return [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in sizes]
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    # ---- configs[1]: 65 tensors like the swish/FRN ResNet-20
+    for fuse in (False, True):
+        params = tensors(D_RESNET20, 65)
+        base = torch.optim.SGD(params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=3e-4)
+
+        def reset():
+            with torch.no_grad():
+                params[-1].normal_(0, 0.05)
+        opt = bde.SVGDOptimizer(params, reset, base, particle_count=M, dataset_size=50000.0, l2_reg=3e-4,
+                                fuse_base_optimizer=fuse)
+        t = timed(lambda: opt.step(lambda: zero, lambda loss: None), 30)
+        out["svgd_step_cifar_resnet20_shell_" + ("fused" if fuse else "unfused")] = {
+            "ms": round(t * 1e3, 4), "steps_per_s": round(1.0 / t, 1), "tensors": 65, "particles": M,
+            "what": "SVGDOptimizer.step, null closures: single-launch update" + (" incl. 8 SGD applications" if fuse else
+                                                                                " + 8 x torch SGD.step")}
+        del opt, params, base
+
+    # ---- SWAG members with all K columns filled
+    def swag_member(d, n_tensors, seed):
+        params = tensors(d, n_tensors)
+        opt = bde.SwagOptimizer(params, torch.optim.SGD(params, lr=1e-3), update_interval=1, deviation_samples=K_SWAG,
+                                rng="philox", seed=seed)
+        with torch.no_grad():
+            for _ in range(K_SWAG + 2):
+                opt._theta[:d] += torch.randn(d, device=dev) * 1e-3
+                opt._swag_update()
+        model = torch.nn.Module()
+        model.p = torch.nn.ParameterList(params)
+        return model, opt
+
+    ens = bde.DeepEnsemble([swag_member(D_RESNET20, 65, 1)])
+    t = timed(lambda: ens.predict(lambda m: zero, S_SWAG), 20)
+    out["swag_predict_30_samples_cifar_resnet20"] = {"ms": round(t * 1e3, 4), "samples_per_s": round(S_SWAG / t, 1),
+                                                     "K": K_SWAG, "what": "DeepEnsemble.predict(30): one batched MFMA "
+                                                     "sampling pass + 30 x re-pointing 65 tensors, null predict closure"}
+    del ens
+    ens = bde.DeepEnsemble([swag_member(D_DENSENET, 364, 10 + i) for i in range(5)])
+    t = timed(lambda: ens.predict(lambda m: zero, 5 * S_SWAG), 5)
+    out["multiswag_predict_5x30_camelyon_densenet121"] = {
+        "ms": round(t * 1e3, 3), "samples_per_s": round(5 * S_SWAG / t, 1), "members": 5, "K": K_SWAG, "D": D_DENSENET,
+        "what": "DeepEnsemble.predict(150) over 5 SWAG members (364 tensors each): 5 batched sampling passes + 150 x "
+                "re-pointing, null predict closure; with N GPUs each rank does 1/N of the units (predict_distributed)"}
+    del ens
+    torch.cuda.empty_cache()
+    return out
+
+
 def timed_blocks(step, steps, blocks, dist, dev):
     """`blocks` blocks of exactly `steps` steps, each bracketed by barrier + synchronize; MAX over ranks per block."""
     out = []
@@ -514,6 +585,12 @@ def main():
                     log(f"  svgd_shell_step_ms {res['extra']['svgd_shell_step_ms']}")
                 except Exception as e:
                     log(f"  svgd_shell_step_ms skipped: {e}")
+                try:
+                    res["extra"]["other_baseline_configs"] = config_extras(dev)
+                    for k, v in res["extra"]["other_baseline_configs"].items():
+                        log(f"  {k}: {v['ms']} ms")
+                except Exception as e:
+                    log(f"  other_baseline_configs skipped: {type(e).__name__}: {e}")
         print(json.dumps(res), flush=True)
     if dist:
         dist.barrier()
