@@ -42,10 +42,25 @@ class FlatLayout:
         self.d = off
         # >= ROW_HEADER spare floats per row, rows 256-byte aligned
         self.ld = pad4(self.d + ROW_HEADER)
+        from . import _host
+        native = _host.load()
+        self._native = native.Layout(self.offsets, self.numels, [list(s) for s in self.shapes]) \
+            if native is not None and hasattr(native, "Layout") else None
 
     def views(self, row: torch.Tensor) -> List[torch.Tensor]:
         """Per-parameter views into a flat row (no copies)."""
+        if self._native is not None:
+            return self._native.views(row)
         return [row[o:o + n].view(s) for o, n, s in zip(self.offsets, self.numels, self.shapes)]
+
+    def point_data(self, params: Sequence[torch.nn.Parameter], row: torch.Tensor) -> None:
+        """``param.data = its view of row`` for every parameter: ``vector_to_parameters`` without the copy
+        (``swag.py:58``), one call for the whole list."""
+        if self._native is not None:
+            self._native.point_data(params, row)
+            return
+        for p, v in zip(params, self.views(row)):
+            p.data = v
 
 
 def check_params(params: Sequence[torch.Tensor], ops) -> None:

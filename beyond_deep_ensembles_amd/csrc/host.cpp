@@ -69,9 +69,43 @@ void clear_grads(const std::vector<at::Tensor>& params) {
   }
 }
 
+// Offsets / shapes of a list of parameters inside one flat row (algo.FlatLayout): per-parameter views of a row, and
+// "point the parameters at this row" (vector_to_parameters without the copy, swag.py:58), as single calls.
+class Layout {
+ public:
+  Layout(std::vector<int64_t> offsets, std::vector<int64_t> numels, std::vector<std::vector<int64_t>> shapes)
+      : offsets_(std::move(offsets)), numels_(std::move(numels)), shapes_(std::move(shapes)) {
+    TORCH_CHECK(offsets_.size() == numels_.size() && numels_.size() == shapes_.size(), "Layout: ragged description");
+  }
+
+  std::vector<at::Tensor> views(const at::Tensor& row) const {
+    std::vector<at::Tensor> out;
+    out.reserve(offsets_.size());
+    for (size_t i = 0; i < offsets_.size(); ++i) out.push_back(row.narrow(0, offsets_[i], numels_[i]).view(shapes_[i]));
+    return out;
+  }
+
+  void point_data(const std::vector<at::Tensor>& params, const at::Tensor& row) const {
+    TORCH_CHECK(params.size() == offsets_.size(), "Layout.point_data: ", offsets_.size(), " tensors in the layout but ",
+                params.size(), " parameters");
+    for (size_t i = 0; i < offsets_.size(); ++i) {
+      at::Tensor p = params[i];
+      p.set_data(row.narrow(0, offsets_[i], numels_[i]).view(shapes_[i]));
+    }
+  }
+
+ private:
+  std::vector<int64_t> offsets_, numels_;
+  std::vector<std::vector<int64_t>> shapes_;
+};
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  py::class_<Layout>(m, "Layout")
+      .def(py::init<std::vector<int64_t>, std::vector<int64_t>, std::vector<std::vector<int64_t>>>())
+      .def("views", &Layout::views, "per-parameter views of a flat row")
+      .def("point_data", &Layout::point_data, "param.data = its view of the row, for every parameter");
   m.def("repoint", &repoint, "param.data / param.grad = views, for whole parameter lists", py::arg("params"),
         py::arg("datas"), py::arg("grads"));
   m.def("clear_grads", &clear_grads, "param.grad = None for a whole parameter list");

@@ -56,6 +56,7 @@ class SwagOptimizer(BayesianOptimizer):
         self.noise_source: Optional[Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]]] = None
         self._sample_counter = 0
         self._prefetched = None          # (rows [n, ld], next row): samples generated ahead by prefetch_samples()
+        self._points_at = "theta"        # which buffer the parameters currently view: "theta" | "sample" | "row"
 
         plist = list(self._params())
         check_params(plist, self._ops)
@@ -63,6 +64,8 @@ class SwagOptimizer(BayesianOptimizer):
         self._layout = FlatLayout(plist)
         dev = self._params_device()
         d, ld, k = self._layout.d, self._layout.ld, deviation_samples
+        # serving a prefetched sample: re-point n_tensors views (~1 us of host time each) or copy the row (8 D bytes)
+        self._copy_is_cheaper = len(plist) * 1e-6 > 8.0 * d / 5e12
 
         # flat training weights; the parameters become views of it
         self._theta = torch.zeros(ld, dtype=torch.float32, device=dev)
@@ -130,7 +133,15 @@ class SwagOptimizer(BayesianOptimizer):
         self.state["__params_dirty"] = True
         if self._prefetched is not None:
             rows, nxt = self._prefetched
-            repoint(self._plist, self._layout.views(rows[nxt]), None)
+            if self._copy_is_cheaper:
+                # many tensors: one device copy of the row into the sample vector the parameters already view
+                # (8 D bytes of HBM traffic) beats re-pointing every tensor (~1 us of host time each)
+                with torch.no_grad():
+                    self._sample.copy_(rows[nxt])
+                self._point_at_sample_vector()
+            else:
+                self._layout.point_data(self._plist, rows[nxt])
+                self._points_at = "row"
             self._sample_counter += 1
             self._prefetched = [rows, nxt + 1] if nxt + 1 < rows.shape[0] else None
             return
@@ -151,7 +162,12 @@ class SwagOptimizer(BayesianOptimizer):
                                   seed=self.seed, stream_id=self._sample_counter)
         self._sample_counter += 1
         # vector_to_parameters (swag.py:58): the parameters become views of the sampled vector
-        repoint(self._plist, self._sample_views, None)
+        self._point_at_sample_vector()
+
+    def _point_at_sample_vector(self):
+        if self._points_at != "sample":         # consecutive samples land in the same vector: nothing to re-point
+            repoint(self._plist, self._sample_views, None)
+            self._points_at = "sample"
 
     def complete_epoch(self):
         self.state["__epoch"] += 1
@@ -171,6 +187,7 @@ class SwagOptimizer(BayesianOptimizer):
     def _restore_original_params(self):
         if self.state["__params_dirty"]:
             repoint(self._plist, self._theta_views, None)    # swag.py:81 clones; here the weights were never overwritten
+            self._points_at = "theta"
             self.state["__params_dirty"] = False
 
     def _save_original_params(self):
@@ -227,8 +244,8 @@ class SwagOptimizer(BayesianOptimizer):
     def use_sample(self, flat_sample: torch.Tensor) -> None:
         """Point the parameters at a row of ``sample_batch`` (no copy)."""
         self.state["__params_dirty"] = True
-        for param, view in zip(self._plist, self._layout.views(flat_sample)):
-            param.data = view
+        self._layout.point_data(self._plist, flat_sample)
+        self._points_at = "row"
 
     # ---- checkpoints in the reference's wire layout ---------------------
     def state_dict(self):
@@ -270,3 +287,4 @@ class SwagOptimizer(BayesianOptimizer):
             param.data = view
             self.state[param]["original_param"] = view
         self.state["__params_dirty"] = False
+        self._points_at = "theta"

@@ -180,6 +180,22 @@ def test_svgd_single_launch_path(ops):
     # the target word
     words = ws[:384].view(torch.int32).cpu()
     assert int(words[32:32 + 32 * 8:32].sum()) == int(words[32 + 32 * 8]) and int(words[32 + 32 * 8]) > 0           # all hand-off words are back to zero
+    # the in-kernel hand-off under UNEVEN load: another stream keeps the CUs busy with unrelated streaming work while
+    # the single-launch kernel runs 100 times; every result must equal the quiet-machine result bit for bit
+    hog_stream, hog = torch.cuda.Stream(), torch.empty(64 << 20, device=DEV)
+    outs = [torch.empty_like(G0) for _ in range(4)]
+    torch.cuda.synchronize()
+    for it in range(100):
+        with torch.cuda.stream(hog_stream):
+            hog.add_(1.0)
+            if it % 3 == 0:
+                hog[: (1 << 20) * (1 + it % 7)].mul_(0.5)
+        ops.svgd_step_small(Pb, G0, outs[it % 4], d, 3e-4, 1.0, 50000.0, -1.0, ws, ks)
+        if it % 4 == 3:
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o[:, :d], ref[:, :d]), it
+    torch.cuda.synchronize()
     # rbf mode (grad_kernel) through the same launch
     out = torch.zeros_like(Pb)
     ops.svgd_step_small(Pb, None, out, d, 0.0, 1.0, 1.0, 1.0, ws, ks, mode=1)
