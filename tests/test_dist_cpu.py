@@ -22,10 +22,11 @@ def _free_port():
     return port
 
 
-def _make(seed, m, ops, pg=None, fuse=False, base="sgd", **kw):
+def _make(seed, m, ops, pg=None, fuse=False, base="sgd", tiny=False, **kw):
     import beyond_deep_ensembles_amd as bde
     torch.manual_seed(seed)
-    model = nn.Sequential(nn.Linear(13, 20), nn.Tanh(), nn.Linear(20, 1))
+    # tiny: 14 parameters -> with two ranks the second rank's column slice holds no parameter at all
+    model = nn.Sequential(nn.Linear(13, 1)) if tiny else nn.Sequential(nn.Linear(13, 20), nn.Tanh(), nn.Linear(20, 1))
     if base == "sgd":
         base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
     else:
@@ -72,8 +73,9 @@ def _svgd_worker(rank, world, port, m, fuse, kw, out_dir):
     (4, False, {}), (2, True, {}),
     (4, False, {"exchange_chunks": 3}), (4, True, {"exchange_chunks": 2}), (2, True, {"exchange_chunks": 4, "base": "adam"}),
     (4, True, {"exchange": "alltoall"}), (2, True, {"exchange": "alltoall"}), (4, True, {"exchange": "alltoall", "base": "adam"}),
+    (2, True, {"exchange": "alltoall", "tiny": True}), (4, False, {"exchange_chunks": 7, "tiny": True}),
 ], ids=["allgather", "allgather_fused", "pipelined", "pipelined_fused", "pipelined_fused_adam", "alltoall_2per",
-        "alltoall_1per", "alltoall_adam"])
+        "alltoall_1per", "alltoall_adam", "alltoall_empty_slice", "pipelined_more_chunks_than_columns"])
 def test_svgd_sharded_equals_single_process(tmp_path, m, fuse, kw):
     """One exchange of gradient rows (all-gather, chunk-pipelined all-gather, or the dimension-sharded all-to-all
     pair) + the deterministic update reproduces the single-process trajectory, with identical particles on all ranks."""
@@ -89,7 +91,7 @@ def test_svgd_sharded_equals_single_process(tmp_path, m, fuse, kw):
     assert int(r0["fwd"]) == 3 * m // world and int(r1["fwd"]) == 3 * m // world
     # single-process run from rank 0's initial state
     torch.set_num_threads(1)
-    model, opt = _make(100, m, OracleOps(), fuse=fuse, base=kw.get("base", "sgd"))
+    model, opt = _make(100, m, OracleOps(), fuse=fuse, base=kw.get("base", "sgd"), tiny=kw.get("tiny", False))
     losses = _run_steps(model, opt)
     np.testing.assert_allclose(r0["particles"], opt.particles.numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=1e-6)
