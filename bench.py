@@ -297,14 +297,16 @@ def config_extras(dev):
     t = timed(lambda: ens.predict(lambda m: zero, S_SWAG), 20)
     out["swag_predict_30_samples_cifar_resnet20"] = {"ms": round(t * 1e3, 4), "samples_per_s": round(S_SWAG / t, 1),
                                                      "K": K_SWAG, "what": "DeepEnsemble.predict(30): one batched MFMA "
-                                                     "sampling pass + 30 x re-pointing 65 tensors, null predict closure"}
+                                                     "sampling pass, each sample served by one device copy into the vector "
+                                                     "the 65 parameters view; null predict closure"}
     del ens
     ens = bde.DeepEnsemble([swag_member(D_DENSENET, 364, 10 + i) for i in range(5)])
     t = timed(lambda: ens.predict(lambda m: zero, 5 * S_SWAG), 5)
     out["multiswag_predict_5x30_camelyon_densenet121"] = {
         "ms": round(t * 1e3, 3), "samples_per_s": round(5 * S_SWAG / t, 1), "members": 5, "K": K_SWAG, "D": D_DENSENET,
-        "what": "DeepEnsemble.predict(150) over 5 SWAG members (364 tensors each): 5 batched sampling passes + 150 x "
-                "re-pointing, null predict closure; with N GPUs each rank does 1/N of the units (predict_distributed)"}
+        "what": "DeepEnsemble.predict(150) over 5 SWAG members (364 tensors each): 5 batched sampling passes, each sample "
+                "served by one device copy; null predict closure; with N GPUs each rank does 1/N of the units "
+                "(predict_distributed)"}
     del ens
     torch.cuda.empty_cache()
     return out
