@@ -160,3 +160,77 @@ def test_ensemble_predict_matches_imported_reference(ref):
         ra = ref["ens"].DeepEnsemble(a).predict(lambda m: torch.zeros(2), samples)
         rb = bde.DeepEnsemble(b).predict(lambda m: torch.zeros(2), samples)
         assert ra.shape == rb.shape and [o.n for _, o in a] == [o.n for _, o in b]
+
+
+@pytest.mark.parametrize("seed,prior_kind,mc,l2_scale,base_kind,freeze", [
+    (1, "gauss", 1, 0.0, "sgd", False), (2, "gauss", 3, 0.3, "adam", False), (3, "mixture", 2, 0.1, "sgd", False),
+    (4, "mixture", 1, 0.0, "adam", True), (5, "gauss", 2, 1.0, "sgd_wd", True)])
+def test_bbb_matches_imported_reference(ref, seed, prior_kind, mc, l2_scale, base_kind, freeze):
+    """BBBOptimizer (shell + checker kernels) next to the reference's BBBOptimizer over weight-sampling layers built on
+    each side's GaussianParameter, same replayed noise: 4 steps, losses and every parameter.  Covers the Gaussian
+    prior (fused KL), the MixturePrior (fused mixture term), plain parameters with l2_scale, frozen parameters and
+    optimizer-level zero_grad semantics (bbb.py:59-89)."""
+    import beyond_deep_ensembles_amd as bde
+    from beyond_deep_ensembles_amd.bbb import MixturePrior
+    from tests.oracle_ops import OracleOps
+    ops = OracleOps()
+    g = torch.Generator().manual_seed(1000 + seed)
+    tape = [torch.randn(s, generator=g) for _ in range(4 * mc) for s in ((7, 6), (7,), (2, 7), (2,))]
+    x, y = torch.randn(40, 6, generator=g), torch.randn(40, 2, generator=g)
+
+    def build(side):
+        noise = [t.clone() for t in tape]
+        GP = ref["util"].GaussianParameter if side == "ref" else (lambda size: bde.GaussianParameter(size, _ops=ops))
+
+        class Lin(nn.Module):
+            def __init__(self, i, o):
+                super().__init__()
+                self.weight, self.bias = GP((o, i)), GP((o,))
+
+            def forward(self, inp):
+                return F.linear(inp, self.weight.sample(), self.bias.sample())
+        torch.manual_seed(seed)
+        model = nn.Sequential(Lin(6, 7), nn.Tanh(), Lin(7, 2))
+        with torch.no_grad():
+            for p in model.parameters():
+                p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(seed * 7 + p.numel())) * 0.3
+                        - (2.0 if getattr(p, "_is_gaussian_rho", False) else 0.0))
+        extra = nn.Parameter(torch.full((3,), 0.2))
+        if freeze:
+            model[0].weight.mean.requires_grad_(False)
+            model[2].bias.rho.requires_grad_(False)
+            extra.requires_grad_(False)
+        params = list(model.parameters()) + [extra]
+        base = {"sgd": lambda: torch.optim.SGD(params, lr=0.05, momentum=0.9),
+                "sgd_wd": lambda: torch.optim.SGD(params, lr=0.05, momentum=0.9, weight_decay=0.05),
+                "adam": lambda: torch.optim.Adam(params, lr=0.01)}[base_kind]()
+        if side == "ref":
+            prior = ref["bbb"].GaussianPrior(0.1, 0.7) if prior_kind == "gauss" else ref["bbb"].MixturePrior(0.3, 1.0, 0.02)
+            ref["util"].normal_like = lambda t: noise.pop(0)
+            opt = ref["bbb"].BBBOptimizer(params, base, prior, dataset_size=40, mc_samples=mc, kl_rescaling=0.7,
+                                          l2_scale=l2_scale)
+        else:
+            prior = bde.GaussianPrior(0.1, 0.7) if prior_kind == "gauss" else MixturePrior(0.3, 1.0, 0.02)
+            for mod in model.modules():
+                if isinstance(mod, bde.GaussianParameter):
+                    mod.noise_source = lambda rho: noise.pop(0)
+            opt = bde.BBBOptimizer(params, base, prior, dataset_size=40, mc_samples=mc, kl_rescaling=0.7,
+                                   l2_scale=l2_scale, _ops=ops)
+        return model, extra, params, opt
+
+    old = ref["util"].normal_like
+    try:
+        m_r, e_r, p_r, o_r = build("ref")
+        losses_r, traj_r = [], []
+        for t in range(4):
+            xb, yb = x[t * 10:(t + 1) * 10], y[t * 10:(t + 1) * 10]
+            losses_r.append(float(o_r.step(lambda: F.mse_loss(m_r(xb), yb) + e_r.sum() * 0.01, lambda l: l.backward()).detach()))
+            traj_r.append(flat(p_r))
+    finally:
+        ref["util"].normal_like = old
+    m_o, e_o, p_o, o_o = build("ours")
+    for t in range(4):
+        xb, yb = x[t * 10:(t + 1) * 10], y[t * 10:(t + 1) * 10]
+        loss = float(o_o.step(lambda: F.mse_loss(m_o(xb), yb) + e_o.sum() * 0.01, lambda l: l.backward()).detach())
+        assert abs(loss - losses_r[t]) <= 2e-5 * abs(losses_r[t]), (t, loss, losses_r[t])
+        np.testing.assert_allclose(flat(p_o).numpy(), traj_r[t].numpy(), rtol=2e-4, atol=2e-5)
