@@ -304,6 +304,29 @@ def config_extras(dev):
                                                                                 " + 8 x torch SGD.step")}
         del opt, params, base
 
+    # ---- the BBB layer forward of the iWildCam head (2048 -> 182) at batch 16: fused op vs the reference's op sequence
+    import torch.nn.functional as F
+    prior = bde.GaussianPrior(0, 1.0)
+    for name, (bsz, fi, fo) in {"iwildcam_head_b16": (16, 2048, 182), "uci_mlp_layer_b32": (32, 13, 50),
+                                "mlp_4096x4096_b64": (64, 4096, 4096)}.items():
+        layer = bde.BBBLinear(fi, fo, prior, prior, rng="philox").to(dev)
+        xin = torch.randn(bsz, fi, device=dev)
+
+        def torch_sequence():                                   # bbb_layers.py:70-80 as ATen ops
+            w, b = layer.weight, layer.bias
+            mean = F.linear(xin, w.mean, b.mean)
+            var = F.linear((xin ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), (b.std ** 2).clamp(min=1e-4))
+            return mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)
+        with torch.no_grad():
+            t_f = time_loop(lambda: layer(xin), 50)
+            t_t = time_loop(torch_sequence, 50)
+        out["bbb_linear_forward_" + name] = {"ms": round(t_f * 1e3, 4), "torch_sequence_ms": round(t_t * 1e3, 4),
+                                             "speedup": round(t_t / t_f, 2), "B": bsz, "I": fi, "O": fo,
+                                             "weights_GBps": round(8.0 * fi * fo / t_f / 1e9, 1),
+                                             "what": "BBBLinear.forward (training mode, in-kernel noise): bde_lrt_linear_fwd "
+                                                     "vs the reference's ~14 ATen launches"}
+        del layer
+
     # ---- SWAG members with all K columns filled
     def swag_member(d, n_tensors, seed):
         params = tensors(d, n_tensors)

@@ -7,8 +7,11 @@ Same constructor arguments, attributes (``weight`` / ``bias`` GaussianParameters
 ``sampling="activations"`` mode: the layer's pre-activations are sampled from
 ``N(x W_mu + b_mu, x^2 W_sigma^2 + b_sigma^2)`` (inputs^2 and variances clamped at 1e-4),
 with ONE noise draw shared across the batch in eval mode when ``freeze_on_eval``.
-The two GEMMs / convolutions stay stock PyTorch-ROCm (model code); what BBBOptimizer needs from
-the layer -- mean / rho parameters paired through GaussianParameter -- feeds the fused KL kernel.
+``BBBLinear`` runs its whole forward as ONE fused op for batches of up to 128 rows (``bde_lrt_linear_fwd``: the
+weights are streamed once, sigma^2 / x^2 are formed on the fly, both products run on the MFMA, the noise is applied
+in the finish pass); larger batches and ``BBBConv2d`` keep the two stock GEMMs / convolutions with the fused
+epilogue kernel.  What BBBOptimizer needs from the layer -- mean / rho parameters paired through
+GaussianParameter -- feeds the fused KL kernel.
 
 Differences from the reference, on purpose:
 * ``kl`` is evaluated lazily when read (the reference recomputes it on every forward although
@@ -52,6 +55,53 @@ class _LocalReparam(torch.autograd.Function):
         return grad_out, gvar.view(shape), None, None, None, None
 
 
+class _LrtLinear(torch.autograd.Function):
+    """The whole forward of a mean-field linear layer in local-reparameterisation form (bbb_layers.py:61-80) as ONE
+    fused op (bde_lrt_linear_fwd: the weights are streamed once, sigma^2 and x^2 formed on the fly, both products on
+    the MFMA); the backward restates the autograd graph of those lines with PyTorch ops from the saved variance and
+    noise."""
+
+    @staticmethod
+    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops):
+        x2d = x.reshape(-1, x.shape[-1])
+        if x2d.stride(-1) != 1:
+            x2d = x2d.contiguous()
+        b, o = x2d.shape[0], w_mu.shape[0]
+        out = torch.empty((b, o), dtype=torch.float32, device=x.device)
+        var = torch.empty_like(out)
+        e = None if eps is None else eps.reshape(b, o).contiguous()
+        ops.lrt_linear_fwd(x2d.detach(), w_mu.detach().contiguous(), w_rho.detach().contiguous(),
+                           None if b_mu is None else b_mu.detach(), None if b_rho is None else b_rho.detach(),
+                           clamp_bias, out, var, eps=e, seed=seed, stream_id=stream_id)
+        ctx.save_for_backward(x2d, w_mu, w_rho, b_rho, var, e)
+        ctx.meta = (clamp_bias, seed, stream_id, ops, x.shape)
+        return out.view(x.shape[:-1] + (o,))
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w_mu, w_rho, b_rho, var, eps = ctx.saved_tensors
+        clamp_bias, seed, stream_id, ops, x_shape = ctx.meta
+        g = grad_out.reshape(var.shape)
+        if eps is None:                                   # regenerate the in-kernel noise (same element indexing)
+            eps = torch.empty_like(var)
+            ops.philox_normal(seed, stream_id, eps_d=eps.view(-1), d=eps.numel())
+        gvar = g * eps / (2 * torch.sqrt(var))            # d out / d activation_var
+        sig = F.softplus(w_rho)
+        s2 = sig * sig
+        x2 = x * x
+        g_x = g @ w_mu + (gvar @ s2.clamp(min=_CLAMP)) * (2 * x) * (x2 >= _CLAMP)
+        g_wmu = g.t() @ x
+        g_wrho = (gvar.t() @ x2.clamp(min=_CLAMP)) * (s2 >= _CLAMP) * (2 * sig * torch.sigmoid(w_rho))
+        g_bmu = g_brho = None
+        if b_rho is not None:
+            g_bmu = g.sum(0)
+            sb = F.softplus(b_rho)
+            g_brho = gvar.sum(0) * (2 * sb * torch.sigmoid(b_rho))
+            if clamp_bias:
+                g_brho = g_brho * (sb * sb >= _CLAMP)
+        return g_x.view(x_shape), g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None
+
+
 class _LocalReparamLayer(nn.Module):
     """Shared machinery: Gaussian weight/bias, noise policy, lazy KL."""
 
@@ -62,6 +112,7 @@ class _LocalReparamLayer(nn.Module):
         self.kl_on_eval = kwargs.get("kl_on_eval", False)
         self.use_bias = kwargs.get("bias", True)
         self.fused_epilogue = kwargs.get("fused_epilogue", True)     # one HIP pass for mean + sqrt(var) * eps
+        self.fused_linear = kwargs.get("fused_linear", True)         # BBBLinear: the whole forward as one fused op
         self.weight_prior, self.bias_prior = weight_prior, bias_prior
         gp_kwargs = {k: kwargs[k] for k in ("rng", "seed", "_ops") if k in kwargs}
         self.weight = GaussianParameter(weight_shape, **gp_kwargs)
@@ -110,6 +161,17 @@ class BBBLinear(_LocalReparamLayer):
     def forward(self, input: torch.Tensor):
         if self.sampling == "activations":
             w, b = self.weight, (self.bias if self.use_bias else None)
+            frozen = not self.training and self.freeze_on_eval       # eval: ONE noise draw shared by the batch
+            rows = input.numel() // max(1, input.shape[-1])
+            if self.fused_linear and not frozen and input.dtype == torch.float32 and input.is_cuda == w.mean.is_cuda \
+                    and w._get_ops().lrt_linear_supported(rows, self.in_features, self.out_features):
+                eps = None
+                if not (w.rng == "philox" and w.noise_source is None):
+                    eps = normal_like(input.new_empty(input.shape[:-1] + (self.out_features,)))
+                out = _LrtLinear.apply(input, w.mean, w.rho, b.mean if b is not None else None,
+                                       b.rho if b is not None else None, True, eps, w.seed, next(_philox_stream),
+                                       w._get_ops())
+                return out / self.mc_sample
             mean = F.linear(input, w.mean, b.mean if b is not None else None)
             var = F.linear((input ** 2).clamp(min=_CLAMP), (w.std ** 2).clamp(min=_CLAMP),
                            (b.std ** 2).clamp(min=_CLAMP) if b is not None else None)

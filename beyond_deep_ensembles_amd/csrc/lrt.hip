@@ -1,0 +1,187 @@
+// Local-reparameterisation forward of a mean-field linear layer, fused.
+//
+// Reference: BBBLinear.forward, sampling="activations" (src/algos/bbb_layers.py:61-80):
+//   activation_mean = x W_mu^T + b_mu
+//   activation_var  = clamp(x^2, 1e-4) clamp(softplus(W_rho)^2, 1e-4)^T + clamp(softplus(b_rho)^2, 1e-4)
+//   out             = activation_mean + sqrt(activation_var) * eps
+// i.e. ~14 ATen launches (softplus, square, clamp for W and b, square and clamp for x, two GEMMs with bias, sqrt,
+// normal_, mul, add) that write and re-read sigma^2, its clamp and x^2 -- six extra passes over the [O, I]
+// weight-shaped tensors.  For the batch sizes this path sees (tens of rows) the layer is a weight-streaming
+// problem: W_mu and W_rho should be read ONCE.  Here:
+//
+//   lrt_partial_kernel   one wave per (32-output tile, K-slice): streams its slice of W_mu / W_rho once (float4 per
+//                        lane, 32 rows x 8 columns per wave-load), forms sigma^2 on the fly (softplus from ONE
+//                        exponential, bde_common.hpp) and feeds TWO accumulator tiles on the f32 MFMA
+//                        (v_mfma_f32_32x32x2_f32): mean += x W_mu^T and var += clamp(x^2) clamp(sigma^2)^T, for up to
+//                        4 batch tiles of 32 rows held in registers; split-K partials go to a workspace
+//   lrt_finish_kernel    fixed-order sum of the K-slices (bit-reproducible, no atomics), bias terms, sqrt, noise
+//                        (caller-supplied or in-kernel Philox), writes out and the variance the backward needs
+//
+// HBM traffic 8*O*I (weights, once) + O(B*(I + O)) instead of ~32*O*I.  The backward pass stays with PyTorch
+// (bbb_layers.py's autograd graph, restated by the caller from the saved variance and noise).
+#include "bde_common.hpp"
+
+namespace bde {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kLrtKSlice = 64;        // columns of W per wave (8 k-steps of 8)
+constexpr int kLrtWavesPerWG = 4;
+constexpr float kLrtClamp = 1e-4f;    // bbb_layers.py:71-72
+
+// float4 of row `r` at columns [k, k+4); rows / columns outside the matrix read as 0.  ALIGNED: I % 4 == 0 and a
+// 16-byte aligned base, so the four columns are one load and either all valid or all invalid.
+template <bool ALIGNED>
+__device__ __forceinline__ f32x4 lrt_load4(const float* __restrict__ base, int64_t ld, int r, int rows, int k, int cols) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (r < rows) {
+    const float* p = base + static_cast<int64_t>(r) * ld + k;
+    if (ALIGNED) {
+      if (k < cols) v = ld4(p);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (k + c < cols) v[c] = p[c];
+    }
+  }
+  return v;
+}
+
+// NB = batch tiles of 32 rows handled by one wave (B <= 32 * NB).
+template <int NB, bool ALIGNED>
+__global__ __launch_bounds__(kLrtWavesPerWG * 64) void lrt_partial_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_mu, const float* __restrict__ w_rho, int B,
+    int I, int O, int n_slices, float* __restrict__ ws) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * kLrtWavesPerWG + wave;            // (o-tile, K-slice)
+  const int o_tiles = (O + 31) >> 5;
+  if (unit >= o_tiles * n_slices) return;
+  const int ot = unit / n_slices, sl = unit % n_slices;
+  const int r = lane & 31, h = lane >> 5;                         // row within the tile, k-half
+  const int k0 = sl * kLrtKSlice, k1 = min(I, k0 + kLrtKSlice);
+
+  f32x16 accm[NB], accv[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) accm[t] = accv[t] = f32x16{};
+
+  for (int k = k0 + 4 * h; k < k1 + 4 * h; k += 8) {              // both halves run the same number of steps
+    const f32x4 wm = lrt_load4<ALIGNED>(w_mu, I, ot * 32 + r, O, k, k1);
+    const f32x4 wr = lrt_load4<ALIGNED>(w_rho, I, ot * 32 + r, O, k, k1);
+    f32x4 xs[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) xs[t] = lrt_load4<ALIGNED>(x, ldx, t * 32 + r, B, k, k1);
+    f32x4 s2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float s = softplus(wr[c]);
+      s2[c] = fmaxf(s * s, kLrtClamp);                            // clamp(softplus(rho)^2, 1e-4)
+    }
+    const bool live = (ot * 32 + r < O) && (k < k1);              // padding rows / columns contribute nothing
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool ok = live && (ALIGNED || k + c < k1);
+      const float bm = ok ? wm[c] : 0.f, bv = ok ? s2[c] : 0.f;
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const float a = xs[t][c];
+        const bool xok = (t * 32 + r < B) && (k < k1) && (ALIGNED || k + c < k1);
+        const float a2 = xok ? fmaxf(a * a, kLrtClamp) : 0.f;     // clamp(x^2, 1e-4)
+        accm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bm, accm[t], 0, 0, 0);
+        accv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv, accv[t], 0, 0, 0);
+      }
+    }
+  }
+  // C[b][o]: lane holds column o = lane & 31, rows b = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int o_pad = o_tiles * 32, b_pad = NB * 32;
+  float* base = ws + static_cast<int64_t>(sl) * 2 * b_pad * o_pad;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int b = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      base[static_cast<int64_t>(b) * o_pad + ot * 32 + r] = accm[t][reg];
+      base[static_cast<int64_t>(b_pad + b) * o_pad + ot * 32 + r] = accv[t][reg];
+    }
+  }
+}
+
+template <bool RNG>
+__global__ __launch_bounds__(kBlock) void lrt_finish_kernel(const float* __restrict__ ws, int n_slices, int b_pad,
+                                                           int o_pad, const float* __restrict__ b_mu,
+                                                           const float* __restrict__ b_rho, int clamp_bias,
+                                                           const float* __restrict__ eps, uint64_t seed,
+                                                           uint64_t stream_id, float* __restrict__ out,
+                                                           float* __restrict__ var_out, int B, int O) {
+  const int64_t n = static_cast<int64_t>(B) * O;
+  const int64_t slice_stride = static_cast<int64_t>(2) * b_pad * o_pad;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(e / O), o = static_cast<int>(e % O);
+    const float* pm = ws + static_cast<int64_t>(b) * o_pad + o;
+    const float* pv = ws + static_cast<int64_t>(b_pad + b) * o_pad + o;
+    float m = 0.f, v = 0.f;
+    for (int s = 0; s < n_slices; ++s) {                          // fixed order
+      m += pm[s * slice_stride];
+      v += pv[s * slice_stride];
+    }
+    if (b_mu) m += b_mu[o];
+    if (b_rho) {
+      const float sb = softplus(b_rho[o]);
+      const float vb = sb * sb;
+      v += clamp_bias ? fmaxf(vb, kLrtClamp) : vb;                // BBBLinear clamps the bias variance, BBBConv2d does not
+    }
+    const float z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag)[e & 3] : eps[e];
+    if (var_out) var_out[e] = v;
+    out[e] = m + __builtin_sqrtf(v) * z;
+  }
+}
+
+}  // namespace bde
+
+using namespace bde;
+
+static inline int lrt_slices(int I) { return (I + kLrtKSlice - 1) / kLrtKSlice; }
+
+extern "C" int bde_lrt_linear_supported(int B, int I, int O) {
+  return B >= 1 && B <= 128 && I >= 1 && O >= 1 && static_cast<int64_t>(I) * O <= (int64_t{1} << 31);
+}
+
+extern "C" size_t bde_lrt_linear_ws_bytes(int B, int I, int O) {
+  if (!bde_lrt_linear_supported(B, I, O)) return 0;
+  const int nb = (B + 31) / 32 == 3 ? 4 : (B + 31) / 32;
+  const size_t o_pad = static_cast<size_t>((O + 31) / 32) * 32, b_pad = static_cast<size_t>(nb) * 32;
+  return sizeof(float) * static_cast<size_t>(lrt_slices(I)) * 2 * b_pad * o_pad;
+}
+
+extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* b_mu,
+                                  const float* b_rho, int clamp_bias_var, const float* eps, uint64_t seed,
+                                  uint64_t stream_id, float* out, float* var_out, int B, int I, int O, void* ws,
+                                  void* stream) {
+  if (!x || !w_mu || !w_rho || !out || !ws || !bde_lrt_linear_supported(B, I, O) || ldx < I) return BDE_ERR_INVALID;
+  if ((b_mu == nullptr) != (b_rho == nullptr)) return BDE_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int n_slices = lrt_slices(I), o_tiles = (O + 31) / 32;
+  const int nbt = (B + 31) / 32;
+  const int nb = nbt == 3 ? 4 : nbt;
+  const bool aligned = (I % 4 == 0) && (ldx % 4 == 0) && aligned16(x) && aligned16(w_mu) && aligned16(w_rho);
+  const int units = o_tiles * n_slices;
+  const int grid = (units + kLrtWavesPerWG - 1) / kLrtWavesPerWG;
+  float* wsf = static_cast<float*>(ws);
+#define BDE_LRT(NB, AL) \
+  hipLaunchKernelGGL((lrt_partial_kernel<NB, AL>), dim3(grid), dim3(kLrtWavesPerWG * 64), 0, s, x, ldx, w_mu, w_rho, B, I, O, n_slices, wsf)
+  if (nb == 1) { if (aligned) BDE_LRT(1, true); else BDE_LRT(1, false); }
+  else if (nb == 2) { if (aligned) BDE_LRT(2, true); else BDE_LRT(2, false); }
+  else { if (aligned) BDE_LRT(4, true); else BDE_LRT(4, false); }
+#undef BDE_LRT
+  int rc = to_err(hipGetLastError());
+  if (rc) return rc;
+  const int fgrid = stream_grid(static_cast<int64_t>(B) * O);
+  const int o_pad = o_tiles * 32, b_pad = nb * 32;
+  if (eps)
+    hipLaunchKernelGGL(lrt_finish_kernel<false>, dim3(fgrid), dim3(kBlock), 0, s, wsf, n_slices, b_pad, o_pad, b_mu, b_rho,
+                       clamp_bias_var, eps, seed, stream_id, out, var_out, B, O);
+  else
+    hipLaunchKernelGGL(lrt_finish_kernel<true>, dim3(fgrid), dim3(kBlock), 0, s, wsf, n_slices, b_pad, o_pad, b_mu, b_rho,
+                       clamp_bias_var, eps, seed, stream_id, out, var_out, B, O);
+  return to_err(hipGetLastError());
+}

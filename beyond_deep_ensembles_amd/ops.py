@@ -279,6 +279,25 @@ class HipOps:
         _check(self.lib.bde_local_reparam_bwd(_ptr(g), _ptr(var), _ptr(eps), seed, stream_id, _ptr(gvar), n, _stream()),
                "bde_local_reparam_bwd")
 
+    def lrt_linear_supported(self, b: int, i: int, o: int) -> bool:
+        return bool(self.lib.bde_lrt_linear_supported(b, i, o))
+
+    @_on_device_of
+    def lrt_linear_fwd(self, x, w_mu, w_rho, b_mu, b_rho, clamp_bias_var, out, var_out, eps=None, seed=0, stream_id=0):
+        """Fused local-reparameterisation forward of a mean-field linear layer (bbb_layers.py:61-80): x [B, I] (row
+        stride free), w_mu / w_rho [O, I] contiguous, out / var_out / eps [B, O] contiguous."""
+        b, i = x.shape
+        o = w_mu.shape[0]
+        if not (w_mu.is_contiguous() and w_rho.is_contiguous() and out.is_contiguous()):
+            raise BdeKernelError("w_mu, w_rho and out must be contiguous")
+        n = self.lib.bde_lrt_linear_ws_bytes(b, i, o)
+        if n == 0:
+            raise BdeKernelError(f"lrt_linear_fwd: unsupported shape B={b}, I={i}, O={o}")
+        ws = torch.empty(n // 4, dtype=torch.float32, device=x.device)
+        _check(self.lib.bde_lrt_linear_fwd(_ptr(x, "x"), x.stride(0), _ptr(w_mu), _ptr(w_rho), _ptr(b_mu), _ptr(b_rho),
+                                           int(clamp_bias_var), _ptr(eps), seed, stream_id, _ptr(out), _ptr(var_out), b, i,
+                                           o, _ptr(ws), _stream()), "bde_lrt_linear_fwd")
+
     # ------------------------------------------------------------ iVON --
     @_on_device_of
     def ivon_sample(self, mean, prec, param, delta_sum, n, n_eff, first, eps=None, seed=0, stream_id=0,

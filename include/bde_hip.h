@@ -273,6 +273,21 @@ int bde_local_reparam_fwd(const float* mean, const float* var, const float* eps,
 int bde_local_reparam_bwd(const float* g, const float* var, const float* eps, uint64_t seed,
                           uint64_t stream_id, float* gvar, int64_t n, void* stream);
 
+/* The whole local-reparameterisation forward of a mean-field LINEAR layer (bbb_layers.py:61-80, sampling =
+ * "activations") for small batches (B <= 128): W_mu / W_rho [O, I] row-major are streamed ONCE, sigma^2 =
+ * clamp(softplus(rho)^2, 1e-4) and clamp(x^2, 1e-4) are formed on the fly and both products run on the f32 MFMA
+ * (split-K partials in `ws`, fixed-order finish):
+ *   out[b, o] = (x W_mu^T + b_mu)[b, o] + sqrt((clamp(x^2) clamp(sigma_W^2)^T + var_b)[b, o]) * eps[b, o]
+ * with var_b = softplus(b_rho)^2, clamped at 1e-4 iff clamp_bias_var (BBBLinear clamps it, BBBConv2d does not).
+ * x [B, I] with row stride ldx; b_mu / b_rho both NULL for a bias-free layer; eps [B, O] or NULL (Philox: element
+ * e = b * O + o of stream stream_id, as bde_philox_normal writes it); var_out [B, O] (may be NULL) receives the
+ * activation variance the backward pass needs. */
+int bde_lrt_linear_supported(int B, int I, int O);
+size_t bde_lrt_linear_ws_bytes(int B, int I, int O);
+int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* b_mu,
+                       const float* b_rho, int clamp_bias_var, const float* eps, uint64_t seed, uint64_t stream_id,
+                       float* out, float* var_out, int B, int I, int O, void* ws, void* stream);
+
 /* ------------------------------------------------------------------ iVON --
  * src/algos/ivorn.py:102-115 (weight-noise draw) and :66-89 (update). */
 

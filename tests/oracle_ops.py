@@ -251,6 +251,25 @@ class OracleOps:
             eps = _philox(seed, stream_id, n)
         gvar[:n] = (g[:n] * eps[:n]) / (2 * torch.sqrt(var[:n]))
 
+    def lrt_linear_supported(self, b, i, o):
+        return 1 <= b <= 128
+
+    def lrt_linear_fwd(self, x, w_mu, w_rho, b_mu, b_rho, clamp_bias_var, out, var_out, eps=None, seed=0, stream_id=0):
+        # bbb_layers.py:70-80 with torch ops
+        sw = torch.nn.functional.softplus(w_rho)
+        mean = torch.nn.functional.linear(x, w_mu, b_mu)
+        vb = None
+        if b_rho is not None:
+            vb = torch.nn.functional.softplus(b_rho) ** 2
+            if clamp_bias_var:
+                vb = vb.clamp(min=1e-4)
+        var = torch.nn.functional.linear((x ** 2).clamp(min=1e-4), (sw ** 2).clamp(min=1e-4), vb)
+        if eps is None:
+            eps = _philox(seed, stream_id, mean.numel()).view(mean.shape)
+        if var_out is not None:
+            var_out.copy_(var)
+        out.copy_(mean + torch.sqrt(var) * eps)
+
     # ------------------------------------------------------------ iVON --
     def ivon_sample(self, mean, prec, param, delta_sum, n, n_eff, first, eps=None, seed=0, stream_id=0,
                     deterministic=False):

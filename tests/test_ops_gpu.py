@@ -781,3 +781,51 @@ def test_local_reparam_epilogue(ops):
         assert torch.allclose(out2, (mean + torch.sqrt(var) * e2[:n]).detach(), rtol=1e-6, atol=1e-7)
         ops.local_reparam_bwd(gout, var.detach(), gvar2, n, seed=3, stream_id=8)
         assert torch.allclose(gvar2, gout * e2[:n] / (2 * torch.sqrt(var.detach())), rtol=2e-6, atol=1e-7)
+
+
+def test_lrt_linear_forward(ops):
+    """bde_lrt_linear_fwd (the whole local-reparameterisation forward of BBBLinear, bbb_layers.py:61-80, as one
+    fused op: weights streamed once, both products on the MFMA, split-K with a fixed-order finish) against the fp64
+    evaluation of those lines; the allowance is twice the deviation of the reference's own fp32 op sequence."""
+    import torch.nn.functional as F
+    torch.manual_seed(21)
+    from oracle import philox as PH
+    for b, i, o, bias in [(16, 13, 50, True), (5, 50, 1, True), (16, 2048, 182, True), (128, 300, 70, False),
+                          (33, 64, 32, True), (1, 7, 3, True), (96, 1000, 200, True), (64, 4096, 512, False), (70, 129, 33, True)]:
+        x = torch.randn(b, i)
+        x[0, : min(i, 3)] = 0.0                                       # exercises the clamp on x^2
+        w_mu, w_rho = torch.randn(o, i) * 0.1, torch.randn(o, i) * 1.5 - 3.0
+        w_rho[0, : min(i, 4)] = -8.0                                   # ... and on sigma^2
+        b_mu, b_rho = (torch.randn(o) * 0.1, torch.randn(o) - 3.0) if bias else (None, None)
+        eps = torch.randn(b, o)
+
+        def ref(dt):
+            xx, wm, wr = x.to(dt), w_mu.to(dt), w_rho.to(dt)
+            mean = F.linear(xx, wm, None if b_mu is None else b_mu.to(dt))
+            vb = None if b_rho is None else (F.softplus(b_rho.to(dt)) ** 2).clamp(min=1e-4)
+            var = F.linear((xx ** 2).clamp(min=1e-4), (F.softplus(wr) ** 2).clamp(min=1e-4), vb)
+            return mean, var
+        m64, v64 = ref(torch.float64)
+        m32, v32 = ref(torch.float32)
+        out64 = m64 + v64.sqrt() * eps.double()
+        out32 = m32 + v32.sqrt() * eps
+        dev = lambda t: None if t is None else t.to(DEV)
+        out, var = torch.empty(b, o, device=DEV), torch.empty(b, o, device=DEV)
+        ops.lrt_linear_fwd(dev(x), dev(w_mu), dev(w_rho), dev(b_mu), dev(b_rho), True, out, var, eps=dev(eps))
+        tol_v = max(2 * (v32.double() - v64).abs().max().item(), 3e-6 * v64.abs().max().item())
+        tol_o = max(2 * (out32.double() - out64).abs().max().item(), 3e-6 * out64.abs().max().item())
+        assert (var.cpu().double() - v64).abs().max().item() <= tol_v, (b, i, o)
+        assert (out.cpu().double() - out64).abs().max().item() <= tol_o, (b, i, o)
+        # deterministic (fixed-order split-K finish), and the in-kernel noise is the Philox stream of element b*O + o
+        out2 = torch.empty_like(out)
+        ops.lrt_linear_fwd(dev(x), dev(w_mu), dev(w_rho), dev(b_mu), dev(b_rho), True, out2, None, eps=dev(eps))
+        assert torch.equal(out, out2)
+        ops.lrt_linear_fwd(dev(x), dev(w_mu), dev(w_rho), dev(b_mu), dev(b_rho), True, out2, None, seed=9, stream_id=4)
+        z = torch.from_numpy(PH.normals(9, 4, b * o)).view(b, o)
+        assert (out2.cpu().double() - (m64 + v64.sqrt() * z)).abs().max().item() <= tol_o + 5e-6 * v64.sqrt().max().item()
+        # a strided input (a column slice of a wider activation matrix)
+        wide = torch.randn(b, i + 5, device=DEV)
+        wide[:, :i] = dev(x)
+        ops.lrt_linear_fwd(wide[:, :i], dev(w_mu), dev(w_rho), dev(b_mu), dev(b_rho), True, out2, None, eps=dev(eps))
+        assert (out2 - out).abs().max().item() <= tol_o
+    assert not ops.lrt_linear_supported(129, 10, 10) and ops.lrt_linear_supported(128, 10, 10)
