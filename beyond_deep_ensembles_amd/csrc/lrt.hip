@@ -25,7 +25,8 @@ namespace bde {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kLrtKSlice = 64;        // columns of W per wave (8 k-steps of 8)
+constexpr int kLrtMinKSlice = 64;     // columns of W per wave at least (8 k-steps of 8)
+constexpr int kLrtTargetWaves = 2048; // (o-tile, K-slice) units wanted: 2 waves per SIMD on 256 CUs
 constexpr int kLrtWavesPerWG = 4;
 constexpr float kLrtClamp = 1e-4f;    // bbb_layers.py:71-72
 
@@ -51,14 +52,14 @@ __device__ __forceinline__ f32x4 lrt_load4(const float* __restrict__ base, int64
 template <int NB, bool ALIGNED>
 __global__ __launch_bounds__(kLrtWavesPerWG * 64) void lrt_partial_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_mu, const float* __restrict__ w_rho, int B,
-    int I, int O, int n_slices, float* __restrict__ ws) {
+    int I, int O, int n_slices, int kslice, float* __restrict__ ws) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int unit = blockIdx.x * kLrtWavesPerWG + wave;            // (o-tile, K-slice)
   const int o_tiles = (O + 31) >> 5;
   if (unit >= o_tiles * n_slices) return;
   const int ot = unit / n_slices, sl = unit % n_slices;
   const int r = lane & 31, h = lane >> 5;                         // row within the tile, k-half
-  const int k0 = sl * kLrtKSlice, k1 = min(I, k0 + kLrtKSlice);
+  const int k0 = sl * kslice, k1 = min(I, k0 + kslice);
 
   f32x16 accm[NB], accv[NB];
 #pragma unroll
@@ -140,7 +141,21 @@ __global__ __launch_bounds__(kBlock) void lrt_finish_kernel(const float* __restr
 
 using namespace bde;
 
-static inline int lrt_slices(int I) { return (I + kLrtKSlice - 1) / kLrtKSlice; }
+// Split of the reduction dimension: enough (o-tile, K-slice) units to fill the chip, but no more K-slices than that
+// needs (every slice costs a [2, B, O] partial in the workspace); slices are multiples of 8 columns.
+struct LrtPlan {
+  int n_slices, kslice;
+};
+static inline LrtPlan lrt_plan(int I, int O) {
+  const int o_tiles = (O + 31) / 32;
+  int want = (kLrtTargetWaves + o_tiles - 1) / o_tiles;
+  const int most = (I + kLrtMinKSlice - 1) / kLrtMinKSlice;
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  int kslice = ((I + want - 1) / want + 7) / 8 * 8;
+  if (kslice < kLrtMinKSlice) kslice = kLrtMinKSlice;
+  return LrtPlan{(I + kslice - 1) / kslice, kslice};
+}
 
 extern "C" int bde_lrt_linear_supported(int B, int I, int O) {
   return B >= 1 && B <= 128 && I >= 1 && O >= 1 && static_cast<int64_t>(I) * O <= (int64_t{1} << 31);
@@ -150,7 +165,7 @@ extern "C" size_t bde_lrt_linear_ws_bytes(int B, int I, int O) {
   if (!bde_lrt_linear_supported(B, I, O)) return 0;
   const int nb = (B + 31) / 32 == 3 ? 4 : (B + 31) / 32;
   const size_t o_pad = static_cast<size_t>((O + 31) / 32) * 32, b_pad = static_cast<size_t>(nb) * 32;
-  return sizeof(float) * static_cast<size_t>(lrt_slices(I)) * 2 * b_pad * o_pad;
+  return sizeof(float) * static_cast<size_t>(lrt_plan(I, O).n_slices) * 2 * b_pad * o_pad;
 }
 
 extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* b_mu,
@@ -160,7 +175,8 @@ extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu
   if (!x || !w_mu || !w_rho || !out || !ws || !bde_lrt_linear_supported(B, I, O) || ldx < I) return BDE_ERR_INVALID;
   if ((b_mu == nullptr) != (b_rho == nullptr)) return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int n_slices = lrt_slices(I), o_tiles = (O + 31) / 32;
+  const LrtPlan plan = lrt_plan(I, O);
+  const int n_slices = plan.n_slices, o_tiles = (O + 31) / 32;
   const int nbt = (B + 31) / 32;
   const int nb = nbt == 3 ? 4 : nbt;
   const bool aligned = (I % 4 == 0) && (ldx % 4 == 0) && aligned16(x) && aligned16(w_mu) && aligned16(w_rho);
@@ -168,7 +184,7 @@ extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu
   const int grid = (units + kLrtWavesPerWG - 1) / kLrtWavesPerWG;
   float* wsf = static_cast<float*>(ws);
 #define BDE_LRT(NB, AL) \
-  hipLaunchKernelGGL((lrt_partial_kernel<NB, AL>), dim3(grid), dim3(kLrtWavesPerWG * 64), 0, s, x, ldx, w_mu, w_rho, B, I, O, n_slices, wsf)
+  hipLaunchKernelGGL((lrt_partial_kernel<NB, AL>), dim3(grid), dim3(kLrtWavesPerWG * 64), 0, s, x, ldx, w_mu, w_rho, B, I, O, n_slices, plan.kslice, wsf)
   if (nb == 1) { if (aligned) BDE_LRT(1, true); else BDE_LRT(1, false); }
   else if (nb == 2) { if (aligned) BDE_LRT(2, true); else BDE_LRT(2, false); }
   else { if (aligned) BDE_LRT(4, true); else BDE_LRT(4, false); }
