@@ -26,7 +26,7 @@ namespace bde {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kLrtMinKSlice = 64;     // columns of W per wave at least (8 k-steps of 8)
-constexpr int kLrtTargetWaves = 2048; // (o-tile, K-slice) units wanted: 2 waves per SIMD on 256 CUs
+constexpr int kLrtTargetWaves = 4096; // (o-tile, K-slice) units wanted: 4 waves per SIMD on 256 CUs
 constexpr int kLrtWavesPerWG = 4;
 constexpr float kLrtClamp = 1e-4f;    // bbb_layers.py:71-72
 
@@ -65,32 +65,43 @@ __global__ __launch_bounds__(kLrtWavesPerWG * 64) void lrt_partial_kernel(
 #pragma unroll
   for (int t = 0; t < NB; ++t) accm[t] = accv[t] = f32x16{};
 
-  for (int k = k0 + 4 * h; k < k1 + 4 * h; k += 8) {              // both halves run the same number of steps
-    const f32x4 wm = lrt_load4<ALIGNED>(w_mu, I, ot * 32 + r, O, k, k1);
-    const f32x4 wr = lrt_load4<ALIGNED>(w_rho, I, ot * 32 + r, O, k, k1);
-    f32x4 xs[NB];
+  // register double buffering: the loads of k-step n+1 are issued before the softplus / MFMA work of step n
+  struct Operands {
+    f32x4 wm, wr, xs[NB];
+  };
+  auto load = [&](Operands& q, int k) {
+    q.wm = lrt_load4<ALIGNED>(w_mu, I, ot * 32 + r, O, k, k1);
+    q.wr = lrt_load4<ALIGNED>(w_rho, I, ot * 32 + r, O, k, k1);
 #pragma unroll
-    for (int t = 0; t < NB; ++t) xs[t] = lrt_load4<ALIGNED>(x, ldx, t * 32 + r, B, k, k1);
+    for (int t = 0; t < NB; ++t) q.xs[t] = lrt_load4<ALIGNED>(x, ldx, t * 32 + r, B, k, k1);
+  };
+  Operands cur, nxt;
+  const int kend = k1 + 4 * h;                                    // both halves run the same number of steps
+  int k = k0 + 4 * h;
+  if (k < kend) load(cur, k);
+  for (; k < kend; k += 8) {
+    if (k + 8 < kend) load(nxt, k + 8);
     f32x4 s2;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float s = softplus(wr[c]);
+      const float s = softplus(cur.wr[c]);
       s2[c] = fmaxf(s * s, kLrtClamp);                            // clamp(softplus(rho)^2, 1e-4)
     }
     const bool live = (ot * 32 + r < O) && (k < k1);              // padding rows / columns contribute nothing
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const bool ok = live && (ALIGNED || k + c < k1);
-      const float bm = ok ? wm[c] : 0.f, bv = ok ? s2[c] : 0.f;
+      const float bm = ok ? cur.wm[c] : 0.f, bv = ok ? s2[c] : 0.f;
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
-        const float a = xs[t][c];
+        const float a = cur.xs[t][c];
         const bool xok = (t * 32 + r < B) && (k < k1) && (ALIGNED || k + c < k1);
         const float a2 = xok ? fmaxf(a * a, kLrtClamp) : 0.f;     // clamp(x^2, 1e-4)
         accm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bm, accm[t], 0, 0, 0);
         accv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv, accv[t], 0, 0, 0);
       }
     }
+    cur = nxt;
   }
   // C[b][o]: lane holds column o = lane & 31, rows b = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int o_pad = o_tiles * 32, b_pad = NB * 32;
