@@ -26,7 +26,7 @@ namespace bde {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kLrtMinKSlice = 64;     // columns of W per wave at least (8 k-steps of 8)
-constexpr int kLrtTargetWaves = 4096; // (o-tile, K-slice) units wanted: 4 waves per SIMD on 256 CUs
+constexpr int kLrtTargetWaves = 2048; // (o-tile, K-slice) units wanted: 2 waves per SIMD on 256 CUs
 constexpr int kLrtWavesPerWG = 4;
 constexpr float kLrtClamp = 1e-4f;    // bbb_layers.py:71-72
 

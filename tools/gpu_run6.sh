@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r2i; mkdir -p $O
+O=gpurun_out/r2j; mkdir -p $O
 export PYTHONDONTWRITEBYTECODE=1
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 tail -12 $O/bench.err
