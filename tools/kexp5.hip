@@ -59,6 +59,43 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ in, float
   if (NW == 0 && sink[0] + sink[1] + sink[2] + sink[3] == 12345.678f) out[0] = sink[0];
 }
 
+// Layout probe: the same NR-in / NW-out shape, but the rows INTERLEAVED at `CH` floats: memory = [chunk][row][CH]
+// (what a per-tensor blocked particle layout would look like to the combine kernel) -- one contiguous region per
+// chunk instead of NR + NW streams 95 MB apart.  A thread still owns one float4 column of all rows.
+template <int NR, int NW, int CH>
+__global__ __launch_bounds__(256) void probe_blocked(const float* __restrict__ in, float* __restrict__ out, int64_t n4) {
+  constexpr int C4 = CH / 4;
+  const int64_t step = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
+    const int64_t chunk = i / C4, c = i % C4;
+    const float* src = in + chunk * (int64_t)NR * CH + 4 * c;
+    float* dst = out + chunk * (int64_t)NW * CH + 4 * c;
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc += ld4_nt(src + (int64_t)r * CH);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) st4_nt(dst + (int64_t)w * CH, acc + (float)w);
+  }
+}
+// Adjacent pairs: each lane owns TWO adjacent float4 columns (32 contiguous bytes per row), rows 95 MB apart.
+template <int NR, int NW>
+__global__ __launch_bounds__(256) void probe_pair(const float* __restrict__ in, float* __restrict__ out, int64_t ld, int64_t n4) {
+  const int64_t step = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; 2 * i + 1 < n4; i += step) {
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      a0 += ld4_nt(in + r * ld + 8 * i);
+      a1 += ld4_nt(in + r * ld + 8 * i + 4);
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      st4_nt(out + w * ld + 8 * i, a0 + (float)w);
+      st4_nt(out + w * ld + 8 * i + 4, a1 + (float)w);
+    }
+  }
+}
+
 // ----------------------------------------------------------- swag sample variants --
 __device__ __forceinline__ f32x4 dstd(f32x4 m, f32x4 s) {
   f32x4 v = s - m * m, r;
@@ -258,6 +295,22 @@ int main(int argc, char** argv) {
     PRB(16, 8, 1, false, true, 2048) PRB(16, 8, 1, true, true, 2048) PRB(16, 8, 1, true, true, 1024) PRB(16, 8, 1, true, true, 4096)
     PRB(22, 30, 1, true, true, 2048) PRB(22, 30, 1, false, true, 2048)
     run_table("HBM probes at D = 23,880,950 (bytes = 4 D (NR + NW))", vs, st);
+  }
+
+  if (want("layout")) {
+    std::vector<Variant> vs;
+    const double B16 = 4.0 * D * 24;
+    vs.push_back({"R16 W8 rows 95 MB apart, stride g2048", [&] { hipLaunchKernelGGL((probe<16, 8, 1, false, true>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, B16});
+    vs.push_back({"R16 W8 adjacent float4 pairs g2048", [&] { hipLaunchKernelGGL((probe_pair<16, 8>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, B16});
+    vs.push_back({"R16 W8 adjacent float4 pairs g1024", [&] { hipLaunchKernelGGL((probe_pair<16, 8>), dim3(1024), dim3(256), 0, st, in, out, ld, n4); }, B16});
+#define PBL(CH, G) vs.push_back({"R16 W8 blocked layout chunk " #CH " floats g" #G, [&] { hipLaunchKernelGGL((probe_blocked<16, 8, CH>), dim3(G), dim3(256), 0, st, in, out, n4); }, B16});
+    PBL(256, 2048) PBL(1024, 2048) PBL(4096, 2048) PBL(16384, 2048) PBL(65536, 2048) PBL(1024, 4096) PBL(4096, 1024)
+    vs.push_back({"R8 W0 rows apart (gram's shape)", [&] { hipLaunchKernelGGL((probe<8, 0, 1, false, true>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * 8});
+#define PBR(CH) vs.push_back({"R8 W0 blocked chunk " #CH, [&] { hipLaunchKernelGGL((probe_blocked<8, 0, CH>), dim3(2048), dim3(256), 0, st, in, out, n4); }, 4.0 * D * 8});
+    PBR(1024) PBR(16384)
+    vs.push_back({"R22 W30 rows apart (batched sampler's shape)", [&] { hipLaunchKernelGGL((probe<22, 30, 1, false, true>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * 52});
+    vs.push_back({"R22 W30 blocked chunk 4096", [&] { hipLaunchKernelGGL((probe_blocked<22, 30, 4096>), dim3(2048), dim3(256), 0, st, in, out, n4); }, 4.0 * D * 52});
+    run_table("layout probes: separate rows vs rows interleaved per chunk (bytes = 4 D (NR + NW))", vs, st);
   }
 
   if (want("sample")) {
