@@ -96,6 +96,30 @@ __global__ __launch_bounds__(256) void probe_pair(const float* __restrict__ in, 
   }
 }
 
+// Shape of the fused SVGD step: M particle rows read-modify-written in place, M gradient rows read, one state row
+// read-modify-written.  PB / GB: that operand stored blocked ([chunk][M][CH]) instead of as M rows `ld` apart.
+template <int M, bool PB, bool GB, int CH>
+__global__ __launch_bounds__(256) void probe_fused(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ buf,
+                                                   int64_t ld, int64_t n4) {
+  constexpr int C4 = CH / 4;
+  const int64_t step = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
+    const int64_t chunk = i / C4, c = i % C4;
+    const int64_t pb = PB ? chunk * (int64_t)M * CH + 4 * c : 4 * i, ps = PB ? CH : ld;
+    const int64_t gb = GB ? chunk * (int64_t)M * CH + 4 * c : 4 * i, gs = GB ? CH : ld;
+    f32x4 p[M];
+    f32x4 acc = ld4(buf + 4 * i);
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      p[r] = ld4_nt(P + pb + r * ps);
+      acc += ld4_nt(G + gb + r * gs);
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r) st4_nt(P + pb + r * ps, p[r] * 0.999f + acc * 1e-6f);
+    st4(buf + 4 * i, acc * 0.5f);
+  }
+}
+
 // ----------------------------------------------------------- swag sample variants --
 __device__ __forceinline__ f32x4 dstd(f32x4 m, f32x4 s) {
   f32x4 v = s - m * m, r;
@@ -311,6 +335,17 @@ int main(int argc, char** argv) {
     vs.push_back({"R22 W30 rows apart (batched sampler's shape)", [&] { hipLaunchKernelGGL((probe<22, 30, 1, false, true>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * 52});
     vs.push_back({"R22 W30 blocked chunk 4096", [&] { hipLaunchKernelGGL((probe_blocked<22, 30, 4096>), dim3(2048), dim3(256), 0, st, in, out, n4); }, 4.0 * D * 52});
     run_table("layout probes: separate rows vs rows interleaved per chunk (bytes = 4 D (NR + NW))", vs, st);
+    {
+      std::vector<Variant> vf;
+      float* Pm = out;                      // 8 rows of the 32-row output buffer as the in-place particle matrix
+      float* buf = out + 16 * ld;
+      const double BF = 4.0 * D * (3 * 8 + 2);
+#define PF(PB, GB, CH, G) vf.push_back({std::string("fused shape P ") + (PB ? "blocked" : "rows") + " G " + (GB ? "blocked" : "rows") + " chunk " #CH " g" #G, \
+        [&] { hipLaunchKernelGGL((probe_fused<8, PB, GB, CH>), dim3(G), dim3(256), 0, st, Pm, in, buf, ld, n4); }, BF});
+      PF(false, false, 4096, 2048) PF(false, true, 4096, 2048) PF(true, true, 4096, 2048) PF(false, true, 16384, 2048) PF(true, true, 16384, 2048)
+      PF(false, true, 1024, 2048) PF(false, false, 4096, 1024) PF(false, true, 4096, 1024)
+      run_table("fused-step shape: particles RMW in place + gradients read + state RMW (bytes = 4 D (3 M + 2))", vf, st);
+    }
   }
 
   if (want("sample")) {
