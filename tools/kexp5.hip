@@ -348,6 +348,19 @@ int main(int argc, char** argv) {
     }
   }
 
+  if (want("ldsweep")) {
+    // does the row stride matter?  same R16 W8 / fused shapes, rows `ld + pad` floats apart (the buffers are large
+    // enough: 24 input rows and 32 output rows were allocated with the base ld)
+    std::vector<Variant> vs;
+    const double B16 = 4.0 * D * 24;
+    for (int64_t pad : {0LL, 64LL, 192LL, 448LL, 1024LL, 1088LL, 4096LL, 4160LL, 16448LL, 65600LL, 262208LL, 524352LL}) {
+      const int64_t l2 = ld + pad;
+      if (16 * l2 > (int64_t)NROWS * ld || 8 * l2 > 32 * ld) continue;
+      vs.push_back({"R16 W8 rows, ld + " + std::to_string(pad) + " floats", [=] { hipLaunchKernelGGL((probe<16, 8, 1, false, true>), dim3(2048), dim3(256), 0, st, in, out, l2, n4); }, B16});
+    }
+    run_table("row-stride sweep (bytes = 4 D 24)", vs, st);
+  }
+
   if (want("sample")) {
     float *mean = in + (int64_t)K * ld, *sq = mean + ld;
     std::vector<Variant> vs;
