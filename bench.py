@@ -559,21 +559,13 @@ def main():
             dist.barrier()
         t_single = time_loop(lambda: ops.swag_sample(mean, sq, ring, 3, o1, d, seed=1, stream_id=2), 20)
         t_batch = time_loop(lambda: ops.swag_sample_batched(mean, sq, ring, 3, ob, d, seed=1, stream_id0=0), 8)
-        del ob
-        obi = torch.empty((ld + 4095) // 4096, S_SWAG, 4096, device=dev)       # the layout prefetch_samples() uses
-        t_batch_i = time_loop(lambda: ops.swag_sample_batched(mean, sq, ring, 3, obi, d, seed=1, stream_id0=0), 8)
-        ob = obi
-        rates = torch.tensor([1.0 / t_single, S_SWAG / t_batch, S_SWAG / t_batch_i], device=dev, dtype=torch.float64)
+        rates = torch.tensor([1.0 / t_single, S_SWAG / t_batch], device=dev, dtype=torch.float64)
         if dist:
             dist.all_reduce(rates, op=dist.ReduceOp.SUM)
         swag = {"samples_per_s": round(float(rates[0]), 1), "samples_per_s_batched_S30": round(float(rates[1]), 1),
                 "K": K_SWAG, "D": d, "scaling": "weak (independent posterior samples on every GPU)",
                 "per_sample_hbm_frac_rank0": round(4 * d * (K_SWAG + 3) / t_single / 1e9 / HBM_PEAK_GBS, 4),
-                "batched_hbm_frac_rank0": round(4 * d * (K_SWAG + 2 + S_SWAG) / t_batch / 1e9 / HBM_PEAK_GBS, 4),
-                "samples_per_s_batched_S30_interleaved": round(float(rates[2]), 1),
-                "batched_interleaved_hbm_frac_rank0": round(4 * d * (K_SWAG + 2 + S_SWAG) / t_batch_i / 1e9 / HBM_PEAK_GBS, 4),
-                "interleaved": "the 30 samples written [chunk][sample][4096] instead of as 30 rows (what "
-                               "SwagOptimizer.prefetch_samples does when samples are served by copy)"}
+                "batched_hbm_frac_rank0": round(4 * d * (K_SWAG + 2 + S_SWAG) / t_batch / 1e9 / HBM_PEAK_GBS, 4)}
         del mean, sq, ring, o1, ob
         out = None
 

@@ -48,7 +48,7 @@ SIGNATURES = {
     "bde_swag_update": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P]),
     "bde_swag_sample": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_swag_sample_batched": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64,
-                                        c_int, c_int64, c_int, _P]),
+                                        c_int, c_int64, _P]),
     "bde_philox_normal": (c_int, [c_uint64, c_uint64, _P, c_int, _P, c_int64, _P]),
     "bde_philox_bits": (c_int, [c_uint64, c_uint64, c_uint32, c_uint64, _P, c_int64, _P]),
     "bde_gauss_draw_fwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, c_int64, _P]),

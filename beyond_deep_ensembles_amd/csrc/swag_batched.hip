@@ -33,17 +33,8 @@ template <bool RNG>
 __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
     const float* __restrict__ mean, const float* __restrict__ sq, const float* __restrict__ dev, int K, int64_t ld,
     int head, const float* __restrict__ eps_w, const float* __restrict__ eps_d, uint64_t seed, uint64_t stream0,
-    float* __restrict__ out, int64_t ld_out, int S, int64_t D, int chunk_log2) {
+    float* __restrict__ out, int64_t ld_out, int S, int64_t D) {
   extern __shared__ __attribute__((aligned(16))) float w[];   // [K + (K & 1)][32]: weight of ring row r for sample s
-  // Output layout: S rows `ld_out` apart (chunk_log2 == 0), or the S samples INTERLEAVED per chunk of 2^chunk_log2
-  // parameters -- [chunk][sample][2^chunk_log2] -- which keeps the 30 write streams of a tile within one contiguous
-  // region (+3...17 % on this write-heavy kernel, profiles/r02_layout_probes.txt); element e of sample s then lives at
-  // (e >> c) * S * 2^c + s * 2^c + (e & (2^c - 1)).
-  auto out_at = [&](int s, int64_t e) -> float* {
-    if (chunk_log2 == 0) return out + static_cast<int64_t>(s) * ld_out + e;
-    const int64_t cmask = (int64_t{1} << chunk_log2) - 1;
-    return out + (((e >> chunk_log2) * S + s) << chunk_log2) + (e & cmask);
-  };
   const int kpad = K + (K & 1);
   const int ksteps = kpad >> 1;
   const float denom = __builtin_sqrtf(2.0f * static_cast<float>(K - 1));   // swag.py:113
@@ -104,7 +95,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
           const f32x4 z = RNG ? philox_normal4(seed, stream0 + s, static_cast<uint64_t>(g4), kDomainDiag)
                               : ld4_nt(eps_d + static_cast<int64_t>(s) * ld_out + 4 * g4);
           const f32x4 lr = {acc0[reg], acc1[reg], acc2[reg], acc3[reg]};
-          st4_nt(out_at(s, 4 * g4), (m + lr) + sd * z);
+          st4_nt(out + static_cast<int64_t>(s) * ld_out + 4 * g4, (m + lr) + sd * z);
         }
       }
     }
@@ -126,7 +117,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
       } else {
         z = eps_d[static_cast<int64_t>(s) * ld_out + e];
       }
-      *out_at(s, e) = (m + acc) + __builtin_sqrtf(0.5f * (fmaxf(sq[e] - m * m, 0.0f) + 1e-6f)) * z;
+      out[static_cast<int64_t>(s) * ld_out + e] = (m + acc) + __builtin_sqrtf(0.5f * (fmaxf(sq[e] - m * m, 0.0f) + 1e-6f)) * z;
     }
   }
 }
@@ -137,11 +128,10 @@ using namespace bde;
 
 extern "C" int bde_swag_sample_batched(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
                                        const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id0,
-                                       float* out, int64_t ld_out, int S, int64_t D, int out_chunk_log2, void* stream) {
+                                       float* out, int64_t ld_out, int S, int64_t D, void* stream) {
   if (!mean || !sq || !dev || !out || D <= 0 || K < 1 || K > BDE_MAX_RANK || S < 1 || S > BDE_MAX_BATCH)
     return BDE_ERR_INVALID;
   if (head < 0 || head >= K || ld < D || (ld & 3) || ld_out < D || (ld_out & 3)) return BDE_ERR_INVALID;
-  if (out_chunk_log2 != 0 && (out_chunk_log2 < 7 || out_chunk_log2 > 24)) return BDE_ERR_INVALID;   // >= one 128-parameter tile
   if (!aligned16(mean) || !aligned16(sq) || !aligned16(dev) || !aligned16(out) || (eps_d && !aligned16(eps_d)))
     return BDE_ERR_INVALID;
   const int64_t n_tiles = ((D >> 2) + 31) / 32;
@@ -150,9 +140,9 @@ extern "C" int bde_swag_sample_batched(const float* mean, const float* sq, const
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (eps_d)
     hipLaunchKernelGGL(swag_sample_batched_kernel<false>, dim3(grid), dim3(kBlock), lds, s, mean, sq, dev, K, ld, head,
-                       eps_w, eps_d, seed, stream_id0, out, ld_out, S, D, out_chunk_log2);
+                       eps_w, eps_d, seed, stream_id0, out, ld_out, S, D);
   else
     hipLaunchKernelGGL(swag_sample_batched_kernel<true>, dim3(grid), dim3(kBlock), lds, s, mean, sq, dev, K, ld, head,
-                       eps_w, eps_d, seed, stream_id0, out, ld_out, S, D, out_chunk_log2);
+                       eps_w, eps_d, seed, stream_id0, out, ld_out, S, D);
   return to_err(hipGetLastError());
 }

@@ -215,21 +215,11 @@ class HipOps:
 
     @_on_device_of
     def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0):
-        """``out [S, ld]``: S sample rows; or ``out [chunks, S, C]`` (C a power of two >= 128, chunks * C >= d): the
-        samples interleaved per chunk of C parameters (sample s = ``out[:, s, :].reshape(-1)[:d]``)."""
-        k = dev.shape[0]
-        if out.dim() == 3:
-            if not out.is_contiguous() or out.shape[2] & (out.shape[2] - 1) or out.shape[0] * out.shape[2] < d:
-                raise BdeKernelError("blocked output must be a contiguous [chunks, S, C] tensor with C a power of two")
-            if eps_d is not None:
-                raise BdeKernelError("blocked output goes with in-kernel noise")
-            s, ld_out, clog = out.shape[1], out.shape[0] * out.shape[2], out.shape[2].bit_length() - 1
-        else:
-            s, ld_out, clog = out.shape[0], _ld(out), 0
-            if eps_d is not None and _ld(eps_d) != ld_out:
-                raise BdeKernelError("eps_d and out must share one leading dimension")
+        k, s = dev.shape[0], out.shape[0]
+        if eps_d is not None and _ld(eps_d) != _ld(out):
+            raise BdeKernelError("eps_d and out must share one leading dimension")
         _check(self.lib.bde_swag_sample_batched(_ptr(mean), _ptr(sq), _ptr(dev), k, _ld(dev), head, _ptr(eps_w),
-                                                _ptr(eps_d), seed, stream_id0, _ptr(out), ld_out, s, d, clog, _stream()),
+                                                _ptr(eps_d), seed, stream_id0, _ptr(out), _ld(out), s, d, _stream()),
                "bde_swag_sample_batched")
 
     def philox_normal(self, seed, stream_id, eps_w=None, eps_d=None, d=None):

@@ -32,27 +32,6 @@ import torch
 from .algo import BayesianOptimizer, FlatLayout, check_params, repoint, _default_ops
 
 
-_PREFETCH_CHUNK = 4096      # parameters per interleaving chunk of prefetched samples (a power of two >= 128)
-
-
-class _BlockedRows:
-    """Prefetched samples stored ``[chunk][sample][C]`` in batches of <= 32 samples (what
-    ``bde_swag_sample_batched`` writes with ``out_chunk_log2``); sample i is the strided slice ``[:, i, :]``."""
-
-    def __init__(self, batches, ld):
-        self.batches, self.ld = batches, ld
-        self.shape = (sum(b.shape[1] for b in batches), ld)
-
-    def copy_row_into(self, dst: torch.Tensor, i: int) -> None:
-        b = self.batches[i // 32]
-        n_chunks, _, chunk = b.shape
-        full = self.ld // chunk                       # chunks that lie completely inside the destination row
-        if full:
-            dst[:full * chunk].view(full, chunk).copy_(b[:full, i % 32, :])
-        if full < n_chunks:                           # the row's tail: part of the last chunk
-            dst[full * chunk:self.ld].copy_(b[full, i % 32, :self.ld - full * chunk])
-
-
 class SwagOptimizer(BayesianOptimizer):
     '''
         Stochastic Weight Averaging-Gaussian (drop-in for src/algos/swag.py:10-114)
@@ -138,24 +117,14 @@ class SwagOptimizer(BayesianOptimizer):
         if self.rng != "philox" or self.noise_source is not None or n_samples < 2:
             return 0
         n = int(min(n_samples, max(1, max_bytes // (4 * self._layout.ld))))
-        d, ld, dev = self._layout.d, self._layout.ld, self._params_device()
-        if self._copy_is_cheaper:
-            # samples that will be served by a device copy may live in any layout: interleave them per chunk of 4096
-            # parameters ([chunk][sample][4096]), which the write-heavy batched kernel streams 3-17 % faster than
-            # n rows ld apart (profiles/r02_layout_probes.txt)
-            chunk = _PREFETCH_CHUNK
-            n_chunks = (ld + chunk - 1) // chunk
-            batches = [torch.empty((n_chunks, min(32, n - lo), chunk), dtype=torch.float32, device=dev)
-                       for lo in range(0, n, 32)]
-            rows = _BlockedRows(batches, ld)
-        else:
-            rows = torch.empty((n, ld), dtype=torch.float32, device=dev)
-            batches = [rows[lo:min(n, lo + 32)] for lo in range(0, n, 32)]
+        rows = torch.empty((n, self._layout.ld), dtype=torch.float32, device=self._params_device())
+        d = self._layout.d
         with torch.no_grad():
-            for b, out in enumerate(batches):
+            for lo in range(0, n, 32):
+                hi = min(n, lo + 32)
                 self._ops.swag_sample_batched(self.state["__mean"], self.state["__sq_weights"],
-                                              self.state["__deviations"], self.state["__dev_head"], out, d,
-                                              seed=self.seed, stream_id0=self._sample_counter + 32 * b)
+                                              self.state["__deviations"], self.state["__dev_head"], rows[lo:hi], d,
+                                              seed=self.seed, stream_id0=self._sample_counter + lo)
         self._prefetched = [rows, 0]
         return n
 
@@ -164,11 +133,11 @@ class SwagOptimizer(BayesianOptimizer):
         self.state["__params_dirty"] = True
         if self._prefetched is not None:
             rows, nxt = self._prefetched
-            if isinstance(rows, _BlockedRows):
-                # many tensors: one device copy of the sample into the vector the parameters already view
+            if self._copy_is_cheaper:
+                # many tensors: one device copy of the row into the sample vector the parameters already view
                 # (8 D bytes of HBM traffic) beats re-pointing every tensor (~1 us of host time each)
                 with torch.no_grad():
-                    rows.copy_row_into(self._sample, nxt)
+                    self._sample.copy_(rows[nxt])
                 self._point_at_sample_vector()
             else:
                 self._layout.point_data(self._plist, rows[nxt])

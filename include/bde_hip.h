@@ -202,13 +202,10 @@ int bde_swag_sample(const float* mean, const float* sq, const float* dev, int K,
 /* S posterior samples in one pass over the statistics: out [S, ld_out].
  * The deviation-matrix x noise product [D,K]x[K,S] runs on the f32 MFMA.
  * eps_w [S, K] (logical columns) / eps_d [S, ld_out] may be NULL (Philox
- * streams stream_id0 + s, identical to S calls of bde_swag_sample).
- * out_chunk_log2 == 0: S output rows ld_out apart.  Otherwise (7..24) the samples are written INTERLEAVED per chunk
- * of C = 2^out_chunk_log2 parameters, out = [ceil(D / C)][S][C] (element e of sample s at
- * ((e / C) * S + s) * C + e % C): one contiguous region per chunk instead of S write streams ld_out apart. */
+ * streams stream_id0 + s, identical to S calls of bde_swag_sample). */
 int bde_swag_sample_batched(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
                             const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id0,
-                            float* out, int64_t ld_out, int S, int64_t D, int out_chunk_log2, void* stream);
+                            float* out, int64_t ld_out, int S, int64_t D, void* stream);
 
 /* The Philox normals bde_swag_sample would use, written out (for tests and for
  * callers that want the noise): eps_w [K] and/or eps_d [D] (either may be NULL). */

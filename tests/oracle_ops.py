@@ -179,13 +179,6 @@ class OracleOps:
         out[:d] = O.swag_sample(mean[:d], sq[:d], self._logical(dev, head, d), eps_w, eps_d[:d])
 
     def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0):
-        if out.dim() == 3:                                   # [chunks, S, C]: samples interleaved per chunk
-            row = torch.zeros(out.shape[0] * out.shape[2])
-            for s in range(out.shape[1]):
-                self.swag_sample(mean, sq, dev, head, row, d, None if eps_w is None else eps_w[s], None, seed,
-                                 stream_id0 + s)
-                out[:, s, :] = row.view(out.shape[0], out.shape[2])
-            return
         for s in range(out.shape[0]):
             self.swag_sample(mean, sq, dev, head, out[s], d, None if eps_w is None else eps_w[s],
                              None if eps_d is None else eps_d[s], seed, stream_id0 + s)

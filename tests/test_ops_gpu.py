@@ -829,24 +829,3 @@ def test_lrt_linear_forward(ops):
         ops.lrt_linear_fwd(wide[:, :i], dev(w_mu), dev(w_rho), dev(b_mu), dev(b_rho), True, out2, None, eps=dev(eps))
         assert (out2 - out).abs().max().item() <= tol_o
     assert not ops.lrt_linear_supported(129, 10, 10) and ops.lrt_linear_supported(128, 10, 10)
-
-
-def test_swag_batched_interleaved_output(ops):
-    """bde_swag_sample_batched with out_chunk_log2: the samples written [chunk][sample][C] hold exactly the values
-    of the row layout (same kernel arithmetic, different addresses), for ragged D, every S, several chunk sizes."""
-    torch.manual_seed(31)
-    for d, k, s_count, chunk in [(10007, 6, 4, 128), (70001, 20, 30, 4096), (4096 * 3, 5, 32, 4096), (131, 3, 1, 128),
-                                 (273_610, 20, 30, 16384), (4095, 4, 7, 256)]:
-        ld = (d + 16 + 63) // 64 * 64
-        mean, sq = torch.randn(ld, device=DEV) * 0.05, torch.rand(ld, device=DEV)
-        ring = torch.randn(k, ld, device=DEV) * 1e-3
-        rows = torch.zeros(s_count, ld, device=DEV)
-        ops.swag_sample_batched(mean, sq, ring, 1, rows, d, seed=3, stream_id0=11)
-        n_chunks = (ld + chunk - 1) // chunk
-        blocked = torch.full((n_chunks, s_count, chunk), float("nan"), device=DEV)
-        ops.swag_sample_batched(mean, sq, ring, 1, blocked, d, seed=3, stream_id0=11)
-        for s in range(s_count):
-            got = blocked[:, s, :].reshape(-1)[:d]
-            assert torch.equal(got, rows[s, :d]), (d, k, s_count, chunk, s)
-    with pytest.raises(Exception):
-        ops.swag_sample_batched(mean, sq, ring, 1, torch.zeros(3, 2, 100, device=DEV), d)       # C not a power of two

@@ -437,10 +437,8 @@ int main(int argc, char** argv) {
     float *mean = in + (int64_t)K * ld, *sq = mean + ld;
     std::vector<Variant> vs;
     const int S = 30;
-    vs.push_back({"product bde_swag_sample_batched S30", [&] { bde_swag_sample_batched(mean, sq, in, K, ld, 3, nullptr, nullptr, 1, 0, out, ld, S, D, 0, st); }, 4.0 * D * (K + 2 + S)});
-    vs.push_back({"product batched S30, output interleaved per 4096", [&] { bde_swag_sample_batched(mean, sq, in, K, ld, 3, nullptr, nullptr, 1, 0, out, ld, S, D, 12, st); }, 4.0 * D * (K + 2 + S)});
-    vs.push_back({"product batched S30, output interleaved per 16384", [&] { bde_swag_sample_batched(mean, sq, in, K, ld, 3, nullptr, nullptr, 1, 0, out, ld, S, D, 14, st); }, 4.0 * D * (K + 2 + S)});
-    vs.push_back({"product batched S30 supplied eps_d", [&] { bde_swag_sample_batched(mean, sq, in, K, ld, 3, nullptr, out, 1, 0, out, ld, S, D, 0, st); }, 4.0 * D * (K + 2 + 2 * S)});
+    vs.push_back({"product bde_swag_sample_batched S30", [&] { bde_swag_sample_batched(mean, sq, in, K, ld, 3, nullptr, nullptr, 1, 0, out, ld, S, D, st); }, 4.0 * D * (K + 2 + S)});
+    vs.push_back({"product batched S30 supplied eps_d", [&] { bde_swag_sample_batched(mean, sq, in, K, ld, 3, nullptr, out, 1, 0, out, ld, S, D, st); }, 4.0 * D * (K + 2 + 2 * S)});
     vs.push_back({"probe R22 W30 contig (same bytes)", [&] { hipLaunchKernelGGL((probe<22, 30, 1, true, true>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * (K + 2 + S)});
     run_table("swag_sample_batched (K = 20, S = 30)", vs, st, 5, 3);
   }
