@@ -32,7 +32,7 @@ __global__ __launch_bounds__(kBlock) void gauss_draw_fwd_kernel(const float* __r
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = m[j] + e[j] * softplus(r[j]);   // util.py:171: mean + eps * std
-    st4_nt(w + 4 * i, o);
+    BDE_OUT_ST(w + 4 * i, o);
     if (RNG && eps_out) st4_nt(eps_out + 4 * i, e);
   }
   if (blockIdx.x == 0) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void local_reparam_fwd_kernel(const float* 
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = m[j] + __builtin_sqrtf(v[j]) * e[j];
-    st4_nt(out + 4 * i, o);
+    BDE_OUT_ST(out + 4 * i, o);
   }
   if (blockIdx.x == 0) {
     const int64_t k = (n4 << 2) + threadIdx.x;

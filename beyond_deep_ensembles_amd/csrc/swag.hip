@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
         const f32x4 m = ld4_nt(mean + 4 * c);
         const f32x4 s = ld4_nt(sq + 4 * c);
         const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(c), kDomainDiag) : ld4_nt(eps_d + 4 * c);
-        st4_nt(out + 4 * c, (m + acc[u]) + diag_std(m, s) * z);
+        BDE_OUT_ST(out + 4 * c, (m + acc[u]) + diag_std(m, s) * z);
       }
     }
   }

@@ -5,6 +5,7 @@
 #include "../beyond_deep_ensembles_amd/csrc/svgd_small.hip"
 #include "../beyond_deep_ensembles_amd/csrc/svgd_fused.hip"
 #include "../beyond_deep_ensembles_amd/csrc/swag.hip"
+#include "../beyond_deep_ensembles_amd/csrc/gauss.hip"
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -118,6 +119,20 @@ int main(int argc, char** argv) {
     std::vector<Variant> v2;
     v2.push_back({"swag_sample K20 (product)", [&] { bde_swag_sample(mean, sq, P, std::min(K, 8), ld, 3, nullptr, nullptr, 1, 2, out, D, st); }, 4.0 * D * (8 + 3)});
     run_table("swag_sample K = 8 rows available here (sanity)", v2, st, 5, 5, false);
+    // full-size sampling kernels (store-flavour A/B): a K = 20 ring needs its own allocation
+    {
+      const int K2 = 20;
+      float *ring, *o2;
+      CK(hipMalloc(&ring, sizeof(float) * (K2 + 2) * ld)); CK(hipMalloc(&o2, sizeof(float) * ld));
+      for (int r = 0; r < K2 + 2; ++r) CK(hipMemcpy(ring + (int64_t)r * ld, P + (int64_t)(r % M) * ld, sizeof(float) * ld, hipMemcpyDeviceToDevice));
+      float *mean2 = ring + (int64_t)K2 * ld, *sq2 = mean2 + ld;
+      std::vector<Variant> v3;
+      v3.push_back({"swag_sample K20", [&] { bde_swag_sample(mean2, sq2, ring, K2, ld, 3, nullptr, nullptr, 1, 2, o2, D, st); }, 4.0 * D * (K2 + 3)});
+      v3.push_back({"gauss_draw_fwd", [&] { bde_gauss_draw_fwd(mean2, sq2, nullptr, 1, 0, o2, nullptr, D, st); }, 12.0 * D});
+      v3.push_back({"local_reparam_fwd", [&] { bde_local_reparam_fwd(mean2, sq2, nullptr, 1, 0, o2, D, st); }, 12.0 * D});
+      run_table("single-output sampling kernels at D = 23,880,950", v3, st, 9, 5, false);
+      CK(hipFree(ring)); CK(hipFree(o2));
+    }
   }
   return 0;
 }
