@@ -46,10 +46,12 @@ __device__ __forceinline__ void st4(float* __restrict__ p, f32x4 v) {
 __device__ __forceinline__ void st4_nt(float* __restrict__ p, f32x4 v) {
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 }
-// A/B switch (tools/kexp6.hip): how the single-output sampling kernels (swag_sample, gauss_draw_fwd,
-// local_reparam_fwd) store their result row.
+// How the single-output sampling kernels (swag_sample, gauss_draw_fwd, local_reparam_fwd) store their result row:
+// with PLAIN stores.  The sampled weights / activations are read again by the very next kernels (the model's
+// forward), so they are not a streaming output; measured +2-4 % on the 12*D kernels and neutral on swag_sample
+// (A/B over alternating processes, profiles/r02_output_store_ab.txt).
 #ifndef BDE_OUT_ST
-#define BDE_OUT_ST st4_nt
+#define BDE_OUT_ST st4
 #endif
 __device__ __forceinline__ f32x4 ld4_nt(const float* __restrict__ p) {
   return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
