@@ -60,10 +60,19 @@ __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __re
   f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   f32x4 cur[kGramU], nxt[kGramU];
   int64_t t = static_cast<int64_t>(blockIdx.x) * (kGramBlock / 64) + wave;
-  if (t < n_tiles) gram_load_tile<W4, BDE_GRAM_NT>(cur, rowp, valid, BDE_GRAM_TILE(t), tile4, c4, n4, D);
+  // BDE_GRAM_NT_SPLIT (per mille of the walk, A/B switch): tiles before the split are loaded non-temporally, the
+  // rest normally -- only the tail of the walk can still be in the Infinity Cache when the combine pass starts
+  const int64_t nt_until = n_tiles * BDE_GRAM_NT_SPLIT / 1000;
+  auto load_tile = [&](f32x4 (&v)[kGramU], int64_t tt) {
+    if (BDE_GRAM_NT_SPLIT > 0 && tt < nt_until)
+      gram_load_tile<W4, true>(v, rowp, valid, BDE_GRAM_TILE(tt), tile4, c4, n4, D);
+    else
+      gram_load_tile<W4, BDE_GRAM_NT>(v, rowp, valid, BDE_GRAM_TILE(tt), tile4, c4, n4, D);
+  };
+  if (t < n_tiles) load_tile(cur, t);
   for (; t < n_tiles; t += waves_total) {
     const int64_t tn = t + waves_total;
-    if (tn < n_tiles) gram_load_tile<W4, BDE_GRAM_NT>(nxt, rowp, valid, BDE_GRAM_TILE(tn), tile4, c4, n4, D);
+    if (tn < n_tiles) load_tile(nxt, tn);
 #pragma unroll
     for (int u = 0; u < kGramU; ++u) {
 #pragma unroll

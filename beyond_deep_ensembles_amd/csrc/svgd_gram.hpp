@@ -12,6 +12,9 @@ namespace bde {
 #ifndef BDE_GRAM_NT
 #define BDE_GRAM_NT false
 #endif
+#ifndef BDE_GRAM_NT_SPLIT
+#define BDE_GRAM_NT_SPLIT 0
+#endif
 #ifndef BDE_GRAM_REVERSE
 #define BDE_GRAM_REVERSE 0
 #endif
