@@ -60,11 +60,14 @@ __global__ __launch_bounds__(kGramBlock) void svgd_gram_kernel(const float* __re
   f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   f32x4 cur[kGramU], nxt[kGramU];
   int64_t t = static_cast<int64_t>(blockIdx.x) * (kGramBlock / 64) + wave;
-  // BDE_GRAM_NT_SPLIT (per mille of the walk, A/B switch): tiles before the split are loaded non-temporally, the
-  // rest normally -- only the tail of the walk can still be in the Infinity Cache when the combine pass starts
-  const int64_t nt_until = n_tiles * BDE_GRAM_NT_SPLIT / 1000;
+  // Tiles before rows.nt_split (per mille of the walk) are loaded non-temporally, the rest normally: only the tail
+  // of the walk -- as much as the 256 MB Infinity Cache holds -- can still be resident when the combine pass re-reads
+  // the particles, and the streaming head of the walk is 14 % faster with nt loads.  Measured at M = 8, D = 23.9 M:
+  // step 0.534-0.538 ms with the head (2/3) nt vs 0.544 all plain, 0.579 all nt, 0.548-0.553 with 80 % nt
+  // (profiles/r02_gram_split_ab.txt).
+  const int64_t nt_until = n_tiles * rows.nt_split / 1000;
   auto load_tile = [&](f32x4 (&v)[kGramU], int64_t tt) {
-    if (BDE_GRAM_NT_SPLIT > 0 && tt < nt_until)
+    if (tt < nt_until)
       gram_load_tile<W4, true>(v, rowp, valid, BDE_GRAM_TILE(tt), tile4, c4, n4, D);
     else
       gram_load_tile<W4, BDE_GRAM_NT>(v, rowp, valid, BDE_GRAM_TILE(tt), tile4, c4, n4, D);
@@ -468,14 +471,15 @@ extern "C" int bde_svgd_gram(const float* P, int M, int64_t D, int64_t ld, void*
   if (M <= 8) {
     const int64_t tiles = (n4 + kGramU * 8 - 1) / (kGramU * 8);
     const int grid = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, kGramMaxBlocks));
-    hipLaunchKernelGGL(svgd_gram_kernel<2>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, wsf, GramRows{});
+    hipLaunchKernelGGL(svgd_gram_kernel<2>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, wsf,
+                       GramRows{0, 0, 0, 0, 0, gram_nt_split(M, D)});
     return to_err(hipGetLastError());
   }
   const int64_t tiles = (n4 + kGramU * 4 - 1) / (kGramU * 4);
   const int grid = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, kGramMaxBlocks));
   if (M <= BDE_FAST_PARTICLES) {
     hipLaunchKernelGGL(svgd_gram_kernel<1>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, wsf,
-                       GramRows{0, 8, 8, M - 8, 0});
+                       GramRows{0, 8, 8, M - 8, 0, gram_nt_split(M, D)});
     return to_err(hipGetLastError());
   }
   // generic: one 16-row tile per pair of 8-particle groups, then the pairs' tiles -> d2 [M, M]

@@ -6,14 +6,10 @@
 
 namespace bde {
 
-// A/B switches (tools/kexp6.hip): how the three-stage Gram pass loads the particles and in which direction it
-// walks them.  Measured (profiles/r02_small_step_timeline_v3_and_gram_ab.txt): non-temporal loads make the Gram pass itself 9 % faster but the
-// combine pass behind it slower by more, so the default is plain loads.
+// A/B switches (tools/kexp6.hip) for the three-stage Gram pass: BDE_GRAM_NT = flavour of the loads behind the
+// nt/cacheable split point (GramRows::nt_split), BDE_GRAM_REVERSE = direction of the walk.
 #ifndef BDE_GRAM_NT
 #define BDE_GRAM_NT false
-#endif
-#ifndef BDE_GRAM_NT_SPLIT
-#define BDE_GRAM_NT_SPLIT 0
 #endif
 #ifndef BDE_GRAM_REVERSE
 #define BDE_GRAM_REVERSE 0
@@ -82,7 +78,17 @@ __device__ __forceinline__ void gram_load_tile(f32x4 (&v)[kGramU], const float* 
 // tile per PAIR of 8-particle groups, each into its own slice of ws (tile_slot).
 struct GramRows {
   int rowA, nA, rowB, nB, tile_slot;
+  int nt_split = 0;      // per mille of the tile walk loaded non-temporally (the rest stays cacheable)
 };
+
+// The tail of the Gram walk that is kept cacheable for the combine pass: what fits the Infinity Cache (256 MiB,
+// minus headroom for the pass's own partials and whatever else is live).
+static inline int gram_nt_split(int M, int64_t D) {
+  const double total = 4.0 * static_cast<double>(M) * static_cast<double>(D);
+  const double keep = 240e6;
+  if (total <= keep) return 0;
+  return static_cast<int>(1000.0 * (1.0 - keep / total));
+}
 
 
 // ---------------------------------------------------------------- statistics --
