@@ -126,22 +126,17 @@ __device__ __forceinline__ void reduce_gram_partials(const float* __restrict__ w
   const int tid = threadIdx.x;
   const int nslices = kStatsBlock / mp2;
   {
-    // 32 unconditional loads in flight per thread and batch (a dependent chain of single loads made this
-    // latency-bound: 45 us for 2048 partials; 8 in flight: 4 us); slots past the last partial re-read it and are
-    // dropped by the select.  The summation order is fixed: batch by batch, slot by slot.
+    // 8 independent accumulators keep 8 loads in flight (a single dependent chain made this
+    // latency-bound: 45 us for 2048 partials); the summation order is still fixed.
     const int e = tid % mp2, slice = tid / mp2;
-    double s = 0.0;
-    for (int b0 = slice; b0 < nb; b0 += 32 * nslices) {
-      float x[32];
+    double s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int b = slice;
+    for (; b + 7 * nslices < nb; b += 8 * nslices) {
 #pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        const int b = b0 + u * nslices;
-        x[u] = part[static_cast<int64_t>(b < nb ? b : nb - 1) * mp2 + e];
-      }
-#pragma unroll
-      for (int u = 0; u < 32; ++u) s += (b0 + u * nslices < nb) ? static_cast<double>(x[u]) : 0.0;
+      for (int u = 0; u < 8; ++u) s8[u] += static_cast<double>(part[static_cast<int64_t>(b + u * nslices) * mp2 + e]);
     }
-    red[tid] = s;
+    for (int u = 0; b < nb; b += nslices, ++u) s8[u] += static_cast<double>(part[static_cast<int64_t>(b) * mp2 + e]);
+    red[tid] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   }
   __syncthreads();
   if (tid < mp2) {
@@ -159,11 +154,7 @@ __global__ __launch_bounds__(kStatsBlock) void svgd_kstats_kernel(const float* _
   __shared__ double gmat[256];
   int MP;
   reduce_gram_partials(ws, red, gmat, MP);
-  if (MP == 8) {                                    // M <= 8: one wave, shuffles instead of LDS round trips
-    if (threadIdx.x < 64) svgd_stats_wave(gmat, M, sp, kstat, nullptr, nullptr);
-  } else {
-    svgd_stats_core(gmat, M, MP, sp, kstat, nullptr, nullptr);
-  }
+  svgd_stats_core(gmat, M, MP, sp, kstat, nullptr, nullptr);
 }
 
 // Dimension-sharded multi-GPU update: every rank reduces the Gram partials of ITS column slice to an fp64
