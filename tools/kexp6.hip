@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
     vs.push_back({"single launch bde_svgd_step_small", [&] { bde_svgd_step_small(P, G, o, M, d, l, 3e-4f, 1.f, 50000.f, -1.f, 0.f, 0, ws, ks, st); }, B});
     vs.push_back({"three stages gram+kstats+combine", [&] { bde_svgd_gram(P, M, d, l, ws, st); bde_svgd_kstats(ws, M, 3e-4f, 1.f, 50000.f, -1.f, 0.f, 0, ks, st);
                                                           bde_svgd_combine(P, G, o, M, d, l, l, ks, st); }, B});
+    vs.push_back({"  kstats only (small ws)", [&] { bde_svgd_kstats(ws, M, 3e-4f, 1.f, 50000.f, -1.f, 0.f, 0, ks, st); }, 0});
     run_table("SVGD step at D = 273,610, M = 8", vs, st, 9, 50, true);
 #ifdef BDE_SMALL_TIMING
     for (int rep = 0; rep < 3; ++rep) {
@@ -111,6 +112,7 @@ int main(int argc, char** argv) {
                                                         bde_svgd_fused_sgd(P, G, buf, M, D, ld, ld, ks, 1e-12, 0.9, 0.0, 3e-4, 1, 0, ws, st); }, (12.0 * M + 8) * D});
     vs.push_back({"kstats + fused sgd (no gram)", [&] { bde_svgd_kstats(ws, M, 0.f, 1.f, 129809.f, -1.f, 0.f, 0, ks, st);
                                                       bde_svgd_fused_sgd(P, G, buf, M, D, ld, ld, ks, 1e-12, 0.9, 0.0, 3e-4, 1, 0, nullptr, st); }, (12.0 * M + 8) * D});
+    vs.push_back({"kstats only (full ws)", [&] { bde_svgd_kstats(ws, M, 0.f, 1.f, 129809.f, -1.f, 0.f, 0, ks, st); }, 0});
     vs.push_back({"combine in place (out = G)", [&] { bde_svgd_combine(P, G, G, M, D, ld, ld, ks, st); }, 12.0 * M * D});
     vs.push_back({"step: gram + kstats + combine", [&] { bde_svgd_step(P, G, G, M, D, ld, 0.f, 1.f, 129809.f, -1.f, ws, ks, st); }, 16.0 * M * D});
     run_table("fused SVGD step at D = 23,880,950", vs, st, 7, 5, false);
