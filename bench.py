@@ -325,7 +325,79 @@ def config_extras(dev):
                                              "weights_GBps": round(8.0 * fi * fo / t_f / 1e9, 1),
                                              "what": "BBBLinear.forward (training mode, in-kernel noise): bde_lrt_linear_fwd "
                                                      "vs the reference's ~14 ATen launches"}
+        # forward + backward (weights and input): bde_lrt_linear_fwd + bde_lrt_linear_bwd vs autograd over the sequence
+        xg = xin.clone().requires_grad_(True)
+        leaves = [xg, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho]
+
+        def fused_fb():
+            torch.autograd.grad(layer(xg).sum(), leaves)
+
+        def torch_fb():
+            w, b = layer.weight, layer.bias
+            mean = F.linear(xg, w.mean, b.mean)
+            var = F.linear((xg ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), (b.std ** 2).clamp(min=1e-4))
+            torch.autograd.grad((mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)).sum(), leaves)
+        t_f = time_loop(fused_fb, 30)
+        t_t = time_loop(torch_fb, 30)
+        out["bbb_linear_fwd_bwd_" + name] = {"ms": round(t_f * 1e3, 4), "torch_sequence_ms": round(t_t * 1e3, 4),
+                                             "speedup": round(t_t / t_f, 2), "B": bsz, "I": fi, "O": fo,
+                                             "weights_GBps": round(28.0 * fi * fo / t_f / 1e9, 1),
+                                             "what": "BBBLinear forward + backward (all five gradients): 2 + 3..4 launches, "
+                                                     "28*O*I algorithmic bytes, vs autograd over the reference's op sequence"}
         del layer
+
+    # ---- configs[0]: BBBOptimizer.step on the UCI-housing MLP (13 -> 50 -> 1 BBBLinear, 5 MC samples, Adam), whole
+    # step incl. forward/backward; beside it the reference's op sequence for the same step in plain PyTorch on this GPU
+    def uci_model():
+        return torch.nn.Sequential(bde.BBBLinear(13, 50, prior, prior, rng="philox"), torch.nn.ReLU(),
+                                   bde.BBBLinear(50, 1, prior, prior, rng="philox")).to(dev)
+    xb, yb = torch.randn(32, 13, device=dev), torch.randn(32, 1, device=dev)
+    model = uci_model()
+    opt = bde.BBBOptimizer(model.parameters(), torch.optim.Adam(model.parameters(), lr=1e-3), prior, dataset_size=455,
+                           mc_samples=5)
+    t_ours = time_loop(lambda: opt.step(lambda: F.mse_loss(model(xb), yb), lambda loss: loss.backward()), 30)
+    ref = uci_model()
+    ref_layers = [ref[0], ref[2]]
+    ref_adam = torch.optim.Adam(ref.parameters(), lr=1e-3)
+
+    def ref_forward():                                           # bbb_layers.py:62-87 (the CUDA branch, incl. the per-forward KL)
+        hcur = xb
+        for li, layer in enumerate(ref_layers):
+            w, b = layer.weight, layer.bias
+            w_std, b_std = F.softplus(w.rho), F.softplus(b.rho)
+            batch_in = torch.stack((hcur, (hcur ** 2).clamp(min=1e-4)))
+            batch_mat = torch.stack((w.mean.transpose(0, 1), (w_std.transpose(0, 1) ** 2).clamp(min=1e-4)))
+            batch_add = torch.stack((b.mean.expand((hcur.shape[0], w.mean.shape[0])),
+                                     (b_std ** 2).clamp(min=1e-4).expand((hcur.shape[0], w.mean.shape[0]))))
+            both = torch.baddbmm(batch_add, batch_in, batch_mat)
+            hcur = both[0] + torch.sqrt(both[1]) * torch.empty_like(both[0]).normal_(0, 1)
+            layer._ref_kl = prior.kl_divergence(w.mean, w_std) + prior.kl_divergence(b.mean, b_std)
+            if li == 0:
+                hcur = F.relu(hcur)
+        return F.mse_loss(hcur, yb)
+
+    def ref_step():                                              # bbb.py:59-89
+        ref_adam.zero_grad()
+        total = None
+        for _ in range(5):
+            total = ref_forward() if total is None else total + ref_forward()
+        kl = torch.tensor(0.0, device=dev)
+        for layer in ref_layers:
+            for gp in (layer.weight, layer.bias):
+                kl += prior.kl_divergence(gp.mean, F.softplus(gp.rho))
+        loss = (1.0 / 455) * kl + total / 5
+        if not loss.isnan().any():
+            loss.backward()
+            ref_adam.step()
+        return loss
+    t_ref = time_loop(ref_step, 30)
+    out["bbb_step_uci_mlp_mc5"] = {"ms": round(t_ours * 1e3, 4), "torch_sequence_ms": round(t_ref * 1e3, 4),
+                                   "speedup": round(t_ref / t_ours, 2), "steps_per_s": round(1.0 / t_ours, 1),
+                                   "what": "BASELINE configs[0]: BBBOptimizer.step (5 MC samples, batch 32, Adam) on the UCI "
+                                           "MLP of BBBLinear layers, forward and backward included: fused layer forward / "
+                                           "backward ops + one KL launch, vs the reference's op sequence (bbb_layers.py:62-87, "
+                                           "bbb.py:59-89) in PyTorch on this GPU; both are host-bound"}
+    del model, opt, ref, ref_adam
 
     # ---- SWAG members with all K columns filled
     def swag_member(d, n_tensors, seed):

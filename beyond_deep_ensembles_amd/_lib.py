@@ -63,6 +63,9 @@ SIGNATURES = {
     "bde_lrt_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "bde_lrt_linear_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int, _P, c_uint64, c_uint64, _P, _P, c_int, c_int, c_int,
                                    _P, _P]),
+    "bde_lrt_linear_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "bde_lrt_linear_bwd": (c_int, [_P, c_int64, _P, _P, _P, c_int, _P, _P, _P, c_uint64, c_uint64, _P, _P, _P, _P, _P,
+                                   c_int, c_int, c_int, _P, _P]),
     "bde_ivon_sample": (c_int, [_P, _P, _P, c_uint64, c_uint64, c_float, c_int, c_int, _P, _P, c_int64, _P]),
     "bde_ivon_update": (c_int, [_P, _P, _P, _P, _P] + [c_float] * 11 + [c_int64, _P]),
 }

@@ -58,8 +58,8 @@ class _LocalReparam(torch.autograd.Function):
 class _LrtLinear(torch.autograd.Function):
     """The whole forward of a mean-field linear layer in local-reparameterisation form (bbb_layers.py:61-80) as ONE
     fused op (bde_lrt_linear_fwd: the weights are streamed once, sigma^2 and x^2 formed on the fly, both products on
-    the MFMA); the backward restates the autograd graph of those lines with PyTorch ops from the saved variance and
-    noise."""
+    the MFMA); the backward is bde_lrt_linear_bwd (the autograd graph of those lines in three launches, from the saved
+    variance and noise)."""
 
     @staticmethod
     def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops):
@@ -81,25 +81,16 @@ class _LrtLinear(torch.autograd.Function):
     def backward(ctx, grad_out):
         x, w_mu, w_rho, b_rho, var, eps = ctx.saved_tensors
         clamp_bias, seed, stream_id, ops, x_shape = ctx.meta
-        g = grad_out.reshape(var.shape)
-        if eps is None:                                   # regenerate the in-kernel noise (same element indexing)
-            eps = torch.empty_like(var)
-            ops.philox_normal(seed, stream_id, eps_d=eps.view(-1), d=eps.numel())
-        gvar = g * eps / (2 * torch.sqrt(var))            # d out / d activation_var
-        sig = F.softplus(w_rho)
-        s2 = sig * sig
-        x2 = x * x
-        g_x = g @ w_mu + (gvar @ s2.clamp(min=_CLAMP)) * (2 * x) * (x2 >= _CLAMP)
-        g_wmu = g.t() @ x
-        g_wrho = (gvar.t() @ x2.clamp(min=_CLAMP)) * (s2 >= _CLAMP) * (2 * sig * torch.sigmoid(w_rho))
+        g = grad_out.reshape(var.shape).contiguous()
+        g_x = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
+        g_wmu, g_wrho = torch.empty_like(w_mu), torch.empty_like(w_rho)
         g_bmu = g_brho = None
         if b_rho is not None:
-            g_bmu = g.sum(0)
-            sb = F.softplus(b_rho)
-            g_brho = gvar.sum(0) * (2 * sb * torch.sigmoid(b_rho))
-            if clamp_bias:
-                g_brho = g_brho * (sb * sb >= _CLAMP)
-        return g_x.view(x_shape), g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None
+            g_bmu, g_brho = torch.empty_like(b_rho), torch.empty_like(b_rho)
+        # eps None: the kernel regenerates the forward's in-kernel noise (same element indexing)
+        ops.lrt_linear_bwd(x, w_mu.detach().contiguous(), w_rho.detach().contiguous(), None if b_rho is None else b_rho.detach(),
+                           clamp_bias, g, var, g_x, g_wmu, g_wrho, g_bmu, g_brho, eps=eps, seed=seed, stream_id=stream_id)
+        return (None if g_x is None else g_x.view(x_shape)), g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None
 
 
 class _LocalReparamLayer(nn.Module):

@@ -1,0 +1,336 @@
+// Backward of the fused local-reparameterisation linear layer (forward: lrt.hip).
+//
+// Reference: the autograd graph of BBBLinear.forward, sampling="activations" (src/algos/bbb_layers.py:61-80):
+//   mean = x W_mu^T + b_mu,  var = clamp(x^2, 1e-4) clamp(sigma_W^2, 1e-4)^T + clamp(sigma_b^2, 1e-4),
+//   out  = mean + sqrt(var) * eps,  sigma = softplus(rho)
+// which autograd runs as ~25 ATen launches re-reading sigma, sigma^2, its clamp mask, x^2 and its mask.  With
+// g = d loss / d out and gvar = g * eps / (2 sqrt(var)):
+//   g_x     = g W_mu + (gvar clamp(sigma_W^2)) * 2 x * [x^2 >= 1e-4]
+//   g_Wmu   = g^T x
+//   g_Wrho  = (gvar^T clamp(x^2)) * [sigma_W^2 >= 1e-4] * 2 sigma_W sigmoid(rho_W)
+//   g_bmu   = sum_b g,   g_brho = (sum_b gvar) * [sigma_b^2 >= 1e-4] * 2 sigma_b sigmoid(rho_b)
+// Three launches (four when the reduction over O is split):
+//   lrt_bwd_prep_kernel   gvar [B, O] once (noise supplied or regenerated from the forward's Philox stream) and the
+//                         two bias gradients (column sums in a fixed order)
+//   lrt_bwd_w_kernel      one wave per 32 x 32 tile of [O, I]: both weight gradients as two accumulator tiles on
+//                         v_mfma_f32_32x32x2_f32 over K = B, the rho chain rule applied in the C layout (rows of
+//                         W_rho read and rows of the gradients written as 128-byte segments)
+//   lrt_bwd_x_kernel      one wave per (32 input columns, O-slice): streams rows of W_mu / W_rho (128-byte segments
+//                         per row), sigma^2 on the fly, for up to 4 batch tiles; O-slice partials + fixed-order finish
+//                         only when the layer is large enough to need the split
+// HBM traffic 20*O*I (W_rho, W_mu + W_rho again, two gradients written) + O(B (I + O)).
+#include "bde_common.hpp"
+
+namespace bde {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float kLrtBwdClamp = 1e-4f;   // bbb_layers.py:66-67,71
+constexpr int kLrtBwdWaves = 4;         // waves per workgroup (independent units)
+constexpr int kPrepCols = 32, kPrepRows = 8, kPrepMaxB = 128;
+
+// gvar [B, O] (for the weight-gradient kernel: lanes along o), the transposed copies gT / gvarT [O, b_pad] (for the
+// input-gradient kernel: lanes along b; rows b >= B are written as zeros, so that kernel needs no batch masks) and
+// the bias gradients.  One workgroup per 32 output columns; the transposition goes through LDS so that both the
+// [B, O] reads and the [O, b_pad] writes are contiguous.
+template <bool RNG>
+__global__ __launch_bounds__(kPrepCols* kPrepRows) void lrt_bwd_prep_kernel(
+    const float* __restrict__ g, const float* __restrict__ var, const float* __restrict__ eps, uint64_t seed,
+    uint64_t stream_id, const float* __restrict__ b_rho, int clamp_bias, float* __restrict__ gvar,
+    float* __restrict__ gT, float* __restrict__ gvT, float* __restrict__ g_bmu, float* __restrict__ g_brho, int B,
+    int b_pad, int O) {
+  __shared__ float tile_g[kPrepMaxB][kPrepCols + 1], tile_v[kPrepMaxB][kPrepCols + 1];
+  __shared__ float red_g[kPrepRows][kPrepCols], red_v[kPrepRows][kPrepCols];
+  const int c = threadIdx.x % kPrepCols, q = threadIdx.x / kPrepCols;
+  const int o0 = blockIdx.x * kPrepCols, o = o0 + c;
+  float sg = 0.f, sv = 0.f;
+  for (int b = q; b < b_pad; b += kPrepRows) {
+    float gg = 0.f, gv = 0.f;
+    if (b < B && o < O) {
+      const int64_t e = static_cast<int64_t>(b) * O + o;
+      const float z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag)[e & 3] : eps[e];
+      gg = g[e];
+      gv = gg * z / (2.0f * __builtin_sqrtf(var[e]));
+      gvar[e] = gv;
+    }
+    tile_g[b][c] = gg;
+    tile_v[b][c] = gv;
+    sg += gg;
+    sv += gv;
+  }
+  red_g[q][c] = sg;
+  red_v[q][c] = sv;
+  __syncthreads();
+  if (gT) {
+    for (int idx = threadIdx.x; idx < kPrepCols * b_pad; idx += kPrepCols * kPrepRows) {
+      const int cc = idx / b_pad, b = idx - cc * b_pad;
+      if (o0 + cc < O) {
+        gT[static_cast<int64_t>(o0 + cc) * b_pad + b] = tile_g[b][cc];
+        gvT[static_cast<int64_t>(o0 + cc) * b_pad + b] = tile_v[b][cc];
+      }
+    }
+  }
+  if (q == 0 && o < O && g_bmu) {
+    float tg = 0.f, tv = 0.f;
+#pragma unroll
+    for (int k = 0; k < kPrepRows; ++k) {                          // fixed order
+      tg += red_g[k][c];
+      tv += red_v[k][c];
+    }
+    const SoftplusSigmoid s = softplus_sigmoid(b_rho[o]);
+    const float keep = (!clamp_bias || s.sp * s.sp >= kLrtBwdClamp) ? 1.f : 0.f;
+    g_bmu[o] = tg;
+    g_brho[o] = tv * keep * (2.0f * s.sp * s.sg);
+  }
+}
+
+// Both weight gradients of one 32 x 32 tile of [O, I]: D[m = o][n = i] = sum_b A[o][b] B[b][i].
+__global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_w_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_rho, const float* __restrict__ g,
+    const float* __restrict__ gvar, int B, int I, int O, float* __restrict__ g_wmu, float* __restrict__ g_wrho) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i_tiles = (I + 31) >> 5, o_tiles = (O + 31) >> 5;
+  const int unit = blockIdx.x * kLrtBwdWaves + wave;
+  if (unit >= i_tiles * o_tiles) return;
+  const int ot = unit / i_tiles, it = unit % i_tiles;              // neighbouring waves: neighbouring column tiles
+  const int r = lane & 31, h = lane >> 5;
+  const int o = ot * 32 + r, i = it * 32 + r;
+  const bool o_ok = o < O, i_ok = i < I;
+  const int oc = o_ok ? o : O - 1, ic = i_ok ? i : I - 1;         // clamped: every load is unconditional
+  // the rho rows of the epilogue (C layout: lane = column i, rows o = ot*32 + (reg & 3) + 8 (reg >> 2) + 4 h) are
+  // requested first and arrive while the products run
+  float rho[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int oo = min(ot * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, O - 1);
+    rho[reg] = w_rho[static_cast<int64_t>(oo) * I + ic];
+  }
+  constexpr int U = 8;                                             // k-steps (of 2 batch rows) per operand set
+  struct Operands {
+    float ag[U], av[U], xv[U];
+  };
+  auto load = [&](Operands& q, int s0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int bc = min(2 * (s0 + u) + h, B - 1);
+      q.ag[u] = g[static_cast<int64_t>(bc) * O + oc];
+      q.av[u] = gvar[static_cast<int64_t>(bc) * O + oc];
+      q.xv[u] = x[static_cast<int64_t>(bc) * ldx + ic];
+    }
+  };
+  f32x16 accm = {}, accv = {};
+  const int steps = (B + 1) >> 1;
+  Operands cur, nxt;
+  load(cur, 0);
+  for (int s0 = 0; s0 < steps; s0 += U) {
+    if (s0 + U < steps) load(nxt, s0 + U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool b_ok = 2 * (s0 + u) + h < B;                      // rows past B: clamped loads, zero operands
+      const float xv = cur.xv[u];
+      const float bx = (b_ok && i_ok) ? xv : 0.f, bx2 = (b_ok && i_ok) ? fmaxf(xv * xv, kLrtBwdClamp) : 0.f;
+      accm = __builtin_amdgcn_mfma_f32_32x32x2f32(o_ok ? cur.ag[u] : 0.f, bx, accm, 0, 0, 0);
+      accv = __builtin_amdgcn_mfma_f32_32x32x2f32(o_ok ? cur.av[u] : 0.f, bx2, accv, 0, 0, 0);
+    }
+    cur = nxt;
+  }
+  if (!i_ok) return;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int oo = ot * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (oo < O) {
+      const int64_t idx = static_cast<int64_t>(oo) * I + i;
+      const SoftplusSigmoid sp = softplus_sigmoid(rho[reg]);
+      const float keep = sp.sp * sp.sp >= kLrtBwdClamp ? 1.f : 0.f;
+      g_wmu[idx] = accm[reg];
+      g_wrho[idx] = accv[reg] * keep * (2.0f * sp.sp * sp.sg);
+    }
+  }
+}
+
+// Input gradient of (NB batch tiles, 32 input columns) over one O-slice: D[m = b][n = i] = sum_o A[b][o] B[o][i], A
+// from the transposed copies (lanes along b: one 128-byte segment per k), B = rows of W_mu / clamp(sigma_W^2)
+// (lanes along i).  Register double buffering: the loads of the next 4 k-steps are issued before the softplus / MFMA
+// work of the current ones.  DIRECT: the slice is all of O and the epilogue writes g_x; otherwise the two partial
+// tiles go to the workspace.
+template <int NB, bool DIRECT>
+__global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_x_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_mu, const float* __restrict__ w_rho,
+    const float* __restrict__ gT, const float* __restrict__ gvT, int B, int I, int O, int n_slices, int oslice,
+    float* __restrict__ g_x, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i_tiles = (I + 31) >> 5;
+  const int unit = blockIdx.x * kLrtBwdWaves + wave;
+  if (unit >= i_tiles * n_slices) return;
+  const int sl = unit / i_tiles, it = unit % i_tiles;
+  const int r = lane & 31, h = lane >> 5;
+  const int i = it * 32 + r;
+  const bool i_ok = i < I;
+  const int ic = i_ok ? i : I - 1;
+  const int o0 = sl * oslice, o1 = min(O, o0 + oslice);
+  constexpr int b_pad = NB * 32;
+  constexpr int U = 4;
+  struct Operands {
+    float wm[U], wr[U], ag[U][NB], av[U][NB];
+  };
+  auto load = [&](Operands& q, int ob0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int oc = min(ob0 + 2 * u + h, o1 - 1);
+      q.wm[u] = w_mu[static_cast<int64_t>(oc) * I + ic];
+      q.wr[u] = w_rho[static_cast<int64_t>(oc) * I + ic];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        q.ag[u][t] = gT[static_cast<int64_t>(oc) * b_pad + t * 32 + r];
+        q.av[u][t] = gvT[static_cast<int64_t>(oc) * b_pad + t * 32 + r];
+      }
+    }
+  };
+  f32x16 accm[NB], accv[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) accm[t] = accv[t] = f32x16{};
+  Operands cur, nxt;
+  load(cur, o0);
+  for (int ob0 = o0; ob0 < o1; ob0 += 2 * U) {
+    if (ob0 + 2 * U < o1) load(nxt, ob0 + 2 * U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool w_ok = (ob0 + 2 * u + h < o1) && i_ok;           // rows past the slice / columns past I add zeros
+      const float sg = softplus(cur.wr[u]);
+      const float bm = w_ok ? cur.wm[u] : 0.f, bv = w_ok ? fmaxf(sg * sg, kLrtBwdClamp) : 0.f;
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        accm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.ag[u][t], bm, accm[t], 0, 0, 0);
+        accv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.av[u][t], bv, accv[t], 0, 0, 0);
+      }
+    }
+    cur = nxt;
+  }
+  if (!i_ok) return;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int b = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (DIRECT) {
+        if (b < B) {
+          const float xv = x[static_cast<int64_t>(b) * ldx + i];
+          const float keep = xv * xv >= kLrtBwdClamp ? 1.f : 0.f;
+          g_x[static_cast<int64_t>(b) * I + i] = accm[t][reg] + accv[t][reg] * keep * (2.0f * xv);
+        }
+      } else {
+        float* base = part + static_cast<int64_t>(sl) * 2 * b_pad * I;
+        base[static_cast<int64_t>(b) * I + i] = accm[t][reg];
+        base[static_cast<int64_t>(b_pad + b) * I + i] = accv[t][reg];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void lrt_bwd_x_finish_kernel(const float* __restrict__ part, int n_slices, int b_pad,
+                                                                 const float* __restrict__ x, int64_t ldx,
+                                                                 float* __restrict__ g_x, int B, int I) {
+  const int64_t n = static_cast<int64_t>(B) * I;
+  const int64_t slice_stride = static_cast<int64_t>(2) * b_pad * I;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int b = static_cast<int>(e / I), i = static_cast<int>(e % I);
+    const float* pm = part + static_cast<int64_t>(b) * I + i;
+    const float* pv = part + static_cast<int64_t>(b_pad + b) * I + i;
+    float m = 0.f, v = 0.f;
+    for (int s = 0; s < n_slices; ++s) {                          // fixed order
+      m += pm[s * slice_stride];
+      v += pv[s * slice_stride];
+    }
+    const float xv = x[static_cast<int64_t>(b) * ldx + i];
+    const float keep = xv * xv >= kLrtBwdClamp ? 1.f : 0.f;
+    g_x[e] = m + v * keep * (2.0f * xv);
+  }
+}
+
+}  // namespace bde
+
+using namespace bde;
+
+// Split of the reduction over O in the input-gradient kernel: none for layers with few outputs (one launch less),
+// otherwise enough (column tile, O-slice) waves to fill the chip; every slice costs a [2, b_pad, I] partial.
+struct LrtBwdPlan {
+  int n_slices, oslice;
+};
+#ifndef BDE_LRT_BWD_TARGET_WAVES
+#define BDE_LRT_BWD_TARGET_WAVES 2048
+#endif
+static inline LrtBwdPlan lrt_bwd_plan(int I, int O) {
+  if (O <= 256) return LrtBwdPlan{1, O};
+  const int i_tiles = (I + 31) / 32;
+  int want = (BDE_LRT_BWD_TARGET_WAVES + i_tiles - 1) / i_tiles;
+  const int most = (O + 63) / 64;
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  const int oslice = ((O + want - 1) / want + 7) / 8 * 8;
+  return LrtBwdPlan{(O + oslice - 1) / oslice, oslice};
+}
+static inline int lrt_bwd_nb(int B) {
+  const int nbt = (B + 31) / 32;
+  return nbt == 3 ? 4 : nbt;
+}
+static inline size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
+
+// workspace: gvar [B, O] | gT [O, b_pad] | gvarT [O, b_pad] | input-gradient partials [n_slices, 2, b_pad, I]
+extern "C" size_t bde_lrt_linear_bwd_ws_bytes(int B, int I, int O) {
+  if (!bde_lrt_linear_supported(B, I, O)) return 0;
+  const LrtBwdPlan plan = lrt_bwd_plan(I, O);
+  const size_t b_pad = static_cast<size_t>(lrt_bwd_nb(B)) * 32;
+  size_t floats = pad64(static_cast<size_t>(B) * O) + 2 * pad64(static_cast<size_t>(O) * b_pad);
+  if (plan.n_slices > 1) floats += static_cast<size_t>(plan.n_slices) * 2 * b_pad * I;
+  return sizeof(float) * floats;
+}
+
+extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho,
+                                  const float* b_rho, int clamp_bias_var, const float* g, const float* var,
+                                  const float* eps, uint64_t seed, uint64_t stream_id, float* g_x, float* g_wmu,
+                                  float* g_wrho, float* g_bmu, float* g_brho, int B, int I, int O, void* ws,
+                                  void* stream) {
+  if (!x || !w_mu || !w_rho || !g || !var || !g_wmu || !g_wrho || !ws || !bde_lrt_linear_supported(B, I, O) || ldx < I)
+    return BDE_ERR_INVALID;
+  if ((b_rho == nullptr) != (g_bmu == nullptr) || (g_bmu == nullptr) != (g_brho == nullptr)) return BDE_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nb = lrt_bwd_nb(B), b_pad = nb * 32;
+  float* gvar = static_cast<float*>(ws);
+  float* gT = gvar + pad64(static_cast<size_t>(B) * O);
+  float* gvT = gT + pad64(static_cast<size_t>(O) * b_pad);
+  float* part = gvT + pad64(static_cast<size_t>(O) * b_pad);
+  const int pgrid = (O + kPrepCols - 1) / kPrepCols;
+  float* gT_arg = g_x ? gT : nullptr;                                // no input gradient wanted: no transposed copies
+  if (eps)
+    hipLaunchKernelGGL(lrt_bwd_prep_kernel<false>, dim3(pgrid), dim3(kPrepCols * kPrepRows), 0, s, g, var, eps, seed,
+                       stream_id, b_rho, clamp_bias_var, gvar, gT_arg, gvT, g_bmu, g_brho, B, b_pad, O);
+  else
+    hipLaunchKernelGGL(lrt_bwd_prep_kernel<true>, dim3(pgrid), dim3(kPrepCols * kPrepRows), 0, s, g, var, eps, seed,
+                       stream_id, b_rho, clamp_bias_var, gvar, gT_arg, gvT, g_bmu, g_brho, B, b_pad, O);
+  int rc = to_err(hipGetLastError());
+  if (rc) return rc;
+  const int i_tiles = (I + 31) / 32, o_tiles = (O + 31) / 32;
+  const int64_t w_units = static_cast<int64_t>(i_tiles) * o_tiles;
+  hipLaunchKernelGGL(lrt_bwd_w_kernel, dim3(static_cast<unsigned>((w_units + kLrtBwdWaves - 1) / kLrtBwdWaves)),
+                     dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_rho, g, gvar, B, I, O, g_wmu, g_wrho);
+  rc = to_err(hipGetLastError());
+  if (rc || !g_x) return rc;
+  const LrtBwdPlan plan = lrt_bwd_plan(I, O);
+  const int x_units = i_tiles * plan.n_slices;
+  const int xgrid = (x_units + kLrtBwdWaves - 1) / kLrtBwdWaves;
+#define BDE_LRT_X(NB, DIRECT) \
+  hipLaunchKernelGGL((lrt_bwd_x_kernel<NB, DIRECT>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu, w_rho, gT, \
+                     gvT, B, I, O, plan.n_slices, plan.oslice, g_x, part)
+  if (plan.n_slices == 1) {
+    if (nb == 1) BDE_LRT_X(1, true); else if (nb == 2) BDE_LRT_X(2, true); else BDE_LRT_X(4, true);
+  } else {
+    if (nb == 1) BDE_LRT_X(1, false); else if (nb == 2) BDE_LRT_X(2, false); else BDE_LRT_X(4, false);
+  }
+#undef BDE_LRT_X
+  rc = to_err(hipGetLastError());
+  if (rc || plan.n_slices == 1) return rc;
+  hipLaunchKernelGGL(lrt_bwd_x_finish_kernel, dim3(stream_grid(static_cast<int64_t>(B) * I)), dim3(kBlock), 0, s, part,
+                     plan.n_slices, b_pad, x, ldx, g_x, B, I);
+  return to_err(hipGetLastError());
+}

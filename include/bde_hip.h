@@ -288,6 +288,22 @@ int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const flo
                        const float* b_rho, int clamp_bias_var, const float* eps, uint64_t seed, uint64_t stream_id,
                        float* out, float* var_out, int B, int I, int O, void* ws, void* stream);
 
+/* Backward of bde_lrt_linear_fwd: the autograd graph of bbb_layers.py:61-80 in three launches (four when the layer
+ * is large enough for the reduction over O to be split).  With g = d loss / d out [B, O] and
+ * gvar = g * eps / (2 sqrt(var)) (var = the var_out of the forward call; eps as supplied there, or NULL to regenerate
+ * the forward's Philox noise from (seed, stream_id)):
+ *   g_x    [B, I] = g W_mu + (gvar clamp(sigma_W^2)) * 2 x * [x^2 >= 1e-4]           (NULL: not computed)
+ *   g_wmu  [O, I] = g^T x
+ *   g_wrho [O, I] = (gvar^T clamp(x^2)) * [sigma_W^2 >= 1e-4] * 2 sigma_W sigmoid(rho_W)
+ *   g_bmu  [O]    = sum_b g,     g_brho [O] = (sum_b gvar) * [clamp_bias_var ? sigma_b^2 >= 1e-4 : 1] * 2 sigma_b sigmoid(rho_b)
+ * (b_rho, g_bmu, g_brho all NULL for a bias-free layer).  Every output is OVERWRITTEN (autograd accumulates).
+ * Reductions are MFMA tiles and fixed-order sums: bit-reproducible.  ws: bde_lrt_linear_bwd_ws_bytes(B, I, O). */
+size_t bde_lrt_linear_bwd_ws_bytes(int B, int I, int O);
+int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* b_rho,
+                       int clamp_bias_var, const float* g, const float* var, const float* eps, uint64_t seed,
+                       uint64_t stream_id, float* g_x, float* g_wmu, float* g_wrho, float* g_bmu, float* g_brho,
+                       int B, int I, int O, void* ws, void* stream);
+
 /* ------------------------------------------------------------------ iVON --
  * src/algos/ivorn.py:102-115 (weight-noise draw) and :66-89 (update). */
 

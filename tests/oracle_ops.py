@@ -270,6 +270,34 @@ class OracleOps:
             var_out.copy_(var)
         out.copy_(mean + torch.sqrt(var) * eps)
 
+    def lrt_linear_bwd(self, x, w_mu, w_rho, b_rho, clamp_bias_var, g, var, g_x, g_wmu, g_wrho, g_bmu, g_brho, eps=None,
+                       seed=0, stream_id=0):
+        # torch autograd over the forward lines (bbb_layers.py:70-80)
+        if eps is None:
+            eps = _philox(seed, stream_id, g.numel()).view(g.shape)
+        with torch.enable_grad():
+            leaves = [t.detach().clone().requires_grad_(True) for t in (x, w_mu, w_rho)]
+            xb, wm, wr = leaves
+            br = None if b_rho is None else b_rho.detach().clone().requires_grad_(True)
+            bm = None if b_rho is None else torch.zeros_like(b_rho, requires_grad=True)
+            vb = None
+            if br is not None:
+                vb = torch.nn.functional.softplus(br) ** 2
+                if clamp_bias_var:
+                    vb = vb.clamp(min=1e-4)
+            mean = torch.nn.functional.linear(xb, wm, bm)
+            v = torch.nn.functional.linear((xb ** 2).clamp(min=1e-4), (torch.nn.functional.softplus(wr) ** 2).clamp(min=1e-4), vb)
+            out = mean + torch.sqrt(v) * eps
+            wanted = leaves + ([bm, br] if br is not None else [])
+            grads = torch.autograd.grad(out, wanted, grad_outputs=g)
+        if g_x is not None:
+            g_x.copy_(grads[0])
+        g_wmu.copy_(grads[1])
+        g_wrho.copy_(grads[2])
+        if br is not None:
+            g_bmu.copy_(grads[3])
+            g_brho.copy_(grads[4])
+
     # ------------------------------------------------------------ iVON --
     def ivon_sample(self, mean, prec, param, delta_sum, n, n_eff, first, eps=None, seed=0, stream_id=0,
                     deterministic=False):

@@ -829,3 +829,73 @@ def test_lrt_linear_forward(ops):
         ops.lrt_linear_fwd(wide[:, :i], dev(w_mu), dev(w_rho), dev(b_mu), dev(b_rho), True, out2, None, eps=dev(eps))
         assert (out2 - out).abs().max().item() <= tol_o
     assert not ops.lrt_linear_supported(129, 10, 10) and ops.lrt_linear_supported(128, 10, 10)
+
+
+def test_lrt_linear_backward(ops):
+    """bde_lrt_linear_bwd (the autograd graph of bbb_layers.py:61-80 in three or four launches) against fp64 autograd
+    over those lines; the allowance is twice the deviation of fp32 autograd over the same lines (CPU)."""
+    import torch.nn.functional as F
+    from oracle import philox as PH
+    torch.manual_seed(22)
+    dev = lambda t: None if t is None else t.to(DEV)
+    for b, i, o, bias, clamp_bias in [(16, 13, 50, True, True), (5, 50, 1, True, True), (16, 2048, 182, True, True),
+                                      (128, 300, 70, False, True), (33, 64, 32, True, False), (1, 7, 3, True, True),
+                                      (96, 1000, 200, True, True), (64, 2100, 520, True, True), (70, 129, 33, True, True)]:
+        x = torch.randn(b, i)
+        x[0, : min(i, 3)] = 0.0                                       # x^2 below the clamp: no gradient through it
+        w_mu, w_rho = torch.randn(o, i) * 0.1, torch.randn(o, i) * 1.5 - 3.0
+        w_rho[0, : min(i, 4)] = -8.0                                   # sigma^2 below the clamp
+        b_rho = torch.randn(o) - 3.0 if bias else None
+        if bias:
+            b_rho[0] = -8.0
+        eps, g = torch.randn(b, o), torch.randn(b, o)
+
+        def ref(dt):
+            leaves = [t.to(dt).requires_grad_(True) for t in (x, w_mu, w_rho)]
+            xx, wm, wr = leaves
+            bm = br = vb = None
+            if bias:
+                bm, br = torch.zeros(o, dtype=dt, requires_grad=True), b_rho.to(dt).requires_grad_(True)
+                vb = F.softplus(br) ** 2
+                if clamp_bias:
+                    vb = vb.clamp(min=1e-4)
+                leaves += [bm, br]
+            var = F.linear((xx ** 2).clamp(min=1e-4), (F.softplus(wr) ** 2).clamp(min=1e-4), vb)
+            out = F.linear(xx, wm, bm) + var.sqrt() * eps.to(dt)
+            return var.detach(), [t.double() for t in torch.autograd.grad(out, leaves, grad_outputs=g.to(dt))]
+        v64, g64 = ref(torch.float64)
+        v32, g32 = ref(torch.float32)
+        var = dev(v32)
+        outs = [torch.full((b, i), float("nan"), device=DEV), torch.full((o, i), float("nan"), device=DEV),
+                torch.full((o, i), float("nan"), device=DEV)]
+        outs += [torch.full((o,), float("nan"), device=DEV), torch.full((o,), float("nan"), device=DEV)] if bias else [None, None]
+        ops.lrt_linear_bwd(dev(x), dev(w_mu), dev(w_rho), dev(b_rho), clamp_bias, dev(g), var, *outs, eps=dev(eps))
+        names = ["g_x", "g_wmu", "g_wrho", "g_bmu", "g_brho"]
+        for name, ours, r64, r32 in zip(names, outs, g64, g32):
+            tol = max(2 * (r32 - r64).abs().max().item(), 3e-6 * r64.abs().max().item())
+            assert (ours.cpu().double() - r64).abs().max().item() <= tol, (name, b, i, o)
+        # the clamp masks: exactly zero where the reference's clamp blocks the gradient
+        assert (outs[2][0, : min(i, 4)] == 0).all()
+        if bias and clamp_bias:
+            assert outs[4][0].item() == 0.0
+        # bit-reproducible; g_x optional; in-kernel noise = the Philox stream the forward used
+        again = [torch.empty_like(t) if t is not None else None for t in outs]
+        ops.lrt_linear_bwd(dev(x), dev(w_mu), dev(w_rho), dev(b_rho), clamp_bias, dev(g), var, *again, eps=dev(eps))
+        assert all(a is None or torch.equal(a, t) for a, t in zip(again, outs))
+        again[0] = None
+        ops.lrt_linear_bwd(dev(x), dev(w_mu), dev(w_rho), dev(b_rho), clamp_bias, dev(g), var, *again, eps=dev(eps))
+        assert torch.equal(again[1], outs[1]) and torch.equal(again[2], outs[2])
+        z = torch.from_numpy(PH.normals(9, 4, b * o)).view(b, o).float()
+        with_z = [torch.empty_like(t) if t is not None else None for t in outs]
+        ops.lrt_linear_bwd(dev(x), dev(w_mu), dev(w_rho), dev(b_rho), clamp_bias, dev(g), var, *with_z, eps=dev(z))
+        philox = [torch.empty_like(t) if t is not None else None for t in outs]
+        ops.lrt_linear_bwd(dev(x), dev(w_mu), dev(w_rho), dev(b_rho), clamp_bias, dev(g), var, *philox, seed=9, stream_id=4)
+        for name, a, c in zip(names, philox, with_z):
+            if a is not None:
+                assert (a - c).abs().max().item() <= 2e-5 * max(c.abs().max().item(), 1e-6), name
+        # strided input rows
+        wide = torch.randn(b, i + 5, device=DEV)
+        wide[:, :i] = dev(x)
+        strided = [torch.empty_like(t) if t is not None else None for t in outs]
+        ops.lrt_linear_bwd(wide[:, :i], dev(w_mu), dev(w_rho), dev(b_rho), clamp_bias, dev(g), var, *strided, eps=dev(eps))
+        assert all(a is None or torch.equal(a, t) for a, t in zip(strided, outs))
