@@ -14,11 +14,12 @@
 //                        exponential, bde_common.hpp) and feeds TWO accumulator tiles on the f32 MFMA
 //                        (v_mfma_f32_32x32x2_f32): mean += x W_mu^T and var += clamp(x^2) clamp(sigma^2)^T, for up to
 //                        4 batch tiles of 32 rows held in registers; split-K partials go to a workspace
+//   lrt_wide_kernel      the same products for wide layers (O*I >= 2^20): coalesced loads staged through per-wave LDS
+//                        tiles, four K-quarters per workgroup summed in LDS (see the comment at the kernel)
 //   lrt_finish_kernel    fixed-order sum of the K-slices (bit-reproducible, no atomics), bias terms, sqrt, noise
 //                        (caller-supplied or in-kernel Philox), writes out and the variance the backward needs
 //
-// HBM traffic 8*O*I (weights, once) + O(B*(I + O)) instead of ~32*O*I.  The backward pass stays with PyTorch
-// (bbb_layers.py's autograd graph, restated by the caller from the saved variance and noise).
+// HBM traffic 8*O*I (weights, once) + O(B*(I + O)) instead of ~32*O*I.  The backward pass is lrt_bwd.hip.
 #include "bde_common.hpp"
 
 namespace bde {
@@ -117,6 +118,126 @@ __global__ __launch_bounds__(kLrtWavesPerWG * 64) void lrt_partial_kernel(
   }
 }
 
+// Wide layers (I % 4 == 0, O * I >= 2^20): the row-per-lane loads of lrt_partial_kernel touch 32 cache lines per
+// instruction and use 16 bytes of each (89 us for 2 x 67 MB at B = 64; this kernel: 71 us, of which the 16.7 M
+// softplus evaluations are ~25 us of VALU time and the fp32 MFMA products ~27 us -- the layer is co-bound, not HBM-bound).
+// Here one workgroup = 4 waves owns (32-output tile, K-group); wave w streams its quarter of the group in chunks of
+// 32 columns with COALESCED float4 loads (8 lanes cover 128 bytes of a row, 8 rows per instruction), forms sigma^2
+// in that layout, parks the chunk in its private LDS tiles (row stride 36 floats: 16-byte aligned, conflict-free
+// b128 reads in the MFMA layout) and reads the MFMA operands back from there; the next chunk's global loads are in
+// flight while the current chunk's 16 * NB MFMAs run.  No barrier inside the loop (the tiles are per wave); at the
+// end the four accumulator sets are summed through LDS in wave order (fixed order, bit-reproducible) and ONE partial
+// per (tile, group) goes to the workspace: 4 x fewer partial bytes than one partial per wave.
+constexpr int kWideChunk = 32, kWideLd = 36, kWideSub = 4;
+
+template <int NB>
+__global__ __launch_bounds__(kWideSub * 64) void lrt_wide_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_mu, const float* __restrict__ w_rho, int B,
+    int I, int O, int n_groups, int kgroup, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int kTileFloats = (64 + NB * 32) * kWideLd;            // W_mu, sigma^2 and NB x tiles of 32 rows
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ot = blockIdx.x / n_groups, gp = blockIdx.x % n_groups;
+  const int ksub = kgroup / kWideSub;                               // host: kgroup % (4 * 32) == 0
+  const int k0 = min(I, gp * kgroup + wave * ksub), k1 = min(I, k0 + ksub);
+  float* Wm = lds + wave * kTileFloats;
+  float* S2 = Wm + 32 * kWideLd;
+  float* X = S2 + 32 * kWideLd;
+  const int lr = lane >> 3, lc = 4 * (lane & 7);                   // coalesced layout: row 8 j + lr, columns lc .. lc+3
+  const int r = lane & 31, h = lane >> 5;                          // MFMA layout
+
+  struct Stage {
+    f32x4 wm[4], wr[4], xs[NB * 4];
+  };
+  auto gload = [&](Stage& q, int kc) {
+    const int col = (kc + lc < k1) ? kc + lc : k0;                 // past the slice: any valid address, masked at the stash
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = min(ot * 32 + 8 * j + lr, O - 1);
+      q.wm[j] = ld4(w_mu + static_cast<int64_t>(row) * I + col);
+      q.wr[j] = ld4(w_rho + static_cast<int64_t>(row) * I + col);
+    }
+#pragma unroll
+    for (int j = 0; j < NB * 4; ++j) q.xs[j] = ld4(x + static_cast<int64_t>(min(8 * j + lr, B - 1)) * ldx + col);
+  };
+  auto stash = [&](const Stage& q, int kc) {
+    const bool c_ok = kc + lc < k1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = c_ok && (ot * 32 + 8 * j + lr < O);          // padding rows / columns of W contribute nothing
+      f32x4 m, v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float sp = softplus(q.wr[j][c]);
+        m[c] = ok ? q.wm[j][c] : 0.f;
+        v[c] = ok ? fmaxf(sp * sp, kLrtClamp) : 0.f;               // clamp(softplus(rho)^2, 1e-4)
+      }
+      *reinterpret_cast<f32x4*>(Wm + (8 * j + lr) * kWideLd + lc) = m;
+      *reinterpret_cast<f32x4*>(S2 + (8 * j + lr) * kWideLd + lc) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NB * 4; ++j) *reinterpret_cast<f32x4*>(X + (8 * j + lr) * kWideLd + lc) = q.xs[j];
+  };
+
+  f32x16 accm[NB], accv[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) accm[t] = accv[t] = f32x16{};
+  auto products = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bm = *reinterpret_cast<const f32x4*>(Wm + r * kWideLd + 8 * q + 4 * h);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(S2 + r * kWideLd + 8 * q + 4 * h);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(X + (t * 32 + r) * kWideLd + 8 * q + 4 * h);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          accm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], bm[c], accm[t], 0, 0, 0);
+          accv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(a[c] * a[c], kLrtClamp), bv[c], accv[t], 0, 0, 0);
+        }
+      }
+    }
+  };
+  Stage st;
+  if (k0 < k1) gload(st, k0);
+  for (int kc = k0; kc < k1; kc += kWideChunk) {
+    stash(st, kc);
+    if (kc + kWideChunk < k1) gload(st, kc + kWideChunk);
+    products();
+  }
+  // the four K-quarters of this group, summed in wave order
+  __syncthreads();
+  float* red = lds;                                                // [3][2 * NB * 16][64]
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        red[((wave - 1) * (2 * NB * 16) + (2 * t) * 16 + reg) * 64 + lane] = accm[t][reg];
+        red[((wave - 1) * (2 * NB * 16) + (2 * t + 1) * 16 + reg) * 64 + lane] = accv[t][reg];
+      }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const int o_tiles = (O + 31) >> 5, o_pad = o_tiles * 32, b_pad = NB * 32;
+  float* base = ws + static_cast<int64_t>(gp) * 2 * b_pad * o_pad;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      float m = accm[t][reg], v = accv[t][reg];
+#pragma unroll
+      for (int w = 0; w < kWideSub - 1; ++w) {
+        m += red[(w * (2 * NB * 16) + (2 * t) * 16 + reg) * 64 + lane];
+        v += red[(w * (2 * NB * 16) + (2 * t + 1) * 16 + reg) * 64 + lane];
+      }
+      const int b = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;   // C[b][o]: lane holds column o = lane & 31
+      base[static_cast<int64_t>(b) * o_pad + ot * 32 + r] = m;
+      base[static_cast<int64_t>(b_pad + b) * o_pad + ot * 32 + r] = v;
+    }
+  }
+}
+
 template <bool RNG>
 __global__ __launch_bounds__(kBlock) void lrt_finish_kernel(const float* __restrict__ ws, int n_slices, int b_pad,
                                                            int o_pad, const float* __restrict__ b_mu,
@@ -168,6 +289,43 @@ static inline LrtPlan lrt_plan(int I, int O) {
   return LrtPlan{(I + kslice - 1) / kslice, kslice};
 }
 
+// Wide path: (o-tile, K-group) workgroups, about two per CU; groups are multiples of 128 columns (4 waves x 32).
+#ifndef BDE_LRT_WIDE_TARGET_WGS
+#define BDE_LRT_WIDE_TARGET_WGS 512
+#endif
+#ifndef BDE_LRT_WIDE
+#define BDE_LRT_WIDE 1
+#endif
+struct LrtWidePlan {
+  int n_groups, kgroup;
+};
+static inline bool lrt_wide_shape(int I, int O) {
+  return BDE_LRT_WIDE && I % 4 == 0 && I >= 512 && static_cast<int64_t>(I) * O >= (int64_t{1} << 20);
+}
+static inline LrtWidePlan lrt_wide_plan(int I, int O) {
+  const int o_tiles = (O + 31) / 32;
+  int want = (BDE_LRT_WIDE_TARGET_WGS + o_tiles / 2) / o_tiles;
+  const int unit = kWideSub * kWideChunk;
+  const int most = (I + unit - 1) / unit;
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  const int kgroup = ((I + want - 1) / want + unit - 1) / unit * unit;
+  return LrtWidePlan{(I + kgroup - 1) / kgroup, kgroup};
+}
+template <int NB>
+static int lrt_wide_launch(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, int B, int I, int O,
+                           const LrtWidePlan& plan, float* ws, hipStream_t s) {
+  constexpr int tile_bytes = kWideSub * (64 + NB * 32) * kWideLd * 4, red_bytes = 3 * 2 * NB * 16 * 64 * 4;
+  constexpr int lds_bytes = tile_bytes > red_bytes ? tile_bytes : red_bytes;
+  static int attr_rc = to_err(hipFuncSetAttribute(reinterpret_cast<const void*>(&lrt_wide_kernel<NB>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  if (attr_rc) return attr_rc;
+  const int o_tiles = (O + 31) / 32;
+  hipLaunchKernelGGL((lrt_wide_kernel<NB>), dim3(o_tiles * plan.n_groups), dim3(kWideSub * 64), lds_bytes, s, x, ldx,
+                     w_mu, w_rho, B, I, O, plan.n_groups, plan.kgroup, ws);
+  return to_err(hipGetLastError());
+}
+
 extern "C" int bde_lrt_linear_supported(int B, int I, int O) {
   return B >= 1 && B <= 128 && I >= 1 && O >= 1 && static_cast<int64_t>(I) * O <= (int64_t{1} << 31);
 }
@@ -176,7 +334,9 @@ extern "C" size_t bde_lrt_linear_ws_bytes(int B, int I, int O) {
   if (!bde_lrt_linear_supported(B, I, O)) return 0;
   const int nb = (B + 31) / 32 == 3 ? 4 : (B + 31) / 32;
   const size_t o_pad = static_cast<size_t>((O + 31) / 32) * 32, b_pad = static_cast<size_t>(nb) * 32;
-  return sizeof(float) * static_cast<size_t>(lrt_plan(I, O).n_slices) * 2 * b_pad * o_pad;
+  int slices = lrt_plan(I, O).n_slices;
+  if (lrt_wide_shape(I, O)) slices = std::max(slices, lrt_wide_plan(I, O).n_groups);
+  return sizeof(float) * static_cast<size_t>(slices) * 2 * b_pad * o_pad;
 }
 
 extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* b_mu,
@@ -187,21 +347,34 @@ extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu
   if ((b_mu == nullptr) != (b_rho == nullptr)) return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const LrtPlan plan = lrt_plan(I, O);
-  const int n_slices = plan.n_slices, o_tiles = (O + 31) / 32;
+  int n_slices = plan.n_slices;
+  const int o_tiles = (O + 31) / 32;
   const int nbt = (B + 31) / 32;
   const int nb = nbt == 3 ? 4 : nbt;
   const bool aligned = (I % 4 == 0) && (ldx % 4 == 0) && aligned16(x) && aligned16(w_mu) && aligned16(w_rho);
-  const int units = o_tiles * n_slices;
-  const int grid = (units + kLrtWavesPerWG - 1) / kLrtWavesPerWG;
   float* wsf = static_cast<float*>(ws);
-#define BDE_LRT(NB, AL) \
-  hipLaunchKernelGGL((lrt_partial_kernel<NB, AL>), dim3(grid), dim3(kLrtWavesPerWG * 64), 0, s, x, ldx, w_mu, w_rho, B, I, O, n_slices, plan.kslice, wsf)
-  if (nb == 1) { if (aligned) BDE_LRT(1, true); else BDE_LRT(1, false); }
-  else if (nb == 2) { if (aligned) BDE_LRT(2, true); else BDE_LRT(2, false); }
-  else { if (aligned) BDE_LRT(4, true); else BDE_LRT(4, false); }
+  const bool wide = aligned && lrt_wide_shape(I, O);
+  int rc = 0;
+  if (wide) {
+    const LrtWidePlan wp = lrt_wide_plan(I, O);
+    n_slices = wp.n_groups;
+    rc = nb == 1 ? lrt_wide_launch<1>(x, ldx, w_mu, w_rho, B, I, O, wp, wsf, s)
+                 : nb == 2 ? lrt_wide_launch<2>(x, ldx, w_mu, w_rho, B, I, O, wp, wsf, s)
+                           : lrt_wide_launch<4>(x, ldx, w_mu, w_rho, B, I, O, wp, wsf, s);
+    if (rc) return rc;
+  } else {
+    const int units = o_tiles * n_slices;
+    const int grid = (units + kLrtWavesPerWG - 1) / kLrtWavesPerWG;
+#define BDE_LRT(NB, AL)                                                                                              \
+  hipLaunchKernelGGL((lrt_partial_kernel<NB, AL>), dim3(grid), dim3(kLrtWavesPerWG * 64), 0, s, x, ldx, w_mu, w_rho, B, \
+                     I, O, n_slices, plan.kslice, wsf)
+    if (nb == 1) { if (aligned) BDE_LRT(1, true); else BDE_LRT(1, false); }
+    else if (nb == 2) { if (aligned) BDE_LRT(2, true); else BDE_LRT(2, false); }
+    else { if (aligned) BDE_LRT(4, true); else BDE_LRT(4, false); }
 #undef BDE_LRT
-  int rc = to_err(hipGetLastError());
-  if (rc) return rc;
+    rc = to_err(hipGetLastError());
+    if (rc) return rc;
+  }
   const int fgrid = stream_grid(static_cast<int64_t>(B) * O);
   const int o_pad = o_tiles * 32, b_pad = nb * 32;
   if (eps)

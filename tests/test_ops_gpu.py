@@ -791,7 +791,8 @@ def test_lrt_linear_forward(ops):
     torch.manual_seed(21)
     from oracle import philox as PH
     for b, i, o, bias in [(16, 13, 50, True), (5, 50, 1, True), (16, 2048, 182, True), (128, 300, 70, False),
-                          (33, 64, 32, True), (1, 7, 3, True), (96, 1000, 200, True), (64, 4096, 512, False), (70, 129, 33, True)]:
+                          (33, 64, 32, True), (1, 7, 3, True), (96, 1000, 200, True), (64, 4096, 512, False), (70, 129, 33, True),
+                          (96, 1000, 1200, True), (20, 640, 2000, True), (128, 2048, 700, True)]:   # the last four: wide path
         x = torch.randn(b, i)
         x[0, : min(i, 3)] = 0.0                                       # exercises the clamp on x^2
         w_mu, w_rho = torch.randn(o, i) * 0.1, torch.randn(o, i) * 1.5 - 3.0
