@@ -27,6 +27,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr float kLrtBwdClamp = 1e-4f;   // bbb_layers.py:66-67,71
 constexpr int kLrtBwdWaves = 4;         // waves per workgroup (independent units)
+#ifndef BDE_LRT_BWD_WU
+#define BDE_LRT_BWD_WU 8
+#endif
+#ifndef BDE_LRT_BWD_XU
+#define BDE_LRT_BWD_XU 4
+#endif
 constexpr int kPrepCols = 32, kPrepRows = 8, kPrepMaxB = 128;
 
 // gvar [B, O] (for the weight-gradient kernel: lanes along o), the transposed copies gT / gvarT [O, b_pad] (for the
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_w_kernel(
     const int oo = min(ot * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, O - 1);
     rho[reg] = w_rho[static_cast<int64_t>(oo) * I + ic];
   }
-  constexpr int U = 8;                                             // k-steps (of 2 batch rows) per operand set
+  constexpr int U = BDE_LRT_BWD_WU;                                // k-steps (of 2 batch rows) per operand set
   struct Operands {
     float ag[U], av[U], xv[U];
   };
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_x_kernel(
   const int ic = i_ok ? i : I - 1;
   const int o0 = sl * oslice, o1 = min(O, o0 + oslice);
   constexpr int b_pad = NB * 32;
-  constexpr int U = 4;
+  constexpr int U = NB <= 2 ? BDE_LRT_BWD_XU : 4;                  // k-steps (of 2 rows of W) per operand set
   struct Operands {
     float wm[U], wr[U], ag[U][NB], av[U][NB];
   };
