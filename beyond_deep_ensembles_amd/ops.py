@@ -87,6 +87,25 @@ class HipOps:
         self.lib = _lib.load()
 
     # ------------------------------------------------------------ SVGD --
+    def warm_up_svgd(self, device) -> None:
+        """Launch every SVGD kernel family once on a tiny problem and wait for it.  HIP uploads a code object the first
+        time one of its kernels is launched; a multi-rank optimizer calls this before its first collective so that
+        the upload never coincides with communication threads driving copies on other streams (observed with 8 ranks
+        sharing one device over gloo: the first Gram launch occasionally executed garbage)."""
+        with torch.cuda.device(device):
+            m, d = 2, 256
+            P = torch.zeros((m, pad4(d)), dtype=torch.float32, device=device)
+            P[1, :d] = 1.0
+            G, out = torch.zeros_like(P), torch.zeros_like(P)
+            buf = torch.zeros(pad4(d), dtype=torch.float32, device=device)
+            ws, ks = self.svgd_ws(m, device), self.svgd_kstat(m, device)
+            self.svgd_gram(P, d, ws)
+            self.svgd_kstats(ws, m, 0.0, 1.0, 1.0, -1.0, ks)
+            self.svgd_combine(P, G, out, d, ks)
+            self.svgd_fused_sgd(P, G, buf, d, ks, 0.0, 0.0, 0.0, 0.0, False, True)
+            self.svgd_step(P, G, out, d, 0.0, 1.0, 1.0, -1.0, ws, ks)          # the single-launch path
+            torch.cuda.synchronize(device)
+
     def svgd_ws(self, m: int, device) -> torch.Tensor:
         n = self.lib.bde_svgd_ws_bytes(m)
         if n == 0:

@@ -35,6 +35,7 @@ each rank runs the forward/backward passes of its own M/W particles, then
 """
 from __future__ import annotations
 
+import os
 import warnings
 from typing import List, Optional
 
@@ -142,6 +143,8 @@ class SVGDOptimizer(BayesianOptimizer):
             self._world, self._rank = dist.get_world_size(process_group), dist.get_rank(process_group)
             if particle_count % self._world != 0:
                 raise ValueError(f"particle_count ({particle_count}) must be a multiple of the group size ({self._world})")
+            if self._world > 1 and hasattr(self._ops, "warm_up_svgd") and not os.environ.get("BDE_NO_WARMUP"):
+                self._ops.warm_up_svgd(self._P.device)       # code objects resident before the first collective
             # identical particles on every rank whatever the local RNG state was
             dist.broadcast(self._P, src=dist.get_global_rank(process_group, 0), group=process_group)
             if self._world > 1:
