@@ -346,6 +346,28 @@ def config_extras(dev):
                                                      "28*O*I algorithmic bytes, vs autograd over the reference's op sequence"}
         del layer
 
+    # ---- a BBBConv2d layer of the CIFAR ResNet-20 (BASELINE configs[1] model family: 3x3, 16 -> 16 channels, 32x32, batch 128):
+    # stock convolutions, every element-wise piece around them fused, vs the reference's op sequence
+    conv = bde.BBBConv2d(16, 16, 3, prior, prior, padding=1, rng="philox").to(dev)
+    xc = torch.randn(128, 16, 32, 32, device=dev, requires_grad=True)
+    cleaves = [xc, conv.weight.mean, conv.weight.rho, conv.bias.mean, conv.bias.rho]
+
+    def conv_fused():
+        torch.autograd.grad(conv(xc).sum(), cleaves)
+
+    def conv_torch():                                            # bbb_layers.py:146-154
+        w, b = conv.weight, conv.bias
+        mean = F.conv2d(xc, w.mean, b.mean, padding=1)
+        var = F.conv2d((xc ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), b.std ** 2, padding=1)
+        torch.autograd.grad((mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)).sum(), cleaves)
+    t_f, t_t = time_loop(conv_fused, 30), time_loop(conv_torch, 30)
+    out["bbb_conv2d_fwd_bwd_resnet20_layer_b128"] = {
+        "ms": round(t_f * 1e3, 4), "torch_sequence_ms": round(t_t * 1e3, 4), "speedup": round(t_t / t_f, 2),
+        "what": "BBBConv2d (16 -> 16, 3x3, 32x32, batch 128) forward + backward vs the reference's op sequence; at this size "
+                "(2 M activations, host-bound) the layer keeps native ATen nodes for the element-wise pieces -- the fused "
+                "passes take over from 4 M elements (tools/conv_layer_bench.py)"}
+    del conv, xc
+
     # ---- configs[0]: BBBOptimizer.step on the UCI-housing MLP (13 -> 50 -> 1 BBBLinear, 5 MC samples, Adam), whole
     # step incl. forward/backward; beside it the reference's op sequence for the same step in plain PyTorch on this GPU
     def uci_model():

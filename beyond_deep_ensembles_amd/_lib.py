@@ -59,6 +59,8 @@ SIGNATURES = {
     "bde_mixture_nll": (c_int, [_P, c_float, c_float, c_float, c_float, _P, _P, c_int, _P, _P, c_int64, _P]),
     "bde_local_reparam_fwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_local_reparam_bwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
+    "bde_var_operand_fwd": (c_int, [_P, c_int, _P, c_int64, _P]),
+    "bde_var_operand_bwd": (c_int, [_P, _P, c_int, _P, c_int64, _P]),
     "bde_lrt_linear_supported": (c_int, [c_int, c_int, c_int]),
     "bde_lrt_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "bde_lrt_linear_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int, _P, c_uint64, c_uint64, _P, _P, c_int, c_int, c_int,

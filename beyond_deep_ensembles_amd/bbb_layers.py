@@ -9,8 +9,9 @@ Same constructor arguments, attributes (``weight`` / ``bias`` GaussianParameters
 with ONE noise draw shared across the batch in eval mode when ``freeze_on_eval``.
 ``BBBLinear`` runs its whole forward as ONE fused op for batches of up to 128 rows (``bde_lrt_linear_fwd``: the
 weights are streamed once, sigma^2 / x^2 are formed on the fly, both products run on the MFMA, the noise is applied
-in the finish pass); larger batches and ``BBBConv2d`` keep the two stock GEMMs / convolutions with the fused
-epilogue kernel.  What BBBOptimizer needs from the layer -- mean / rho parameters paired through
+in the finish pass) and its backward as three launches; larger batches and ``BBBConv2d`` keep the two stock GEMMs /
+convolutions, with every element-wise piece around them fused: one pass per operand of the variance product
+(``bde_var_operand_*``) and one for the epilogue (``bde_local_reparam_*``).  What BBBOptimizer needs from the layer -- mean / rho parameters paired through
 GaussianParameter -- feeds the fused KL kernel.
 
 Differences from the reference, on purpose:
@@ -30,6 +31,10 @@ import torch.nn.functional as F
 from .util import GaussianParameter, normal_like, _philox_stream
 
 _CLAMP = 1e-4
+# A custom Python autograd node costs ~40-55 us of host time against ~8 us for a native ATen node, so an element-wise
+# piece gets its own fused pass only where the GPU time of the ATen sequence it replaces exceeds that (measured with
+# tools/conv_layer_bench.py: break-even at a few million elements).
+_FUSE_MIN_ELEMS = 1 << 22
 
 
 class _LocalReparam(torch.autograd.Function):
@@ -53,6 +58,28 @@ class _LocalReparam(torch.autograd.Function):
         gvar = torch.empty_like(g)
         ops.local_reparam_bwd(g, v, gvar, g.numel(), eps=e, seed=seed, stream_id=stream_id)
         return grad_out, gvar.view(shape), None, None, None, None
+
+
+class _VarOperand(torch.autograd.Function):
+    """An operand of the variance product, one pass (bde_var_operand_fwd/bwd) -- mode 0: clamp(x^2, 1e-4);
+    1: clamp(softplus(rho)^2, 1e-4); 2: softplus(rho)^2 (bbb_layers.py:66-67,71,150-153)."""
+
+    @staticmethod
+    def forward(ctx, v, mode, ops):
+        vc = v.detach().contiguous()
+        out = torch.empty_like(vc)
+        ops.var_operand_fwd(vc, mode, out)
+        ctx.save_for_backward(vc)
+        ctx.meta = (mode, ops)
+        return out.view(v.shape)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (vc,) = ctx.saved_tensors
+        mode, ops = ctx.meta
+        gv = torch.empty_like(vc)
+        ops.var_operand_bwd(grad_out.contiguous(), vc, mode, gv)
+        return gv.view(grad_out.shape), None, None
 
 
 class _LrtLinear(torch.autograd.Function):
@@ -125,6 +152,23 @@ class _LocalReparamLayer(nn.Module):
             total = total + self.bias_prior.kl_divergence(self.bias.mean, self.bias.std)
         return total
 
+    def _var_operands(self, input: torch.Tensor, clamp_bias: bool):
+        """clamp(x^2), clamp(sigma_W^2) and the bias variance of the variance product (bbb_layers.py:66-67,71,150-153):
+        one fused pass each on fp32 device tensors, the reference's op sequence otherwise."""
+        w, b = self.weight, (self.bias if self.use_bias else None)
+        fusable = self.fused_epilogue and input.dtype == torch.float32 and input.is_cuda == w.mean.is_cuda
+        ops = w._get_ops() if fusable else None
+
+        def operand(t, mode):
+            if fusable and t.numel() >= _FUSE_MIN_ELEMS:
+                return _VarOperand.apply(t, mode, ops)
+            if mode == 0:
+                return (t ** 2).clamp(min=_CLAMP)
+            s2 = F.softplus(t) ** 2
+            return s2.clamp(min=_CLAMP) if mode == 1 else s2
+        vb = None if b is None else operand(b.rho, 1 if clamp_bias else 2)
+        return operand(input, 0), operand(w.rho, 1), vb
+
     def _noise(self, mean: torch.Tensor) -> torch.Tensor:
         if not self.training and self.freeze_on_eval:
             # one draw for the whole batch, so an eval pass uses ONE set of weights per call
@@ -137,7 +181,16 @@ class _LocalReparamLayer(nn.Module):
         if frozen or not self.fused_epilogue or mean.dtype != torch.float32:
             return mean + torch.sqrt(var) * self._noise(mean)       # stock PyTorch (eval: broadcast noise)
         gp = self.weight
-        eps = None if gp.rng == "philox" and gp.noise_source is None else normal_like(mean)
+        philox = gp.rng == "philox" and gp.noise_source is None
+        if mean.numel() < _FUSE_MIN_ELEMS:
+            # small activations: native nodes are cheaper than a custom one; the noise stays the layer's Philox stream
+            if philox:
+                eps = torch.empty_like(mean, memory_format=torch.contiguous_format)
+                gp._get_ops().philox_normal(gp.seed, next(_philox_stream), eps_d=eps.view(-1), d=eps.numel())
+            else:
+                eps = normal_like(mean)
+            return mean + torch.sqrt(var) * eps
+        eps = None if philox else normal_like(mean)
         return _LocalReparam.apply(mean, var, eps, gp.seed, next(_philox_stream), gp._get_ops())
 
 
@@ -164,8 +217,7 @@ class BBBLinear(_LocalReparamLayer):
                                        w._get_ops())
                 return out / self.mc_sample
             mean = F.linear(input, w.mean, b.mean if b is not None else None)
-            var = F.linear((input ** 2).clamp(min=_CLAMP), (w.std ** 2).clamp(min=_CLAMP),
-                           (b.std ** 2).clamp(min=_CLAMP) if b is not None else None)
+            var = F.linear(*self._var_operands(input, clamp_bias=True))
             return self._sample_activations(mean, var) / self.mc_sample
         if self.sampling == "parameters":
             out = None
@@ -198,8 +250,8 @@ class BBBConv2d(_LocalReparamLayer):
             raise ValueError("Invalid value of sampling")
         w, b = self.weight, (self.bias if self.use_bias else None)
         mean = F.conv2d(input, w.mean, b.mean if b is not None else None, stride=self.stride, padding=self.padding)
-        var = F.conv2d((input ** 2).clamp(min=_CLAMP), (w.std ** 2).clamp(min=_CLAMP),
-                       b.std ** 2 if b is not None else None, stride=self.stride, padding=self.padding)
+        x2, s2, vb = self._var_operands(input, clamp_bias=False)     # the conv layer does not clamp its bias variance
+        var = F.conv2d(x2, s2, vb, stride=self.stride, padding=self.padding)
         return self._sample_activations(mean, var)
 
 

@@ -180,6 +180,44 @@ __global__ __launch_bounds__(kBlock) void local_reparam_bwd_kernel(const float* 
   }
 }
 
+// Operands of the variance product of the local-reparameterisation layers (bbb_layers.py:66-67,71,150-153):
+//   MODE 0: clamp(x^2, 1e-4)                      backward: g * 2 x * [x^2 >= 1e-4]
+//   MODE 1: clamp(softplus(rho)^2, 1e-4)          backward: g * [sigma^2 >= 1e-4] * 2 sigma sigmoid(rho)
+//   MODE 2: softplus(rho)^2 (BBBConv2d's bias)    backward: g * 2 sigma sigmoid(rho)
+// -- two to three ATen launches each in the reference (pow, clamp; softplus, pow, clamp), and twice that in autograd.
+constexpr float kVarClamp = 1e-4f;
+template <int MODE>
+__device__ __forceinline__ float var_operand(float v) {
+  if (MODE == 0) return fmaxf(v * v, kVarClamp);
+  const float s = softplus(v);
+  return MODE == 1 ? fmaxf(s * s, kVarClamp) : s * s;
+}
+template <int MODE>
+__device__ __forceinline__ float var_operand_grad(float g, float v) {
+  if (MODE == 0) return v * v >= kVarClamp ? g * (2.0f * v) : 0.f;
+  const SoftplusSigmoid ss = softplus_sigmoid(v);
+  const bool keep = MODE == 2 || ss.sp * ss.sp >= kVarClamp;
+  return keep ? g * (2.0f * ss.sp * ss.sg) : 0.f;
+}
+template <int MODE, bool BWD>
+__global__ __launch_bounds__(kBlock) void var_operand_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                            float* __restrict__ out, int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 a = ld4_nt(v + 4 * i);
+    f32x4 go = {0.f, 0.f, 0.f, 0.f}, o;
+    if (BWD) go = ld4_nt(g + 4 * i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = BWD ? var_operand_grad<MODE>(go[j], a[j]) : var_operand<MODE>(a[j]);
+    st4(out + 4 * i, o);                                          // read again right away by the product that follows
+  }
+  if (blockIdx.x == 0) {
+    const int64_t k = (n4 << 2) + threadIdx.x;
+    if (k < n) out[k] = BWD ? var_operand_grad<MODE>(g[k], v[k]) : var_operand<MODE>(v[k]);
+  }
+}
+
 // -------------------------------------------------------------------- KL --
 // Per element (bbb.py:20): 0.5 * (2 ln(sp/s) - 1 + (s/sp)^2 + ((mp - m)/sp)^2).
 // One exp, two hardware logs and two hardware reciprocals per element; the divisions by the
@@ -516,5 +554,27 @@ extern "C" int bde_local_reparam_bwd(const float* g, const float* var, const flo
     hipLaunchKernelGGL(local_reparam_bwd_kernel<false>, dim3(grid), dim3(kBlock), 0, s, g, var, eps, seed, stream_id, gvar, n);
   else
     hipLaunchKernelGGL(local_reparam_bwd_kernel<true>, dim3(grid), dim3(kBlock), 0, s, g, var, eps, seed, stream_id, gvar, n);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_var_operand_fwd(const float* v, int mode, float* out, int64_t n, void* stream) {
+  if (!v || !out || n <= 0 || mode < 0 || mode > 2 || !aligned16(v) || !aligned16(out)) return BDE_ERR_INVALID;
+  const int grid = stream_grid((n + 3) / 4);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* none = nullptr;
+  if (mode == 0) hipLaunchKernelGGL((var_operand_kernel<0, false>), dim3(grid), dim3(kBlock), 0, s, none, v, out, n);
+  else if (mode == 1) hipLaunchKernelGGL((var_operand_kernel<1, false>), dim3(grid), dim3(kBlock), 0, s, none, v, out, n);
+  else hipLaunchKernelGGL((var_operand_kernel<2, false>), dim3(grid), dim3(kBlock), 0, s, none, v, out, n);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_var_operand_bwd(const float* g, const float* v, int mode, float* gv, int64_t n, void* stream) {
+  if (!g || !v || !gv || n <= 0 || mode < 0 || mode > 2 || !aligned16(g) || !aligned16(v) || !aligned16(gv))
+    return BDE_ERR_INVALID;
+  const int grid = stream_grid((n + 3) / 4);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (mode == 0) hipLaunchKernelGGL((var_operand_kernel<0, true>), dim3(grid), dim3(kBlock), 0, s, g, v, gv, n);
+  else if (mode == 1) hipLaunchKernelGGL((var_operand_kernel<1, true>), dim3(grid), dim3(kBlock), 0, s, g, v, gv, n);
+  else hipLaunchKernelGGL((var_operand_kernel<2, true>), dim3(grid), dim3(kBlock), 0, s, g, v, gv, n);
   return to_err(hipGetLastError());
 }

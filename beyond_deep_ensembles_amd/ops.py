@@ -305,6 +305,20 @@ class HipOps:
         _check(self.lib.bde_local_reparam_bwd(_ptr(g), _ptr(var), _ptr(eps), seed, stream_id, _ptr(gvar), n, _stream()),
                "bde_local_reparam_bwd")
 
+    @_on_device_of
+    def var_operand_fwd(self, v, mode: int, out):
+        """mode 0: clamp(v^2, 1e-4); 1: clamp(softplus(v)^2, 1e-4); 2: softplus(v)^2 (bbb_layers.py:66-67,71,150-153)."""
+        if not (v.is_contiguous() and out.is_contiguous()):
+            raise BdeKernelError("var_operand_fwd: contiguous tensors expected")
+        _check(self.lib.bde_var_operand_fwd(_ptr(v, "v"), mode, _ptr(out), v.numel(), _stream()), "bde_var_operand_fwd")
+
+    @_on_device_of
+    def var_operand_bwd(self, g, v, mode: int, gv):
+        if not (g.is_contiguous() and v.is_contiguous() and gv.is_contiguous()):
+            raise BdeKernelError("var_operand_bwd: contiguous tensors expected")
+        _check(self.lib.bde_var_operand_bwd(_ptr(g, "g"), _ptr(v), mode, _ptr(gv), v.numel(), _stream()),
+               "bde_var_operand_bwd")
+
     def lrt_linear_supported(self, b: int, i: int, o: int) -> bool:
         return bool(self.lib.bde_lrt_linear_supported(b, i, o))
 

@@ -273,6 +273,15 @@ int bde_local_reparam_fwd(const float* mean, const float* var, const float* eps,
 int bde_local_reparam_bwd(const float* g, const float* var, const float* eps, uint64_t seed,
                           uint64_t stream_id, float* gvar, int64_t n, void* stream);
 
+/* Operands of the variance product of the local-reparameterisation layers (bbb_layers.py:66-67,71,150-153), one pass
+ * each instead of 2-3 ATen launches (and their autograd nodes):
+ *   mode 0: out = clamp(v^2, 1e-4)               (v = the layer input)     bwd: gv = g * 2 v * [v^2 >= 1e-4]
+ *   mode 1: out = clamp(softplus(v)^2, 1e-4)     (v = rho of the weights)  bwd: gv = g * [sigma^2 >= 1e-4] * 2 sigma sigmoid(v)
+ *   mode 2: out = softplus(v)^2                  (BBBConv2d's bias)        bwd: gv = g * 2 sigma sigmoid(v)
+ * Contiguous, 16-byte aligned buffers of n floats; outputs are overwritten. */
+int bde_var_operand_fwd(const float* v, int mode, float* out, int64_t n, void* stream);
+int bde_var_operand_bwd(const float* g, const float* v, int mode, float* gv, int64_t n, void* stream);
+
 /* The whole local-reparameterisation forward of a mean-field LINEAR layer (bbb_layers.py:61-80, sampling =
  * "activations") for small batches (B <= 128): W_mu / W_rho [O, I] row-major are streamed ONCE, sigma^2 =
  * clamp(softplus(rho)^2, 1e-4) and clamp(x^2, 1e-4) are formed on the fly and both products run on the f32 MFMA

@@ -241,6 +241,13 @@ class OracleOps:
             else:
                 gmean[:n] = g
 
+    def philox_normal(self, seed, stream_id, eps_w=None, eps_d=None, d=None):
+        if eps_w is not None:
+            eps_w.copy_(_philox(seed, stream_id, eps_w.numel(), PH.DOMAIN_LOWRANK))
+        if eps_d is not None:
+            n = d if d is not None else eps_d.numel()
+            eps_d[:n] = _philox(seed, stream_id, n)
+
     def local_reparam_fwd(self, mean, var, out, n, eps=None, seed=0, stream_id=0):
         if eps is None:
             eps = _philox(seed, stream_id, n)
@@ -250,6 +257,24 @@ class OracleOps:
         if eps is None:
             eps = _philox(seed, stream_id, n)
         gvar[:n] = (g[:n] * eps[:n]) / (2 * torch.sqrt(var[:n]))
+
+    def var_operand_fwd(self, v, mode, out):
+        if mode == 0:
+            out.copy_((v ** 2).clamp(min=1e-4))
+        else:
+            s2 = torch.nn.functional.softplus(v) ** 2
+            out.copy_(s2.clamp(min=1e-4) if mode == 1 else s2)
+
+    def var_operand_bwd(self, g, v, mode, gv):
+        with torch.enable_grad():
+            leaf = v.detach().clone().requires_grad_(True)
+            if mode == 0:
+                y = (leaf ** 2).clamp(min=1e-4)
+            else:
+                y = torch.nn.functional.softplus(leaf) ** 2
+                if mode == 1:
+                    y = y.clamp(min=1e-4)
+            gv.copy_(torch.autograd.grad(y, leaf, grad_outputs=g)[0])
 
     def lrt_linear_supported(self, b, i, o):
         return 1 <= b <= 128

@@ -900,3 +900,38 @@ def test_lrt_linear_backward(ops):
         strided = [torch.empty_like(t) if t is not None else None for t in outs]
         ops.lrt_linear_bwd(wide[:, :i], dev(w_mu), dev(w_rho), dev(b_rho), clamp_bias, dev(g), var, *strided, eps=dev(eps))
         assert all(a is None or torch.equal(a, t) for a, t in zip(strided, outs))
+
+
+def test_var_operand_kernels(ops):
+    """bde_var_operand_fwd/bwd (the operands of the variance product, bbb_layers.py:66-67,71,150-153) against the
+    reference's op sequence and its autograd, incl. the clamp boundaries, ragged sizes and the mode without clamp."""
+    import torch.nn.functional as F
+    torch.manual_seed(23)
+    for n in (1, 3, 4, 5, 1000, 4099, 1 << 20):
+        v = torch.randn(n) * 2 - 1
+        v[0] = 0.0                                   # x^2 below the clamp; softplus(0)^2 = 0.48 above it
+        if n > 2:
+            v[1], v[2] = -9.0, 0.01                  # softplus(-9)^2 = 1.5e-8 below the clamp; x = 0.01: x^2 = 1e-4 (boundary)
+        g = torch.randn(n)
+        for mode in (0, 1, 2):
+            leaf = v.clone().double().requires_grad_(True)
+            if mode == 0:
+                ref = (leaf ** 2).clamp(min=1e-4)
+            else:
+                ref = F.softplus(leaf) ** 2
+                if mode == 1:
+                    ref = ref.clamp(min=1e-4)
+            gref = torch.autograd.grad(ref, leaf, grad_outputs=g.double())[0]
+            out, gv = torch.full((n,), float("nan"), device=DEV), torch.full((n,), float("nan"), device=DEV)
+            ops.var_operand_fwd(v.to(DEV), mode, out)
+            ops.var_operand_bwd(g.to(DEV), v.to(DEV), mode, gv)
+            assert (out.cpu().double() - ref.detach()).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item()), (n, mode)
+            # the masks of the clamp are decided in fp32 on the device: compare away from the boundary |value - 1e-4| tiny
+            val32 = (v ** 2) if mode == 0 else F.softplus(v) ** 2
+            safe = ((val32 - 1e-4).abs() > 1e-9) | torch.tensor(mode == 2)
+            err = (gv.cpu().double() - gref).abs()
+            assert err[safe].max().item() <= 2e-6 * max(1.0, gref.abs().max().item()), (n, mode)
+            if mode == 1 and n > 2:
+                assert gv[1].item() == 0.0 and out[1].item() == pytest.approx(1e-4)
+            if mode == 2 and n > 2:
+                assert gv[1].item() != 0.0

@@ -898,11 +898,16 @@ class _BdeCNN(nn.Module):
         return self.fc(x)
 
 
-def test_bbb_conv_layers_reproduce_reference_cnn_trajectory(golden, backend, monkeypatch):
+@pytest.mark.parametrize("element_wise", ["native_below_threshold", "fused_passes"])
+def test_bbb_conv_layers_reproduce_reference_cnn_trajectory(golden, backend, monkeypatch, element_wise):
     """bde.BBBConv2d (padding / stride / bias-free) + bde.BBBLinear under BBBOptimizer against the trajectory of the
-    REFERENCE's BBBConv2d + BBBLinear + BBBOptimizer on the same small CNN (bbb_layers.py:105-159), noise replayed."""
+    REFERENCE's BBBConv2d + BBBLinear + BBBOptimizer on the same small CNN (bbb_layers.py:105-159), noise replayed.
+    Once as a layer of this size runs (element-wise pieces as native ATen nodes) and once with the size threshold at
+    zero, so that the fused variance-operand and epilogue passes (bde_var_operand_*, bde_local_reparam_*) carry it."""
     ops, dev = backend
     import beyond_deep_ensembles_amd.bbb_layers as L
+    if element_wise == "fused_passes":
+        monkeypatch.setattr(L, "_FUSE_MIN_ELEMS", 0)
     g = golden("bbb2.npz")
     tape = [T(g[f"f_eps_{i}"]) for i in range(int(g["f_n_eps"]))]
     monkeypatch.setattr(L, "normal_like", lambda t: tape.pop(0).to(t.device))

@@ -1,0 +1,50 @@
+"""BBBConv2d forward + backward: which element-wise pieces are worth a custom autograd node at which size?
+(a custom Python autograd Function costs ~40-55 us of host time, a native ATen node ~8 us)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+import beyond_deep_ensembles_amd as bde
+from beyond_deep_ensembles_amd import bbb_layers as BL
+
+dev = torch.device("cuda:0")
+prior = bde.GaussianPrior(0, 1.0)
+
+
+def ev(fn, iters=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+print(f"{'input':>22} {'elements':>10} {'torch us':>9} {'epilogue':>9} {'ep+x2':>9} {'all fused':>10}")
+for (n, c, hw) in [(128, 16, 32), (128, 64, 8), (128, 64, 32), (512, 64, 32), (64, 256, 56)]:
+    conv = bde.BBBConv2d(c, c, 3, prior, prior, padding=1, rng="philox").to(dev)
+    x = torch.randn(n, c, hw, hw, device=dev, requires_grad=True)
+    leaves = [x, conv.weight.mean, conv.weight.rho, conv.bias.mean, conv.bias.rho]
+    ops = conv.weight._get_ops()
+
+    def run(mode):
+        w, b = conv.weight, conv.bias
+        mean = F.conv2d(x, w.mean, b.mean, padding=1)
+        if mode == "all":
+            x2, s2, vb = BL._VarOperand.apply(x, 0, ops), BL._VarOperand.apply(w.rho, 1, ops), BL._VarOperand.apply(b.rho, 2, ops)
+        elif mode == "ep+x2":
+            x2, s2, vb = BL._VarOperand.apply(x, 0, ops), (w.std ** 2).clamp(min=1e-4), b.std ** 2
+        else:
+            x2, s2, vb = (x ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), b.std ** 2
+        var = F.conv2d(x2, s2, vb, padding=1)
+        if mode == "torch":
+            out = mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)
+        else:
+            out = BL._LocalReparam.apply(mean, var, None, 1, 7, ops)
+        torch.autograd.grad(out.sum(), leaves)
+    ts = [ev(lambda m=m: run(m)) for m in ("torch", "epilogue", "ep+x2", "all")]
+    print(f"{str((n, c, hw, hw)):>22} {x.numel():>10} " + " ".join(f"{t:9.1f}" for t in ts))
