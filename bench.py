@@ -348,6 +348,7 @@ def config_extras(dev):
 
     # ---- a BBBConv2d layer of the CIFAR ResNet-20 (BASELINE configs[1] model family: 3x3, 16 -> 16 channels, 32x32, batch 128):
     # stock convolutions, every element-wise piece around them fused, vs the reference's op sequence
+    from beyond_deep_ensembles_amd import bbb_layers as _bl
     conv = bde.BBBConv2d(16, 16, 3, prior, prior, padding=1, rng="philox").to(dev)
     xc = torch.randn(128, 16, 32, 32, device=dev, requires_grad=True)
     cleaves = [xc, conv.weight.mean, conv.weight.rho, conv.bias.mean, conv.bias.rho]
@@ -363,9 +364,10 @@ def config_extras(dev):
     t_f, t_t = time_loop(conv_fused, 30), time_loop(conv_torch, 30)
     out["bbb_conv2d_fwd_bwd_resnet20_layer_b128"] = {
         "ms": round(t_f * 1e3, 4), "torch_sequence_ms": round(t_t * 1e3, 4), "speedup": round(t_t / t_f, 2),
-        "what": "BBBConv2d (16 -> 16, 3x3, 32x32, batch 128) forward + backward vs the reference's op sequence; at this size "
-                "(2 M activations, host-bound) the layer keeps native ATen nodes for the element-wise pieces -- the fused "
-                "passes take over from 4 M elements (tools/conv_layer_bench.py)"}
+        "what": "BBBConv2d (16 -> 16, 3x3, 32x32, batch 128) forward + backward vs the reference's op sequence: two stock "
+                "convolutions; the three variance operands and the epilogue as fused passes behind C++ autograd nodes "
+                "(lib/_bde_host.so; as Python nodes they would cost more host time than they save below ~4 M elements, "
+                "tools/conv_layer_bench.py)", "native_autograd_nodes": _bl._native_nodes(conv.weight._get_ops()) is not None}
     del conv, xc
 
     # ---- configs[0]: BBBOptimizer.step on the UCI-housing MLP (13 -> 50 -> 1 BBBLinear, 5 MC samples, Adam), whole

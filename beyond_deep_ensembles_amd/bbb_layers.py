@@ -28,13 +28,50 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _host
 from .util import GaussianParameter, normal_like, _philox_stream
 
 _CLAMP = 1e-4
-# A custom Python autograd node costs ~40-55 us of host time against ~8 us for a native ATen node, so an element-wise
-# piece gets its own fused pass only where the GPU time of the ATen sequence it replaces exceeds that (measured with
-# tools/conv_layer_bench.py: break-even at a few million elements).
+# With the C++ autograd nodes of lib/_bde_host.so a fused element-wise pass costs about what one native ATen node costs,
+# and every piece is fused at every size.  As a Python autograd Function a node costs 40-55 us of host time against ~8 us
+# for a native one, so without the helper a piece gets its own pass only where the GPU time of the ATen sequence it
+# replaces exceeds that (tools/conv_layer_bench.py: break-even at a few million elements).
 _FUSE_MIN_ELEMS = 1 << 22
+
+
+def _fuse_min(ops) -> int:
+    return 0 if _native_nodes(ops) is not None else _FUSE_MIN_ELEMS
+
+
+
+def _native_nodes(ops):
+    """The C++ autograd nodes of lib/_bde_host.so (csrc/host_autograd.cpp) when the kernels are the HIP library's; the
+    Python Functions below are the same nodes for any other backend (the tests' CPU checker) or without the helper."""
+    if type(ops).__name__ != "HipOps":
+        return None
+    mod = _host.load()
+    return mod if mod is not None and hasattr(mod, "lrt_linear") else None
+
+
+def _lrt_linear(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops):
+    native = _native_nodes(ops)
+    if native is not None:
+        return native.lrt_linear(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id)
+    return _LrtLinear.apply(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops)
+
+
+def _local_reparam(mean, var, eps, seed, stream_id, ops):
+    native = _native_nodes(ops)
+    if native is not None:
+        return native.local_reparam(mean, var, eps, seed, stream_id)
+    return _LocalReparam.apply(mean, var, eps, seed, stream_id, ops)
+
+
+def _var_operand(v, mode, ops):
+    native = _native_nodes(ops)
+    if native is not None:
+        return native.var_operand(v, mode)
+    return _VarOperand.apply(v, mode, ops)
 
 
 class _LocalReparam(torch.autograd.Function):
@@ -158,10 +195,11 @@ class _LocalReparamLayer(nn.Module):
         w, b = self.weight, (self.bias if self.use_bias else None)
         fusable = self.fused_epilogue and input.dtype == torch.float32 and input.is_cuda == w.mean.is_cuda
         ops = w._get_ops() if fusable else None
+        fuse_min = _fuse_min(ops) if fusable else 0
 
         def operand(t, mode):
-            if fusable and t.numel() >= _FUSE_MIN_ELEMS:
-                return _VarOperand.apply(t, mode, ops)
+            if fusable and t.numel() >= fuse_min:
+                return _var_operand(t, mode, ops)
             if mode == 0:
                 return (t ** 2).clamp(min=_CLAMP)
             s2 = F.softplus(t) ** 2
@@ -182,8 +220,8 @@ class _LocalReparamLayer(nn.Module):
             return mean + torch.sqrt(var) * self._noise(mean)       # stock PyTorch (eval: broadcast noise)
         gp = self.weight
         philox = gp.rng == "philox" and gp.noise_source is None
-        if mean.numel() < _FUSE_MIN_ELEMS:
-            # small activations: native nodes are cheaper than a custom one; the noise stays the layer's Philox stream
+        if mean.numel() < _fuse_min(gp._get_ops()):
+            # small activations, Python nodes only: ATen nodes are cheaper; the noise stays the layer's Philox stream
             if philox:
                 eps = torch.empty_like(mean, memory_format=torch.contiguous_format)
                 gp._get_ops().philox_normal(gp.seed, next(_philox_stream), eps_d=eps.view(-1), d=eps.numel())
@@ -191,7 +229,7 @@ class _LocalReparamLayer(nn.Module):
                 eps = normal_like(mean)
             return mean + torch.sqrt(var) * eps
         eps = None if philox else normal_like(mean)
-        return _LocalReparam.apply(mean, var, eps, gp.seed, next(_philox_stream), gp._get_ops())
+        return _local_reparam(mean, var, eps, gp.seed, next(_philox_stream), gp._get_ops())
 
 
 class BBBLinear(_LocalReparamLayer):
@@ -212,9 +250,8 @@ class BBBLinear(_LocalReparamLayer):
                 eps = None
                 if not (w.rng == "philox" and w.noise_source is None):
                     eps = normal_like(input.new_empty(input.shape[:-1] + (self.out_features,)))
-                out = _LrtLinear.apply(input, w.mean, w.rho, b.mean if b is not None else None,
-                                       b.rho if b is not None else None, True, eps, w.seed, next(_philox_stream),
-                                       w._get_ops())
+                out = _lrt_linear(input, w.mean, w.rho, b.mean if b is not None else None,
+                                  b.rho if b is not None else None, True, eps, w.seed, next(_philox_stream), w._get_ops())
                 return out / self.mc_sample
             mean = F.linear(input, w.mean, b.mean if b is not None else None)
             var = F.linear(*self._var_operands(input, clamp_bias=True))

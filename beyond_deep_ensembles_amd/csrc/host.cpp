@@ -1,4 +1,5 @@
-// Native host helper of the optimizer shells: the per-tensor pointer-aliasing loops in C++.
+// Native host helper of the optimizer shells: the per-tensor pointer-aliasing loops in C++ (the layers' autograd
+// nodes live in host_autograd.cpp, same module).
 //
 // The reference re-points `param.data` (and hands over `param.grad`) tensor by tensor in Python
 // (src/algos/svgd.py:93-96,120-127; swag.py:58,81; ivorn.py:111).  With ResNet-50's 161 tensors an
@@ -101,7 +102,10 @@ class Layout {
 
 }  // namespace
 
+void bind_autograd_nodes(py::module_& m);   // host_autograd.cpp: the Bayesian layers' autograd nodes
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  bind_autograd_nodes(m);
   py::class_<Layout>(m, "Layout")
       .def(py::init<std::vector<int64_t>, std::vector<int64_t>, std::vector<std::vector<int64_t>>>())
       .def("views", &Layout::views, "per-parameter views of a flat row")

@@ -1,0 +1,170 @@
+// Autograd nodes of the Bayesian layers in C++ (part of lib/_bde_host.so).
+//
+// The layers' fused ops (bde_lrt_linear_fwd/bwd, bde_local_reparam_fwd/bwd, bde_var_operand_fwd/bwd) are single
+// launches of 10-40 us; wrapped as Python torch.autograd.Function they cost 40-55 us of interpreter time per node and
+// direction, more than the ATen nodes they replace below a few million elements (tools/lrt_host_profile.py,
+// tools/conv_layer_bench.py).  The same nodes here: argument checks, output allocation and ONE call through the C ABI
+// on torch's current stream.  No arithmetic lives in this file; the Python Functions in bbb_layers.py remain the
+// fallback when the helper is not built (same kernels, same results).
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/core/DeviceGuard.h>
+
+#include "../../include/bde_hip.h"
+
+namespace {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+void* current_stream(const at::Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check_f32_cuda(const at::Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat, name, ": expected a float32 CUDA (HIP) tensor");
+}
+const float* ptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+float* mptr(at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+at::Tensor opt(const c10::optional<at::Tensor>& t) { return t.has_value() ? *t : at::Tensor(); }
+
+// ---- BBBLinear, sampling="activations" (bbb_layers.py:61-80): forward bde_lrt_linear_fwd, backward bde_lrt_linear_bwd
+struct LrtLinear : public torch::autograd::Function<LrtLinear> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho,
+                            const c10::optional<at::Tensor>& b_mu_, const c10::optional<at::Tensor>& b_rho_,
+                            bool clamp_bias, const c10::optional<at::Tensor>& eps_, int64_t seed, int64_t stream_id) {
+    at::Tensor b_mu = opt(b_mu_), b_rho = opt(b_rho_), eps = opt(eps_);
+    check_f32_cuda(x, "x");
+    check_f32_cuda(w_mu, "w_mu");
+    check_f32_cuda(w_rho, "w_rho");
+    TORCH_CHECK(b_mu.defined() == b_rho.defined(), "bias mean and rho come together");
+    c10::DeviceGuard guard(x.device());
+    at::Tensor x2d = x.reshape({-1, x.size(-1)});
+    if (x2d.stride(-1) != 1) x2d = x2d.contiguous();
+    const at::Tensor wm = w_mu.detach().contiguous(), wr = w_rho.detach().contiguous();
+    const int B = static_cast<int>(x2d.size(0)), I = static_cast<int>(x2d.size(1)), O = static_cast<int>(wm.size(0));
+    const size_t ws_bytes = bde_lrt_linear_ws_bytes(B, I, O);
+    TORCH_CHECK(ws_bytes > 0, "lrt_linear: unsupported shape B=", B, ", I=", I, ", O=", O);
+    at::Tensor out = at::empty({B, O}, x2d.options()), var = at::empty({B, O}, x2d.options());
+    at::Tensor ws = at::empty({static_cast<int64_t>(ws_bytes / 4)}, x2d.options());
+    at::Tensor e;
+    if (eps.defined()) e = eps.reshape({B, O}).contiguous();
+    const at::Tensor xd = x2d.detach();
+    const int rc = bde_lrt_linear_fwd(ptr(xd), xd.stride(0), ptr(wm), ptr(wr), ptr(b_mu), ptr(b_rho), clamp_bias ? 1 : 0,
+                                      ptr(e), static_cast<uint64_t>(seed), static_cast<uint64_t>(stream_id), mptr(out),
+                                      mptr(var), B, I, O, ws.data_ptr(), current_stream(x2d));
+    TORCH_CHECK(rc == 0, "bde_lrt_linear_fwd failed with code ", rc);
+    ctx->save_for_backward({x2d, w_mu, w_rho, b_rho, var, e});
+    ctx->saved_data["clamp_bias"] = clamp_bias;
+    ctx->saved_data["seed"] = seed;
+    ctx->saved_data["stream_id"] = stream_id;
+    ctx->saved_data["x_shape"] = x.sizes().vec();
+    ctx->saved_data["has_bias"] = b_rho.defined();
+    std::vector<int64_t> out_shape = x.sizes().vec();
+    out_shape.back() = O;
+    return out.view(out_shape);
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
+    const variable_list saved = ctx->get_saved_variables();
+    const at::Tensor &x = saved[0], &w_mu = saved[1], &w_rho = saved[2], &b_rho = saved[3], &var = saved[4], &eps = saved[5];
+    const bool has_bias = ctx->saved_data["has_bias"].toBool();
+    c10::DeviceGuard guard(x.device());
+    const at::Tensor g = grad_outputs[0].reshape(var.sizes()).contiguous();
+    const int B = static_cast<int>(x.size(0)), I = static_cast<int>(x.size(1)), O = static_cast<int>(w_mu.size(0));
+    const at::Tensor wm = w_mu.detach().contiguous(), wr = w_rho.detach().contiguous();
+    at::Tensor g_x;
+    if (ctx->needs_input_grad(0)) g_x = at::empty({B, I}, var.options());
+    at::Tensor g_wmu = at::empty_like(wm), g_wrho = at::empty_like(wr), g_bmu, g_brho, br;
+    if (has_bias) {
+      br = b_rho.detach();
+      g_bmu = at::empty_like(br);
+      g_brho = at::empty_like(br);
+    }
+    at::Tensor ws = at::empty({static_cast<int64_t>(bde_lrt_linear_bwd_ws_bytes(B, I, O) / 4)}, var.options());
+    const at::Tensor xd = x.detach();
+    const int rc = bde_lrt_linear_bwd(ptr(xd), xd.stride(0), ptr(wm), ptr(wr), ptr(br), ctx->saved_data["clamp_bias"].toBool() ? 1 : 0,
+                                      ptr(g), ptr(var), ptr(eps), static_cast<uint64_t>(ctx->saved_data["seed"].toInt()),
+                                      static_cast<uint64_t>(ctx->saved_data["stream_id"].toInt()), mptr(g_x), mptr(g_wmu),
+                                      mptr(g_wrho), mptr(g_bmu), mptr(g_brho), B, I, O, ws.data_ptr(), current_stream(x));
+    TORCH_CHECK(rc == 0, "bde_lrt_linear_bwd failed with code ", rc);
+    if (g_x.defined()) g_x = g_x.view(ctx->saved_data["x_shape"].toIntVector());
+    return {g_x, g_wmu, g_wrho, g_bmu, g_brho, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+// ---- epilogue out = mean + sqrt(var) * eps (bbb_layers.py:70-80): bde_local_reparam_fwd / bwd
+struct LocalReparam : public torch::autograd::Function<LocalReparam> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& mean, const at::Tensor& var,
+                            const c10::optional<at::Tensor>& eps_, int64_t seed, int64_t stream_id) {
+    check_f32_cuda(mean, "mean");
+    check_f32_cuda(var, "var");
+    c10::DeviceGuard guard(mean.device());
+    const at::Tensor m = mean.detach().contiguous(), v = var.detach().contiguous();
+    at::Tensor e = opt(eps_);
+    if (e.defined()) e = e.contiguous();
+    at::Tensor out = at::empty_like(m);
+    const int rc = bde_local_reparam_fwd(ptr(m), ptr(v), ptr(e), static_cast<uint64_t>(seed), static_cast<uint64_t>(stream_id),
+                                         mptr(out), m.numel(), current_stream(m));
+    TORCH_CHECK(rc == 0, "bde_local_reparam_fwd failed with code ", rc);
+    ctx->save_for_backward({v, e});
+    ctx->saved_data["seed"] = seed;
+    ctx->saved_data["stream_id"] = stream_id;
+    return out.view(mean.sizes());
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
+    const variable_list saved = ctx->get_saved_variables();
+    const at::Tensor &v = saved[0], &e = saved[1];
+    c10::DeviceGuard guard(v.device());
+    const at::Tensor g = grad_outputs[0].contiguous();
+    at::Tensor gvar = at::empty_like(v);
+    const int rc = bde_local_reparam_bwd(ptr(g), ptr(v), ptr(e), static_cast<uint64_t>(ctx->saved_data["seed"].toInt()),
+                                         static_cast<uint64_t>(ctx->saved_data["stream_id"].toInt()), mptr(gvar), v.numel(),
+                                         current_stream(v));
+    TORCH_CHECK(rc == 0, "bde_local_reparam_bwd failed with code ", rc);
+    return {grad_outputs[0], gvar.view(grad_outputs[0].sizes()), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+// ---- operands of the variance product (bbb_layers.py:66-67,71,150-153): bde_var_operand_fwd / bwd
+struct VarOperand : public torch::autograd::Function<VarOperand> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& v, int64_t mode) {
+    check_f32_cuda(v, "v");
+    c10::DeviceGuard guard(v.device());
+    const at::Tensor vc = v.detach().contiguous();
+    at::Tensor out = at::empty_like(vc);
+    const int rc = bde_var_operand_fwd(ptr(vc), static_cast<int>(mode), mptr(out), vc.numel(), current_stream(vc));
+    TORCH_CHECK(rc == 0, "bde_var_operand_fwd failed with code ", rc);
+    ctx->save_for_backward({vc});
+    ctx->saved_data["mode"] = mode;
+    return out.view(v.sizes());
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
+    const at::Tensor vc = ctx->get_saved_variables()[0];
+    c10::DeviceGuard guard(vc.device());
+    const at::Tensor g = grad_outputs[0].contiguous();
+    at::Tensor gv = at::empty_like(vc);
+    const int rc = bde_var_operand_bwd(ptr(g), ptr(vc), static_cast<int>(ctx->saved_data["mode"].toInt()), mptr(gv),
+                                       vc.numel(), current_stream(vc));
+    TORCH_CHECK(rc == 0, "bde_var_operand_bwd failed with code ", rc);
+    return {gv.view(grad_outputs[0].sizes()), at::Tensor()};
+  }
+};
+
+}  // namespace
+
+void bind_autograd_nodes(py::module_& m) {
+  m.def("lrt_linear",
+        [](const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho, const c10::optional<at::Tensor>& b_mu,
+           const c10::optional<at::Tensor>& b_rho, bool clamp_bias, const c10::optional<at::Tensor>& eps, int64_t seed,
+           int64_t stream_id) { return LrtLinear::apply(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id); },
+        "BBBLinear forward (local reparameterisation) with its fused backward", py::arg("x"), py::arg("w_mu"),
+        py::arg("w_rho"), py::arg("b_mu"), py::arg("b_rho"), py::arg("clamp_bias"), py::arg("eps"), py::arg("seed"),
+        py::arg("stream_id"));
+  m.def("local_reparam",
+        [](const at::Tensor& mean, const at::Tensor& var, const c10::optional<at::Tensor>& eps, int64_t seed,
+           int64_t stream_id) { return LocalReparam::apply(mean, var, eps, seed, stream_id); },
+        "mean + sqrt(var) * eps", py::arg("mean"), py::arg("var"), py::arg("eps"), py::arg("seed"), py::arg("stream_id"));
+  m.def("var_operand", [](const at::Tensor& v, int64_t mode) { return VarOperand::apply(v, mode); },
+        "clamp(v^2) / clamp(softplus(v)^2) / softplus(v)^2", py::arg("v"), py::arg("mode"));
+}

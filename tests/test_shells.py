@@ -1051,3 +1051,55 @@ def test_svgd_fused_state_lives_in_the_base_optimizer(backend, kind):
         base_b.load_state_dict(sd)                             # per-parameter step counters as torch expects them
     step(model_b, opt_c)
     np.testing.assert_allclose(opt_c.particles.cpu().numpy(), opt_a.particles.cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_native_autograd_nodes_equal_python_nodes():
+    """The C++ autograd nodes of lib/_bde_host.so (csrc/host_autograd.cpp) and the Python Functions of bbb_layers.py are
+    the same nodes: same kernels through the same C ABI, bit-identical outputs and gradients."""
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    from beyond_deep_ensembles_amd.ops import HipOps
+    ops, dev = HipOps(), torch.device("cuda:0")
+    native = L._native_nodes(ops)
+    assert native is not None, "lib/_bde_host.so is missing or does not load: run __graft_entry__.build()"
+    torch.manual_seed(31)
+    for b, i, o, bias in [(16, 2048, 182, True), (5, 13, 50, True), (70, 129, 33, False), (64, 1024, 1100, True)]:
+        x = torch.randn(3, b // 3 + 1, i, device=dev)[:, : max(1, b // 3)]          # a batch with leading dimensions
+        w_mu, w_rho = torch.randn(o, i, device=dev) * 0.1, torch.randn(o, i, device=dev) - 3
+        b_mu, b_rho = (torch.randn(o, device=dev) * 0.1, torch.randn(o, device=dev) - 3) if bias else (None, None)
+        for eps in (None, torch.randn(x.shape[:-1] + (o,), device=dev)):
+            res = []
+            for node in ("native", "python"):
+                leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (x, w_mu, w_rho, b_mu, b_rho)]
+                if node == "native":
+                    out = native.lrt_linear(*leaves, True, eps, 5, 9)
+                else:
+                    out = L._LrtLinear.apply(*leaves, True, eps, 5, 9, ops)
+                grads = torch.autograd.grad(out, [t for t in leaves if t is not None], grad_outputs=torch.ones_like(out) * 0.5)
+                res.append([out.detach()] + list(grads))
+            assert all(torch.equal(a, c) for a, c in zip(*res)), (b, i, o, bias, eps is None)
+    mean, var = torch.randn(4, 6, 5, 5, device=dev), torch.rand(4, 6, 5, 5, device=dev) + 0.1
+    for eps in (None, torch.randn_like(mean)):
+        res = []
+        for node in ("native", "python"):
+            m, v = mean.clone().requires_grad_(True), var.clone().requires_grad_(True)
+            out = native.local_reparam(m, v, eps, 3, 4) if node == "native" else L._LocalReparam.apply(m, v, eps, 3, 4, ops)
+            res.append([out.detach()] + list(torch.autograd.grad(out, [m, v], grad_outputs=torch.full_like(out, 2.0))))
+        assert all(torch.equal(a, c) for a, c in zip(*res))
+    for mode in (0, 1, 2):
+        v0 = torch.randn(7, 11, device=dev) * 2
+        res = []
+        for node in ("native", "python"):
+            v = v0.clone().requires_grad_(True)
+            out = native.var_operand(v, mode) if node == "native" else L._VarOperand.apply(v, mode, ops)
+            res.append([out.detach(), torch.autograd.grad(out, v, grad_outputs=torch.full_like(out, 0.3))[0]])
+        assert all(torch.equal(a, c) for a, c in zip(*res)), mode
+    # a layer without input gradient, and errors raised as exceptions
+    xin = torch.randn(8, 13, device=dev)
+    leaves = [t.requires_grad_(True) for t in (torch.randn(50, 13, device=dev), torch.randn(50, 13, device=dev) - 3)]
+    out = native.lrt_linear(xin, leaves[0], leaves[1], None, None, True, None, 1, 2)
+    assert all(g is not None for g in torch.autograd.grad(out.sum(), leaves))
+    with pytest.raises(RuntimeError):
+        native.lrt_linear(xin.double(), leaves[0], leaves[1], None, None, True, None, 1, 2)
+    with pytest.raises(RuntimeError):
+        native.lrt_linear(torch.randn(200, 13, device=dev), leaves[0], leaves[1], None, None, True, None, 1, 2)   # B > 128

@@ -1,5 +1,6 @@
 """BBBConv2d forward + backward: which element-wise pieces are worth a custom autograd node at which size?
-(a custom Python autograd Function costs ~40-55 us of host time, a native ATen node ~8 us)"""
+(a custom Python autograd Function costs ~40-55 us of host time, a native ATen node ~8 us; with the C++ nodes of
+lib/_bde_host.so -- BDE_NO_HOST_HELPER=1 switches them off -- the custom nodes cost about as much as native ones)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -35,16 +36,16 @@ for (n, c, hw) in [(128, 16, 32), (128, 64, 8), (128, 64, 32), (512, 64, 32), (6
         w, b = conv.weight, conv.bias
         mean = F.conv2d(x, w.mean, b.mean, padding=1)
         if mode == "all":
-            x2, s2, vb = BL._VarOperand.apply(x, 0, ops), BL._VarOperand.apply(w.rho, 1, ops), BL._VarOperand.apply(b.rho, 2, ops)
+            x2, s2, vb = BL._var_operand(x, 0, ops), BL._var_operand(w.rho, 1, ops), BL._var_operand(b.rho, 2, ops)
         elif mode == "ep+x2":
-            x2, s2, vb = BL._VarOperand.apply(x, 0, ops), (w.std ** 2).clamp(min=1e-4), b.std ** 2
+            x2, s2, vb = BL._var_operand(x, 0, ops), (w.std ** 2).clamp(min=1e-4), b.std ** 2
         else:
             x2, s2, vb = (x ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), b.std ** 2
         var = F.conv2d(x2, s2, vb, padding=1)
         if mode == "torch":
             out = mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)
         else:
-            out = BL._LocalReparam.apply(mean, var, None, 1, 7, ops)
+            out = BL._local_reparam(mean, var, None, 1, 7, ops)
         torch.autograd.grad(out.sum(), leaves)
     ts = [ev(lambda m=m: run(m)) for m in ("torch", "epilogue", "ep+x2", "all")]
     print(f"{str((n, c, hw, hw)):>22} {x.numel():>10} " + " ".join(f"{t:9.1f}" for t in ts))
