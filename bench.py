@@ -494,6 +494,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=8, help="column chunks of the pipelined all-gather")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config-extras", action="store_true",
+                    help="skip extra.other_baseline_configs (smaller launches of the same kernels; PMC passes average per kernel)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -741,6 +743,8 @@ def main():
                 except Exception as e:
                     log(f"  svgd_shell_step_ms skipped: {e}")
                 try:
+                    if args.no_config_extras:
+                        raise RuntimeError("--no-config-extras")
                     res["extra"]["other_baseline_configs"] = config_extras(dev)
                     for k, v in res["extra"]["other_baseline_configs"].items():
                         log(f"  {k}: {v['ms']} ms")

@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_main -o t -- py
 # (c) PMC passes over the bench with extras (every kernel at ResNet-50 size), counters only
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAVES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$tag -o p -- python3 bench.py --gpus 1 --steps 3 --warmup 1 --blocks 1 --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err; echo "pmc $tag rc=$?"
+  rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$tag -o p -- python3 bench.py --gpus 1 --steps 3 --warmup 1 --blocks 1 --no-cpu-baseline --no-config-extras > $O/pmc_$tag.json 2> $O/pmc_$tag.err; echo "pmc $tag rc=$?"
 done
 echo "--- sizes before pruning"; du -sh $O/* | sort -h | tail -12; find $O -type f -size +1M | head -20
 f=$(find $O/pmc_FETCH_SIZE -name "*counter_collection*" | head -1); echo "counter file: $f"; head -2 "$f" | cut -c1-600
