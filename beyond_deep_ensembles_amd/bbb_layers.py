@@ -47,7 +47,8 @@ def _fuse_min(ops) -> int:
 def _native_nodes(ops):
     """The C++ autograd nodes of lib/_bde_host.so (csrc/host_autograd.cpp) when the kernels are the HIP library's; the
     Python Functions below are the same nodes for any other backend (the tests' CPU checker) or without the helper."""
-    if type(ops).__name__ != "HipOps":
+    from .ops import HipOps
+    if not isinstance(ops, HipOps):
         return None
     mod = _host.load()
     return mod if mod is not None and hasattr(mod, "lrt_linear") else None
