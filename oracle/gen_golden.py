@@ -17,6 +17,7 @@ Fixture list:
   swag_stats.npz      moments / deviation columns / samples (swag.py:98-114, 53-58)
   bbb.npz             GaussianParameter draw, KL, one BBBOptimizer trajectory
   bbb2.npz            BBBOptimizer with MixturePrior; with frozen parameters; over the reference's BBBConv2d CNN
+  lrt.npz             the reference's BBBLinear layer: output and all five gradients at five sizes (bbb_layers.py:61-80)
   ivon.npz            iVON trajectories with recorded noise (ivorn.py:41-115)
   ensemble.npz        DeepEnsemble.predict sample split     (ensemble.py:37-40)
   ref_*_checkpoint.pt state_dict()s written by the reference optimizers (wire compatibility)
@@ -422,6 +423,45 @@ def gen_bbb2():
 
 
 # ------------------------------------------------------------------ iVON
+from lrt_cases import LRT_CASES, lrt_case_inputs   # oracle/lrt_cases.py: seeded inputs shared with the tests
+
+
+def gen_lrt():
+    """lrt.npz: the REFERENCE's BBBLinear (bbb_layers.py:10-90, sampling="activations", training mode) on seeded inputs:
+    the output and d(sum(out * g)) / d(input, weight mean / rho, bias mean / rho) from its autograd graph.  The [O, I]
+    gradients are stored as row sums, column sums and one seeded projection (the inputs are regenerated by the tests
+    from the seeds), which keeps the fixture small at the iWildCam-head size and at a wide layer."""
+    out = {"cases": np.array(LRT_CASES)}
+    prior = ref_bbb.GaussianPrior(0, 1.0)
+    for seed, b, i, o in LRT_CASES:
+        x, w_mu, w_rho, b_mu, b_rho, eps, g, probe = lrt_case_inputs(seed, b, i, o)
+        layer = ref_bbb_layers.BBBLinear(i, o, prior, prior)
+        layer.train()
+        with torch.no_grad():
+            layer.weight.mean.copy_(torch.from_numpy(w_mu))
+            layer.weight.rho.copy_(torch.from_numpy(w_rho))
+            layer.bias.mean.copy_(torch.from_numpy(b_mu))
+            layer.bias.rho.copy_(torch.from_numpy(b_rho))
+        xin = torch.from_numpy(x).requires_grad_(True)
+        old = ref_bbb_layers.normal_like
+        ref_bbb_layers.normal_like = lambda t: torch.from_numpy(eps)
+        try:
+            y = layer(xin)
+        finally:
+            ref_bbb_layers.normal_like = old
+        leaves = [xin, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho]
+        gx, gwm, gwr, gbm, gbr = torch.autograd.grad(y, leaves, grad_outputs=torch.from_numpy(g))
+        t = f"c{seed}_"
+        out[t + "out"], out[t + "g_x"], out[t + "g_bmu"], out[t + "g_brho"] = npy(y), npy(gx), npy(gbm), npy(gbr)
+        pr = torch.from_numpy(probe).double()
+        for name, gw in (("g_wmu", gwm), ("g_wrho", gwr)):
+            out[t + name + "_rowsum"] = gw.double().sum(1).numpy()
+            out[t + name + "_colsum"] = gw.double().sum(0).numpy()
+            out[t + name + "_proj"] = np.array((gw.double() * pr).sum().item())
+            out[t + name + "_absmax"] = np.array(gw.abs().max().item())
+    np.savez_compressed(os.path.join(OUT, "lrt.npz"), **out)
+
+
 def gen_ivon():
     out = {}
     cases = []
@@ -581,6 +621,7 @@ elif __name__ == "__main__":
     gen_swag_stats()
     gen_bbb()
     gen_bbb2()
+    gen_lrt()
     gen_ivon()
     gen_ensemble()
     gen_checkpoints()

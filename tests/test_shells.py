@@ -1103,3 +1103,44 @@ def test_native_autograd_nodes_equal_python_nodes():
         native.lrt_linear(xin.double(), leaves[0], leaves[1], None, None, True, None, 1, 2)
     with pytest.raises(RuntimeError):
         native.lrt_linear(torch.randn(200, 13, device=dev), leaves[0], leaves[1], None, None, True, None, 1, 2)   # B > 128
+
+
+def test_bbb_linear_layer_matches_reference_layer(golden, backend, monkeypatch):
+    """bde.BBBLinear forward + backward (fused ops: bde_lrt_linear_fwd / bde_lrt_linear_bwd on the GPU, their CPU
+    restatement in the checker backend) against the REFERENCE's BBBLinear on the same seeded inputs (lrt.npz: output and
+    all five gradients from the reference's autograd graph, at the UCI size, the iWildCam head, a wide layer)."""
+    ops, dev = backend
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    from oracle.lrt_cases import lrt_case_inputs
+    g = golden("lrt.npz")
+    prior = bde.GaussianPrior(0, 1.0)
+    for seed, b, i, o in g["cases"].tolist():
+        x, w_mu, w_rho, b_mu, b_rho, eps, gout, probe = [T(a).to(dev) for a in lrt_case_inputs(seed, b, i, o)]
+        layer = bde.BBBLinear(i, o, prior, prior, _ops=ops).to(dev).train()
+        with torch.no_grad():
+            layer.weight.mean.copy_(w_mu)
+            layer.weight.rho.copy_(w_rho)
+            layer.bias.mean.copy_(b_mu)
+            layer.bias.rho.copy_(b_rho)
+        monkeypatch.setattr(L, "normal_like", lambda t: eps.to(t.device))
+        xin = x.clone().requires_grad_(True)
+        out = layer(xin)
+        leaves = [xin, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho]
+        gx, gwm, gwr, gbm, gbr = [t.detach().cpu().double() for t in torch.autograd.grad(out, leaves, grad_outputs=gout)]
+        t = f"c{seed}_"
+
+        def close(ours, want, scale, what):
+            want = torch.as_tensor(np.asarray(want), dtype=torch.float64)
+            tol = 2e-5 * max(float(scale), 1e-6)                      # fp32 GEMMs in a different summation order
+            assert (torch.as_tensor(ours, dtype=torch.float64) - want).abs().max().item() <= tol, (what, b, i, o)
+        close(out.detach().cpu(), g[t + "out"], np.abs(g[t + "out"]).max(), "out")
+        close(gx, g[t + "g_x"], np.abs(g[t + "g_x"]).max(), "g_x")
+        close(gbm, g[t + "g_bmu"], np.abs(g[t + "g_bmu"]).max(), "g_bmu")
+        close(gbr, g[t + "g_brho"], max(np.abs(g[t + "g_brho"]).max(), 1e-3), "g_brho")
+        pr = probe.cpu().double()
+        for name, gw in (("g_wmu", gwm), ("g_wrho", gwr)):
+            amax = float(g[t + name + "_absmax"])
+            close(gw.sum(1), g[t + name + "_rowsum"], amax * np.sqrt(i), name + " row sums")
+            close(gw.sum(0), g[t + name + "_colsum"], amax * np.sqrt(o), name + " column sums")
+            close((gw * pr).sum(), g[t + name + "_proj"], amax * np.sqrt(i * o), name + " projection")
+            assert abs(gw.abs().max().item() - amax) <= 2e-5 * amax, name
