@@ -88,7 +88,11 @@ class SVGDOptimizer(BayesianOptimizer):
                               (dimension-sharded particles and optimizer state; needs fuse_base_optimizer)
           exchange_chunks     "allgather" only: pipeline the gather and the update over this many column chunks
           fuse_base_optimizer apply a torch.optim.SGD / Adam base optimizer inside the update kernel (one pass over
-                              P and G that writes the updated particles; -phi is never materialised)
+                              P and G that writes the updated particles; -phi is never materialised).  "auto": fused
+                              exactly when that is indistinguishable from particle_count calls of base.step() -- a
+                              plain torch.optim.SGD / Adam (not a subclass) over exactly this optimizer's parameters,
+                              one set of hyper-parameters, no amsgrad / maximize / capturable / differentiable, no
+                              step hooks, particle_count <= 16 -- and the torch loop otherwise
           reuse_gram          with fuse_base_optimizer: the fused kernel also emits the Gram partials of the updated
                               particles, so the next step skips the Gram pass.  Only valid while nothing but this
                               optimizer modifies the particles between two steps (call invalidate_gram() otherwise).
@@ -149,6 +153,8 @@ class SVGDOptimizer(BayesianOptimizer):
             dist.broadcast(self._P, src=dist.get_global_rank(process_group, 0), group=process_group)
             if self._world > 1:
                 self._exchange = exchange
+        if fuse_base_optimizer == "auto":
+            fuse_base_optimizer = self._fusable(base_optimizer, plist, particle_count)
         if fuse_base_optimizer and particle_count > 16:
             warnings.warn("fuse_base_optimizer needs particle_count <= 16 (single-tile kernels); running unfused")
         self._single_launch = single_launch
@@ -164,6 +170,25 @@ class SVGDOptimizer(BayesianOptimizer):
             self._stage = [torch.zeros((m, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in self._chunks]
         if self._exchange == "alltoall":
             self._init_dimension_sharding()
+
+    @staticmethod
+    def _fusable(base, plist, particle_count) -> bool:
+        """fuse_base_optimizer="auto": True iff the in-kernel SGD / Adam applications are the base optimizer's own."""
+        if type(base) not in (torch.optim.SGD, torch.optim.Adam) or particle_count > 16:
+            return False
+        groups = base.param_groups
+        if {id(p) for g in groups for p in g["params"]} != {id(p) for p in plist}:
+            return False
+        keys = [k for k in groups[0] if k != "params"]
+        if any(g[k] != groups[0][k] for g in groups[1:] for k in keys):
+            return False
+        g0 = groups[0]
+        if any(g0.get(flag, False) for flag in ("amsgrad", "maximize", "capturable", "differentiable")):
+            return False
+        if any(torch.is_tensor(g0.get(k)) for k in ("lr", "momentum", "weight_decay", "eps")):
+            return False
+        hooks = ("_optimizer_step_pre_hooks", "_optimizer_step_post_hooks")
+        return not any(len(getattr(base, h, {}) or {}) for h in hooks)
 
     # ------------------------------------------------------------------
     def _local_particles(self) -> range:
@@ -541,6 +566,9 @@ class SVGDOptimizer(BayesianOptimizer):
             st["first"] = False
         else:
             st["step"] += self.state["__particle_count"]
+        # the base optimizer HAS stepped (inside the kernel): keep torch's LR schedulers from warning that
+        # scheduler.step() ran before optimizer.step() (they look at this flag, set by their wrapper of base.step)
+        self.state["__base_optimizer"]._opt_called = True
 
     # ------------------------------------------------------------------
     def sample_parameters(self):

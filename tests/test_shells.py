@@ -776,10 +776,13 @@ def test_svgd_fused_reuse_gram_tracks_unfused_over_many_steps(backend):
         opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=6,
                                 dataset_size=32, l2_reg=1e-4, fuse_base_optimizer=fused, reuse_gram=fused, _ops=ops)
         sched = torch.optim.lr_scheduler.StepLR(base, step_size=10, gamma=0.5)     # LR schedule reaches the fused kernel
-        for t in range(30):
-            xb, yb = x[(t % 2) * 16:(t % 2 + 1) * 16], y[(t % 2) * 16:(t % 2 + 1) * 16]
-            opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
-            sched.step()
+        import warnings as _w
+        with _w.catch_warnings():
+            _w.simplefilter("error")             # incl. torch's "lr_scheduler.step() before optimizer.step()" (fused: the
+            for t in range(30):                  # base optimizer steps inside the kernel and says so)
+                xb, yb = x[(t % 2) * 16:(t % 2 + 1) * 16], y[(t % 2) * 16:(t % 2 + 1) * 16]
+                opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+                sched.step()
         runs.append(opt.particles.detach().cpu().clone())
     assert torch.isfinite(runs[1]).all()
     np.testing.assert_allclose(runs[1].numpy(), runs[0].numpy(), rtol=2e-3, atol=2e-5)
@@ -1144,3 +1147,35 @@ def test_bbb_linear_layer_matches_reference_layer(golden, backend, monkeypatch):
             close(gw.sum(0), g[t + name + "_colsum"], amax * np.sqrt(o), name + " column sums")
             close((gw * pr).sum(), g[t + name + "_proj"], amax * np.sqrt(i * o), name + " projection")
             assert abs(gw.abs().max().item() - amax) <= 2e-5 * amax, name
+
+
+def test_svgd_fuse_auto_eligibility(backend):
+    """fuse_base_optimizer="auto" fuses exactly the base optimizers whose step() the kernel reproduces."""
+    ops, dev = backend
+
+    def decide(make_base, **kw):
+        torch.manual_seed(1)
+        model = make_mlp().to(dev)
+        ps = list(model.parameters())
+        base = make_base(ps)
+        return bde.SVGDOptimizer(ps, lambda: bde.reset_model_params(model), base, particle_count=kw.pop("m", 4),
+                                 dataset_size=32, fuse_base_optimizer="auto", _ops=ops, **kw)._fuse
+
+    class MySGD(torch.optim.SGD):
+        pass
+    assert decide(lambda ps: torch.optim.SGD(ps, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4))
+    assert decide(lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2))
+    assert not decide(lambda ps: torch.optim.AdamW(ps, lr=1e-3))
+    assert not decide(lambda ps: MySGD(ps, lr=0.1))
+    assert not decide(lambda ps: torch.optim.Adam(ps, lr=1e-3, amsgrad=True))
+    assert not decide(lambda ps: torch.optim.SGD(ps, lr=0.1, maximize=True))
+    assert not decide(lambda ps: torch.optim.SGD([{"params": ps[:2], "lr": 0.1}, {"params": ps[2:], "lr": 0.01}], lr=0.1))
+    assert decide(lambda ps: torch.optim.SGD([{"params": ps[:2]}, {"params": ps[2:]}], lr=0.1))
+    assert not decide(lambda ps: torch.optim.SGD(ps[:2], lr=0.1))                 # not the same parameter set
+    assert not decide(lambda ps: torch.optim.SGD(ps, lr=0.1), m=20)              # > 16 particles: blocked path
+
+    def hooked(ps):
+        base = torch.optim.SGD(ps, lr=0.1)
+        base.register_step_post_hook(lambda opt, args, kwargs: None)
+        return base
+    assert not decide(hooked)
