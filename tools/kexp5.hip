@@ -59,6 +59,34 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ in, float
   if (NW == 0 && sink[0] + sink[1] + sink[2] + sink[3] == 12345.678f) out[0] = sink[0];
 }
 
+// The batched sampler's ACCESS GRANULARITY without its arithmetic: a wave owns a tile of 32 float4 columns (512 B per
+// row); lanes 0-31 and 32-63 read two DIFFERENT rows per instruction (the MFMA B-operand layout) and store two different
+// output rows per instruction.  WIDE: a wave owns 64 float4 columns and every instruction touches 1 KB of ONE row.
+template <int NR, int NW, bool WIDE>
+__global__ __launch_bounds__(256) void probe_half(const float* __restrict__ in, float* __restrict__ out, int64_t ld, int64_t n4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t cols = WIDE ? 64 : 32;
+  const int64_t n_tiles = (n4 + cols - 1) / cols;
+  const int64_t waves_total = (int64_t)gridDim.x * 4;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n_tiles; t += waves_total) {
+    const int64_t c = t * cols + (WIDE ? lane : (lane & 31));
+    if (c >= n4) continue;
+    f32x4 acc = {0, 0, 0, 0};
+    if (WIDE) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc += ld4_nt(in + r * ld + 4 * c);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) st4_nt(out + w * ld + 4 * c, acc + (float)w);
+    } else {
+      const int half = lane >> 5;
+#pragma unroll
+      for (int r = 0; r < NR / 2; ++r) acc += ld4_nt(in + (2 * r + half) * ld + 4 * c);
+#pragma unroll
+      for (int w = 0; w < NW / 2; ++w) st4_nt(out + (2 * w + half) * ld + 4 * c, acc + (float)w);
+    }
+  }
+}
+
 // Layout probe: the same NR-in / NW-out shape, but the rows INTERLEAVED at `CH` floats: memory = [chunk][row][CH]
 // (what a per-tensor blocked particle layout would look like to the combine kernel) -- one contiguous region per
 // chunk instead of NR + NW streams 95 MB apart.  A thread still owns one float4 column of all rows.
@@ -439,6 +467,11 @@ int main(int argc, char** argv) {
     const int S = 30;
     vs.push_back({"product bde_swag_sample_batched S30", [&] { bde_swag_sample_batched(mean, sq, in, K, ld, 3, nullptr, nullptr, 1, 0, out, ld, S, D, st); }, 4.0 * D * (K + 2 + S)});
     vs.push_back({"product batched S30 supplied eps_d", [&] { bde_swag_sample_batched(mean, sq, in, K, ld, 3, nullptr, out, 1, 0, out, ld, S, D, st); }, 4.0 * D * (K + 2 + 2 * S)});
+    vs.push_back({"probe R22 W30 grid-stride 4 KB per row per WG g2048", [&] { hipLaunchKernelGGL((probe<22, 30, 1, false, true>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * (K + 2 + S)});
+    vs.push_back({"probe R22 W30 half-wave rows (512 B), g1024", [&] { hipLaunchKernelGGL((probe_half<22, 30, false>), dim3(1024), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * (K + 2 + S)});
+    vs.push_back({"probe R22 W30 half-wave rows (512 B), g2048", [&] { hipLaunchKernelGGL((probe_half<22, 30, false>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * (K + 2 + S)});
+    vs.push_back({"probe R22 W30 whole-wave rows (1 KB), g1024", [&] { hipLaunchKernelGGL((probe_half<22, 30, true>), dim3(1024), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * (K + 2 + S)});
+    vs.push_back({"probe R22 W30 whole-wave rows (1 KB), g2048", [&] { hipLaunchKernelGGL((probe_half<22, 30, true>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * (K + 2 + S)});
     vs.push_back({"probe R22 W30 contig (same bytes)", [&] { hipLaunchKernelGGL((probe<22, 30, 1, true, true>), dim3(2048), dim3(256), 0, st, in, out, ld, n4); }, 4.0 * D * (K + 2 + S)});
     run_table("swag_sample_batched (K = 20, S = 30)", vs, st, 5, 3);
   }
