@@ -263,6 +263,54 @@ def shell_step_ms(dev, steps=10):
                     "of the shell + kernels + fused SGD for 8 particles x 161 tensors"}
 
 
+def other_shell_steps_ms(dev, steps=10):
+    """iVONOptimizer.step and SwagOptimizer.step over 161 parameter tensors totalling ResNet-50 size; the forward
+    closure returns a constant and the backward closure hands out preallocated gradient tensors (no model work): what
+    is timed is the optimizer's own work per training step -- host logic + kernels (+ torch's SGD for SWAG)."""
+    import beyond_deep_ensembles_amd as bde
+    n_tensors, d = 161, D_RESNET50
+    sizes = [d // n_tensors] * (n_tensors - 1)
+    sizes.append(d - sum(sizes))
+    out = {}
+    zero = torch.zeros((), device=dev)
+
+    def make():
+        params = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in sizes]
+        grads = [torch.randn(s, device=dev) * 0.01 for s in sizes]
+
+        def bwd(loss):
+            for p, g in zip(params, grads):
+                p.grad = g
+        return params, bwd
+
+    def run(opt, bwd):
+        for _ in range(3):
+            opt.step(lambda: zero, bwd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            opt.step(lambda: zero, bwd)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    params, bwd = make()
+    opt = bde.iVONOptimizer(params, lr=1e-3, prior_prec=100.0, dataset_size=DATASET_SIZE, mc_samples=2, rng="philox")
+    out["ivon_step_mc2"] = {"ms": round(run(opt, bwd) * 1e3, 3),
+                            "what": "iVONOptimizer.step, 2 MC samples: 2 weight-noise draws + gradient hand-over + update; "
+                                    "kernels alone 2 x 0.073 + 0.116 ms"}
+    del opt, params
+    params, bwd = make()
+    opt = bde.SwagOptimizer(params, torch.optim.SGD(params, lr=1e-3, momentum=0.9), update_interval=1, deviation_samples=K_SWAG,
+                            rng="philox")
+    out["swag_step_update_every_step"] = {"ms": round(run(opt, bwd) * 1e3, 3),
+                                          "what": "SwagOptimizer.step with a moment update on EVERY step (the reference updates "
+                                                  "every 255...3300 steps): torch SGD.step over 161 tensors + bde_swag_update "
+                                                  "(0.088 ms)"}
+    del opt, params
+    out["tensors"] = n_tensors
+    return out
+
+
 def config_extras(dev):
     """The other BASELINE.json configs through the PRODUCT shells (null closures: what is timed is the optimizer's
     own work -- kernels + host logic -- per step / per posterior sample):
@@ -742,6 +790,11 @@ def main():
                     log(f"  svgd_shell_step_ms {res['extra']['svgd_shell_step_ms']}")
                 except Exception as e:
                     log(f"  svgd_shell_step_ms skipped: {e}")
+                try:
+                    res["extra"]["other_shell_steps_ms"] = other_shell_steps_ms(dev)
+                    log(f"  other_shell_steps_ms {res['extra']['other_shell_steps_ms']}")
+                except Exception as e:
+                    log(f"  other_shell_steps_ms skipped: {type(e).__name__}: {e}")
                 try:
                     if not args.no_config_extras:
                         res["extra"]["other_baseline_configs"] = config_extras(dev)
