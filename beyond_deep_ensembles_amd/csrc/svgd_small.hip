@@ -28,6 +28,7 @@
 // <= 256 workgroups of 512 threads, one per CU on a 256-CU device).  Measured timeline at D = 273,610
 // (tools/kexp6.hip, profiles/r02_small_step_timeline_v3_and_gram_ab.txt).
 #include "svgd_gram.hpp"
+#include <atomic>
 
 namespace bde {
 
@@ -415,10 +416,34 @@ static int launch_small(const float* P, const float* G, float* out, int64_t D, i
   return to_err(hipGetLastError());
 }
 
+// The hand-off inside the kernel needs ALL workgroups of the launch resident at once.  A whole MI355X holds 256 of
+// them with room to spare; a partition of the chip (CPX mode: 32 CUs) or a smaller part does not, and the launch would
+// wait for workgroups that can never start.  The limit is what the CURRENT device can hold (CUs x workgroups per CU
+// at this kernel's register / LDS footprint), queried once per device; without a device (the build container) the
+// full-chip figure applies.
+static int small_resident_limit() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return kSmallMaxGrid;
+  int v = cache[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  int cus = 0, per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, svgd_step_small_kernel<8, true, 2>, kSmallBlock, 0) != hipSuccess ||
+      cus < 1 || per_cu < 1)
+    v = 1;                                                          // unknown: never more than one workgroup
+  else
+    v = static_cast<int>(std::min<int64_t>(static_cast<int64_t>(cus) * per_cu, kSmallMaxGrid));
+  cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
 static int small_dispatch(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld, const StatParams& sp,
                           float* ws, float* kstat, const SmallOpt& o, hipStream_t s) {
   const int64_t n_tiles = (((D + 3) >> 2) + kSmallTile4 - 1) / kSmallTile4;
-  const int tpw = static_cast<int>((n_tiles + kSmallMaxGrid - 1) / kSmallMaxGrid);
+  const int max_grid = small_resident_limit();
+  const int tpw = static_cast<int>((n_tiles + max_grid - 1) / max_grid);
+  if (tpw > kSmallMaxTilesPerWG) return BDE_ERR_INVALID;             // bde_svgd_small_supported() says no on this device
   const int grid = static_cast<int>((n_tiles + tpw - 1) / tpw);
   switch (M) {
 #define BDE_CASE(m) \
@@ -437,7 +462,7 @@ using namespace bde;
 extern "C" int bde_svgd_small_supported(int M, int64_t D) {
   if (M < 1 || M > 8 || D < 1) return 0;
   const int64_t n_tiles = (((D + 3) >> 2) + kSmallTile4 - 1) / kSmallTile4;
-  return n_tiles <= static_cast<int64_t>(kSmallMaxGrid) * kSmallMaxTilesPerWG;
+  return n_tiles <= static_cast<int64_t>(small_resident_limit()) * kSmallMaxTilesPerWG;
 }
 
 static StatParams small_stat_params(int M, float l2_reg, float kernel_grad_scale, float dataset_size, float sign,

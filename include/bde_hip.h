@@ -120,8 +120,10 @@ int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, 
  * counter, the kernel statistics evaluated redundantly by every workgroup, and the combine of the columns each
  * workgroup already holds in registers.  12*M*D bytes of HBM traffic, no launch boundaries.  Same results as the
  * three-stage path up to the order of the partial sums.  mode / h_override as in bde_svgd_kstats (mode 1: G may
- * be NULL, out = grad_kernel).  Needs all its (<= 256) workgroups co-resident: use on a device with >= 256 CUs
- * that is not oversubscribed by other persistent kernels. */
+ * be NULL, out = grad_kernel).  Needs all its (<= 256) workgroups co-resident: bde_svgd_small_supported() answers
+ * for the CURRENT device (CUs x resident workgroups per CU, queried once per device), so a partition of the chip
+ * (CPX mode) gets a smaller limit on D or the three-stage path; do not oversubscribe the device with other
+ * persistent kernels. */
 int bde_svgd_small_supported(int M, int64_t D);
 int bde_svgd_step_small(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
                         float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
