@@ -188,7 +188,10 @@ class SVGDOptimizer(BayesianOptimizer):
         if any(torch.is_tensor(g0.get(k)) for k in ("lr", "momentum", "weight_decay", "eps")):
             return False
         hooks = ("_optimizer_step_pre_hooks", "_optimizer_step_post_hooks")
-        return not any(len(getattr(base, h, {}) or {}) for h in hooks)
+        if any(len(getattr(base, h, {}) or {}) for h in hooks):
+            return False
+        import torch.optim.optimizer as _o                               # hooks registered for ALL optimizers
+        return not (getattr(_o, "_global_optimizer_pre_hooks", None) or getattr(_o, "_global_optimizer_post_hooks", None))
 
     # ------------------------------------------------------------------
     def _local_particles(self) -> range:
