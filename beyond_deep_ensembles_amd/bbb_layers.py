@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+from torch.autograd.function import once_differentiable
 import torch.nn.functional as F
 
 from . import _host
@@ -89,6 +90,7 @@ class _LocalReparam(torch.autograd.Function):
         return out.view(mean.shape)
 
     @staticmethod
+    @once_differentiable          # the kernels produce plain tensors: no double backward
     def backward(ctx, grad_out):
         v, e = ctx.saved_tensors
         seed, stream_id, ops, shape = ctx.meta
@@ -112,6 +114,7 @@ class _VarOperand(torch.autograd.Function):
         return out.view(v.shape)
 
     @staticmethod
+    @once_differentiable          # the kernels produce plain tensors: no double backward
     def backward(ctx, grad_out):
         (vc,) = ctx.saved_tensors
         mode, ops = ctx.meta
@@ -143,6 +146,7 @@ class _LrtLinear(torch.autograd.Function):
         return out.view(x.shape[:-1] + (o,))
 
     @staticmethod
+    @once_differentiable          # the kernels produce plain tensors: no double backward
     def backward(ctx, grad_out):
         x, w_mu, w_rho, b_rho, var, eps = ctx.saved_tensors
         clamp_bias, seed, stream_id, ops, x_shape = ctx.meta

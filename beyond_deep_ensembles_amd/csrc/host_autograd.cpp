@@ -22,6 +22,11 @@ void* current_stream(const at::Tensor& t) { return c10::hip::getCurrentHIPStream
 void check_f32_cuda(const at::Tensor& t, const char* name) {
   TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat, name, ": expected a float32 CUDA (HIP) tensor");
 }
+// the kernels produce plain tensors: a second differentiation through a node would silently see constants
+void check_once_differentiable(const variable_list& grad_outputs) {
+  TORCH_CHECK(!(at::GradMode::is_enabled() && grad_outputs[0].defined() && grad_outputs[0].requires_grad()),
+              "the fused layer ops are differentiable once (no double backward)");
+}
 const float* ptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 float* mptr(at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 at::Tensor opt(const c10::optional<at::Tensor>& t) { return t.has_value() ? *t : at::Tensor(); }
@@ -64,6 +69,7 @@ struct LrtLinear : public torch::autograd::Function<LrtLinear> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
+    check_once_differentiable(grad_outputs);
     const variable_list saved = ctx->get_saved_variables();
     const at::Tensor &x = saved[0], &w_mu = saved[1], &w_rho = saved[2], &b_rho = saved[3], &var = saved[4], &eps = saved[5];
     const bool has_bias = ctx->saved_data["has_bias"].toBool();
@@ -112,6 +118,7 @@ struct LocalReparam : public torch::autograd::Function<LocalReparam> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
+    check_once_differentiable(grad_outputs);
     const variable_list saved = ctx->get_saved_variables();
     const at::Tensor &v = saved[0], &e = saved[1];
     c10::DeviceGuard guard(v.device());
@@ -140,6 +147,7 @@ struct VarOperand : public torch::autograd::Function<VarOperand> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
+    check_once_differentiable(grad_outputs);
     const at::Tensor vc = ctx->get_saved_variables()[0];
     c10::DeviceGuard guard(vc.device());
     const at::Tensor g = grad_outputs[0].contiguous();

@@ -16,6 +16,7 @@ from typing import Callable, Optional
 
 import torch
 import torch.nn as nn
+from torch.autograd.function import once_differentiable
 import torch.nn.functional as F
 
 _philox_stream = itertools.count()
@@ -54,6 +55,7 @@ class _GaussDraw(torch.autograd.Function):
         return w.view(mean.shape)
 
     @staticmethod
+    @once_differentiable          # the kernels produce plain tensors: no double backward
     def backward(ctx, grad_out):
         r, e = ctx.saved_tensors
         seed, stream_id, ops, n, shape = ctx.meta
@@ -78,6 +80,7 @@ class _FlatGaussDraw(torch.autograd.Function):
         return tuple(group.gl.views(w))
 
     @staticmethod
+    @once_differentiable          # the kernels produce plain tensors: no double backward
     def backward(ctx, *grads):
         group, ops, seed, stream_id = ctx.meta
         d, ld = group.gl.d, group.gl.ld
