@@ -935,3 +935,46 @@ def test_var_operand_kernels(ops):
                 assert gv[1].item() == 0.0 and out[1].item() == pytest.approx(1e-4)
             if mode == 2 and n > 2:
                 assert gv[1].item() != 0.0
+
+
+def test_lrt_linear_random_shapes(ops):
+    """Forward + backward of the fused BBBLinear ops at seeded random shapes (ragged B / I / O, both the row-per-lane
+    and the wide LDS-staged forward kernels, split and unsplit input-gradient reductions) against fp64 autograd over
+    bbb_layers.py:70-80; allowance = twice the deviation of fp32 autograd over the same lines."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(77)
+    shapes = [(int(rs.randint(1, 129)), int(rs.randint(1, 400)), int(rs.randint(1, 300))) for _ in range(10)]
+    shapes += [(int(rs.randint(1, 129)), 4 * int(rs.randint(130, 600)), int(rs.randint(450, 900))) for _ in range(4)]   # wide
+    torch.manual_seed(78)
+    dev = lambda t: None if t is None else t.to(DEV)
+    for b, i, o in shapes:
+        bias = bool(rs.randint(0, 2))
+        x, eps, g = torch.randn(b, i), torch.randn(b, o), torch.randn(b, o)
+        w_mu, w_rho = torch.randn(o, i) * 0.1, torch.randn(o, i) * 1.5 - 3.0
+        b_mu, b_rho = (torch.randn(o) * 0.1, torch.randn(o) - 3.0) if bias else (None, None)
+
+        def ref(dt):
+            leaves = [t.to(dt).requires_grad_(True) for t in (x, w_mu, w_rho)]
+            xx, wm, wr = leaves
+            bm = br = vb = None
+            if bias:
+                bm, br = b_mu.to(dt).requires_grad_(True), b_rho.to(dt).requires_grad_(True)
+                vb = (F.softplus(br) ** 2).clamp(min=1e-4)
+                leaves += [bm, br]
+            var = F.linear((xx ** 2).clamp(min=1e-4), (F.softplus(wr) ** 2).clamp(min=1e-4), vb)
+            out = F.linear(xx, wm, bm) + var.sqrt() * eps.to(dt)
+            return out.detach().double(), var.detach(), [t.double() for t in torch.autograd.grad(out, leaves, grad_outputs=g.to(dt))]
+        o64, v64, g64 = ref(torch.float64)
+        o32, v32, g32 = ref(torch.float32)
+        out, var = torch.empty(b, o, device=DEV), torch.empty(b, o, device=DEV)
+        ops.lrt_linear_fwd(dev(x), dev(w_mu), dev(w_rho), dev(b_mu), dev(b_rho), True, out, var, eps=dev(eps))
+        tol = max(2 * (o32 - o64).abs().max().item(), 3e-6 * o64.abs().max().item())
+        assert (out.cpu().double() - o64).abs().max().item() <= tol, ("out", b, i, o)
+        outs = [torch.empty(b, i, device=DEV), torch.empty(o, i, device=DEV), torch.empty(o, i, device=DEV)]
+        outs += [torch.empty(o, device=DEV), torch.empty(o, device=DEV)] if bias else [None, None]
+        ops.lrt_linear_bwd(dev(x), dev(w_mu), dev(w_rho), dev(b_rho), True, dev(g), var, *outs, eps=dev(eps))
+        for name, ours, r64, r32 in zip(["g_x", "g_wmu", "g_wrho", "g_bmu", "g_brho"], outs, g64, g32):
+            tol = max(2 * (r32 - r64).abs().max().item(), 3e-6 * r64.abs().max().item())
+            # the backward is evaluated at OUR forward's variance (fp32, 1-2 ulp from the fp32 reference's): allow for it
+            tol += 1e-6 * r64.abs().max().item()
+            assert (ours.cpu().double() - r64).abs().max().item() <= tol, (name, b, i, o, bias)
