@@ -9,7 +9,8 @@
 //   g_Wmu   = g^T x
 //   g_Wrho  = (gvar^T clamp(x^2)) * [sigma_W^2 >= 1e-4] * 2 sigma_W sigmoid(rho_W)
 //   g_bmu   = sum_b g,   g_brho = (sum_b gvar) * [sigma_b^2 >= 1e-4] * 2 sigma_b sigmoid(rho_b)
-// Three launches (four when the reduction over O is split):
+// Two launches for layers up to 2^20 weights (prep + lrt_bwd_fused_kernel: one pass over the weights for all three
+// matrix gradients), otherwise three (four when the reduction over O is split):
 //   lrt_bwd_prep_kernel   gvar [B, O] once (noise supplied or regenerated from the forward's Philox stream) and the
 //                         two bias gradients (column sums in a fixed order)
 //   lrt_bwd_w_kernel      one wave per 32 x 32 tile of [O, I]: both weight gradients as two accumulator tiles on
@@ -233,6 +234,132 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_x_kernel(
   }
 }
 
+// Weight gradients AND input gradient in ONE pass over the weights (layers up to 2^20 weights, batch <= 64): a
+// wave owns 32 input columns and an O-slice and walks the slice in tiles of 32 rows.  Per tile the rows of W_mu / W_rho
+// are read ONCE and softplus / sigmoid evaluated ONCE per element, serving both products:
+//   dX   D[b][i] += sum_o A[b][o] B[o][i]   B = W_mu / clamp(sigma^2) rows (lanes along i), A from the transposed copies
+//   dW   D[o][i]  = sum_b A[o][b] B[b][i]   A = g / gvar (lanes along o), B = x / clamp(x^2) kept in registers for the
+//                                           whole slice; epilogue * [sigma^2 >= 1e-4] * 2 sigma sigmoid(rho)
+// The k-order of the dX product inside a tile is free, so k-step s uses row (s & 3) + 8 (s >> 2) + 4 h -- the row that
+// accumulator register s of the dW tile holds in this lane: every lane needs sigma of exactly the 16 rows it loaded.
+// Against the two separate kernels: W_rho read once instead of twice (20 -> 16 bytes per weight) and half the softplus work.
+template <int NB, bool DIRECT>
+__global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_fused_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_mu, const float* __restrict__ w_rho,
+    const float* __restrict__ g, const float* __restrict__ gvar, const float* __restrict__ gT,
+    const float* __restrict__ gvT, int B, int I, int O, int n_slices, int oslice, float* __restrict__ g_wmu,
+    float* __restrict__ g_wrho, float* __restrict__ g_x, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i_tiles = (I + 31) >> 5;
+  const int unit = blockIdx.x * kLrtBwdWaves + wave;
+  if (unit >= i_tiles * n_slices) return;
+  const int sl = unit / i_tiles, it = unit % i_tiles;
+  const int r = lane & 31, h = lane >> 5;
+  const int i = it * 32 + r;
+  const bool i_ok = i < I;
+  const int ic = i_ok ? i : I - 1;
+  const int o0 = sl * oslice, o1 = min(O, o0 + oslice);             // oslice is a multiple of 32
+  constexpr int b_pad = NB * 32, KB = NB * 16;                       // k-steps of the dW product (2 batch rows each)
+  // this strip of x in the dW B-operand layout (lane: column i, batch rows 2 u + h), masked once
+  float xs[KB];
+#pragma unroll
+  for (int u = 0; u < KB; ++u) {
+    const int b = 2 * u + h;
+    const float v = x[static_cast<int64_t>(min(b, B - 1)) * ldx + ic];
+    xs[u] = (b < B && i_ok) ? v : 0.f;
+  }
+  f32x16 accxm[NB], accxv[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) accxm[t] = accxv[t] = f32x16{};
+
+  for (int ot0 = o0; ot0 < o1; ot0 += 32) {
+    // rows of this tile in the accumulator-register order (see above); clamped, masked at use
+    float wm[16], wr[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = min(ot0 + (s & 3) + 8 * (s >> 2) + 4 * h, O - 1);
+      wm[s] = w_mu[static_cast<int64_t>(row) * I + ic];
+      wr[s] = w_rho[static_cast<int64_t>(row) * I + ic];
+    }
+    // dW: K = B
+    const int oa = ot0 + r;
+    const bool oa_ok = oa < O;
+    const int oac = oa_ok ? oa : O - 1;
+    f32x16 accwm = {}, accwv = {};
+#pragma unroll
+    for (int u0 = 0; u0 < KB; u0 += 8) {
+      float ag[8], av[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bc = min(2 * (u0 + u) + h, B - 1);
+        ag[u] = g[static_cast<int64_t>(bc) * O + oac];
+        av[u] = gvar[static_cast<int64_t>(bc) * O + oac];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool a_ok = oa_ok && (2 * (u0 + u) + h < B);
+        const float xv = xs[u0 + u];
+        const float x2 = (2 * (u0 + u) + h < B && i_ok) ? fmaxf(xv * xv, kLrtBwdClamp) : 0.f;
+        accwm = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ok ? ag[u] : 0.f, xv, accwm, 0, 0, 0);
+        accwv = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ok ? av[u] : 0.f, x2, accwv, 0, 0, 0);
+      }
+    }
+    // dX k-steps + the dW epilogue, 4 rows of transposed-copy operands in flight at a time
+#pragma unroll
+    for (int s0 = 0; s0 < 16; s0 += 4) {
+      float agT[4][NB], avT[4][NB];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int s = s0 + q;
+        const int row = min(ot0 + (s & 3) + 8 * (s >> 2) + 4 * h, O - 1);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          agT[q][t] = gT[static_cast<int64_t>(row) * b_pad + t * 32 + r];
+          avT[q][t] = gvT[static_cast<int64_t>(row) * b_pad + t * 32 + r];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int s = s0 + q;
+        const int row = ot0 + (s & 3) + 8 * (s >> 2) + 4 * h;
+        const bool w_ok = row < o1 && i_ok;                        // rows past the slice / the matrix add nothing
+        const SoftplusSigmoid sp = softplus_sigmoid(wr[s]);
+        const float s2 = sp.sp * sp.sp;
+        const float bm = w_ok ? wm[s] : 0.f, bv = w_ok ? fmaxf(s2, kLrtBwdClamp) : 0.f;
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          accxm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(agT[q][t], bm, accxm[t], 0, 0, 0);
+          accxv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(avT[q][t], bv, accxv[t], 0, 0, 0);
+        }
+        if (w_ok) {
+          const int64_t idx = static_cast<int64_t>(row) * I + i;
+          g_wmu[idx] = accwm[s];
+          g_wrho[idx] = accwv[s] * (s2 >= kLrtBwdClamp ? 1.f : 0.f) * (2.0f * sp.sp * sp.sg);
+        }
+      }
+    }
+  }
+  if (!i_ok) return;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int b = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (DIRECT) {
+        if (b < B) {
+          const float xv = x[static_cast<int64_t>(b) * ldx + i];
+          const float keep = xv * xv >= kLrtBwdClamp ? 1.f : 0.f;
+          g_x[static_cast<int64_t>(b) * I + i] = accxm[t][reg] + accxv[t][reg] * keep * (2.0f * xv);
+        }
+      } else {
+        float* base = part + static_cast<int64_t>(sl) * 2 * b_pad * I;
+        base[static_cast<int64_t>(b) * I + i] = accxm[t][reg];
+        base[static_cast<int64_t>(b_pad + b) * I + i] = accxv[t][reg];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void lrt_bwd_x_finish_kernel(const float* __restrict__ part, int n_slices, int b_pad,
                                                                  const float* __restrict__ x, int64_t ldx,
                                                                  float* __restrict__ g_x, int B, int I) {
@@ -267,13 +394,13 @@ struct LrtBwdPlan {
 #define BDE_LRT_BWD_TARGET_WAVES 2048
 #endif
 static inline LrtBwdPlan lrt_bwd_plan(int I, int O) {
-  if (O <= 256) return LrtBwdPlan{1, O};
-  const int i_tiles = (I + 31) / 32;
+  // slices are whole 32-row tiles (the fused kernel's dW tiles must not straddle two slices)
+  const int i_tiles = (I + 31) / 32, o_tiles = (O + 31) / 32;
+  if (o_tiles < 4) return LrtBwdPlan{1, o_tiles * 32};
   int want = (BDE_LRT_BWD_TARGET_WAVES + i_tiles - 1) / i_tiles;
-  const int most = (O + 63) / 64;
-  if (want > most) want = most;
+  if (want > o_tiles) want = o_tiles;
   if (want < 1) want = 1;
-  const int oslice = ((O + want - 1) / want + 7) / 8 * 8;
+  const int oslice = (o_tiles + want - 1) / want * 32;
   return LrtBwdPlan{(O + oslice - 1) / oslice, oslice};
 }
 static inline int lrt_bwd_nb(int B) {
@@ -317,23 +444,38 @@ extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu
   int rc = to_err(hipGetLastError());
   if (rc) return rc;
   const int i_tiles = (I + 31) / 32, o_tiles = (O + 31) / 32;
-  const int64_t w_units = static_cast<int64_t>(i_tiles) * o_tiles;
-  hipLaunchKernelGGL(lrt_bwd_w_kernel, dim3(static_cast<unsigned>((w_units + kLrtBwdWaves - 1) / kLrtBwdWaves)),
-                     dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_rho, g, gvar, B, I, O, g_wmu, g_wrho);
-  rc = to_err(hipGetLastError());
-  if (rc || !g_x) return rc;
+  // One pass over the weights for layers up to 2^20 weights (the reference's sizes: 23 vs 38 us at the iWildCam head).
+  // Wide layers keep the two kernels: the fused kernel's register set (352 VGPRs at 2 batch tiles, spills at 4) leaves
+  // one wave per SIMD and its per-tile chain un-overlapped (4096 x 4096 at batch 64: 303 vs 180 us).
+  const bool fused = g_x && nb <= 2 && static_cast<int64_t>(I) * O <= (int64_t{1} << 20);
+  if (!fused) {                          // weight gradients: one wave per 32 x 32 tile
+    const int64_t w_units = static_cast<int64_t>(i_tiles) * o_tiles;
+    hipLaunchKernelGGL(lrt_bwd_w_kernel, dim3(static_cast<unsigned>((w_units + kLrtBwdWaves - 1) / kLrtBwdWaves)),
+                       dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_rho, g, gvar, B, I, O, g_wmu, g_wrho);
+    rc = to_err(hipGetLastError());
+    if (rc || !g_x) return rc;
+  }
   const LrtBwdPlan plan = lrt_bwd_plan(I, O);
   const int x_units = i_tiles * plan.n_slices;
   const int xgrid = (x_units + kLrtBwdWaves - 1) / kLrtBwdWaves;
 #define BDE_LRT_X(NB, DIRECT) \
   hipLaunchKernelGGL((lrt_bwd_x_kernel<NB, DIRECT>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu, w_rho, gT, \
                      gvT, B, I, O, plan.n_slices, plan.oslice, g_x, part)
-  if (plan.n_slices == 1) {
-    if (nb == 1) BDE_LRT_X(1, true); else if (nb == 2) BDE_LRT_X(2, true); else BDE_LRT_X(4, true);
+#define BDE_LRT_F(NB, DIRECT) \
+  hipLaunchKernelGGL((lrt_bwd_fused_kernel<NB, DIRECT>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu, w_rho, g, \
+                     gvar, gT, gvT, B, I, O, plan.n_slices, plan.oslice, g_wmu, g_wrho, g_x, part)
+  const bool direct = plan.n_slices == 1;
+  if (!fused) {
+    if (nb == 1) { if (direct) BDE_LRT_X(1, true); else BDE_LRT_X(1, false); }
+    else if (nb == 2) { if (direct) BDE_LRT_X(2, true); else BDE_LRT_X(2, false); }
+    else { if (direct) BDE_LRT_X(4, true); else BDE_LRT_X(4, false); }
+  } else if (nb == 1) {
+    if (direct) BDE_LRT_F(1, true); else BDE_LRT_F(1, false);
   } else {
-    if (nb == 1) BDE_LRT_X(1, false); else if (nb == 2) BDE_LRT_X(2, false); else BDE_LRT_X(4, false);
+    if (direct) BDE_LRT_F(2, true); else BDE_LRT_F(2, false);
   }
 #undef BDE_LRT_X
+#undef BDE_LRT_F
   rc = to_err(hipGetLastError());
   if (rc || plan.n_slices == 1) return rc;
   hipLaunchKernelGGL(lrt_bwd_x_finish_kernel, dim3(stream_grid(static_cast<int64_t>(B) * I)), dim3(kBlock), 0, s, part,
