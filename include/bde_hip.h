@@ -299,8 +299,8 @@ int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const flo
                        const float* b_rho, int clamp_bias_var, const float* eps, uint64_t seed, uint64_t stream_id,
                        float* out, float* var_out, int B, int I, int O, void* ws, void* stream);
 
-/* Backward of bde_lrt_linear_fwd: the autograd graph of bbb_layers.py:61-80 in three launches (four when the layer
- * is large enough for the reduction over O to be split).  With g = d loss / d out [B, O] and
+/* Backward of bde_lrt_linear_fwd: the autograd graph of bbb_layers.py:61-80 in two launches for layers of up to 2^20
+ * weights (one pass over the weights for all three matrix gradients), three or four for larger ones.  With g = d loss / d out [B, O] and
  * gvar = g * eps / (2 sqrt(var)) (var = the var_out of the forward call; eps as supplied there, or NULL to regenerate
  * the forward's Philox noise from (seed, stream_id)):
  *   g_x    [B, I] = g W_mu + (gvar clamp(sigma_W^2)) * 2 x * [x^2 >= 1e-4]           (NULL: not computed)
