@@ -561,10 +561,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("BDE_BENCH_BACKEND", "nccl")
+        import datetime
+        limit = datetime.timedelta(minutes=10)          # a rendezvous / collective that never completes fails, not hangs
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
         if M % world:
             raise SystemExit(f"M={M} particles cannot be sharded over {world} ranks")
 
