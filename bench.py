@@ -14,9 +14,12 @@ HBM to -phi: three launches (MFMA Gram, kernel statistics, streaming combine),
 N > 1: the 8 particles are sharded M/N per rank and a step is the product's own
 multi-GPU posterior update (SVGDOptimizer._posterior_update, fused SGD base
 optimizer): gradient exchange over RCCL/xGMI + update, total work fixed
-("strong").  --exchange picks the exchange: "alltoall" (dimension-sharded,
-default), "pipelined" (chunked all-gather overlapped with the update) or
-"allgather" (one all-gather, then the update).
+("strong").  ONE invocation times every exchange mode, each with a freshly
+built optimizer: "allgather" (one all-gather of the gradient rows, then the
+update -- the exchange north_star names and the headline value), "pipelined"
+(chunked all-gather overlapped with the update) and "alltoall"
+(dimension-sharded); `exchange` in the JSON carries all three and names the
+best.  A failing collective ends the run non-zero (no in-process fallback).
 
 Timing: after W warm-up steps, --blocks (default 5) blocks of EXACTLY K steps,
 each bracketed by barrier + synchronize and reduced with MAX over ranks;
@@ -530,6 +533,98 @@ def median(v):
     return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
 
 
+class _NoKernels:
+    """SVGD kernel calls become no-ops (allocation / capability queries pass through)."""
+    _keep = ("svgd_ws", "svgd_kstat", "svgd_small_supported", "svgd_fused_gram_supported")
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        attr = getattr(self._real, name)
+        if name.startswith("svgd_") and name not in self._keep and callable(attr):
+            return lambda *a, **k: None
+        return attr
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def multi_gpu_mode(kind, args, dist, dev, rank, world, d):
+    """One exchange mode of the product's multi-GPU SVGD update (SVGDOptimizer._posterior_update, fused SGD base
+    optimizer), driven exactly as SVGDOptimizer.step drives it after the backward passes: build, first contact with the
+    collective, warm-up, timed blocks, then the same step re-timed with (a) the kernels and (b) the collectives
+    switched off.  Every mode gets a freshly built optimizer between two barriers; an exception is NOT caught -- the
+    rank exits non-zero and the launcher tears the job down (a process group is not reusable after a failed
+    collective, and a rank-local fallback would leave the ranks in different collectives)."""
+    import contextlib
+    import beyond_deep_ensembles_amd as bde
+    per = M // world
+    dist.barrier()
+    P0, _ = make_svgd_inputs(d, dev, 1234)                          # same seed: identical particles on every rank
+    theta = torch.nn.Parameter(P0[0, :d].clone())
+    rows = [P0[i, :d].clone() for i in range(M)]
+    del P0
+    nxt = iter(range(1, M))
+
+    def reset():
+        with torch.no_grad():
+            theta.copy_(rows[next(nxt)])
+    base = torch.optim.SGD([theta], lr=1e-12, momentum=0.9, nesterov=True, weight_decay=3e-4)
+    kw = {"alltoall": dict(exchange="alltoall"), "pipelined": dict(exchange_chunks=args.chunks), "allgather": {}}[kind]
+    opt = bde.SVGDOptimizer([theta], reset, base, particle_count=M, dataset_size=DATASET_SIZE,
+                            process_group=dist.group.WORLD, fuse_base_optimizer=True, **kw)
+    del rows
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)          # own gradient rows differ per rank
+    for i in opt._local_particles():
+        opt._grad_row(i)[:d] = torch.randn(d, device=dev, generator=g) * 0.01
+    loss0 = torch.zeros((), device=dev)
+
+    def step(i=None):
+        opt._posterior_update(loss0)
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    blocks_ms = timed_blocks(step, args.steps, max(1, args.blocks), dist, dev)
+    ms = median(blocks_ms)
+    assert torch.isfinite(opt.particles).all()
+
+    @contextlib.contextmanager
+    def no_collectives():
+        saved = (dist.all_gather_into_tensor, dist.all_to_all_single)
+        fake = lambda *a, async_op=False, **k: _Done() if async_op else None
+        dist.all_gather_into_tensor, dist.all_to_all_single = fake, fake
+        try:
+            yield
+        finally:
+            dist.all_gather_into_tensor, dist.all_to_all_single = saved
+    real_ops = opt._ops
+    opt._ops = _NoKernels(real_ops)
+    exchange_only = median(timed_blocks(step, args.steps, 1, dist, dev))
+    opt._ops = real_ops
+    with no_collectives():
+        update_only = median(timed_blocks(step, args.steps, 1, dist, dev))
+    hidden = exchange_only + update_only - ms
+    # bytes a rank puts on the wire per step (what the per-link xGMI bound applies to)
+    ldp = pad_ld(d)
+    sent = {"allgather": 4 * per * ldp * (world - 1), "pipelined": 4 * per * ldp * (world - 1),
+            "alltoall": 2 * 4 * per * ldp * (world - 1) // world}[kind]
+    per_rank_bytes = (12 * M + 8) * d / (world if kind == "alltoall" else 1)
+    res = {"mode": kind, "step_ms": round(ms, 4), "steps_per_s": round(1e3 / ms, 2),
+           "exchange_ms": round(exchange_only, 4), "update_ms": round(update_only, 4),
+           "overlap": round(max(0.0, hidden) / max(1e-9, min(exchange_only, update_only)), 3),
+           "ms_per_step_blocks": [round(x, 4) for x in blocks_ms],
+           "bytes_sent_per_rank": int(sent), "update_bytes_per_rank": int(per_rank_bytes),
+           "update_GBps_per_rank": round(per_rank_bytes / (update_only * 1e-3) / 1e9, 1),
+           "_blocks": blocks_ms}
+    del opt, theta, base
+    torch.cuda.empty_cache()
+    dist.barrier()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -537,8 +632,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps; the median is reported")
     ap.add_argument("--dim", type=int, default=D_RESNET50)
-    ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "pipelined", "allgather"],
-                    help="N > 1: gradient exchange of the SVGD update")
+    ap.add_argument("--exchange", default="all", choices=["all", "allgather", "pipelined", "alltoall"],
+                    help="N > 1: gradient exchange(s) of the SVGD update to time; 'all' = every mode in this one run "
+                         "(headline = allgather, the exchange north_star names)")
     ap.add_argument("--chunks", type=int, default=8, help="column chunks of the pipelined all-gather")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -576,7 +672,11 @@ def main():
     per = M // world
     exchange_used, exchange_note = "none", None
     phases = None
+    if world > 1 and os.environ.get("BDE_BENCH_BACKEND", "nccl") != "nccl":
+        exchange_note = "smoke run: all ranks share one device over " + os.environ["BDE_BENCH_BACKEND"] + \
+                        " (exchange times are host-staged copies, not xGMI)"
 
+    modes_out, headline_mode, best_mode = None, None, None
     if world == 1:
         P, G = make_svgd_inputs(d, dev, 1234)
         out = torch.empty_like(G)
@@ -591,101 +691,31 @@ def main():
             ops.svgd_combine(P, G, out, d, ks)
             if i is not None:
                 ev[i][1].record()
-    else:
-        # the product's multi-GPU update, driven exactly as SVGDOptimizer.step drives it after the backward passes
-        import beyond_deep_ensembles_amd as bde
-        P0, G0 = make_svgd_inputs(d, dev, 1234)                     # same seed: identical particles on every rank
-        theta = torch.nn.Parameter(P0[0, :d].clone())
-        rows = [P0[i, :d].clone() for i in range(M)]
-        del P0
-        it = iter(range(1, M))
 
-        def reset():
-            with torch.no_grad():
-                theta.copy_(rows[next(it)])
-        base = torch.optim.SGD([theta], lr=1e-12, momentum=0.9, nesterov=True, weight_decay=3e-4)
-
-        def build(kind):
-            nonlocal it
-            it = iter(range(1, M))
-            with torch.no_grad():
-                theta.data = rows[0].clone()
-            kw = {"alltoall": dict(exchange="alltoall"), "pipelined": dict(exchange_chunks=args.chunks), "allgather": {}}[kind]
-            return bde.SVGDOptimizer([theta], reset, base, particle_count=M, dataset_size=DATASET_SIZE,
-                                     process_group=dist.group.WORLD, fuse_base_optimizer=True, **kw)
-        try:
-            opt = build(args.exchange)
-            exchange_used = args.exchange
-            opt._posterior_update(torch.zeros((), device=dev))       # first contact with the collective
-            torch.cuda.synchronize()
-        except Exception as e:                                         # reported, never silent
-            exchange_note = f"{args.exchange} failed ({type(e).__name__}: {e}); fell back to allgather"
-            log(exchange_note)
-            opt = build("allgather")
-            exchange_used = "allgather"
-        # own gradient rows differ per rank
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        grow = opt._Gown if exchange_used == "alltoall" else opt._G[rank * per:(rank + 1) * per]
-        grow[:, :d] = torch.randn(per, d, device=dev, generator=g) * 0.01
-        del rows, G0
-        loss0 = torch.zeros((), device=dev)
-        ev = None
-
-        def step(i=None):
-            opt._posterior_update(loss0)
-
-    for _ in range(args.warmup):
-        step()
-    blocks_ms = timed_blocks(step, args.steps, max(1, args.blocks), dist, dev)
-    ms_per_step = median(blocks_ms)
-    combine_ms = None
-    if world == 1:
+        for _ in range(args.warmup):
+            step()
+        blocks_ms = timed_blocks(step, args.steps, max(1, args.blocks), dist, dev)
+        ms_per_step = median(blocks_ms)
         combine_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps     # HIP events of the last block
         assert torch.isfinite(out[:, :d]).all()
     else:
-        assert torch.isfinite(opt.particles).all()
-        # where the time goes: the same update with (a) the kernels and (b) the collectives switched off
-        import contextlib
-
-        class _NoKernels:
-            """SVGD kernel calls become no-ops (allocation / capability queries pass through)."""
-            _keep = ("svgd_ws", "svgd_kstat", "svgd_small_supported", "svgd_fused_gram_supported")
-
-            def __init__(self, real):
-                self._real = real
-
-            def __getattr__(self, name):
-                attr = getattr(self._real, name)
-                if name.startswith("svgd_") and name not in self._keep and callable(attr):
-                    return lambda *a, **k: None
-                return attr
-
-        class _Done:
-            def wait(self):
-                return True
-
-        @contextlib.contextmanager
-        def no_collectives():
-            saved = (dist.all_gather_into_tensor, dist.all_to_all_single)
-            fake = lambda *a, async_op=False, **k: _Done() if async_op else None
-            dist.all_gather_into_tensor, dist.all_to_all_single = fake, fake
-            try:
-                yield
-            finally:
-                dist.all_gather_into_tensor, dist.all_to_all_single = saved
-        real_ops = opt._ops
-        opt._ops = _NoKernels(real_ops)
-        exchange_only = median(timed_blocks(step, args.steps, 1, dist, dev))
-        opt._ops = real_ops
-        with no_collectives():
-            update_only = median(timed_blocks(step, args.steps, 1, dist, dev))
-        hidden = exchange_only + update_only - ms_per_step
-        phases = {"mode": exchange_used, "exchange_ms": round(exchange_only, 4), "update_ms": round(update_only, 4),
-                  "step_ms": round(ms_per_step, 4),
-                  "overlap": round(max(0.0, hidden) / max(1e-9, min(exchange_only, update_only)), 3),
-                  "what": "exchange_ms = the step with the SVGD kernels switched off (collectives + host logic), "
-                          "update_ms = the step with the collectives switched off (kernels + host logic), "
-                          "overlap = (exchange + update - step) / min(exchange, update)"}
+        # every exchange mode of the product's multi-GPU update in ONE invocation; headline = north_star's all-gather
+        wanted = ["allgather", "pipelined", "alltoall"] if args.exchange == "all" else [args.exchange]
+        modes_out = {}
+        for kind in wanted:
+            modes_out[kind] = multi_gpu_mode(kind, args, dist, dev, rank, world, d)
+            if rank == 0:
+                log(f"[{kind}] {modes_out[kind]['step_ms']} ms/step  exchange {modes_out[kind]['exchange_ms']}  "
+                    f"update {modes_out[kind]['update_ms']}")
+        headline_mode = "allgather" if "allgather" in modes_out else wanted[0]
+        best_mode = min(modes_out, key=lambda k: modes_out[k]["step_ms"])
+        blocks_ms = modes_out[headline_mode].pop("_blocks")
+        for k in modes_out:
+            modes_out[k].pop("_blocks", None)
+        ms_per_step = median(blocks_ms)
+        exchange_used = headline_mode
+        phases = modes_out[headline_mode]
+        combine_ms = None
 
     # ---- SWAG posterior samples/s (the second half of BASELINE's metric): every rank samples independently
     # (MultiSWAG fan-out, DeepEnsemble.predict(rank=, world_size=)); aggregate = sum over ranks ("weak").
@@ -693,8 +723,6 @@ def main():
     if d == D_RESNET50:
         if world == 1:
             del out
-        else:
-            del opt, grow
         torch.cuda.empty_cache()
         ld = pad_ld(d)
         gsw = torch.Generator(device=dev).manual_seed(99 + rank)
@@ -732,7 +760,7 @@ def main():
                                       "applications) + return of the updated particles to their owners"),
                        "particles": M, "D": d, "ld": pad_ld(d), "l2_reg": 0.0, "kernel_grad_scale": 1.0,
                        "dataset_size": DATASET_SIZE, "particles_per_rank": per,
-                       "exchange": exchange_used, "exchange_note": exchange_note,
+                       "exchange": exchange_used, "exchange_note": exchange_note, "best_exchange": best_mode,
                        "algorithmic_bytes_per_step": 16 * M * d if world == 1 else (12 * M + 8) * d},
             "step_hbm_frac": round((16 * M * d if world == 1 else (12 * M + 8) * d / world) / (ms_per_step * 1e-3) / 1e9
                                    / HBM_PEAK_GBS, 4),
@@ -767,7 +795,12 @@ def main():
                                "algorithmic_bytes_per_launch": int(per_rank), "avg_launch_ms": phases["update_ms"],
                                "avg_launch_source": "the step re-timed with the collectives switched off (kernels + host logic "
                                                     "of one rank): a lower bound on the kernel's rate"}
-            res["exchange"] = phases
+            # every mode of this one run; the headline (value / ms_per_step) is `headline` = north_star's all-gather
+            res["exchange"] = dict(modes_out, headline=headline_mode, best=best_mode,
+                                   what="per mode: step_ms = median timed block; exchange_ms = the step with the SVGD kernels "
+                                        "switched off (collectives + host logic); update_ms = the step with the collectives "
+                                        "switched off (kernels + host logic); overlap = (exchange + update - step) / "
+                                        "min(exchange, update)")
         if swag is not None:
             res["swag"] = swag
         log(f"svgd_step: {ms_per_step:.4f} ms/step (blocks {[round(x, 4) for x in blocks_ms]}) = {res['value']} steps/s; "

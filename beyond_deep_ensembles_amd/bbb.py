@@ -125,19 +125,46 @@ class _Group:
             self.rho, self.grho, self.grho_views = flatten(self.gl, rhos)
             # GaussianParameter.sample() (rng="philox") draws the whole group in one launch through this object
             self._draw, self._consumed = None, []
+            self._draw_grad_mode, self._draw_versions = True, []
             for i, p in enumerate(means):
                 p._bde_gaussian._flat_group = self
                 p._bde_gaussian._flat_index = i
         if plain:
             self.p, self.gp, self.gp_views = flatten(self.pl, plain)
 
+    def invalidate_draw(self):
+        """Forget the current group-wide draw (BBBOptimizer.step calls this when it starts and when it ends: the
+        weights change there, and a draw never outlives the step it was made in)."""
+        if self.means:
+            self._draw, self._consumed = None, []
+
     def flat_sample(self, index, ops, seed):
-        """Tensor `index` of the current group-wide draw; a new draw (ONE launch for all tensors of the group) starts
-        whenever a tensor is asked for a second time, i.e. at the first sample() of the next forward pass."""
-        from .util import _FlatGaussDraw, _philox_stream
-        if self._draw is None or self._consumed[index]:
-            self._draw = _FlatGaussDraw.apply(self, ops, seed, next(_philox_stream), *self.means, *self.rhos)
-            self._consumed = [False] * len(self.means)
+        """Tensor ``index`` of the current group-wide draw (ONE launch for all tensors of the group).
+
+        A draw is served only while it is known to be current: made in the same grad mode as this request, from the
+        version of this tensor's mean / rho that is live now, and not yet handed out for this tensor.  Otherwise:
+
+        * every tensor of the draw was consumed -> this is the first ``sample()`` of the next forward pass: new
+          group-wide draw;
+        * the draw is stale for this tensor (mean / rho modified since, other grad mode) -> new group-wide draw;
+        * the tensor is asked again while others are still unconsumed (``mc_sample > 1`` inside one layer forward,
+          or forward passes that touch different subsets of the group) -> an independent draw of THIS tensor only
+          (``_GaussDraw``, 12 * numel bytes), the group-wide draw stays available to the tensors not yet served.
+        """
+        from .util import _FlatGaussDraw, _GaussDraw, _philox_stream
+        mean, rho = self.means[index], self.rhos[index]
+        grad_mode = torch.is_grad_enabled()
+        current = self._draw is not None and self._draw_grad_mode == grad_mode \
+            and self._draw_versions[index] == (mean._version, rho._version)
+        if current and not self._consumed[index]:
+            self._consumed[index] = True
+            return self._draw[index]
+        if current and not all(self._consumed):
+            return _GaussDraw.apply(mean, rho, None, seed, next(_philox_stream), ops)
+        self._draw = _FlatGaussDraw.apply(self, ops, seed, next(_philox_stream), *self.means, *self.rhos)
+        self._draw_grad_mode = grad_mode
+        self._draw_versions = [(m._version, r._version) for m, r in zip(self.means, self.rhos)]
+        self._consumed = [False] * len(self.means)
         self._consumed[index] = True
         return self._draw[index]
 
@@ -189,6 +216,8 @@ class BBBOptimizer(BayesianOptimizer):
         # zero_grad default), so nothing accumulates from step to step.
         for p in self._not_in_flat_buffers():
             p.grad = None
+        for fg in self._groups:
+            fg.invalidate_draw()                        # a group-wide weight draw never outlives a step
         pi = self.kl_rescaling / self.dataset_size
         scale_dev = None
         if grad_scaler is not None and grad_scaler.is_enabled():
@@ -257,6 +286,8 @@ class BBBOptimizer(BayesianOptimizer):
                 grad_scaler.step(self.state["__base_optimizer"])
             else:
                 self.state["__base_optimizer"].step()
+        for fg in self._groups:
+            fg.invalidate_draw()
 
         return loss
 

@@ -105,35 +105,51 @@ class DeepEnsemble(nn.Module):
         """MultiX fan-out over the ranks of ``process_group`` (one GPU per rank): every rank evaluates its
         share of the (member, sample) units, then ONE all-gather of the (small) prediction tensors puts the
         full ``[samples, ...]`` result, in the reference's output order, on every rank.  Callers reduce it
-        exactly as they reduce ``predict()``'s output (e.g. ``logsumexp(out, 0) - log(S)``, camelyon.py:29-30)."""
+        exactly as they reduce ``predict()``'s output (e.g. ``logsumexp(out, 0) - log(S)``, camelyon.py:29-30).
+
+        Every rank owns at least one unit whenever ``samples >= world size`` and then knows the shape of a
+        prediction from its own output; only a call with fewer samples than ranks needs one small object
+        all-gather beside it."""
         import torch.distributed as dist
         world, rank = dist.get_world_size(process_group), dist.get_rank(process_group)
-        local = self.predict(predict_closure, samples, rank=rank, world_size=world) if fan_out(
-            samples, len(self.models), rank, world) else None
-        counts = [len(fan_out(samples, len(self.models), r, world)) for r in range(world)]
-        most = max(counts)
-        # every rank needs the per-unit shape to size its padded contribution
-        shape_src = counts.index(most)
-        if local is None:
-            unit_shape = None
-        else:
-            unit_shape = list(local.shape[1:])
-        shapes = [None] * world
-        dist.all_gather_object(shapes, (unit_shape, str(local.dtype) if local is not None else None), group=process_group)
-        unit_shape, dtype_name = shapes[shape_src]
-        dtype = getattr(torch, dtype_name.split(".")[-1])
+        n_members = len(self.models)
+        plan = self._fan_out_plan(samples, n_members, world)
+        counts, most = plan["counts"], plan["most"]
+        local = self.predict(predict_closure, samples, rank=rank, world_size=world) if counts[rank] else None
+        unit_shape, dtype = (list(local.shape[1:]), local.dtype) if local is not None else (None, None)
+        if min(counts) == 0:
+            # some rank has nothing to evaluate and therefore does not know what a prediction looks like
+            shapes = [None] * world
+            dist.all_gather_object(shapes, (unit_shape, str(dtype) if dtype is not None else None), group=process_group)
+            unit_shape, dtype_name = shapes[counts.index(most)]
+            dtype = getattr(torch, dtype_name.split(".")[-1])
         device = local.device if local is not None else next(self.models.parameters()).device
-        padded = torch.zeros([most] + unit_shape, dtype=dtype, device=device)
-        if local is not None:
-            padded[:local.shape[0]] = local
+        if local is not None and local.shape[0] == most:
+            padded = local.contiguous()
+        else:
+            padded = torch.zeros([most] + unit_shape, dtype=dtype, device=device)
+            if local is not None:
+                padded[:local.shape[0]] = local
         gathered = torch.empty([world * most] + unit_shape, dtype=dtype, device=device)
         dist.all_gather_into_tensor(gathered, padded, group=process_group)
-        total = sum(counts)
-        out = torch.empty([total] + unit_shape, dtype=dtype, device=device)
-        for r in range(world):
-            for j, (u, _, _) in enumerate(fan_out(samples, len(self.models), r, world)):
-                out[u] = gathered[r * most + j]
-        return out
+        if plan["dense"]:
+            return gathered                          # every rank holds `most` units: already in unit order
+        if plan["take"].device != device:
+            plan["take"] = plan["take"].to(device)
+        return gathered.index_select(0, plan["take"])   # drop the padding rows: one gather, unit order
+
+    def _fan_out_plan(self, samples, n_members, world):
+        """Rows of the all-gathered (padded) prediction tensor in unit order, per (samples, members, world): computed once."""
+        key = (samples, n_members, world)
+        cache = self.__dict__.setdefault("_plans", {})
+        if key not in cache:
+            counts = [len(fan_out(samples, n_members, r, world)) for r in range(world)]
+            most = max(counts)
+            # ranks own contiguous unit ranges in rank order, so unit order = rank order with the padding rows skipped
+            take = [r * most + j for r in range(world) for j in range(counts[r])]
+            cache[key] = {"counts": counts, "most": most, "dense": all(c == most for c in counts),
+                          "take": torch.tensor(take, dtype=torch.long)}
+        return cache[key]
 
 
 def _sampler_position(optimizer):

@@ -251,8 +251,14 @@ class HipOps:
     def philox_normal(self, seed, stream_id, eps_w=None, eps_d=None, d=None):
         k = 0 if eps_w is None else eps_w.numel()
         n = 0 if eps_d is None else (d if d is not None else eps_d.numel())
-        _check(self.lib.bde_philox_normal(seed, stream_id, _ptr(eps_w), k, _ptr(eps_d), n, _stream()),
-               "bde_philox_normal")
+        target = eps_d if eps_d is not None else eps_w
+        if target is None:
+            return
+        if eps_w is not None and eps_d is not None and eps_w.device != eps_d.device:
+            raise BdeKernelError("philox_normal: eps_w and eps_d live on different devices")
+        pw, pd = _ptr(eps_w, "eps_w"), _ptr(eps_d, "eps_d")
+        with torch.cuda.device(target.device):           # the launch goes to the stream of the OUTPUT's device
+            _check(self.lib.bde_philox_normal(seed, stream_id, pw, k, pd, n, _stream()), "bde_philox_normal")
 
     def philox_bits(self, seed, stream_id, n_groups, device, domain=0, idx0=0) -> torch.Tensor:
         """Raw Philox4x32-10 words [n_groups, 4] (int64 holding uint32 values) -- the known-answer hook."""

@@ -46,10 +46,6 @@ from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, clea
 from .ops import pad4
 
 
-import os as _os
-_INPLACE_GRADS = bool(_os.environ.get("BDE_SVGD_INPLACE_GRADS"))
-
-
 def rbf(particles: torch.Tensor, h_override=None, _ops=None):
     """Pairwise RBF kernel with the median heuristic and its repulsive gradient
     (drop-in for ``src/algos/svgd.py:14-32``): returns ``(kernel [M, M],
@@ -164,6 +160,9 @@ class SVGDOptimizer(BayesianOptimizer):
         self._fused_state = None
         self._reuse_gram = bool(reuse_gram) and self._fuse and self._ops.svgd_fused_gram_supported(particle_count)
         self._gram_valid = False
+        if int(exchange_chunks) > 1 and particle_count > 16:
+            raise ValueError("exchange_chunks > 1 (pipelined all-gather) needs particle_count <= 16: the blocked update "
+                             "for more particles re-reads all gradient rows per pass and cannot consume a staged chunk")
         if self._exchange == "allgather" and self._world > 1 and int(exchange_chunks) > 1:
             clen = pad4((ld + int(exchange_chunks) - 1) // int(exchange_chunks))
             self._chunks = [(c0, min(ld, c0 + clen)) for c0 in range(0, ld, clen)]
@@ -210,24 +209,25 @@ class SVGDOptimizer(BayesianOptimizer):
         total_loss = torch.tensor(0.0, device=self._params_device())
         for particle_idx in self._local_particles():
             self._set_grad_scaler_state(grad_scaler, OptState.READY, base)
-            # _use_particle (svgd.py:120-127) and base_optimizer.zero_grad() (svgd.py:70)
-            if _INPLACE_GRADS:
-                # round-1 hand-over, kept for A/B timing (tools/shell_bench.py): the gradient row is zeroed and
-                # param.grad pointed at it, so backward() accumulates in place -- one add launch PER TENSOR
-                self._grad_row(particle_idx).zero_()
-                repoint(self._plist, self._pviews[particle_idx], self._gviews[particle_idx])
-            else:
-                repoint(self._plist, self._pviews[particle_idx], None)
-                clear_grads(self._plist)
-
+            self._begin_particle(particle_idx)
             loss = forward_closure()
             total_loss += loss.detach()
             backward_closure(loss)
             if not self._prepare_and_check_grads(grad_scaler, base):
                 return None
-            adopt_grads(self._plist, self._gviews[particle_idx])      # _store_grads (svgd.py:129-133)
+            self._end_particle(particle_idx)
 
         return self._posterior_update(total_loss, grad_scaler)
+
+    def _begin_particle(self, particle_idx: int) -> None:
+        """_use_particle (svgd.py:120-127) and base_optimizer.zero_grad() (svgd.py:70): the parameters view particle
+        ``particle_idx`` and carry no gradient, so backward() hands over the fresh tensors its kernels produce."""
+        repoint(self._plist, self._pviews[particle_idx], None)
+        clear_grads(self._plist)
+
+    def _end_particle(self, particle_idx: int) -> None:
+        """_store_grads (svgd.py:129-133): the particle's gradients move into its row of the flat gradient buffer."""
+        adopt_grads(self._plist, self._gviews[particle_idx])
 
     def _posterior_update(self, total_loss, grad_scaler=None):
         """Everything after the forward/backward passes (svgd.py:82-105): gradient exchange (multi-GPU), kernel

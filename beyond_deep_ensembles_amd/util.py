@@ -76,13 +76,18 @@ class _FlatGaussDraw(torch.autograd.Function):
         d, ld = group.gl.d, group.gl.ld
         w = torch.empty(ld, dtype=torch.float32, device=group.mu.device)
         ops.gauss_draw_fwd(group.mu, group.rho, w, d, eps=None, seed=seed, stream_id=stream_id)
-        ctx.meta = (group, ops, seed, stream_id)
+        # backward re-reads the group's rho buffer (nothing is saved but the seed): remember which rho it was
+        ctx.meta = (group, ops, seed, stream_id, sum(r._version for r in group.rhos))
         return tuple(group.gl.views(w))
 
     @staticmethod
     @once_differentiable          # the kernels produce plain tensors: no double backward
     def backward(ctx, *grads):
-        group, ops, seed, stream_id = ctx.meta
+        group, ops, seed, stream_id, rho_versions = ctx.meta
+        if sum(r._version for r in group.rhos) != rho_versions:
+            raise RuntimeError("one of the rho parameters of this BBBOptimizer group was modified in place between the "
+                               "forward pass that drew the weights and its backward pass; the draw's backward "
+                               "re-reads rho (softplus'(rho) * eps) and would use the new values")
         d, ld = group.gl.d, group.gl.ld
         dev = group.mu.device
         g = torch.zeros(ld, dtype=torch.float32, device=dev) if any(x is None for x in grads) \

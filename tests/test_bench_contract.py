@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _lines():
     out = []
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*bench*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*bench*.json")) +
+                       glob.glob(os.path.join(ROOT, "profiles", "r03_*bench*.json"))):
         with open(path) as fh:
             text = fh.read().strip().splitlines()[-1]
         out.append((os.path.basename(path), json.loads(text)))
@@ -49,4 +50,14 @@ def test_bench_lines_follow_the_contract():
                 assert c["kind"] in ("port", "reference") and c["cores"] >= 1
         else:
             assert d["config"]["exchange"] in ("alltoall", "pipelined", "allgather")
-            assert {"exchange_ms", "update_ms", "step_ms", "overlap"} <= set(d["exchange"])
+            if "headline" in d["exchange"]:
+                # round 3: ONE invocation times every exchange mode; the headline is north_star's all-gather
+                ex = d["exchange"]
+                assert ex["headline"] == d["config"]["exchange"] == "allgather"
+                assert {"allgather", "pipelined", "alltoall"} <= set(ex)
+                for mode in ("allgather", "pipelined", "alltoall"):
+                    assert {"exchange_ms", "update_ms", "step_ms", "overlap", "bytes_sent_per_rank"} <= set(ex[mode]), mode
+                assert ex["best"] == min(("allgather", "pipelined", "alltoall"), key=lambda m: ex[m]["step_ms"])
+                assert abs(ex["allgather"]["step_ms"] - d["ms_per_step"]) <= 1e-3 * d["ms_per_step"]
+            else:
+                assert {"exchange_ms", "update_ms", "step_ms", "overlap"} <= set(d["exchange"])

@@ -1179,3 +1179,87 @@ def test_svgd_fuse_auto_eligibility(backend):
         base.register_step_post_hook(lambda opt, args, kwargs: None)
         return base
     assert not decide(hooked)
+
+
+def test_bbb_group_draw_is_never_stale(backend):
+    """The group-wide weight draw (rng="philox") is served only while it is current: forward passes that touch
+    disjoint subsets of the group, a tensor asked twice inside one forward, a draw made under no_grad followed by a
+    training forward, and parameters modified between two forwards all get fresh, differentiable samples from the
+    live means (util.py:170-171 draws anew at every sample())."""
+    ops, dev = backend
+    torch.manual_seed(11)
+    gps = [bde.GaussianParameter((6, 5), rng="philox", seed=3, _ops=ops).to(dev) for _ in range(3)]
+    for gp in gps:
+        gp.blundell_init()
+    params = [p for gp in gps for p in gp.parameters()]
+    opt = bde.BBBOptimizer(params, torch.optim.SGD(params, lr=0.5), bde.GaussianPrior(0, 1.0), dataset_size=10, _ops=ops)
+    group = gps[0]._flat_group
+    assert group is gps[1]._flat_group and len(group.means) == 3
+
+    # 1. disjoint subsets: pass A touches tensors 0 and 1, pass B touches tensor 2 only, then the means move and
+    #    pass C asks tensor 2 first -- it must come from the NEW means, not from the draw of pass A
+    a0, a1 = gps[0].sample(), gps[1].sample()
+    b2 = gps[2].sample()
+    assert a0.requires_grad and b2.requires_grad
+    with torch.no_grad():
+        for gp in gps:
+            gp.mean.add_(100.0)
+    c2 = gps[2].sample()
+    assert float(c2.mean()) > 90.0, "served from the draw that predates the update of the means"
+    c0 = gps[0].sample()
+    assert float(c0.mean()) > 90.0
+    with torch.no_grad():
+        for gp in gps:
+            gp.mean.sub_(100.0)
+    group.invalidate_draw()
+
+    # 2. a tensor asked twice inside one forward: two DIFFERENT samples, both differentiable, and the tensors not yet
+    #    served keep the group-wide draw (no second whole-group launch)
+    launches = []
+    real = ops.gauss_draw_fwd
+
+    def counted(mean, rho, out, n, **k):
+        launches.append(n)
+        return real(mean, rho, out, n, **k)
+    ops.gauss_draw_fwd = counted
+    try:
+        w_first, w_again = gps[0].sample(), gps[0].sample()
+        w_other = gps[1].sample()
+    finally:
+        ops.gauss_draw_fwd = real
+    assert launches == [group.gl.d, 30], launches          # one group-wide draw + one per-tensor draw of 6 x 5
+    assert not torch.equal(w_first, w_again)
+    (w_first.sum() + 2 * w_again.sum() + w_other.sum()).backward()
+    assert torch.allclose(gps[0].mean.grad, torch.full((6, 5), 3.0, device=dev))
+    assert torch.allclose(gps[1].mean.grad, torch.ones(6, 5, device=dev))
+    for p in params:
+        p.grad = None
+    group.invalidate_draw()
+
+    # 3. an evaluation forward under no_grad must not hand its (non-differentiable) draw to the next training forward
+    with torch.no_grad():
+        e0 = gps[0].sample()
+    assert not e0.requires_grad
+    t1 = gps[1].sample()
+    assert t1.requires_grad
+    t1.sum().backward()
+    assert gps[1].mean.grad is not None
+    for p in params:
+        p.grad = None
+
+    # 4. a step invalidates whatever was drawn before it and leaves nothing behind
+    gps[0].sample()
+    before = gps[2].mean.detach().clone()
+    opt.step(lambda: sum(gp.sample().pow(2).sum() for gp in gps), lambda l: l.backward())
+    assert group._draw is None
+    assert not torch.equal(before, gps[2].mean.detach())
+    after = gps[2].sample()
+    assert (after.detach() - gps[2].mean.detach()).abs().max() < 1.0      # around the UPDATED mean (std ~ 0.05)
+
+    # 5. rho modified between the forward that drew and its backward: refused (the backward re-reads rho)
+    group.invalidate_draw()
+    w = gps[0].sample()
+    with torch.no_grad():
+        gps[1].rho.add_(0.1)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        w.sum().backward()

@@ -9,13 +9,29 @@ launches, base optimizer), not a model:
            closures' own cost is measured separately and subtracted.
 
 BDE_SVGD_INPLACE_GRADS=1 selects the round-1 gradient hand-over (param.grad pre-pointed at the flat row, autograd
-accumulates in place: one add launch per tensor per backward); BDE_NO_HOST_HELPER=1 runs the per-tensor loops in
-Python.  Output of both settings is kept under profiles/."""
+accumulates in place: one add launch per tensor per backward) -- an A/B variant that lives HERE, as a subclass of
+the optimizer, not in the product; BDE_NO_HOST_HELPER=1 runs the per-tensor loops in Python.  Output of both
+settings is kept under profiles/."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import beyond_deep_ensembles_amd as bde
 
+from beyond_deep_ensembles_amd.algo import repoint
+
+
+class InplaceGradsSVGD(bde.SVGDOptimizer):
+    """Round-1 hand-over: the gradient row is zeroed and param.grad pointed at it, so backward() accumulates in place."""
+
+    def _begin_particle(self, particle_idx):
+        self._grad_row(particle_idx).zero_()
+        repoint(self._plist, self._pviews[particle_idx], self._gviews[particle_idx])
+
+    def _end_particle(self, particle_idx):
+        pass
+
+
+SVGD = InplaceGradsSVGD if os.environ.get("BDE_SVGD_INPLACE_GRADS") else bde.SVGDOptimizer
 dev = "cuda:0"
 torch.manual_seed(0)
 n_tensors, D = 161, 23_880_950
@@ -47,7 +63,7 @@ def run(fuse, reuse, base_kind, closures, steps=10):
         with torch.no_grad():
             for p in params[-2:]:
                 p.normal_(0, 0.05)
-    opt = bde.SVGDOptimizer(params, reset, base, particle_count=M, dataset_size=129809, fuse_base_optimizer=fuse, reuse_gram=reuse)
+    opt = SVGD(params, reset, base, particle_count=M, dataset_size=129809, fuse_base_optimizer=fuse, reuse_gram=reuse)
     c = torch.randn(D, device=dev) * 0.01
     zero = torch.zeros((), device=dev)
     ld = opt._layout.ld
