@@ -578,3 +578,10 @@ extern "C" int bde_var_operand_bwd(const float* g, const float* v, int mode, flo
   else hipLaunchKernelGGL((var_operand_kernel<2, true>), dim3(grid), dim3(kBlock), 0, s, g, v, gv, n);
   return to_err(hipGetLastError());
 }
+
+// bde_init(): load this translation unit's code object on the current device now (HIP otherwise uploads it at the
+// first launch of one of its kernels).  Internal to the library (not exported).
+extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_gauss(void) {
+  hipFuncAttributes attr;
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::gauss_draw_fwd_kernel<true>)));
+}

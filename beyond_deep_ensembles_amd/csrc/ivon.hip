@@ -139,3 +139,10 @@ extern "C" int bde_ivon_update(float* mean, float* momentum, float* prec, const 
                      prec, delta_sum, acc_grad, k, n);
   return to_err(hipGetLastError());
 }
+
+// bde_init(): load this translation unit's code object on the current device now (HIP otherwise uploads it at the
+// first launch of one of its kernels).  Internal to the library (not exported).
+extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_ivon(void) {
+  hipFuncAttributes attr;
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::ivon_update_kernel)));
+}

@@ -385,3 +385,10 @@ extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu
                        clamp_bias_var, eps, seed, stream_id, out, var_out, B, O);
   return to_err(hipGetLastError());
 }
+
+// bde_init(): load this translation unit's code object on the current device now (HIP otherwise uploads it at the
+// first launch of one of its kernels).  Internal to the library (not exported).
+extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_lrt(void) {
+  hipFuncAttributes attr;
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::lrt_finish_kernel<true>)));
+}

@@ -572,9 +572,9 @@ extern "C" int bde_svgd_step(const float* P, const float* G, float* out, int M, 
                              float kernel_grad_scale, float dataset_size, float sign, void* ws, float* kstat,
                              void* stream) {
   if (!G) return BDE_ERR_INVALID;
-  if (bde_svgd_small_supported(M, D))
+  if (bde_svgd_small_supported(M, D))   // as two ordinary launches: nothing in them waits for another workgroup
     return bde_svgd_step_small(P, G, out, M, D, ld, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, ws, kstat,
-                               stream);
+                               2, nullptr, stream);
   int rc = bde_svgd_gram(P, M, D, ld, ws, stream);
   if (rc) return rc;
   rc = bde_svgd_kstats(ws, M, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, kstat, stream);
@@ -604,4 +604,11 @@ extern "C" int bde_svgd_apply_adam(float* P, const float* grad, float* exp_avg, 
   hipLaunchKernelGGL(svgd_apply_adam_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), P, grad,
                      exp_avg, exp_avg_sq, M, D, ld, k, make_adam_steps(lr, beta1, beta2, step0));
   return to_err(hipGetLastError());
+}
+
+// bde_init(): load this translation unit's code object on the current device now (HIP otherwise uploads it at the
+// first launch of one of its kernels).  Internal to the library (not exported).
+extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_svgd(void) {
+  hipFuncAttributes attr;
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::svgd_kstats_kernel)));
 }

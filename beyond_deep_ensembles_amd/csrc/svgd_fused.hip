@@ -257,3 +257,10 @@ extern "C" int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, flo
                            make_adam_steps(lr, beta1, beta2, step0), static_cast<float*>(ws_next),
                            static_cast<hipStream_t>(stream));
 }
+
+// bde_init(): load this translation unit's code object on the current device now (HIP otherwise uploads it at the
+// first launch of one of its kernels).  Internal to the library (not exported).
+extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_svgd_fused(void) {
+  hipFuncAttributes attr;
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::svgd_fused_kernel<8, 0, false>)));
+}

@@ -24,11 +24,28 @@
 // P is read once from HBM (4 M D), G once (4 M D), out written once (4 M D): 12 M D bytes, no
 // second pass over P.  The counters only count up (each launch waits for "previous total + grid
 // size", kept in the workspace), so nothing is reset and the caller only has to hand in a
-// workspace that was zeroed once.  All workgroups must be co-resident (they are:
-// <= 256 workgroups of 512 threads, one per CU on a 256-CU device).  Measured timeline at D = 273,610
-// (tools/kexp6.hip, profiles/r02_small_step_timeline_v3_and_gram_ab.txt).
+// workspace that was zeroed once.  Measured timeline at D = 273,610 (tools/kexp6.hip,
+// profiles/r02_small_step_timeline_v3_and_gram_ab.txt).
+//
+// The hand-off waits for workgroups of the same launch, which only works while all of them are resident at once.
+// On an otherwise idle MI355X they are (<= 256 workgroups of 512 threads, one per CU), but this is an ordinary launch:
+// other processes or streams can hold CUs, and two such launches could each be partly resident and wait for the
+// rest.  Therefore the wait is BOUNDED and the launch decides as ONE unit whether the update happens:
+//   * the polling wave gives up after `timeout` ticks of the 100 MHz wall clock (default 2 ms);
+//   * the outcome of a launch is ONE 64-bit word of the workspace, (stamp, status), written by compare-and-swap: the
+//     first workgroup that sees all arrivals proposes (want, COMMIT), the first that times out proposes (want, ABORT);
+//     whoever loses the CAS follows the winner.  So either every workgroup runs phase 2 or none does -- an aborted
+//     launch leaves P, the optimizer state and `out` untouched;
+//   * ABORT is sticky: later workgroups of that launch, and later single launches on the workspace, see it when they
+//     start and return at once (they do not arrive, so the counters stay consistent); an aborting workgroup also sets
+//     the caller's `abort_flag` word (host-visible memory), which is how the caller learns that it must redo the update;
+//   * the redo is the SAME kernel as two ordinary launches (`phase` 1: Gram partials only; `phase` 2: everything
+//     after the hand-off) -- no inter-workgroup wait, hence no residency requirement, and bit-identical results
+//     (same grid, same partials, same summation order).  Phase 2 also repairs an aborted workspace (target word :=
+//     arrivals counted so far, status cleared).
 #include "svgd_gram.hpp"
 #include <atomic>
+#include <cstdlib>
 
 namespace bde {
 
@@ -52,6 +69,11 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 __device__ __forceinline__ float ld_sc1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// Outcome word of a launch (kWsStateWord, 64 bit): low half = the launch's arrival target, high half = status.
+constexpr unsigned kSmallCommit = 1u, kSmallAbort = 2u;
+constexpr unsigned kSmallDefaultTimeoutTicks = 200000u;          // 2 ms of the 100 MHz wall clock
+enum : int { kSmallSingle = 0, kSmallGramOnly = 1, kSmallAfterGram = 2 };
 
 // The kernel statistics of svgd_stats_core for M <= 8 (M * M <= 64 entries), evaluated by ONE wave with
 // cross-lane shuffles instead of LDS round trips and workgroup barriers (2.0 us -> well under 1 us on the
@@ -144,8 +166,11 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
                                                                         int64_t D, int64_t ld, int tiles_per_wg,
                                                                         StatParams sp, float* __restrict__ ws,
                                                                         float* __restrict__ kstat, float* s0, float* s1,
-                                                                        SgdParams sk, AdamParams ak, AdamSteps ast) {
+                                                                        SgdParams sk, AdamParams ak, AdamSteps ast,
+                                                                        int phase, unsigned timeout_ticks,
+                                                                        int* abort_flag) {
   constexpr int MP = 8, MP2 = 64;
+  __shared__ int s_decision;
   __shared__ float tile[kSmallWaves][16][17];
   __shared__ double red[(kSmallBlock / (MP2 / 2)) * MP2];           // [16 slices][64]
   __shared__ double gmat[MP2];
@@ -158,9 +183,17 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
   float* part = ws + kWsHeaderFloats;
 
   BDE_TS(0)
-  // arrivals counted so far on this workspace (all launches before this one); requested first, needed at the poll
+  // arrivals counted so far on this workspace (all launches before this one) and the outcome word as this workgroup
+  // finds it; requested first, needed at the poll
   unsigned arrived_before = 0;
-  if (wave == 0) arrived_before = __hip_atomic_load(words + kWsTargetWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long state_seen = 0;
+  unsigned long long* state = reinterpret_cast<unsigned long long*>(words + kWsStateWord);
+  if (phase == kSmallSingle && wave == 0) {
+    arrived_before = __hip_atomic_load(words + kWsTargetWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    state_seen = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // an earlier launch on this workspace (or this one, before this workgroup started) was abandoned: do not arrive
+  const bool poisoned = static_cast<unsigned>(state_seen >> 32) == kSmallAbort;
   // ---------------- phase 1: centred Gram partial of this workgroup's columns ----------------
   const int r16 = lane & 15, kq = lane >> 4;
   const int c4 = (r16 >> 3) * 4 + kq;
@@ -174,7 +207,7 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
   const int64_t t1 = (t0 + tiles_per_wg < n_tiles) ? t0 + tiles_per_wg : n_tiles;
 
   f32x4acc acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  {
+  if (phase != kSmallAfterGram) {
     // all of this wave's tiles are requested before the first DPP/MFMA chain waits on them
     constexpr int TW = kSmallMaxTilesPerWG / kSmallWaves;          // tiles per wave, at most
     f32x4 v[TW][kGramU];
@@ -203,11 +236,13 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
       }
     }
   }
+  if (phase != kSmallAfterGram) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][r16] = acc0[r] + acc1[r];
-  __syncthreads();
+    for (int r = 0; r < 4; ++r) tile[wave][4 * kq + r][r16] = acc0[r] + acc1[r];
+    __syncthreads();
+  }
   BDE_TS(1)
-  if (tid < MP2) {                                                 // one wave, one store instruction per 128-B line
+  if (phase != kSmallAfterGram && tid < MP2) {                     // one wave, one store instruction per 128-B line
     const int pi = tid / MP, pj = tid % MP;
     float s = 0.f;
 #pragma unroll
@@ -216,11 +251,18 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the write-through stores have left this CU
     BDE_TS(2)
     // arrive: one agent-scope add on this workgroup's shard counter, fire and forget
-    if (tid == 0)
+    if (tid == 0 && phase == kSmallSingle && !poisoned)
       __hip_atomic_fetch_add(words + kWsArriveWord + 32 * (blockIdx.x & (kWsShards - 1)), 1u, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
   }
   BDE_TS(3)
+  if (phase == kSmallGramOnly) {                                   // first of two launches: the partials are the result
+    if (blockIdx.x == 0 && tid == 0) {
+      ws[0] = static_cast<float>(nwg);
+      ws[1] = static_cast<float>(MP);
+    }
+    return;
+  }
 
   // ---------------- phase 2 operands: requested now, consumed after the hand-off ----------------
   const int64_t n4 = D >> 2;                                       // full float4 columns
@@ -242,26 +284,69 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
     if (OPT == 2) a1 = ld4(s1 + 4 * cA);
   }
 
-  // ---------------- hand-off: wave 0 polls the 8 shard counters (one 8-lane load per poll) ----------------
-  if (wave == 0) {
+  // ---------------- hand-off: wave 0 polls the 8 shard counters (one 8-lane load per poll), for a bounded time ----------------
+  if (phase == kSmallSingle && wave == 0) {
     const unsigned* ctr = words + kWsArriveWord + 32 * (lane & (kWsShards - 1));
     const unsigned want = arrived_before + static_cast<unsigned>(nwg);
-    unsigned total;
-    bool all_here;
-    do {
-      const unsigned c = (lane < kWsShards) ? __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      total = 0;
+    bool all_here = false;
+    if (!poisoned && timeout_ticks != 0u) {
+      const unsigned long long t_start = wall_clock64();
+      unsigned polls = 0;
+      do {
+        const unsigned c = (lane < kWsShards) ? __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        unsigned total = 0;
 #pragma unroll
-      for (int sh = 0; sh < kWsShards; ++sh) total += __builtin_amdgcn_readlane(c, sh);
-      all_here = static_cast<int>(total - want) >= 0;              // difference: immune to uint32 wrap-around
-      if (!all_here) __builtin_amdgcn_s_sleep(4);
-    } while (!all_here);
-    // every workgroup read the old target before it arrived, so it can move on now
-    if (blockIdx.x == 0 && lane == 0)
-      __hip_atomic_store(words + kWsTargetWord, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int sh = 0; sh < kWsShards; ++sh) total += __builtin_amdgcn_readlane(c, sh);
+        all_here = static_cast<int>(total - want) >= 0;            // difference: immune to uint32 wrap-around
+        if (all_here) break;
+        // the clock is read on every 8th unsuccessful poll (~1 us apart): workgroups that cannot become resident
+        // together must not wait for each other forever
+        if ((++polls & 7u) == 0u && wall_clock64() - t_start > static_cast<unsigned long long>(timeout_ticks)) break;
+        __builtin_amdgcn_s_sleep(4);
+      } while (true);
+    }
+    // ONE outcome per launch: propose COMMIT (all arrived) or ABORT (timed out / abandoned workspace) by compare-and-swap
+    // on the outcome word; a lost CAS returns what another workgroup of this launch decided, and that is followed
+    int decision = static_cast<int>(kSmallAbort);
+    if (!poisoned) {
+      const unsigned long long proposed = static_cast<unsigned long long>(want) |
+                                          (static_cast<unsigned long long>(all_here ? kSmallCommit : kSmallAbort) << 32);
+      unsigned long long cur = state_seen;
+      if (lane == 0) {
+        if (__hip_atomic_compare_exchange_strong(state, &cur, proposed, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+          cur = proposed;
+      }
+      const unsigned stamp = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur));
+      const unsigned status = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur >> 32));
+      if (status == kSmallCommit && stamp == want) decision = static_cast<int>(kSmallCommit);
+    }
+    if (lane == 0) {
+      s_decision = decision;
+      if (decision == static_cast<int>(kSmallAbort)) {
+        if (abort_flag) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else if (blockIdx.x == 0) {
+        // every workgroup read the old target before it arrived, so it can move on now
+        __hip_atomic_store(words + kWsTargetWord, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  if (phase == kSmallAfterGram && blockIdx.x == 0 && tid == 0) {
+    // second of two launches (stream-ordered behind whatever ran on this workspace before): if a single launch was
+    // abandoned here, count its arrivals into the target and clear the status, so the workspace is usable again
+    const unsigned long long st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (static_cast<unsigned>(st >> 32) == kSmallAbort) {
+      unsigned total = 0;
+      for (int sh = 0; sh < kWsShards; ++sh)
+        total += __hip_atomic_load(words + kWsArriveWord + 32 * sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(words + kWsTargetWord, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(state, static_cast<unsigned long long>(total) | (static_cast<unsigned long long>(kSmallCommit) << 32),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   BDE_TS(4)
   __syncthreads();
+  if (phase == kSmallSingle && s_decision != static_cast<int>(kSmallCommit)) return;     // uniform: nothing was written
 
   // fixed-order fp64 reduction of ALL partial tiles (every workgroup computes the same bits): 8-byte sc1 loads, all
   // of a thread's loads in flight before the first add, unconditional (a predicated load gets a basic block and an
@@ -402,16 +487,44 @@ struct SmallOpt {
   AdamSteps ast{};
 };
 
+// How long the polling wave of a single launch waits for the other workgroups, in ticks of the 100 MHz wall clock.
+// Process-wide; BDE_SMALL_TIMEOUT_US in the environment (read once) or bde_svgd_small_set_timeout_us() change it.
+// 0 = give up without polling (every single launch is abandoned: the test hook for the recovery path).
+static std::atomic<unsigned>& small_timeout_ticks() {
+  static std::atomic<unsigned> ticks{[] {
+    const char* e = std::getenv("BDE_SMALL_TIMEOUT_US");
+    if (e && *e) {
+      const long long us = std::atoll(e);
+      if (us >= 0) return static_cast<unsigned>(std::min<long long>(us, 40000000LL) * 100);
+    }
+    return kSmallDefaultTimeoutTicks;
+  }()};
+  return ticks;
+}
+
 template <int M>
 static int launch_small(const float* P, const float* G, float* out, int64_t D, int64_t ld, int grid, int tpw,
-                        const StatParams& sp, float* ws, float* kstat, const SmallOpt& o, hipStream_t s) {
-#define BDE_SMALL_LAUNCH(HG, OPT)                                                                                    \
+                        const StatParams& sp, float* ws, float* kstat, const SmallOpt& o, int launches, int* abort_flag,
+                        hipStream_t s) {
+  const unsigned timeout = small_timeout_ticks().load(std::memory_order_relaxed);
+#define BDE_SMALL_LAUNCH(HG, OPT, PHASE)                                                                             \
   hipLaunchKernelGGL((svgd_step_small_kernel<M, HG, OPT>), dim3(grid), dim3(kSmallBlock), 0, s, P, G, out, D, ld, tpw, \
-                     sp, ws, kstat, o.s0, o.s1, o.sk, o.ak, o.ast)
-  if (o.kind == 1) BDE_SMALL_LAUNCH(true, 1);
-  else if (o.kind == 2) BDE_SMALL_LAUNCH(true, 2);
-  else if (G) BDE_SMALL_LAUNCH(true, 0);
-  else BDE_SMALL_LAUNCH(false, 0);
+                     sp, ws, kstat, o.s0, o.s1, o.sk, o.ak, o.ast, PHASE, timeout, abort_flag)
+#define BDE_SMALL_VARIANT(PHASE)                   \
+  do {                                             \
+    if (o.kind == 1) BDE_SMALL_LAUNCH(true, 1, PHASE);      \
+    else if (o.kind == 2) BDE_SMALL_LAUNCH(true, 2, PHASE); \
+    else if (G) BDE_SMALL_LAUNCH(true, 0, PHASE);           \
+    else BDE_SMALL_LAUNCH(false, 0, PHASE);                 \
+  } while (0)
+  if (launches == 2) {
+    // the same kernel as two ordinary launches: no inter-workgroup wait, same partials, same summation order
+    BDE_SMALL_VARIANT(kSmallGramOnly);
+    BDE_SMALL_VARIANT(kSmallAfterGram);
+  } else {
+    BDE_SMALL_VARIANT(kSmallSingle);
+  }
+#undef BDE_SMALL_VARIANT
 #undef BDE_SMALL_LAUNCH
   return to_err(hipGetLastError());
 }
@@ -439,7 +552,8 @@ static int small_resident_limit() {
 }
 
 static int small_dispatch(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld, const StatParams& sp,
-                          float* ws, float* kstat, const SmallOpt& o, hipStream_t s) {
+                          float* ws, float* kstat, const SmallOpt& o, int launches, int* abort_flag, hipStream_t s) {
+  if (launches != 1 && launches != 2) return BDE_ERR_INVALID;
   const int64_t n_tiles = (((D + 3) >> 2) + kSmallTile4 - 1) / kSmallTile4;
   const int max_grid = small_resident_limit();
   const int tpw = static_cast<int>((n_tiles + max_grid - 1) / max_grid);
@@ -448,7 +562,7 @@ static int small_dispatch(const float* P, const float* G, float* out, int M, int
   switch (M) {
 #define BDE_CASE(m) \
   case m:           \
-    return launch_small<m>(P, G, out, D, ld, grid, tpw, sp, ws, kstat, o, s);
+    return launch_small<m>(P, G, out, D, ld, grid, tpw, sp, ws, kstat, o, launches, abort_flag, s);
     BDE_CASE(1) BDE_CASE(2) BDE_CASE(3) BDE_CASE(4) BDE_CASE(5) BDE_CASE(6) BDE_CASE(7) BDE_CASE(8)
 #undef BDE_CASE
   }
@@ -465,6 +579,13 @@ extern "C" int bde_svgd_small_supported(int M, int64_t D) {
   return n_tiles <= static_cast<int64_t>(small_resident_limit()) * kSmallMaxTilesPerWG;
 }
 
+extern "C" int bde_svgd_small_set_timeout_us(int64_t microseconds) {
+  small_timeout_ticks().store(microseconds < 0 ? kSmallDefaultTimeoutTicks
+                                               : static_cast<unsigned>(std::min<int64_t>(microseconds, 40000000) * 100),
+                              std::memory_order_relaxed);
+  return 0;
+}
+
 static StatParams small_stat_params(int M, float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
                                     float h_override, int mode) {
   return StatParams{l2_reg, kernel_grad_scale, dataset_size, sign, h_override,
@@ -473,20 +594,21 @@ static StatParams small_stat_params(int M, float l2_reg, float kernel_grad_scale
 
 extern "C" int bde_svgd_step_small(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
                                    float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
-                                   float h_override, int mode, void* ws, float* kstat, void* stream) {
+                                   float h_override, int mode, void* ws, float* kstat, int launches, int* abort_flag,
+                                   void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || !out || !ws || !kstat || !aligned16(out) || !aligned16(ws) || (G && !aligned16(G)) ||
       out == P || (mode != 0 && mode != 1) || (mode == 0 && !G))
     return BDE_ERR_INVALID;
   if (!bde_svgd_small_supported(M, D)) return BDE_ERR_INVALID;
   return small_dispatch(P, mode == 0 ? G : nullptr, out, M, D, ld,
                         small_stat_params(M, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, mode),
-                        static_cast<float*>(ws), kstat, SmallOpt{}, static_cast<hipStream_t>(stream));
+                        static_cast<float*>(ws), kstat, SmallOpt{}, launches, abort_flag, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int bde_svgd_step_small_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
                                        float l2_reg, float kernel_grad_scale, float dataset_size, double lr,
                                        double momentum, double dampening, double weight_decay, int nesterov, int first,
-                                       void* ws, float* kstat, void* stream) {
+                                       void* ws, float* kstat, int launches, int* abort_flag, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || !G || !aligned16(G) || !ws || !aligned16(ws) || !kstat ||
       (momentum != 0.0 && (!momentum_buf || !aligned16(momentum_buf))) || !bde_svgd_small_supported(M, D))
     return BDE_ERR_INVALID;
@@ -496,13 +618,13 @@ extern "C" int bde_svgd_step_small_sgd(float* P, const float* G, float* momentum
   o.sk = SgdParams{static_cast<float>(lr), static_cast<float>(momentum), static_cast<float>(1.0 - dampening),
                    static_cast<float>(weight_decay), nesterov, first};
   return small_dispatch(P, G, P, M, D, ld, small_stat_params(M, l2_reg, kernel_grad_scale, dataset_size, -1.f, 0.f, 0),
-                        static_cast<float*>(ws), kstat, o, static_cast<hipStream_t>(stream));
+                        static_cast<float*>(ws), kstat, o, launches, abort_flag, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int bde_svgd_step_small_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D,
                                         int64_t ld, float l2_reg, float kernel_grad_scale, float dataset_size, double lr,
                                         double beta1, double beta2, double eps, double weight_decay, int64_t step0,
-                                        void* ws, float* kstat, void* stream) {
+                                        void* ws, float* kstat, int launches, int* abort_flag, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || !G || !aligned16(G) || !ws || !aligned16(ws) || !kstat || !exp_avg || !exp_avg_sq ||
       !aligned16(exp_avg) || !aligned16(exp_avg_sq) || step0 < 0 || !bde_svgd_small_supported(M, D))
     return BDE_ERR_INVALID;
@@ -514,5 +636,12 @@ extern "C" int bde_svgd_step_small_adam(float* P, const float* G, float* exp_avg
                     static_cast<float>(1.0 - beta2), static_cast<float>(eps), static_cast<float>(weight_decay)};
   o.ast = make_adam_steps(lr, beta1, beta2, step0);
   return small_dispatch(P, G, P, M, D, ld, small_stat_params(M, l2_reg, kernel_grad_scale, dataset_size, -1.f, 0.f, 0),
-                        static_cast<float*>(ws), kstat, o, static_cast<hipStream_t>(stream));
+                        static_cast<float*>(ws), kstat, o, launches, abort_flag, static_cast<hipStream_t>(stream));
+}
+
+// bde_init(): load this translation unit's code object on the current device now (HIP otherwise uploads it at the
+// first launch of one of its kernels).  Internal to the library (not exported).
+extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_svgd_small(void) {
+  hipFuncAttributes attr;
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::svgd_step_small_kernel<8, true, 1>)));
 }

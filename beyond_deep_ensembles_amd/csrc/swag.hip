@@ -212,3 +212,10 @@ extern "C" int bde_philox_bits(uint64_t seed, uint64_t stream_id, uint32_t domai
                      seed, stream_id, domain, idx0, out, n_groups);
   return to_err(hipGetLastError());
 }
+
+// bde_init(): load this translation unit's code object on the current device now (HIP otherwise uploads it at the
+// first launch of one of its kernels).  Internal to the library (not exported).
+extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_swag(void) {
+  hipFuncAttributes attr;
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::swag_update_kernel)));
+}

@@ -149,3 +149,10 @@ extern "C" int bde_swag_sample_batched(const float* mean, const float* sq, const
                        eps_w, eps_d, seed, stream_id0, out, ld_out, S, D);
   return to_err(hipGetLastError());
 }
+
+// bde_init(): load this translation unit's code object on the current device now (HIP otherwise uploads it at the
+// first launch of one of its kernels).  Internal to the library (not exported).
+extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_swag_batched(void) {
+  hipFuncAttributes attr;
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::swag_sample_batched_kernel<true>)));
+}

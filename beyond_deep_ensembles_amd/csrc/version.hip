@@ -1,3 +1,30 @@
 #include "bde_common.hpp"
-extern "C" int bde_version(void) { return 201; /* 0.2.1: + bde_lrt_linear_bwd */ }
+extern "C" int bde_version(void) { return 300; /* 0.3.0: bounded single-launch SVGD step (launches / abort_flag), bde_init */ }
 extern "C" const char* bde_arch(void) { return "gfx950"; }
+
+extern "C" {
+int bde_internal_load_gauss(void);
+int bde_internal_load_ivon(void);
+int bde_internal_load_lrt(void);
+int bde_internal_load_lrt_bwd(void);
+int bde_internal_load_svgd(void);
+int bde_internal_load_svgd_fused(void);
+int bde_internal_load_svgd_small(void);
+int bde_internal_load_swag(void);
+int bde_internal_load_swag_batched(void);
+}
+
+// Load every code object of the library on the CURRENT device.  HIP defers the upload of a code object to the first
+// launch of one of its kernels; a process that is about to start communication threads (torch.distributed) or to share
+// the device with other processes calls this first, from one thread, so that no kernel's first launch coincides with
+// them (profiles/r03_first_launch_*.txt).  Idempotent, cheap after the first call; needs a visible device.
+extern "C" int bde_init(void) {
+  int (*const loaders[])(void) = {bde_internal_load_gauss,      bde_internal_load_ivon,       bde_internal_load_lrt,
+                                  bde_internal_load_lrt_bwd,    bde_internal_load_svgd,       bde_internal_load_svgd_fused,
+                                  bde_internal_load_svgd_small, bde_internal_load_swag,       bde_internal_load_swag_batched};
+  for (auto load : loaders) {
+    const int rc = load();
+    if (rc) return rc;
+  }
+  return 0;
+}

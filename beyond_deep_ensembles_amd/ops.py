@@ -83,28 +83,28 @@ class HipOps:
 
     name = "hip"
 
+    _loaded_devices = set()          # devices whose code objects bde_init() has loaded (process-wide)
+
     def __init__(self):
         self.lib = _lib.load()
+        if torch.cuda.is_available():
+            self.load_code_objects(torch.cuda.current_device())
+
+    def load_code_objects(self, device) -> None:
+        """``bde_init()`` on ``device``: every code object of the library is uploaded NOW, from this thread, instead of
+        at the first launch of one of its kernels (HIP's default).  Done once per device and process, when the first
+        ``HipOps`` is built and again by the shells for the device their parameters live on -- i.e. before a process
+        group's communication threads exist and before the first collective (profiles/r03_first_launch_*.txt)."""
+        index = torch.device(device).index if not isinstance(device, int) else device
+        if index is None:
+            index = torch.cuda.current_device()
+        if index in HipOps._loaded_devices:
+            return
+        with torch.cuda.device(index):
+            _check(self.lib.bde_init(), "bde_init")
+        HipOps._loaded_devices.add(index)
 
     # ------------------------------------------------------------ SVGD --
-    def warm_up_svgd(self, device) -> None:
-        """Launch every SVGD kernel family once on a tiny problem and wait for it.  HIP uploads a code object the first
-        time one of its kernels is launched; a multi-rank optimizer calls this before its first collective so that
-        the upload never coincides with communication threads driving copies on other streams (observed with 8 ranks
-        sharing one device over gloo: the first Gram launch occasionally executed garbage)."""
-        with torch.cuda.device(device):
-            m, d = 2, 256
-            P = torch.zeros((m, pad4(d)), dtype=torch.float32, device=device)
-            P[1, :d] = 1.0
-            G, out = torch.zeros_like(P), torch.zeros_like(P)
-            buf = torch.zeros(pad4(d), dtype=torch.float32, device=device)
-            ws, ks = self.svgd_ws(m, device), self.svgd_kstat(m, device)
-            self.svgd_gram(P, d, ws)
-            self.svgd_kstats(ws, m, 0.0, 1.0, 1.0, -1.0, ks)
-            self.svgd_combine(P, G, out, d, ks)
-            self.svgd_fused_sgd(P, G, buf, d, ks, 0.0, 0.0, 0.0, 0.0, False, True)
-            self.svgd_step(P, G, out, d, 0.0, 1.0, 1.0, -1.0, ws, ks)          # the single-launch path
-            torch.cuda.synchronize(device)
 
     def svgd_ws(self, m: int, device) -> torch.Tensor:
         n = self.lib.bde_svgd_ws_bytes(m)
@@ -166,36 +166,58 @@ class HipOps:
     def svgd_small_supported(self, m: int, d: int) -> bool:
         return bool(self.lib.bde_svgd_small_supported(m, d))
 
+    @staticmethod
+    def small_abort_flag() -> torch.Tensor:
+        """A host-visible int32 word for ``abort_flag``: pinned host memory, which the device addresses directly.  A
+        single launch that gave up sets it to 1; read it once the stream has passed the kernel."""
+        return torch.zeros(1, dtype=torch.int32).pin_memory()
+
+    @staticmethod
+    def _flag_ptr(abort_flag):
+        if abort_flag is None:
+            return None
+        if abort_flag.dtype != torch.int32 or not (abort_flag.is_cuda or abort_flag.is_pinned()):
+            raise BdeKernelError("abort_flag: expected an int32 tensor in pinned host (or device) memory")
+        return abort_flag.data_ptr()
+
+    def svgd_small_set_timeout_us(self, microseconds: int) -> None:
+        """Bound on the in-kernel wait of a single launch (process-wide; < 0: default 2000, 0: give up at once)."""
+        self.lib.bde_svgd_small_set_timeout_us(int(microseconds))
+
     @_on_device_of
     def svgd_step_small(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat, h_override=0.0,
-                        mode=0):
-        """The whole update in one persistent launch (small models); mode 1 = rbf's grad_kernel (G may be None)."""
+                        mode=0, launches=2, abort_flag=None):
+        """The whole update for small models; mode 1 = rbf's grad_kernel (G may be None).  launches = 1: one persistent
+        launch with a bounded in-kernel hand-off (may give up: abort_flag); 2: the same kernel as two ordinary launches."""
         m = P.shape[0]
         if (G is not None and _ld(G) != _ld(P)) or _ld(out) != _ld(P):
             raise BdeKernelError("P, G, out must share one leading dimension")
         _check(self.lib.bde_svgd_step_small(_ptr(P, "P"), _ptr(G, "G"), _ptr(out, "out"), m, d, _ld(P), l2_reg,
                                             kernel_grad_scale, dataset_size, sign, h_override, mode, _ptr(ws),
-                                            _ptr(kstat), _stream()), "bde_svgd_step_small")
+                                            _ptr(kstat), int(launches), self._flag_ptr(abort_flag), _stream()),
+               "bde_svgd_step_small")
 
     @_on_device_of
     def svgd_step_small_sgd(self, P, G, buf, d, l2_reg, kernel_grad_scale, dataset_size, ws, kstat, lr, momentum,
-                            dampening, weight_decay, nesterov, first):
-        """Whole step (statistics, -phi, M shared-state SGD applications, particles updated in place): one launch."""
+                            dampening, weight_decay, nesterov, first, launches=2, abort_flag=None):
+        """Whole step (statistics, -phi, M shared-state SGD applications, particles updated in place)."""
         if _ld(G) != _ld(P):
             raise BdeKernelError("P and G must share one leading dimension")
         _check(self.lib.bde_svgd_step_small_sgd(_ptr(P, "P"), _ptr(G, "G"), _ptr(buf), P.shape[0], d, _ld(P), l2_reg,
                                                 kernel_grad_scale, dataset_size, lr, momentum, dampening, weight_decay,
-                                                int(nesterov), int(first), _ptr(ws), _ptr(kstat), _stream()),
+                                                int(nesterov), int(first), _ptr(ws), _ptr(kstat), int(launches),
+                                                self._flag_ptr(abort_flag), _stream()),
                "bde_svgd_step_small_sgd")
 
     @_on_device_of
     def svgd_step_small_adam(self, P, G, exp_avg, exp_avg_sq, d, l2_reg, kernel_grad_scale, dataset_size, ws, kstat, lr,
-                             beta1, beta2, eps, weight_decay, step0):
+                             beta1, beta2, eps, weight_decay, step0, launches=2, abort_flag=None):
         if _ld(G) != _ld(P):
             raise BdeKernelError("P and G must share one leading dimension")
         _check(self.lib.bde_svgd_step_small_adam(_ptr(P, "P"), _ptr(G, "G"), _ptr(exp_avg), _ptr(exp_avg_sq), P.shape[0],
                                                  d, _ld(P), l2_reg, kernel_grad_scale, dataset_size, lr, beta1, beta2, eps,
-                                                 weight_decay, int(step0), _ptr(ws), _ptr(kstat), _stream()),
+                                                 weight_decay, int(step0), _ptr(ws), _ptr(kstat), int(launches),
+                                                 self._flag_ptr(abort_flag), _stream()),
                "bde_svgd_step_small_adam")
 
     @_on_device_of

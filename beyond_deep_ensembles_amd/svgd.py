@@ -62,7 +62,7 @@ def rbf(particles: torch.Tensor, h_override=None, _ops=None):
     out = torch.zeros_like(P)
     h = float(h_override) if h_override is not None else 0.0
     if ops.svgd_small_supported(m, d):
-        ops.svgd_step_small(P, None, out, d, 0.0, 1.0, 1.0, 1.0, ws, ks, h_override=h, mode=1)   # one launch
+        ops.svgd_step_small(P, None, out, d, 0.0, 1.0, 1.0, 1.0, ws, ks, h_override=h, mode=1)   # two small launches
     else:
         ops.svgd_gram(P, d, ws)
         ops.svgd_kstats(ws, m, 0.0, 1.0, 1.0, 1.0, ks, h_override=h, mode=1)
@@ -92,8 +92,11 @@ class SVGDOptimizer(BayesianOptimizer):
           reuse_gram          with fuse_base_optimizer: the fused kernel also emits the Gram partials of the updated
                               particles, so the next step skips the Gram pass.  Only valid while nothing but this
                               optimizer modifies the particles between two steps (call invalidate_gram() otherwise).
-          single_launch       None (default): small models on one GPU run the whole update as ONE persistent launch
-                              (bde_svgd_step_small*); False forces the staged kernels
+          single_launch       None (default): small models on one GPU run the whole update with the small-model kernel
+                              (bde_svgd_step_small*) -- with a fused base optimizer as ONE persistent launch whose
+                              in-kernel hand-off waits a bounded time; if that launch ever gives up (device shared with
+                              other work), the update is redone as two ordinary launches of the same kernel (identical
+                              results) and stays that way.  "two": always two launches.  False: the staged kernels
     '''
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
@@ -122,6 +125,8 @@ class SVGDOptimizer(BayesianOptimizer):
         self._gviews: List[Optional[List[torch.Tensor]]] = [self._layout.views(self._G[i]) for i in range(m)]
         self._ws = self._ops.svgd_ws(m, dev)
         self._kstat = self._ops.svgd_kstat(m, dev)
+        if hasattr(self._ops, "load_code_objects"):
+            self._ops.load_code_objects(dev)      # every kernel resident on THIS device before any collective / sharing
 
         # particle 0 = the current weights, every further particle = the weights after one more
         # reset_params_closure() (svgd.py:54-59)
@@ -143,8 +148,6 @@ class SVGDOptimizer(BayesianOptimizer):
             self._world, self._rank = dist.get_world_size(process_group), dist.get_rank(process_group)
             if particle_count % self._world != 0:
                 raise ValueError(f"particle_count ({particle_count}) must be a multiple of the group size ({self._world})")
-            if self._world > 1 and hasattr(self._ops, "warm_up_svgd") and not os.environ.get("BDE_NO_WARMUP"):
-                self._ops.warm_up_svgd(self._P.device)       # code objects resident before the first collective
             # identical particles on every rank whatever the local RNG state was
             dist.broadcast(self._P, src=dist.get_global_rank(process_group, 0), group=process_group)
             if self._world > 1:
@@ -153,7 +156,14 @@ class SVGDOptimizer(BayesianOptimizer):
             fuse_base_optimizer = self._fusable(base_optimizer, plist, particle_count)
         if fuse_base_optimizer and particle_count > 16:
             warnings.warn("fuse_base_optimizer needs particle_count <= 16 (single-tile kernels); running unfused")
+        if single_launch not in (None, True, False, "two"):
+            raise ValueError("single_launch must be None, True, False or 'two'")
         self._single_launch = single_launch
+        # the persistent single launch (bounded in-kernel wait): its outcome is checked before anything reads or
+        # overwrites what it worked on -- see _check_single_launch
+        self._small_launches = 2 if single_launch == "two" else 1
+        self._small_flag = None
+        self._small_pending = None
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
         self._fused_decision = None
         self._tmp = None
@@ -202,7 +212,28 @@ class SVGDOptimizer(BayesianOptimizer):
             return self._Gown[particle_idx - self._local_particles().start]
         return self._G[particle_idx]
 
+    def _check_single_launch(self) -> None:
+        """The persistent single launch of the previous step may have given up (its workgroups could not all become
+        resident within the bound: the device is shared).  Then nothing was written; the update is redone NOW from the
+        untouched gradients and optimizer state as two ordinary launches of the same kernel (bit-identical results),
+        and single launches are not used again by this optimizer.  Called on entry of everything that reads or
+        overwrites the particles / gradients; costs one event query when the kernel has long finished."""
+        pending = self._small_pending
+        if pending is None:
+            return
+        self._small_pending = None
+        event, redo = pending
+        event.synchronize()
+        if int(self._small_flag[0]) != 0:
+            self._small_flag[0] = 0
+            self._small_launches = 2
+            warnings.warn("SVGD single-launch update gave up waiting for its workgroups (device shared with other work); "
+                          "redone as two launches, which this optimizer now always uses")
+            with torch.no_grad():
+                redo()
+
     def step(self, forward_closure, backward_closure, grad_scaler=None):
+        self._check_single_launch()
         OptState = _opt_state()
         base = self.state["__base_optimizer"]
         m, d = self.state["__particle_count"], self._layout.d
@@ -233,6 +264,7 @@ class SVGDOptimizer(BayesianOptimizer):
         """Everything after the forward/backward passes (svgd.py:82-105): gradient exchange (multi-GPU), kernel
         statistics, -phi and the base-optimizer applications.  ``total_loss`` = sum of this rank's particle losses;
         returns the mean loss over all particles.  (bench.py times exactly this.)"""
+        self._check_single_launch()
         base = self.state["__base_optimizer"]
         m = self.state["__particle_count"]
         with torch.no_grad():
@@ -480,28 +512,42 @@ class SVGDOptimizer(BayesianOptimizer):
             st = {"kind": "adam", "exp_avg": torch.zeros(n, device=dev), "exp_avg_sq": torch.zeros(n, device=dev),
                   "step": 0}
             names = {"exp_avg": "exp_avg", "exp_avg_sq": "exp_avg_sq"}
+        # What the state starts from, as FULL-length flat vectors: a checkpoint written by the fused path (its "__fused"
+        # entry: full-length buffers in every exchange mode), else whatever the base optimizer already holds per tensor
+        # (a resumed unfused run, or a checkpoint written by the reference: momentum_buffer / exp_avg / exp_avg_sq)
+        ld = self._layout.ld
+        full = {}
         if loaded is not None and loaded.get("kind") == kind:
-            # a checkpoint written by the fused path: its flat buffers are the state
             for key in names:
-                if torch.is_tensor(loaded.get(key)) and loaded[key].numel() == n:
-                    st[key].copy_(loaded[key].to(dev))
+                if torch.is_tensor(loaded.get(key)) and loaded[key].numel() in (n, ld):
+                    full[key] = loaded[key].to(dev)
             for key in ("first", "step"):
                 if key in loaded:
                     st[key] = loaded[key]
-        elif not sharded:
-            # adopt whatever state the base optimizer already has (a resumed unfused / reference run) ...
-            views = {key: self._layout.views(st[key]) for key in names}
+        else:
             seen = False
-            for i, p in enumerate(self._plist):
-                old = base.state.get(p, {})
-                for key, name in names.items():
-                    if torch.is_tensor(old.get(name)):
-                        views[key][i].copy_(old[name].to(dev))
+            for key, name in names.items():
+                vec = torch.zeros(ld, device=dev)
+                for v, p in zip(self._layout.views(vec), self._plist):
+                    old = base.state.get(p, {}).get(name)
+                    if torch.is_tensor(old):
+                        v.copy_(old.to(dev))
                         seen = True
-                if kind == "adam" and "step" in old:
-                    st["step"] = int(old["step"])
+                full[key] = vec
+            if not seen:
+                full = {}
+            for p in self._plist:
+                if kind == "adam" and "step" in base.state.get(p, {}):
+                    st["step"] = int(base.state[p]["step"])
             if kind == "sgd" and seen:
                 st["first"] = False
+        for key, vec in full.items():
+            if vec.numel() == n:
+                st[key].copy_(vec)
+            else:                                  # a full-length vector into this rank's column slice
+                lo = self._rank * self._sl
+                take = max(0, min(ld, lo + n) - lo)
+                st[key][:take].copy_(vec[lo:lo + take])
         if not sharded:
             # ... and publish the flat buffers as that state
             views = {key: self._layout.views(st[key]) for key in names}
@@ -537,9 +583,9 @@ class SVGDOptimizer(BayesianOptimizer):
             for P, G, d, c0 in pieces:
                 if single_launch:
                     l2, scale, n, _ = self._stat_args()
-                    self._ops.svgd_step_small_sgd(P, G, st["buf"], d, l2, scale, n, self._ws, self._kstat, g0["lr"],
-                                                  g0["momentum"], g0["dampening"], g0["weight_decay"], g0["nesterov"],
-                                                  st["first"])
+                    args = (P, G, st["buf"], d, l2, scale, n, self._ws, self._kstat, g0["lr"], g0["momentum"],
+                            g0["dampening"], g0["weight_decay"], g0["nesterov"], st["first"])
+                    self._launch_small(self._ops.svgd_step_small_sgd, args)
                     continue
                 self._ops.svgd_fused_sgd(P, G, st["buf"][c0:], d, self._kstat, g0["lr"], g0["momentum"], g0["dampening"],
                                          g0["weight_decay"], g0["nesterov"], st["first"], ws_next=ws_next)
@@ -550,9 +596,9 @@ class SVGDOptimizer(BayesianOptimizer):
             for P, G, d, c0 in pieces:
                 if single_launch:
                     l2, scale, n, _ = self._stat_args()
-                    self._ops.svgd_step_small_adam(P, G, st["exp_avg"], st["exp_avg_sq"], d, l2, scale, n, self._ws,
-                                                   self._kstat, float(g0["lr"]), g0["betas"][0], g0["betas"][1], g0["eps"],
-                                                   g0["weight_decay"], st["step"])
+                    args = (P, G, st["exp_avg"], st["exp_avg_sq"], d, l2, scale, n, self._ws, self._kstat, float(g0["lr"]),
+                            g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"])
+                    self._launch_small(self._ops.svgd_step_small_adam, args)
                     continue
                 self._ops.svgd_fused_adam(P, G, st["exp_avg"][c0:], st["exp_avg_sq"][c0:], d, self._kstat, float(g0["lr"]),
                                           g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"],
@@ -561,6 +607,19 @@ class SVGDOptimizer(BayesianOptimizer):
             raise RuntimeError(f"fuse_base_optimizer supports torch.optim.SGD and torch.optim.Adam, got {type(base)}")
         if advance:
             self._fused_advance()
+
+    def _launch_small(self, op, args) -> None:
+        """The small-model kernel with the fused optimizer: ONE persistent launch while that has never given up on this
+        optimizer (its outcome is checked by _check_single_launch before the next use of P / G), two launches otherwise."""
+        if self._small_launches == 2 or not hasattr(self._ops, "small_abort_flag"):
+            op(*args, launches=2)
+            return
+        if self._small_flag is None:
+            self._small_flag = self._ops.small_abort_flag()
+        op(*args, launches=1, abort_flag=self._small_flag)
+        event = torch.cuda.Event()
+        event.record()
+        self._small_pending = (event, lambda: op(*args, launches=2))
 
     def _fused_advance(self):
         """One SVGD step = particle_count applications of the shared optimizer."""
@@ -577,6 +636,7 @@ class SVGDOptimizer(BayesianOptimizer):
     def sample_parameters(self):
         '''Point the model at the next particle, round robin (svgd.py:107-112).  With dimension-sharded
         particles only this rank's own particles are available, so the cycle runs over those.'''
+        self._check_single_launch()
         count = self.state["__particle_count"]
         current = self.state["__current_particle"]
         if self._exchange == "alltoall":
@@ -603,6 +663,7 @@ class SVGDOptimizer(BayesianOptimizer):
     def particles(self) -> torch.Tensor:
         """[M, D] view of the flat particle buffer.  With exchange="alltoall" the slices are gathered first
         (a collective: every rank of the group must read this property)."""
+        self._check_single_launch()
         d = self._layout.d
         if self._exchange != "alltoall":
             return self._P[:, :d]
@@ -614,6 +675,7 @@ class SVGDOptimizer(BayesianOptimizer):
 
     @property
     def kernel_stats(self) -> dict:
+        self._check_single_launch()
         m = self.state["__particle_count"]
         ks = self._kstat
         return {"kernel": ks[:m * m].view(m, m), "d2": ks[m * m:2 * m * m].view(m, m),
@@ -623,18 +685,70 @@ class SVGDOptimizer(BayesianOptimizer):
         """Call after modifying the particles outside this optimizer when reuse_gram=True."""
         self._gram_valid = False
 
+    def _gather_slices(self, vec: torch.Tensor) -> torch.Tensor:
+        """This rank's ``[sl]`` slice of a column-sharded vector -> the full ``[ld]`` vector (a collective)."""
+        import torch.distributed as dist
+        out = torch.empty(self._world * self._sl, dtype=vec.dtype, device=vec.device)
+        dist.all_gather_into_tensor(out, vec.contiguous().clone(), group=self._pg)
+        return out[:self._layout.ld]
+
     def state_dict(self):
-        if self._exchange == "alltoall":
-            raise NotImplementedError("exchange='alltoall': the particles are sharded over the ranks; gather them with "
-                                      ".particles (a collective) and save that")
-        return super().state_dict()
+        """The reference's layout in every exchange mode (svgd.py:51-61 through ensemble.py:17-26): per-tensor
+        ``particle_i`` entries for ALL particles and the pickled ``__base_optimizer``.  With exchange="alltoall" the
+        particles and the shared optimizer state are sharded by columns, so this is a COLLECTIVE there (every rank of
+        the group must call it; every rank gets the complete dict): the slices are gathered, the fused optimizer's state
+        is published into ``base_optimizer.state`` in torch's own layout, and ``__fused`` carries full-length buffers."""
+        self._check_single_launch()
+        if self._exchange != "alltoall":
+            return super().state_dict()
+        m, d, ld = self.state["__particle_count"], self._layout.d, self._layout.ld
+        full = torch.zeros((m, ld), dtype=torch.float32, device=self._Ps.device)
+        full[:, :d] = self.particles                                        # collective
+        for i in range(m):
+            for param, view in zip(self._plist, self._layout.views(full[i])):
+                self.state[param][f"particle_{i}"] = view
+        st = self._fused_state
+        if st is not None:
+            base = self.state["__base_optimizer"]
+            names = {"buf": "momentum_buffer"} if st["kind"] == "sgd" else {"exp_avg": "exp_avg", "exp_avg_sq": "exp_avg_sq"}
+            gathered = {key: self._gather_slices(st[key]) for key in names}     # collectives, same order on every rank
+            published = dict(st, **gathered)
+            has_state = st["kind"] == "adam" or not st["first"]
+            for key, name in names.items():
+                for p, v in zip(self._plist, self._layout.views(gathered[key])):
+                    if has_state:
+                        base.state[p][name] = v
+            if st["kind"] == "adam":
+                for p in self._plist:
+                    base.state[p]["step"] = torch.tensor(float(st["step"]))
+            self.state["__fused"] = published
+        try:
+            sd = super().state_dict()
+            sd["state"] = {k: (dict(v) if isinstance(v, dict) else v) for k, v in sd["state"].items()}
+        finally:
+            self._realias_sharded_state()
+            if st is not None:
+                self.state["__fused"] = st
+        return sd
+
+    def _realias_sharded_state(self) -> None:
+        """exchange="alltoall": ``state[param]["particle_i"]`` exists for this rank's own particles only (views of
+        their rows)."""
+        own = self._local_particles()
+        for i in range(self.state["__particle_count"]):
+            if i in own:
+                for param, view in zip(self._plist, self._pviews[i]):
+                    self.state[param][f"particle_{i}"] = view
+            else:
+                for param in self._plist:
+                    self.state[param].pop(f"particle_{i}", None)
 
     def load_state_dict(self, state_dict):
         """Accepts the reference's layout (per-tensor ``particle_i`` entries): the
-        values are copied into the flat buffer and the state re-aliased to it."""
-        if self._exchange == "alltoall":
-            raise NotImplementedError("exchange='alltoall': load the checkpoint before sharding (construct with "
-                                      "exchange='allgather', load, then rebuild)")
+        values are copied into the flat buffer and the state re-aliased to it.  With exchange="alltoall" every rank
+        loads the same (complete) dict and keeps its own particles' rows and its column slice of all particles and of
+        the shared optimizer state; no communication."""
+        self._check_single_launch()
         super().load_state_dict(state_dict)
         self._gram_valid = False
         # shared optimizer state of the fused path: re-adopted (and re-published into base.state) at the next step
@@ -642,6 +756,18 @@ class SVGDOptimizer(BayesianOptimizer):
         self._fused_state = None
         self._fused_decision = None
         m = self.state["__particle_count"]
+        if self._exchange == "alltoall":
+            ld, sl, r = self._layout.ld, self._sl, self._rank
+            own = self._local_particles()
+            full = torch.zeros((m, self._ldw), dtype=torch.float32, device=self._Ps.device)
+            with torch.no_grad():
+                for i in range(m):
+                    loaded = [self.state[param][f"particle_{i}"] for param in self._plist]
+                    torch._foreach_copy_(self._layout.views(full[i, :ld]), [t.to(full.device) for t in loaded])
+                self._Pown.copy_(full[own.start:own.stop])
+                self._Ps.copy_(full[:, r * sl:(r + 1) * sl])
+            self._realias_sharded_state()
+            return
         with torch.no_grad():
             for i in range(m):
                 for param, view in zip(self._plist, self._pviews[i]):

@@ -45,6 +45,11 @@ extern "C" {
 int bde_version(void);
 /* gfx target the device code was compiled for, e.g. "gfx950". */
 const char* bde_arch(void);
+/* Load every code object of the library on the CURRENT device now.  HIP defers that to the first launch of a kernel;
+ * call this once per device, from one thread, before communication threads (torch.distributed) start or other
+ * processes share the device, so that no first launch coincides with them.  Idempotent.  (No reference counterpart:
+ * PyTorch loads its kernels the same lazy way.) */
+int bde_init(void);
 
 /* ------------------------------------------------------------------ SVGD --
  * One SVGD posterior update over M flattened particles P [M, ld] with
@@ -120,14 +125,27 @@ int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, 
  * counter, the kernel statistics evaluated redundantly by every workgroup, and the combine of the columns each
  * workgroup already holds in registers.  12*M*D bytes of HBM traffic, no launch boundaries.  Same results as the
  * three-stage path up to the order of the partial sums.  mode / h_override as in bde_svgd_kstats (mode 1: G may
- * be NULL, out = grad_kernel).  Needs all its (<= 256) workgroups co-resident: bde_svgd_small_supported() answers
- * for the CURRENT device (CUs x resident workgroups per CU, queried once per device), so a partition of the chip
- * (CPX mode) gets a smaller limit on D or the three-stage path; do not oversubscribe the device with other
- * persistent kernels. */
+ * be NULL, out = grad_kernel).  bde_svgd_small_supported() answers for the CURRENT device (CUs x resident workgroups
+ * per CU, queried once per device), so a partition of the chip (CPX mode) gets a smaller limit on D or the
+ * three-stage path.
+ *
+ * `launches` selects how the hand-off between the two halves of the kernel happens:
+ *   1  ONE launch; the workgroups wait for each other inside the kernel, for a BOUNDED time (2 ms by default,
+ *      bde_svgd_small_set_timeout_us).  That needs all (<= 256) workgroups resident at once, which an otherwise idle
+ *      device gives but a shared one may not.  The launch decides as one unit: if any workgroup gives up, NO workgroup
+ *      writes anything (P, out and the optimizer state are untouched), `*abort_flag` (host-visible memory, e.g. pinned;
+ *      may be NULL) is set to 1 and the workspace refuses further single launches until a two-launch call repaired it.
+ *      The caller checks the flag once the stream has passed the kernel and then redoes the update with launches = 2.
+ *   2  the SAME kernel as two ordinary launches (Gram partials; everything after the hand-off): no waiting inside the
+ *      kernel, no residency requirement, bit-identical results.  abort_flag is not used.
+ * bde_svgd_step() uses launches = 2. */
 int bde_svgd_small_supported(int M, int64_t D);
 int bde_svgd_step_small(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
                         float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
-                        float h_override, int mode, void* ws, float* kstat, void* stream);
+                        float h_override, int mode, void* ws, float* kstat, int launches, int* abort_flag, void* stream);
+/* Waiting time of a single launch in microseconds (process-wide; < 0 restores the default, 0 makes every single
+ * launch give up without waiting -- the hook the recovery tests use).  Also BDE_SMALL_TIMEOUT_US in the environment. */
+int bde_svgd_small_set_timeout_us(int64_t microseconds);
 
 /* The same launch continued through the M shared-state base-optimizer applications (svgd.py:92-103, semantics of
  * bde_svgd_fused_sgd / bde_svgd_fused_adam): the updated particles are written back over P -- the whole
@@ -135,11 +153,11 @@ int bde_svgd_step_small(const float* P, const float* G, float* out, int M, int64
 int bde_svgd_step_small_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
                             float l2_reg, float kernel_grad_scale, float dataset_size, double lr, double momentum,
                             double dampening, double weight_decay, int nesterov, int first, void* ws, float* kstat,
-                            void* stream);
+                            int launches, int* abort_flag, void* stream);
 int bde_svgd_step_small_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D, int64_t ld,
                              float l2_reg, float kernel_grad_scale, float dataset_size, double lr, double beta1,
                              double beta2, double eps, double weight_decay, int64_t step0, void* ws, float* kstat,
-                             void* stream);
+                             int launches, int* abort_flag, void* stream);
 
 /* Shared-state base-optimizer apply for the M particles, in particle order
  * (svgd.py:92-103 with ONE torch.optim.SGD / Adam whose state is keyed on the

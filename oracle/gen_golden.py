@@ -20,7 +20,8 @@ Fixture list:
   lrt.npz             the reference's BBBLinear layer: output and all five gradients at five sizes (bbb_layers.py:61-80)
   ivon.npz            iVON trajectories with recorded noise (ivorn.py:41-115)
   ensemble.npz        DeepEnsemble.predict sample split     (ensemble.py:37-40)
-  ref_*_checkpoint.pt state_dict()s written by the reference optimizers (wire compatibility)
+  ref_*_checkpoint.pt state_dict()s written by the reference optimizers (wire compatibility); ref_svgd_checkpoint4*:
+                      four particles, nesterov SGD, two further reference steps (multi-rank resume)
   rank1.npz           BBBOptimizer over the reference's Rank1Linear, 2 components, draws recorded
 """
 import math
@@ -607,6 +608,28 @@ def gen_checkpoints():
     torch.save({"particles_after": after, "loss": float(loss)}, os.path.join(OUT, "ref_svgd_checkpoint_next.pt"))
 
 
+def gen_checkpoints4():
+    """A second reference-written SVGD checkpoint with FOUR particles (divisible by 2 ranks: the multi-rank resume
+    tests), SGD with momentum and nesterov + weight decay, and the reference's step after it."""
+    torch.manual_seed(43)
+    model = make_mlp()
+    base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)
+    sv = ref_svgd.SVGDOptimizer(model.parameters(), lambda: ref_util.reset_model_params(model), base,
+                                particle_count=4, dataset_size=64, l2_reg=0.01)
+    x, y = torch.randn(16, 13), torch.randn(16, 1)
+    for t in range(2):
+        sv.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
+    params = list(model.parameters())
+    particles = torch.stack([flat([sv.state[p][f"particle_{i}"] for p in params]) for i in range(4)])
+    torch.save({"optimizer": sv.state_dict(), "particles": particles, "x": x, "y": y,
+                "model": model.state_dict()}, os.path.join(OUT, "ref_svgd_checkpoint4.pt"))
+    after, losses = [], []
+    for t in range(2):      # two more reference steps from this state: what a resumed run must reproduce
+        losses.append(float(sv.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())))
+        after.append(torch.stack([flat([sv.state[p][f"particle_{i}"] for p in params]) for i in range(4)]))
+    torch.save({"particles_after": after, "losses": losses}, os.path.join(OUT, "ref_svgd_checkpoint4_next.pt"))
+
+
 if __name__ == "__main__" and len(sys.argv) > 1:
     for _name in sys.argv[1:]:
         globals()["gen_" + _name]()
@@ -625,6 +648,7 @@ elif __name__ == "__main__":
     gen_ivon()
     gen_ensemble()
     gen_checkpoints()
+    gen_checkpoints4()
     gen_rank1()
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):

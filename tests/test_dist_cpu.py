@@ -213,3 +213,26 @@ def test_fan_out_reproduces_single_process_predict(kind):
         assert torch.equal(torch.stack([outs2[u] for u in range(samples)]), want2), (kind, world)
     if kind == "svgd":
         assert not torch.equal(want[0], want[1])                           # different particles really differ
+
+
+# ------------------------------------------------------------------ checkpoints in every exchange mode --
+def _resume_worker(rank, world, port, kw, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.ckpt_resume import resume_worker
+        from tests.oracle_ops import OracleOps
+        torch.set_num_threads(1)
+        resume_worker(rank, OracleOps(), torch.device("cpu"), dist.group.WORLD, dict(kw), out_dir)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [{}, {"exchange_chunks": 3}, {"exchange": "alltoall"}], ids=["allgather", "pipelined", "alltoall"])
+def test_reference_checkpoint_resumes_on_two_ranks(tmp_path, kw):
+    """tests/ckpt_resume.py: a reference-written SVGD checkpoint -> 2-rank optimizer -> step -> own state_dict() (a
+    collective in alltoall mode) -> fresh optimizer -> step; both steps == the reference's own next steps."""
+    from tests.ckpt_resume import check
+    mp.spawn(_resume_worker, args=(2, _free_port(), tuple(kw.items()), str(tmp_path)), nprocs=2, join=True)
+    check(str(tmp_path))

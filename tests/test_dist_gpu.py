@@ -196,3 +196,23 @@ def test_predict_distributed_hip_rccl(tmp_path):
     mp.spawn(_predict_worker, args=(world, _free_port(), "nccl", "swag", str(tmp_path)), nprocs=world, join=True)
     a, b = np.load(tmp_path / "pred0.npz"), np.load(tmp_path / "pred1.npz")
     np.testing.assert_array_equal(a["out"], b["out"])
+
+
+# ------------------------------------------------------------------ checkpoints in every exchange mode --
+def _resume_worker(rank, world, port, backend, kw, out_dir):
+    dist, dev = _init(rank, world, port, backend)
+    try:
+        from beyond_deep_ensembles_amd.ops import HipOps
+        from tests.ckpt_resume import resume_worker
+        resume_worker(rank, HipOps(), dev, dist.group.WORLD, dict(kw), out_dir)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [{}, {"exchange_chunks": 3}, {"exchange": "alltoall"}], ids=["allgather", "pipelined", "alltoall"])
+def test_reference_checkpoint_resumes_on_two_ranks_one_device(tmp_path, kw):
+    """tests/ckpt_resume.py with the real kernels: reference-written checkpoint -> 2 ranks -> step -> state_dict()
+    (collective in alltoall mode) -> fresh optimizer -> step; both steps == the reference's own next steps."""
+    from tests.ckpt_resume import check
+    mp.spawn(_resume_worker, args=(2, _free_port(), "gloo", tuple(kw.items()), str(tmp_path)), nprocs=2, join=True)
+    check(str(tmp_path))
