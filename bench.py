@@ -128,20 +128,43 @@ def extras(ops, dev, quick):
     o2 = torch.empty_like(G2)
     rec("svgd_step_M8_resnet20", time_loop(lambda: ops.svgd_step(P2, G2, o2, d20, 3e-4, 1.0, 50000.0, -1.0, ws, ks), 50),
         16 * M * d20, 1, "steps_per_s")
-    del P2, G2, o2
-    # --- SWAG
+    b2 = torch.zeros(pad_ld(d20), device=dev)
+    flag = ops.small_abort_flag()
+    for launches in (1, 2):
+        t = time_loop(lambda: ops.svgd_step_small_sgd(P2, G2, b2, d20, 3e-4, 1.0, 50000.0, ws, ks, 1e-12, 0.9, 0.0, 3e-4,
+                                                      True, False, launches=launches, abort_flag=flag), 50)
+        rec(f"svgd_full_step_fused_sgd_M8_resnet20_{launches}_launch{'es' if launches > 1 else ''}", t,
+            (12 * M + 8) * d20, 1, "steps_per_s")
+    out["svgd_full_step_fused_sgd_M8_resnet20_1_launch"]["gave_up"] = int(flag[0])
+    del P2, G2, o2, b2
+    # --- SWAG: the statistics as the optimizer keeps them (K + 2 rows interleaved in 16 KB pieces, ops.RowBlock) and,
+    # beside it, the same kernels on contiguous rows a row length apart (round 2's layout)
+    from beyond_deep_ensembles_amd.ops import RowBlock
     mean = torch.randn(ld, device=dev, generator=g) * 0.05
     sq = mean * mean + 1e-4
     ring = torch.randn(K_SWAG, ld, device=dev, generator=g) * 1e-3
     theta = torch.randn(ld, device=dev, generator=g) * 0.05
     o = torch.empty(ld, device=dev)
-    rec("swag_update_resnet50", time_loop(lambda: ops.swag_update(theta, mean, sq, ring[3], 5, d), it), 24 * d)
-    t = time_loop(lambda: ops.swag_sample(mean, sq, ring, 3, o, d, seed=1, stream_id=2), it)
+    blk = RowBlock(K_SWAG + 2, d, dev)
+    blk.buf.copy_(torch.randn(blk.buf.shape, device=dev, generator=g) * 1e-3)
+    bm, bs, br = blk.row(K_SWAG), blk.row(K_SWAG + 1), blk.rows(0, K_SWAG)
+    rec("swag_update_resnet50", time_loop(lambda: ops.swag_update(theta, bm, bs, blk.row(3), 5, d, pieces=blk.pieces), it), 24 * d)
+    rec("swag_update_resnet50_contiguous_rows", time_loop(lambda: ops.swag_update(theta, mean, sq, ring[3], 5, d), it), 24 * d)
+    t = time_loop(lambda: ops.swag_sample(bm, bs, br, 3, o, d, seed=1, stream_id=2, pieces=blk.pieces), it)
     rec("swag_sample_K20_resnet50", t, 4 * d * (K_SWAG + 3), 1, "samples_per_s")
+    t = time_loop(lambda: ops.swag_sample(mean, sq, ring, 3, o, d, seed=1, stream_id=2), it)
+    rec("swag_sample_K20_resnet50_contiguous_rows", t, 4 * d * (K_SWAG + 3), 1, "samples_per_s")
+    oblk = RowBlock(S_SWAG, d, dev)
+    t = time_loop(lambda: ops.swag_sample_batched(bm, bs, br, 3, oblk.rows(0, S_SWAG), d, seed=1, stream_id0=0,
+                                                  pieces=blk.pieces, out_pieces=oblk.pieces), max(3, it // 2))
+    rec("swag_sample_batched_K20_S30_resnet50", t, 4 * d * (K_SWAG + 2 + S_SWAG), S_SWAG, "samples_per_s")
+    rec("swag_serve_prefetched_sample_resnet50", time_loop(lambda: ops.swag_copy_row(oblk.row(7), o, d, src_pieces=oblk.pieces), it),
+        8 * d, 1, "samples_per_s")
+    del oblk
     ob = torch.empty(S_SWAG, ld, device=dev)
     t = time_loop(lambda: ops.swag_sample_batched(mean, sq, ring, 3, ob, d, seed=1, stream_id0=0), max(3, it // 2))
-    rec("swag_sample_batched_K20_S30_resnet50", t, 4 * d * (K_SWAG + 2 + S_SWAG), S_SWAG, "samples_per_s")
-    del ob, ring
+    rec("swag_sample_batched_K20_S30_resnet50_contiguous_rows", t, 4 * d * (K_SWAG + 2 + S_SWAG), S_SWAG, "samples_per_s")
+    del ob, ring, blk, bm, bs, br
     # --- BBB
     rho = torch.full((ld,), -3.0, device=dev)
     w = torch.empty(ld, device=dev)
@@ -313,6 +336,90 @@ def shell_step_ms(dev, steps=10):
             "native_host_helper": _host.load() is not None,
             "what": "SVGDOptimizer(fuse_base_optimizer=True, reuse_gram=True).step with null closures: host logic "
                     "of the shell + kernels + fused SGD for 8 particles x 161 tensors"}
+
+
+class _ManyGrads(torch.autograd.Function):
+    """loss = sum_i <p_i, c_i> as ONE autograd node with n_tensors inputs whose backward hands out n_tensors FRESH,
+    separately allocated gradient tensors (c_i * grad_out through one multi-tensor launch) -- what a real model's
+    backward produces, without a model's cost."""
+
+    @staticmethod
+    def forward(ctx, cs, *params):
+        ctx.cs = cs
+        return torch.stack([torch.dot(p.detach().view(-1)[:64], c.view(-1)[:64]) for p, c in zip(params[:2], cs[:2])]).sum()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return (None,) + tuple(torch._foreach_mul(ctx.cs, grad_out))
+
+
+def shell_step_real_grads_ms(dev, n_tensors=161, d=D_RESNET50, steps=20, fuse=True):
+    """SVGDOptimizer.step() with REAL gradients: every particle's backward produces n_tensors fresh gradient tensors
+    (one pre-built autograd node, _ManyGrads).  ONE loop of whole steps is timed; inside it the closures carry their
+    own host timers, so the optimizer's host time = step host time - closure host time of the SAME steps (never
+    negative), and HIP events around the posterior update give its GPU time.  No gradient is copied: the kernels read
+    the tensors autograd produced (svgd.py:129-133's clones removed)."""
+    import beyond_deep_ensembles_amd as bde
+    sizes = [d // n_tensors] * (n_tensors - 1)
+    sizes.append(d - sum(sizes))
+    params = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in sizes]
+    cs = [torch.randn(s, device=dev) * 0.01 for s in sizes]
+    base = torch.optim.SGD(params, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=3e-4)
+
+    def reset():
+        with torch.no_grad():
+            for p in params[-2:]:
+                p.normal_(0, 0.05)
+    opt = bde.SVGDOptimizer(params, reset, base, particle_count=M, dataset_size=DATASET_SIZE, fuse_base_optimizer=fuse,
+                            reuse_gram=fuse)
+    t_closures = [0.0]
+
+    def fwd():
+        t0 = time.perf_counter()
+        out = _ManyGrads.apply(cs, *params)
+        t_closures[0] += time.perf_counter() - t0
+        return out
+
+    def bwd(loss):
+        t0 = time.perf_counter()
+        loss.backward()
+        t_closures[0] += time.perf_counter() - t0
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    inner = opt._posterior_update
+    it = [0]
+
+    def timed_update(*a, **k):
+        i = it[0]
+        if 0 <= i < steps:
+            ev[i][0].record()
+        out = inner(*a, **k)
+        if 0 <= i < steps:
+            ev[i][1].record()
+        it[0] += 1
+        return out
+    opt._posterior_update = timed_update
+    it[0] = -3
+    for _ in range(3):
+        opt.step(fwd, bwd)
+    torch.cuda.synchronize()
+    t_closures[0] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        opt.step(fwd, bwd)
+    host = (time.perf_counter() - t0) / steps
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    clos = t_closures[0] / steps
+    gpu = sum(a.elapsed_time(b) for a, b in ev) / steps
+    del opt, params, cs, base
+    torch.cuda.empty_cache()
+    return {"step_ms": round(wall * 1e3, 3), "step_host_ms": round(host * 1e3, 3), "closures_host_ms": round(clos * 1e3, 3),
+            "optimizer_host_ms": round((host - clos) * 1e3, 3), "optimizer_gpu_ms": round(gpu, 3),
+            "tensors": n_tensors, "particles": M, "fused": fuse,
+            "what": "SVGDOptimizer.step with real gradients (8 backward passes producing n_tensors fresh tensors each), one "
+                    "timed loop: host time of the whole step, of the closures inside it, their difference = the "
+                    "optimizer's own host time (re-pointing, gradient hand-over by reference, launches), and the GPU time "
+                    "of the posterior update (HIP events); no per-particle gradient copy"}
 
 
 def other_shell_steps_ms(dev, steps=10):
@@ -776,15 +883,18 @@ def main():
         torch.cuda.empty_cache()
         ld = pad_ld(d)
         gsw = torch.Generator(device=dev).manual_seed(99 + rank)
-        mean = torch.randn(ld, device=dev, generator=gsw) * 0.05
-        sq = mean * mean + 1e-4
-        ring = torch.randn(K_SWAG, ld, device=dev, generator=gsw) * 1e-3
+        from beyond_deep_ensembles_amd.ops import RowBlock
+        blk = RowBlock(K_SWAG + 2, d, dev)                      # the optimizer's layout: rows interleaved in 16 KB pieces
+        blk.buf.copy_(torch.randn(blk.buf.shape, device=dev, generator=gsw) * 1e-3)
+        blk.buf[:, K_SWAG + 1] += 1e-4
+        bm, bs, br = blk.row(K_SWAG), blk.row(K_SWAG + 1), blk.rows(0, K_SWAG)
         o1 = torch.empty(ld, device=dev)
-        ob = torch.empty(S_SWAG, ld, device=dev)
+        ob = RowBlock(S_SWAG, d, dev)
         if dist:
             dist.barrier()
-        t_single = time_loop(lambda: ops.swag_sample(mean, sq, ring, 3, o1, d, seed=1, stream_id=2), 20)
-        t_batch = time_loop(lambda: ops.swag_sample_batched(mean, sq, ring, 3, ob, d, seed=1, stream_id0=0), 8)
+        t_single = time_loop(lambda: ops.swag_sample(bm, bs, br, 3, o1, d, seed=1, stream_id=2, pieces=blk.pieces), 20)
+        t_batch = time_loop(lambda: ops.swag_sample_batched(bm, bs, br, 3, ob.rows(0, S_SWAG), d, seed=1, stream_id0=0,
+                                                            pieces=blk.pieces, out_pieces=ob.pieces), 8)
         rates = torch.tensor([1.0 / t_single, S_SWAG / t_batch], device=dev, dtype=torch.float64)
         if dist:
             dist.all_reduce(rates, op=dist.ReduceOp.SUM)
@@ -792,7 +902,7 @@ def main():
                 "K": K_SWAG, "D": d, "scaling": "weak (independent posterior samples on every GPU)",
                 "per_sample_hbm_frac_rank0": round(4 * d * (K_SWAG + 3) / t_single / 1e9 / HBM_PEAK_GBS, 4),
                 "batched_hbm_frac_rank0": round(4 * d * (K_SWAG + 2 + S_SWAG) / t_batch / 1e9 / HBM_PEAK_GBS, 4)}
-        del mean, sq, ring, o1, ob
+        del blk, bm, bs, br, o1, ob
         out = None
 
     if rank == 0:
@@ -893,6 +1003,12 @@ def main():
                     log(f"  svgd_shell_step_ms {res['extra']['svgd_shell_step_ms']}")
                 except Exception as e:
                     log(f"  svgd_shell_step_ms skipped: {e}")
+                try:
+                    res["extra"]["svgd_shell_step_real_grads_ms"] = shell_step_real_grads_ms(dev)
+                    res["extra"]["svgd_shell_step_real_grads_densenet121_ms"] = shell_step_real_grads_ms(dev, 364, D_DENSENET)
+                    log(f"  svgd_shell_step_real_grads_ms {res['extra']['svgd_shell_step_real_grads_ms']}")
+                except Exception as e:
+                    log(f"  svgd_shell_step_real_grads_ms skipped: {type(e).__name__}: {e}")
                 try:
                     res["extra"]["other_shell_steps_ms"] = other_shell_steps_ms(dev)
                     log(f"  other_shell_steps_ms {res['extra']['other_shell_steps_ms']}")

@@ -47,10 +47,18 @@ SIGNATURES = {
                                    c_int, c_int, _P, _P]),
     "bde_svgd_fused_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, c_int64, _P, c_double, c_double, c_double,
                                     c_double, c_double, c_int64, _P, _P]),
-    "bde_swag_update": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P]),
-    "bde_swag_sample": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
-    "bde_swag_sample_batched": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64,
-                                        c_int, c_int64, _P]),
+    "bde_svgd_combine_seg": (c_int, [_P, _P, _P, c_int64, _P, c_int, c_int64, c_int64, _P, _P]),
+    "bde_svgd_fused_sgd_seg": (c_int, [_P, _P, _P, c_int64, _P, c_int, c_int64, c_int64, _P, c_double, c_double, c_double,
+                                       c_double, c_int, c_int, _P, _P]),
+    "bde_svgd_fused_adam_seg": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int, c_int64, c_int64, _P, c_double, c_double,
+                                        c_double, c_double, c_double, c_int64, _P, _P]),
+    "bde_svgd_gather_seg": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, _P]),
+    "bde_swag_update": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int, c_int64, _P]),
+    "bde_swag_sample": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64, c_int, c_int64,
+                                _P]),
+    "bde_swag_sample_batched": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_int64, c_uint64, c_uint64, _P, c_int64,
+                                        c_int, c_int64, c_int, c_int64, c_int, c_int64, _P]),
+    "bde_swag_copy_row": (c_int, [_P, c_int, c_int64, _P, c_int, c_int64, c_int64, _P]),
     "bde_philox_normal": (c_int, [c_uint64, c_uint64, _P, c_int, _P, c_int64, _P]),
     "bde_philox_bits": (c_int, [c_uint64, c_uint64, c_uint32, c_uint64, _P, c_int64, _P]),
     "bde_gauss_draw_fwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, c_int64, _P]),

@@ -29,23 +29,45 @@ def _default_ops():
 
 
 class FlatLayout:
-    """Offsets of a list of parameters inside one flat fp32 row."""
+    """Offsets of a list of parameters inside one flat fp32 row.  ``align`` (in floats) pads every tensor's offset up to
+    a multiple of it: with ``align=4`` each tensor starts on a 16-byte boundary of the row, so a kernel can read the
+    tensor's elements EITHER from the row OR from any other 16-byte-aligned buffer (the gradient tensor autograd
+    produced) with the same float4 accesses.  The padding columns belong to no parameter and stay zero."""
 
-    def __init__(self, params: Sequence[torch.Tensor]):
+    def __init__(self, params: Sequence[torch.Tensor], align: int = 1):
         self.shapes = [tuple(p.shape) for p in params]
         self.numels = [p.numel() for p in params]
         self.offsets = []
         off = 0
         for n in self.numels:
+            off = (off + align - 1) // align * align
             self.offsets.append(off)
             off += n
-        self.d = off
+        off = (off + align - 1) // align * align
+        self.d = off                                   # columns in use, padding included
+        self.n_valid = sum(self.numels)                # columns that belong to a parameter
+        self.padded = self.d != self.n_valid
+        self._valid_index = None
         # >= ROW_HEADER spare floats per row, rows 256-byte aligned
         self.ld = pad4(self.d + ROW_HEADER)
         from . import _host
         native = _host.load()
         self._native = native.Layout(self.offsets, self.numels, [list(s) for s in self.shapes]) \
             if native is not None and hasattr(native, "Layout") else None
+
+    def valid_index(self, device) -> torch.Tensor:
+        """Column indices of the parameters' elements, in parameter order (the padding skipped)."""
+        if self._valid_index is None or self._valid_index.device != torch.device(device):
+            idx = torch.cat([torch.arange(o, o + n) for o, n in zip(self.offsets, self.numels)]) if self.numels \
+                else torch.zeros(0, dtype=torch.long)
+            self._valid_index = idx.to(device)
+        return self._valid_index
+
+    def compact(self, rows: torch.Tensor) -> torch.Tensor:
+        """``rows [..., >= d]`` -> the parameters' elements only ``[..., n_valid]`` (a view when nothing is padded)."""
+        if not self.padded:
+            return rows[..., :self.d]
+        return rows.index_select(-1, self.valid_index(rows.device))
 
     def views(self, row: torch.Tensor) -> List[torch.Tensor]:
         """Per-parameter views into a flat row (no copies)."""
@@ -136,6 +158,43 @@ def adopt_grads(params: Sequence[torch.nn.Parameter], views: Sequence[torch.Tens
         else:
             torch._foreach_copy_(dst, src)
     repoint(params, None, views)
+
+
+def collect_grads(params: Sequence[torch.nn.Parameter], views: Sequence[torch.Tensor], table: torch.Tensor, j: int,
+                  m: int) -> List[torch.Tensor]:
+    """``_store_grads`` (``svgd.py:129-133``) without the clones: record WHERE each parameter's gradient lives.
+    ``table[i * m + j]`` (host int64; i = parameter, j = particle) receives the address of the gradient tensor autograd
+    produced when the update kernels can read it in place (fp32, contiguous, 16-byte aligned, on the views' device);
+    otherwise the gradient is copied into -- a missing one zeroes -- its view of the flat gradient row and the view's
+    address is recorded.  Returns the tensors recorded by reference (keep them alive until the update is enqueued)."""
+    from . import _host
+    native = _host.load()
+    if native is not None and hasattr(native, "collect_grads"):
+        return native.collect_grads(params, views, table, int(j), int(m))
+    keep, src, dst, missing = [], [], [], []
+    addrs = []
+    for p, v in zip(params, views):
+        g = p.grad
+        addr = v.data_ptr()
+        if g is None:
+            missing.append(v)
+        elif g.data_ptr() == v.data_ptr():
+            pass
+        elif g.dtype == torch.float32 and g.layout == torch.strided and g.is_contiguous() and g.device == v.device \
+                and g.numel() == v.numel() and g.data_ptr() % 16 == 0:
+            addr = g.data_ptr()
+            keep.append(g)
+        else:
+            src.append(g)
+            dst.append(v)
+        addrs.append(addr)
+    table.view(-1, m)[:len(addrs), j] = torch.tensor(addrs, dtype=torch.int64)
+    with torch.no_grad():
+        if missing:
+            torch._foreach_zero_(missing)
+        if src:
+            torch._foreach_copy_(dst, src)
+    return keep
 
 
 class BayesianOptimizer(Optimizer):

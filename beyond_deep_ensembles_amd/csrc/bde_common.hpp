@@ -57,6 +57,24 @@ __device__ __forceinline__ f32x4 ld4_nt(const float* __restrict__ p) {
   return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
 }
 
+// ---- rows stored in pieces ------------------------------------------------
+// A "row" of D floats is either contiguous (log2_piece = 0) or cut into pieces of 2^log2_piece floats with piece c at
+// offset c * piece_stride from the row's first piece: the SWAG statistics keep their K + 2 rows INTERLEAVED that way
+// ([piece][row][2^log2_piece floats]: one contiguous region per piece instead of K + 2 streams a row length apart).
+struct RowPieces {
+  int log2_piece;          // 0: contiguous row
+  int64_t piece_stride;    // floats from one piece of a row to its next piece
+};
+// Offset (in floats) of element e of such a row; pieces are multiples of 4 floats, so a float4 never straddles two.
+__device__ __forceinline__ int64_t piece_off(int64_t e, RowPieces L) {
+  if (L.log2_piece == 0) return e;
+  return (e >> L.log2_piece) * L.piece_stride + (e & ((int64_t{1} << L.log2_piece) - 1));
+}
+static inline bool pieces_ok(int log2_piece, int64_t piece_stride) {
+  return log2_piece == 0 || (log2_piece >= 7 && log2_piece <= 30 && piece_stride >= (int64_t{1} << log2_piece) &&
+                             (piece_stride & 3) == 0);
+}
+
 // ---- reductions ---------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

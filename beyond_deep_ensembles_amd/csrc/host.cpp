@@ -63,6 +63,46 @@ void adopt_grads(const std::vector<at::Tensor>& params, const std::vector<at::Te
   }
 }
 
+// _store_grads (svgd.py:129-133) WITHOUT the clones: after a backward pass, record WHERE each parameter's gradient
+// lives instead of copying it.  table[i * M + j] (a host int64 tensor, pinned when on a GPU box; i = parameter,
+// j = particle) receives the address of the gradient tensor autograd produced when the update kernels can read it in
+// place (fp32, contiguous, 16-byte aligned, on the views' device); otherwise the gradient is copied into (a missing one
+// zeroes) its view of the flat gradient row and the view's address is recorded.  Returns the tensors recorded by
+// reference: the caller keeps them alive until the update kernel has been enqueued.
+std::vector<at::Tensor> collect_grads(const std::vector<at::Tensor>& params, const std::vector<at::Tensor>& views,
+                                      at::Tensor table, int64_t j, int64_t M) {
+  const size_t n = params.size();
+  TORCH_CHECK(views.size() == n, "collect_grads: ", n, " parameters but ", views.size(), " views");
+  TORCH_CHECK(table.scalar_type() == at::kLong && table.is_contiguous() && !table.is_cuda() &&
+                  table.numel() >= static_cast<int64_t>(n) * M && j >= 0 && j < M,
+              "collect_grads: table must be a contiguous host int64 tensor with n_tensors * M entries");
+  int64_t* t = table.data_ptr<int64_t>();
+  std::vector<at::Tensor> keep, src, dst, missing;
+  keep.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
+    const at::Tensor& g = params[i].grad();
+    const at::Tensor& v = views[i];
+    int64_t addr = reinterpret_cast<int64_t>(v.data_ptr());
+    if (!g.defined()) {
+      missing.push_back(v);
+    } else if (g.data_ptr() == v.data_ptr()) {
+      // accumulated in place: already where it belongs
+    } else if (g.scalar_type() == at::kFloat && g.layout() == at::kStrided && g.is_contiguous() && g.device() == v.device() &&
+               g.numel() == v.numel() && (reinterpret_cast<uintptr_t>(g.data_ptr()) & 15u) == 0) {
+      addr = reinterpret_cast<int64_t>(g.data_ptr());
+      keep.push_back(g);
+    } else {
+      src.push_back(g);
+      dst.push_back(v);
+    }
+    t[static_cast<int64_t>(i) * M + j] = addr;
+  }
+  at::NoGradGuard no_grad;
+  if (!missing.empty()) at::_foreach_zero_(missing);
+  if (!src.empty()) at::_foreach_copy_(dst, src);
+  return keep;
+}
+
 void clear_grads(const std::vector<at::Tensor>& params) {
   for (const at::Tensor& t : params) {
     at::Tensor p = t;
@@ -100,6 +140,70 @@ class Layout {
   std::vector<std::vector<int64_t>> shapes_;
 };
 
+// The per-particle loops of SVGDOptimizer.step as ONE object that owns its tensor lists (the Python lists are converted
+// once, not on every call -- at ResNet-50's 161 tensors the conversions were a third of the step's host time):
+//   begin(i)  _use_particle(i) (svgd.py:120-127) + zero_grad(set_to_none) (svgd.py:70): param.data = particle i's view
+//   end(i)    _store_grads (svgd.py:129-133) without the clones: collect_grads semantics; the gradients are then
+//             detached from the parameters (param.grad = None), so the next backward hands over fresh tensors again
+//   release() the gradient tensors taken by reference go back to the allocator (after the update was enqueued)
+//   set_grads(i) / use(i): the hand-over of -phi rows to the base optimizer (svgd.py:92-96)
+class ParticleSet {
+ public:
+  ParticleSet(std::vector<at::Tensor> params, std::vector<std::vector<at::Tensor>> pviews,
+              std::vector<std::vector<at::Tensor>> gviews)
+      : params_(std::move(params)), pviews_(std::move(pviews)), gviews_(std::move(gviews)) {
+    for (const auto& v : pviews_) TORCH_CHECK(v.empty() || v.size() == params_.size(), "ParticleSet: ragged particle views");
+    for (const auto& v : gviews_) TORCH_CHECK(v.empty() || v.size() == params_.size(), "ParticleSet: ragged gradient views");
+    keep_.resize(pviews_.size());
+  }
+
+  void use(int64_t i) {
+    const auto& views = views_of(pviews_, i, "particle");
+    for (size_t k = 0; k < params_.size(); ++k) params_[k].set_data(views[k]);
+  }
+
+  void begin(int64_t i) {
+    const auto& views = views_of(pviews_, i, "particle");
+    for (size_t k = 0; k < params_.size(); ++k) {
+      at::Tensor& p = params_[k];
+      p.set_data(views[k]);
+      if (p.grad().defined()) p.mutable_grad() = at::Tensor();
+    }
+  }
+
+  void set_grads(int64_t i) {
+    const auto& pv = views_of(pviews_, i, "particle");
+    const auto& gv = views_of(gviews_, i, "gradient");
+    for (size_t k = 0; k < params_.size(); ++k) {
+      params_[k].set_data(pv[k]);
+      params_[k].mutable_grad() = gv[k];
+    }
+  }
+
+  int64_t end(int64_t i, at::Tensor table, int64_t row, int64_t M) {
+    const auto& views = views_of(gviews_, i, "gradient");
+    TORCH_CHECK(row >= 0 && row < static_cast<int64_t>(keep_.size()), "ParticleSet.end: row out of range");
+    keep_[row] = collect_grads(params_, views, std::move(table), row, M);
+    for (at::Tensor& p : params_)
+      if (p.grad().defined()) p.mutable_grad() = at::Tensor();
+    return static_cast<int64_t>(keep_[row].size());
+  }
+
+  void release() {
+    for (auto& k : keep_) k.clear();
+  }
+
+ private:
+  static const std::vector<at::Tensor>& views_of(const std::vector<std::vector<at::Tensor>>& lists, int64_t i, const char* what) {
+    TORCH_CHECK(i >= 0 && i < static_cast<int64_t>(lists.size()) && !lists[i].empty(), "ParticleSet: no ", what,
+                " views for particle ", i);
+    return lists[i];
+  }
+  std::vector<at::Tensor> params_;
+  std::vector<std::vector<at::Tensor>> pviews_, gviews_;
+  std::vector<std::vector<at::Tensor>> keep_;
+};
+
 }  // namespace
 
 void bind_autograd_nodes(py::module_& m);   // host_autograd.cpp: the Bayesian layers' autograd nodes
@@ -110,9 +214,18 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def(py::init<std::vector<int64_t>, std::vector<int64_t>, std::vector<std::vector<int64_t>>>())
       .def("views", &Layout::views, "per-parameter views of a flat row")
       .def("point_data", &Layout::point_data, "param.data = its view of the row, for every parameter");
+  py::class_<ParticleSet>(m, "ParticleSet")
+      .def(py::init<std::vector<at::Tensor>, std::vector<std::vector<at::Tensor>>, std::vector<std::vector<at::Tensor>>>())
+      .def("use", &ParticleSet::use)
+      .def("begin", &ParticleSet::begin)
+      .def("set_grads", &ParticleSet::set_grads)
+      .def("end", &ParticleSet::end)
+      .def("release", &ParticleSet::release);
   m.def("repoint", &repoint, "param.data / param.grad = views, for whole parameter lists", py::arg("params"),
         py::arg("datas"), py::arg("grads"));
   m.def("clear_grads", &clear_grads, "param.grad = None for a whole parameter list");
+  m.def("collect_grads", &collect_grads, "record where the gradients live (no copy); returns the tensors taken by reference",
+        py::arg("params"), py::arg("views"), py::arg("table"), py::arg("j"), py::arg("M"));
   m.def("adopt_grads", &adopt_grads, "gradients -> flat views (multi-tensor copy/add), views become .grad", py::arg("params"),
         py::arg("views"), py::arg("add"));
 }

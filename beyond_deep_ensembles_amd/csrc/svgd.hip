@@ -241,6 +241,64 @@ __global__ __launch_bounds__(kBlock) void svgd_combine_kernel(const float* __res
   }
 }
 
+// The same combine with the gradients read from the tensors autograd produced (svgd_shared.hpp: segments / chunks).
+// One chunk = <= 256 float4 columns of one parameter tensor = one column per thread; chunk descriptor and the M
+// gradient pointers of its segment are wave-uniform (scalar loads).
+template <int M>
+__global__ __launch_bounds__(kBlock) void svgd_combine_seg_kernel(const float* __restrict__ P,
+                                                                 const float* const* __restrict__ seg_ptrs,
+                                                                 const SegChunk* __restrict__ chunks, int n_chunks,
+                                                                 float* out, int64_t ld,
+                                                                 const float* __restrict__ cgT,
+                                                                 const float* __restrict__ cpT) {
+  for (int q = blockIdx.x; q < n_chunks; q += gridDim.x) {
+    const SegChunk ch = chunks[q];
+    const int valid = ch.nflt - 4 * static_cast<int>(threadIdx.x);
+    if (valid <= 0) continue;
+    const float* const* gp = seg_ptrs + static_cast<int64_t>(ch.seg) * M;
+    const int64_t i4 = ch.c4 + threadIdx.x, l4 = ch.loc4 + threadIdx.x;
+    f32x4 acc[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const f32x4 p = ld4_nt(P + j * ld + 4 * i4);
+      const f32x4 g = seg_load(gp[j] + 4 * l4, valid);
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        const float a = cgT[j * M + i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_fmaf(a, g[c], acc[i][c]);
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        const float b = cpT[j * M + i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c] = __builtin_fmaf(b, p[c], acc[i][c]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) __builtin_nontemporal_store(acc[i], reinterpret_cast<f32x4*>(out + i * ld + 4 * i4));
+  }
+}
+
+// Pack segmented gradients into flat rows: G[row, chunk columns] = the chunk of that row's gradient tensor.
+__global__ __launch_bounds__(kBlock) void svgd_gather_seg_kernel(const float* const* __restrict__ seg_ptrs,
+                                                                const SegChunk* __restrict__ chunks, int n_chunks,
+                                                                float* G, int M, int row0, int n_rows, int64_t ld) {
+  for (int q = blockIdx.x; q < n_chunks; q += gridDim.x) {
+    const SegChunk ch = chunks[q];
+    const int valid = ch.nflt - 4 * static_cast<int>(threadIdx.x);
+    const float* const* gp = seg_ptrs + static_cast<int64_t>(ch.seg) * M;
+    for (int j = row0; j < row0 + n_rows; ++j) {
+      const float* src = gp[j] + 4 * ch.loc4;
+      float* dst = G + j * ld + 4 * ch.c4;
+      if (src == dst || valid <= 0) continue;             // the first test is wave-uniform: the piece already lives in G
+      st4_nt(dst + 4 * threadIdx.x, seg_load(src + 4 * threadIdx.x, valid));
+    }
+  }
+}
+
 template <int M>
 static int launch_combine(const float* P, const float* G, float* out, int64_t D, int64_t ld, int64_t ldg,
                           const float* kstat, hipStream_t s) {
@@ -566,6 +624,45 @@ extern "C" int bde_svgd_combine(const float* P, const float* G, float* out, int 
 #undef BDE_CASE
   }
   return BDE_ERR_INVALID;
+}
+
+extern "C" int bde_svgd_combine_seg(const float* P, const void* const* seg_ptrs, const bde_seg_chunk* chunks,
+                                    int64_t n_chunks, float* out, int M, int64_t D, int64_t ld, const float* kstat,
+                                    void* stream) {
+  if (!svgd_args_ok(P, M, D, ld) || M > BDE_FAST_PARTICLES || !seg_args_ok(seg_ptrs, chunks, n_chunks, D) || !out ||
+      !kstat || !aligned16(out) || out == P)
+    return BDE_ERR_INVALID;
+  const int n = M * M;
+  const float* cg = kstat + 2 * n + M + 4;
+  const float* cp = cg + n;
+  const int grid = static_cast<int>(std::min<int64_t>(n_chunks, kMaxStreamBlocks));
+  const float* const* sp = reinterpret_cast<const float* const*>(seg_ptrs);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (M) {
+#define BDE_CASE(m)                                                                                                    \
+  case m:                                                                                                              \
+    hipLaunchKernelGGL((svgd_combine_seg_kernel<m>), dim3(grid), dim3(kBlock), 0, s, P, sp, chunks,                      \
+                       static_cast<int>(n_chunks), out, ld, cg, cp);                                                    \
+    break;
+    BDE_CASE(1) BDE_CASE(2) BDE_CASE(3) BDE_CASE(4) BDE_CASE(5) BDE_CASE(6) BDE_CASE(7) BDE_CASE(8)
+    BDE_CASE(9) BDE_CASE(10) BDE_CASE(11) BDE_CASE(12) BDE_CASE(13) BDE_CASE(14) BDE_CASE(15) BDE_CASE(16)
+#undef BDE_CASE
+    default:
+      return BDE_ERR_INVALID;
+  }
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_svgd_gather_seg(const void* const* seg_ptrs, const bde_seg_chunk* chunks, int64_t n_chunks, float* G,
+                                   int M, int row0, int n_rows, int64_t ld, void* stream) {
+  if (!seg_ptrs || !chunks || n_chunks < 1 || n_chunks > (int64_t{1} << 30) || !G || !aligned16(G) || M < 1 ||
+      M > BDE_MAX_PARTICLES || row0 < 0 || n_rows < 1 || row0 + n_rows > M || (ld & 3))
+    return BDE_ERR_INVALID;
+  const int grid = static_cast<int>(std::min<int64_t>(n_chunks, kMaxStreamBlocks));
+  hipLaunchKernelGGL(svgd_gather_seg_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float* const*>(seg_ptrs), chunks, static_cast<int>(n_chunks), G, M, row0,
+                     n_rows, ld);
+  return to_err(hipGetLastError());
 }
 
 extern "C" int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld, float l2_reg,

@@ -30,12 +30,17 @@ namespace bde {
 
 constexpr int kFusedMaxBlocks = kGramMaxBlocks;   // the Gram partials go into the same ws slots
 
-template <int M, int OPT /* 0 sgd, 1 adam */, bool GRAM>
+// SEG: the gradients come from the tensors autograd produced (svgd_shared.hpp: `G` is then unused, `seg_ptrs` /
+// `chunks` describe them, and the loop runs over chunks of <= 256 float4 columns of one parameter tensor instead of
+// over all float4 columns of the row; D % 4 == 0 there, so there is no scalar tail).
+template <int M, int OPT /* 0 sgd, 1 adam */, bool GRAM, bool SEG>
 __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ P, const float* __restrict__ G,
                                                            float* __restrict__ s0, float* __restrict__ s1, int64_t D,
                                                            int64_t ld, int64_t ldg, const float* __restrict__ cgT,
                                                            const float* __restrict__ cpT, SgdParams sk, AdamParams ak,
-                                                           AdamSteps st, float* __restrict__ ws_next) {
+                                                           AdamSteps st, float* __restrict__ ws_next,
+                                                           const float* const* __restrict__ seg_ptrs,
+                                                           const SegChunk* __restrict__ chunks, int n_chunks) {
   constexpr int NP = M * (M + 1) / 2;
   const int64_t n4 = D >> 2;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -43,14 +48,29 @@ __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ 
 #pragma unroll
   for (int k = 0; k < (GRAM ? NP : 1); ++k) gacc[k] = 0.f;
 
-  for (int64_t i4 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i4 < n4; i4 += stride) {
+  // flat G: thread-strided walk over the float4 columns; SEG: workgroup-strided walk over the chunks
+  const int64_t n_iter = SEG ? static_cast<int64_t>(n_chunks) : n4;
+  const int64_t it0 = SEG ? static_cast<int64_t>(blockIdx.x) : static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t it_step = SEG ? static_cast<int64_t>(gridDim.x) : stride;
+  for (int64_t it = it0; it < n_iter; it += it_step) {
+    int64_t i4 = it, l4 = 0;
+    int valid = 4;
+    const float* const* gp = nullptr;
+    if (SEG) {
+      const SegChunk ch = chunks[it];
+      valid = ch.nflt - 4 * static_cast<int>(threadIdx.x);
+      if (valid <= 0) continue;
+      gp = seg_ptrs + static_cast<int64_t>(ch.seg) * M;
+      i4 = ch.c4 + threadIdx.x;
+      l4 = ch.loc4 + threadIdx.x;
+    }
     f32x4 p[M], u[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       p[j] = BDE_FUSED_PLD(P + j * ld + 4 * i4);
-      const f32x4 g = ld4_nt(G + j * ldg + 4 * i4);
+      const f32x4 g = SEG ? seg_load(gp[j] + 4 * l4, valid) : ld4_nt(G + j * ldg + 4 * i4);
 #pragma unroll
       for (int i = 0; i < M; ++i) {
         const float a = cgT[j * M + i], b = cpT[j * M + i];
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ 
   }
 
   // the D % 4 tail coordinates (block 0, one thread per coordinate)
-  if (blockIdx.x == 0) {
+  if (!SEG && blockIdx.x == 0) {
     const int64_t e = (n4 << 2) + threadIdx.x;
     if (e < D) {
       float p[M], u[M];
@@ -186,34 +206,46 @@ __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ 
   }
 }
 
+struct SegArgs {                     // segmented gradients (null seg_ptrs: flat G)
+  const float* const* seg_ptrs = nullptr;
+  const SegChunk* chunks = nullptr;
+  int n_chunks = 0;
+};
+
 template <int M, int OPT>
 static int launch_fused(float* P, const float* G, float* s0, float* s1, int64_t D, int64_t ld, int64_t ldg,
-                        const float* kstat,
-                        const SgdParams& sk, const AdamParams& ak, const AdamSteps& st, float* ws_next, hipStream_t s) {
+                        const float* kstat, const SgdParams& sk, const AdamParams& ak, const AdamSteps& st,
+                        float* ws_next, const SegArgs& sg, hipStream_t s) {
   const int n = M * M;
   const float* cg = kstat + 2 * n + M + 4;
   const float* cp = cg + n;
-  const int grid = stream_grid((D + 3) / 4, kBlock, kFusedMaxBlocks);
+  const bool seg = sg.seg_ptrs != nullptr;
+  const int grid = seg ? static_cast<int>(std::min<int64_t>(sg.n_chunks, kFusedMaxBlocks))
+                       : stream_grid((D + 3) / 4, kBlock, kFusedMaxBlocks);
+#define BDE_FUSED_LAUNCH(GRAM, SEG, WS)                                                                                \
+  hipLaunchKernelGGL((svgd_fused_kernel<M, OPT, GRAM, SEG>), dim3(grid), dim3(kBlock), 0, s, P, G, s0, s1, D, ld, ldg, \
+                     cg, cp, sk, ak, st, WS, sg.seg_ptrs, sg.chunks, sg.n_chunks)
   if constexpr (M <= 8) {
     if (ws_next) {
-      hipLaunchKernelGGL((svgd_fused_kernel<M, OPT, true>), dim3(grid), dim3(kBlock), 0, s, P, G, s0, s1, D, ld, ldg, cg,
-                         cp, sk, ak, st, ws_next);
+      if (seg) BDE_FUSED_LAUNCH(true, true, ws_next);
+      else BDE_FUSED_LAUNCH(true, false, ws_next);
       return to_err(hipGetLastError());
     }
   }
-  hipLaunchKernelGGL((svgd_fused_kernel<M, OPT, false>), dim3(grid), dim3(kBlock), 0, s, P, G, s0, s1, D, ld, ldg, cg, cp,
-                     sk, ak, st, static_cast<float*>(nullptr));
+  if (seg) BDE_FUSED_LAUNCH(false, true, static_cast<float*>(nullptr));
+  else BDE_FUSED_LAUNCH(false, false, static_cast<float*>(nullptr));
+#undef BDE_FUSED_LAUNCH
   return to_err(hipGetLastError());
 }
 
 template <int OPT>
 static int dispatch_fused(int M, float* P, const float* G, float* s0, float* s1, int64_t D, int64_t ld, int64_t ldg,
                           const float* kstat, const SgdParams& sk, const AdamParams& ak, const AdamSteps& st,
-                          float* ws_next, hipStream_t s) {
+                          float* ws_next, const SegArgs& sg, hipStream_t s) {
   switch (M) {
 #define BDE_CASE(m) \
   case m:           \
-    return launch_fused<m, OPT>(P, G, s0, s1, D, ld, ldg, kstat, sk, ak, st, ws_next, s);
+    return launch_fused<m, OPT>(P, G, s0, s1, D, ld, ldg, kstat, sk, ak, st, ws_next, sg, s);
     BDE_CASE(1) BDE_CASE(2) BDE_CASE(3) BDE_CASE(4) BDE_CASE(5) BDE_CASE(6) BDE_CASE(7) BDE_CASE(8)
     BDE_CASE(9) BDE_CASE(10) BDE_CASE(11) BDE_CASE(12) BDE_CASE(13) BDE_CASE(14) BDE_CASE(15) BDE_CASE(16)
 #undef BDE_CASE
@@ -239,7 +271,22 @@ extern "C" int bde_svgd_fused_sgd(float* P, const float* G, float* momentum_buf,
   const SgdParams sk{static_cast<float>(lr), static_cast<float>(momentum), static_cast<float>(1.0 - dampening),
                      static_cast<float>(weight_decay), nesterov, first};
   return dispatch_fused<0>(M, P, G, momentum_buf, nullptr, D, ld, ldg, kstat, sk, AdamParams{}, AdamSteps{},
-                           static_cast<float*>(ws_next), static_cast<hipStream_t>(stream));
+                           static_cast<float*>(ws_next), SegArgs{}, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int bde_svgd_fused_sgd_seg(float* P, const void* const* seg_ptrs, const bde_seg_chunk* chunks,
+                                      int64_t n_chunks, float* momentum_buf, int M, int64_t D, int64_t ld,
+                                      const float* kstat, double lr, double momentum, double dampening,
+                                      double weight_decay, int nesterov, int first, void* ws_next, void* stream) {
+  if (!svgd_args_ok(P, M, D, ld) || M > BDE_FAST_PARTICLES || !seg_args_ok(seg_ptrs, chunks, n_chunks, D) || !kstat ||
+      (momentum != 0.0 && !momentum_buf))
+    return BDE_ERR_INVALID;
+  if (ws_next && (M > 8 || !aligned16(ws_next))) return BDE_ERR_INVALID;
+  const SgdParams sk{static_cast<float>(lr), static_cast<float>(momentum), static_cast<float>(1.0 - dampening),
+                     static_cast<float>(weight_decay), nesterov, first};
+  const SegArgs sg{reinterpret_cast<const float* const*>(seg_ptrs), chunks, static_cast<int>(n_chunks)};
+  return dispatch_fused<0>(M, P, nullptr, momentum_buf, nullptr, D, ld, ld, kstat, sk, AdamParams{}, AdamSteps{},
+                           static_cast<float*>(ws_next), sg, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D,
@@ -254,7 +301,23 @@ extern "C" int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, flo
   const AdamParams ak{static_cast<float>(beta1), static_cast<float>(beta2), static_cast<float>(1.0 - beta1),
                       static_cast<float>(1.0 - beta2), static_cast<float>(eps), static_cast<float>(weight_decay)};
   return dispatch_fused<1>(M, P, G, exp_avg, exp_avg_sq, D, ld, ldg, kstat, SgdParams{}, ak,
-                           make_adam_steps(lr, beta1, beta2, step0), static_cast<float*>(ws_next),
+                           make_adam_steps(lr, beta1, beta2, step0), static_cast<float*>(ws_next), SegArgs{},
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int bde_svgd_fused_adam_seg(float* P, const void* const* seg_ptrs, const bde_seg_chunk* chunks,
+                                       int64_t n_chunks, float* exp_avg, float* exp_avg_sq, int M, int64_t D, int64_t ld,
+                                       const float* kstat, double lr, double beta1, double beta2, double eps,
+                                       double weight_decay, int64_t step0, void* ws_next, void* stream) {
+  if (!svgd_args_ok(P, M, D, ld) || M > BDE_FAST_PARTICLES || !seg_args_ok(seg_ptrs, chunks, n_chunks, D) || !kstat ||
+      !exp_avg || !exp_avg_sq || step0 < 0)
+    return BDE_ERR_INVALID;
+  if (ws_next && (M > 8 || !aligned16(ws_next))) return BDE_ERR_INVALID;
+  const AdamParams ak{static_cast<float>(beta1), static_cast<float>(beta2), static_cast<float>(1.0 - beta1),
+                      static_cast<float>(1.0 - beta2), static_cast<float>(eps), static_cast<float>(weight_decay)};
+  const SegArgs sg{reinterpret_cast<const float* const*>(seg_ptrs), chunks, static_cast<int>(n_chunks)};
+  return dispatch_fused<1>(M, P, nullptr, exp_avg, exp_avg_sq, D, ld, ld, kstat, SgdParams{}, ak,
+                           make_adam_steps(lr, beta1, beta2, step0), static_cast<float*>(ws_next), sg,
                            static_cast<hipStream_t>(stream));
 }
 
@@ -262,5 +325,5 @@ extern "C" int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, flo
 // first launch of one of its kernels).  Internal to the library (not exported).
 extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_svgd_fused(void) {
   hipFuncAttributes attr;
-  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::svgd_fused_kernel<8, 0, false>)));
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::svgd_fused_kernel<8, 0, false, false>)));
 }

@@ -33,6 +33,31 @@ static inline AdamSteps make_adam_steps(double lr, double beta1, double beta2, i
   return st;
 }
 
+// ---- gradients handed over as the tensors autograd produced (no copy into the flat gradient rows) ----
+// The flat row of a particle is the concatenation of its parameter tensors, each starting on a float4 boundary
+// (FlatLayout(align=4)).  "Segment" s = tensor s: columns [col0_s, col0_s + numel_s).  The gradient of particle j for
+// segment s lives wherever autograd put it: seg_ptrs[s * M + j] (16-byte aligned; the caller substitutes the address
+// of the segment inside a flat gradient row when a gradient is missing, unaligned or not contiguous, after copying /
+// zeroing there).  The kernels walk a STATIC list of chunks -- at most 256 float4 columns of ONE segment, i.e. one
+// float4 column per thread of a workgroup, the same 4 KB-per-row pieces the flat kernels touch per iteration -- so
+// everything about a chunk (segment, position) is wave-uniform and comes through scalar loads.
+using SegChunk = bde_seg_chunk;
+static_assert(sizeof(SegChunk) == 32, "bde_seg_chunk is 32 bytes");
+
+// The gradient float4 of particle row `gj` (already offset to this thread's column) with `valid` floats in bounds.
+__device__ __forceinline__ f32x4 seg_load(const float* gj, int valid) {
+  if (valid >= 4) return ld4_nt(gj);
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    if (c < valid) g[c] = gj[c];
+  return g;
+}
+
+static inline bool seg_args_ok(const void* const* seg_ptrs, const bde_seg_chunk* chunks, int64_t n_chunks, int64_t D) {
+  return seg_ptrs && chunks && n_chunks >= 1 && n_chunks <= (int64_t{1} << 30) && (D & 3) == 0;
+}
+
 // ---- generic path (16 < M <= 64): particles in groups of 8, one 16-row Gram tile per pair of groups ----
 static inline int svgd_groups(int M) { return (M + 7) / 8; }
 static inline int svgd_pairs(int M) { const int g = svgd_groups(M); return g * (g + 1) / 2; }

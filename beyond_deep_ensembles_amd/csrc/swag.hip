@@ -21,29 +21,45 @@ namespace bde {
 __global__ __launch_bounds__(kBlock) void swag_update_kernel(const float* __restrict__ theta,
                                                             float* __restrict__ mean, float* __restrict__ sq,
                                                             float* __restrict__ dev_row, float n, float np1,
-                                                            int64_t D) {
+                                                            int64_t D, RowPieces L) {
   const int64_t n4 = D >> 2;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t o = piece_off(4 * i, L);
     const f32x4 t = ld4_nt(theta + 4 * i);
-    f32x4 m = ld4(mean + 4 * i);
-    f32x4 s = ld4(sq + 4 * i);
+    f32x4 m = ld4(mean + o);
+    f32x4 s = ld4(sq + o);
     m = (n * m + t) / np1;            // swag.py:101
     s = (n * s + t * t) / np1;        // swag.py:102
-    st4(mean + 4 * i, m);
-    st4(sq + 4 * i, s);
-    st4_nt(dev_row + 4 * i, t - m);   // swag.py:104 (deviation from the UPDATED mean)
+    st4(mean + o, m);
+    st4(sq + o, s);
+    st4_nt(dev_row + o, t - m);       // swag.py:104 (deviation from the UPDATED mean)
   }
   if (blockIdx.x == 0) {
     const int64_t e = (n4 << 2) + threadIdx.x;
     if (e < D) {
+      const int64_t o = piece_off(e, L);
       const float t = theta[e];
-      const float m = (n * mean[e] + t) / np1;
-      const float s = (n * sq[e] + t * t) / np1;
-      mean[e] = m;
-      sq[e] = s;
-      dev_row[e] = t - m;
+      const float m = (n * mean[o] + t) / np1;
+      const float s = (n * sq[o] + t * t) / np1;
+      mean[o] = m;
+      sq[o] = s;
+      dev_row[o] = t - m;
     }
+  }
+}
+
+// One row re-laid out: dst (pieces Ld) = src (pieces Ls); either side may be contiguous.  The consumer of a batched
+// sample (its pieces -> the contiguous vector the parameters view), and the accessors / checkpoints.
+__global__ __launch_bounds__(kBlock) void swag_copy_row_kernel(const float* __restrict__ src, RowPieces Ls,
+                                                              float* __restrict__ dst, RowPieces Ld, int64_t D) {
+  const int64_t n4 = D >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride)
+    st4(dst + piece_off(4 * i, Ld), ld4_nt(src + piece_off(4 * i, Ls)));
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < D) dst[piece_off(e, Ld)] = src[piece_off(e, Ls)];
   }
 }
 
@@ -70,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
                                                             int head, const float* __restrict__ eps_w,
                                                             const float* __restrict__ eps_d, uint64_t seed,
                                                             uint64_t stream_id, float* __restrict__ out,
-                                                            int64_t D) {
+                                                            int64_t D, RowPieces L) {
   __shared__ float w[BDE_MAX_RANK];   // noise weight of each PHYSICAL ring row
   const float denom = __builtin_sqrtf(2.0f * static_cast<float>(K - 1));   // swag.py:113
   for (int r = threadIdx.x; r < K; r += blockDim.x) {
@@ -98,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
       for (int u = 0; u < U; ++u) {
         const int64_t c = i + u * stride;
         if (c < n4) {
-          const f32x4 d = ld4_nt(dev + static_cast<int64_t>(r) * ld + 4 * c);
+          const f32x4 d = ld4_nt(dev + static_cast<int64_t>(r) * ld + piece_off(4 * c, L));
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[u][j] = __builtin_fmaf(d[j], wr, acc[u][j]);
         }
@@ -108,8 +124,9 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
     for (int u = 0; u < U; ++u) {
       const int64_t c = i + u * stride;
       if (c < n4) {
-        const f32x4 m = ld4_nt(mean + 4 * c);
-        const f32x4 s = ld4_nt(sq + 4 * c);
+        const int64_t o = piece_off(4 * c, L);
+        const f32x4 m = ld4_nt(mean + o);
+        const f32x4 s = ld4_nt(sq + o);
         const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(c), kDomainDiag) : ld4_nt(eps_d + 4 * c);
         BDE_OUT_ST(out + 4 * c, (m + acc[u]) + diag_std(m, s) * z);
       }
@@ -119,8 +136,9 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
     const int64_t e = (n4 << 2) + threadIdx.x;
     if (e < D) {
       float acc = 0.f;
-      for (int r = 0; r < K; ++r) acc = __builtin_fmaf(dev[static_cast<int64_t>(r) * ld + e], w[r], acc);
-      const float m = mean[e], s = sq[e];
+      const int64_t o = piece_off(e, L);
+      for (int r = 0; r < K; ++r) acc = __builtin_fmaf(dev[static_cast<int64_t>(r) * ld + o], w[r], acc);
+      const float m = mean[o], s = sq[o];
       float z;
       if (RNG) {
         const f32x4 zz = philox_normal4(seed, stream_id, static_cast<uint64_t>(n4), kDomainDiag);
@@ -169,30 +187,42 @@ __global__ __launch_bounds__(kBlock) void philox_bits_kernel(uint64_t seed, uint
 using namespace bde;
 
 extern "C" int bde_swag_update(const float* theta, float* mean, float* sq, float* dev_row, int64_t n, int64_t D,
-                               void* stream) {
-  if (!theta || !mean || !sq || !dev_row || D <= 0 || n < 1) return BDE_ERR_INVALID;
+                               int log2_piece, int64_t piece_stride, void* stream) {
+  if (!theta || !mean || !sq || !dev_row || D <= 0 || n < 1 || !pieces_ok(log2_piece, piece_stride)) return BDE_ERR_INVALID;
   if (!aligned16(theta) || !aligned16(mean) || !aligned16(sq) || !aligned16(dev_row)) return BDE_ERR_INVALID;
   const int grid = stream_grid((D + 3) / 4);
   hipLaunchKernelGGL(swag_update_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), theta, mean, sq,
-                     dev_row, static_cast<float>(n), static_cast<float>(n + 1), D);
+                     dev_row, static_cast<float>(n), static_cast<float>(n + 1), D, RowPieces{log2_piece, piece_stride});
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_swag_copy_row(const float* src, int log2_piece_src, int64_t piece_stride_src, float* dst,
+                                 int log2_piece_dst, int64_t piece_stride_dst, int64_t D, void* stream) {
+  if (!src || !dst || D <= 0 || !aligned16(src) || !aligned16(dst) || !pieces_ok(log2_piece_src, piece_stride_src) ||
+      !pieces_ok(log2_piece_dst, piece_stride_dst))
+    return BDE_ERR_INVALID;
+  hipLaunchKernelGGL(swag_copy_row_kernel, dim3(stream_grid((D + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     src, RowPieces{log2_piece_src, piece_stride_src}, dst, RowPieces{log2_piece_dst, piece_stride_dst}, D);
   return to_err(hipGetLastError());
 }
 
 extern "C" int bde_swag_sample(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
                                const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id, float* out,
-                               int64_t D, void* stream) {
-  if (!mean || !sq || !dev || !out || D <= 0 || K < 1 || K > BDE_MAX_RANK) return BDE_ERR_INVALID;
-  if (head < 0 || head >= K || ld < D || (ld & 3)) return BDE_ERR_INVALID;
+                               int64_t D, int log2_piece, int64_t piece_stride, void* stream) {
+  if (!mean || !sq || !dev || !out || D <= 0 || K < 1 || K > BDE_MAX_RANK || !pieces_ok(log2_piece, piece_stride))
+    return BDE_ERR_INVALID;
+  if (head < 0 || head >= K || (ld & 3) || (log2_piece == 0 ? ld < D : ld < (int64_t{1} << log2_piece))) return BDE_ERR_INVALID;
+  const RowPieces L{log2_piece, piece_stride};
   if (!aligned16(mean) || !aligned16(sq) || !aligned16(dev) || !aligned16(out) || (eps_d && !aligned16(eps_d)))
     return BDE_ERR_INVALID;
   const int grid = stream_grid((D + 3) / 4);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (eps_d)
     hipLaunchKernelGGL(swag_sample_kernel<false>, dim3(grid), dim3(kBlock), 0, s, mean, sq, dev, K, ld, head, eps_w,
-                       eps_d, seed, stream_id, out, D);
+                       eps_d, seed, stream_id, out, D, L);
   else
     hipLaunchKernelGGL(swag_sample_kernel<true>, dim3(grid), dim3(kBlock), 0, s, mean, sq, dev, K, ld, head, eps_w,
-                       eps_d, seed, stream_id, out, D);
+                       eps_d, seed, stream_id, out, D, L);
   return to_err(hipGetLastError());
 }
 

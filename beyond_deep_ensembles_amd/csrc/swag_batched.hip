@@ -32,8 +32,8 @@ constexpr int kBatchCH = 10;   // k-steps (2 ring rows each) whose loads are iss
 template <bool RNG>
 __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
     const float* __restrict__ mean, const float* __restrict__ sq, const float* __restrict__ dev, int K, int64_t ld,
-    int head, const float* __restrict__ eps_w, const float* __restrict__ eps_d, uint64_t seed, uint64_t stream0,
-    float* __restrict__ out, int64_t ld_out, int S, int64_t D) {
+    int head, const float* __restrict__ eps_w, const float* __restrict__ eps_d, int64_t ld_eps, uint64_t seed,
+    uint64_t stream0, float* __restrict__ out, int64_t ld_out, int S, int64_t D, RowPieces L, RowPieces Lo) {
   extern __shared__ __attribute__((aligned(16))) float w[];   // [K + (K & 1)][32]: weight of ring row r for sample s
   const int kpad = K + (K & 1);
   const int ksteps = kpad >> 1;
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave; t < n_tiles; t += waves_total) {
     const int64_t g4 = t * 32 + j;                            // this lane's float4 group
     const bool ok = g4 < n4;
-    const float* col = dev + 4 * g4;
+    // a tile is 128 consecutive parameters and a piece a multiple of that, so a tile lies inside ONE piece
+    const int64_t so = piece_off(4 * g4, L), oo = piece_off(4 * g4, Lo);
+    const float* col = dev + so;
     f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
     // The whole [K, 128] slab of the ring is requested before the first MFMA waits on it: a
     // load -> MFMA -> load chain exposed one HBM latency per k-step (2.7x off the roofline).
@@ -82,8 +84,8 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
       }
     }
     if (ok) {
-      const f32x4 m = ld4(mean + 4 * g4);
-      const f32x4 v = ld4(sq + 4 * g4) - m * m;
+      const f32x4 m = ld4(mean + so);
+      const f32x4 v = ld4(sq + so) - m * m;
       f32x4 sd;
 #pragma unroll
       for (int c = 0; c < 4; ++c) sd[c] = __builtin_sqrtf(0.5f * (fmaxf(v[c], 0.0f) + 1e-6f));   // swag.py:112
@@ -93,9 +95,9 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
         const int s = (reg & 3) + 8 * (reg >> 2) + 4 * half;   // C/D row of the 32x32 tile
         if (s < S) {
           const f32x4 z = RNG ? philox_normal4(seed, stream0 + s, static_cast<uint64_t>(g4), kDomainDiag)
-                              : ld4_nt(eps_d + static_cast<int64_t>(s) * ld_out + 4 * g4);
+                              : ld4_nt(eps_d + static_cast<int64_t>(s) * ld_eps + 4 * g4);
           const f32x4 lr = {acc0[reg], acc1[reg], acc2[reg], acc3[reg]};
-          st4_nt(out + static_cast<int64_t>(s) * ld_out + 4 * g4, (m + lr) + sd * z);
+          st4_nt(out + static_cast<int64_t>(s) * ld_out + oo, (m + lr) + sd * z);
         }
       }
     }
@@ -107,17 +109,19 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
     for (int idx = threadIdx.x; idx < rem * S; idx += blockDim.x) {
       const int s = idx / rem, k = idx % rem;
       const int64_t e = (n4 << 2) + k;
+      const int64_t so = piece_off(e, L);
       float acc = 0.f;
-      for (int r = 0; r < K; ++r) acc = __builtin_fmaf(dev[static_cast<int64_t>(r) * ld + e], w[r * 32 + s], acc);
-      const float m = mean[e];
+      for (int r = 0; r < K; ++r) acc = __builtin_fmaf(dev[static_cast<int64_t>(r) * ld + so], w[r * 32 + s], acc);
+      const float m = mean[so];
       float z;
       if (RNG) {
         const f32x4 zz = philox_normal4(seed, stream0 + s, static_cast<uint64_t>(n4), kDomainDiag);
         z = zz[k];
       } else {
-        z = eps_d[static_cast<int64_t>(s) * ld_out + e];
+        z = eps_d[static_cast<int64_t>(s) * ld_eps + e];
       }
-      out[static_cast<int64_t>(s) * ld_out + e] = (m + acc) + __builtin_sqrtf(0.5f * (fmaxf(sq[e] - m * m, 0.0f) + 1e-6f)) * z;
+      out[static_cast<int64_t>(s) * ld_out + piece_off(e, Lo)] =
+          (m + acc) + __builtin_sqrtf(0.5f * (fmaxf(sq[so] - m * m, 0.0f) + 1e-6f)) * z;
     }
   }
 }
@@ -127,11 +131,17 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
 using namespace bde;
 
 extern "C" int bde_swag_sample_batched(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
-                                       const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id0,
-                                       float* out, int64_t ld_out, int S, int64_t D, void* stream) {
+                                       const float* eps_w, const float* eps_d, int64_t ld_eps, uint64_t seed,
+                                       uint64_t stream_id0, float* out, int64_t ld_out, int S, int64_t D, int log2_piece,
+                                       int64_t piece_stride, int log2_piece_out, int64_t piece_stride_out, void* stream) {
   if (!mean || !sq || !dev || !out || D <= 0 || K < 1 || K > BDE_MAX_RANK || S < 1 || S > BDE_MAX_BATCH)
     return BDE_ERR_INVALID;
-  if (head < 0 || head >= K || ld < D || (ld & 3) || ld_out < D || (ld_out & 3)) return BDE_ERR_INVALID;
+  if (!pieces_ok(log2_piece, piece_stride) || !pieces_ok(log2_piece_out, piece_stride_out)) return BDE_ERR_INVALID;
+  if (head < 0 || head >= K || (ld & 3) || (ld_out & 3) || (log2_piece == 0 ? ld < D : ld < (int64_t{1} << log2_piece)) ||
+      (log2_piece_out == 0 ? ld_out < D : ld_out < (int64_t{1} << log2_piece_out)) ||
+      (eps_d && (ld_eps < D || (ld_eps & 3))))
+    return BDE_ERR_INVALID;
+  const RowPieces L{log2_piece, piece_stride}, Lo{log2_piece_out, piece_stride_out};
   if (!aligned16(mean) || !aligned16(sq) || !aligned16(dev) || !aligned16(out) || (eps_d && !aligned16(eps_d)))
     return BDE_ERR_INVALID;
   const int64_t n_tiles = ((D >> 2) + 31) / 32;
@@ -143,10 +153,10 @@ extern "C" int bde_swag_sample_batched(const float* mean, const float* sq, const
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (eps_d)
     hipLaunchKernelGGL(swag_sample_batched_kernel<false>, dim3(grid), dim3(kBlock), lds, s, mean, sq, dev, K, ld, head,
-                       eps_w, eps_d, seed, stream_id0, out, ld_out, S, D);
+                       eps_w, eps_d, ld_eps, seed, stream_id0, out, ld_out, S, D, L, Lo);
   else
     hipLaunchKernelGGL(swag_sample_batched_kernel<true>, dim3(grid), dim3(kBlock), lds, s, mean, sq, dev, K, ld, head,
-                       eps_w, eps_d, seed, stream_id0, out, ld_out, S, D);
+                       eps_w, eps_d, ld_eps, seed, stream_id0, out, ld_out, S, D, L, Lo);
   return to_err(hipGetLastError());
 }
 

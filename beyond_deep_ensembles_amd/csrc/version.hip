@@ -1,5 +1,5 @@
 #include "bde_common.hpp"
-extern "C" int bde_version(void) { return 300; /* 0.3.0: bounded single-launch SVGD step (launches / abort_flag), bde_init */ }
+extern "C" int bde_version(void) { return 301; /* 0.3.1: segmented gradients (*_seg), SWAG rows stored in pieces, bde_swag_copy_row */ }
 extern "C" const char* bde_arch(void) { return "gfx950"; }
 
 extern "C" {

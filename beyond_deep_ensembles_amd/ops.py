@@ -78,6 +78,88 @@ def pad4(n: int, mult: int = 64) -> int:
     return (n + mult - 1) // mult * mult
 
 
+class RowBlock:
+    """``n_rows`` rows of ``d`` floats stored INTERLEAVED in pieces of ``2 ** log2_piece`` floats: one buffer
+    ``[n_pieces, n_rows, piece]`` (include/bde_hip.h, "Row storage").  ``row(r)`` / ``rows(a, b)`` are the handles the
+    kernels take (views of the rows' first pieces; the distance between two rows inside a piece is ``piece``), and
+    ``pieces = (log2_piece, piece_stride)`` goes with them.  ``gather`` / ``scatter`` move one row to / from a contiguous
+    vector with plain torch indexing (accessors and checkpoints; the hot paths use bde_swag_copy_row)."""
+
+    LOG2_PIECE = 12          # 4096 floats = 16 KB per row and piece: the sweet spot of the layout probes (r02)
+
+    def __init__(self, n_rows: int, d: int, device, log2_piece: int = LOG2_PIECE):
+        self.n_rows, self.d, self.log2_piece = int(n_rows), int(d), int(log2_piece)
+        self.piece = 1 << self.log2_piece
+        self.n_pieces = max(1, (self.d + self.piece - 1) // self.piece)
+        self.buf = torch.zeros((self.n_pieces, self.n_rows, self.piece), dtype=torch.float32, device=device)
+        self.pieces = (self.log2_piece, self.n_rows * self.piece)
+
+    def row(self, r: int) -> torch.Tensor:
+        return self.buf[0, r]
+
+    def rows(self, a: int, b: int) -> torch.Tensor:
+        return self.buf[0, a:b]
+
+    def gather(self, r) -> torch.Tensor:
+        """Row(s) ``r`` (an index, a list of indices or a slice) as contiguous ``[d]`` / ``[n, d]`` copies."""
+        if isinstance(r, int):
+            return self.buf[:, r].reshape(-1)[:self.d]
+        sel = self.buf[:, r]                                         # [n_pieces, n, piece]
+        return sel.permute(1, 0, 2).reshape(sel.shape[1], -1)[:, :self.d]
+
+    def scatter(self, r: int, vec: torch.Tensor) -> None:
+        full = torch.zeros(self.n_pieces * self.piece, dtype=torch.float32, device=self.buf.device)
+        full[:self.d] = vec.to(self.buf.device).float().reshape(-1)[:self.d]
+        self.buf[:, r] = full.view(self.n_pieces, self.piece)
+
+
+class SegTable:
+    """Where the gradients of the M particles live, per parameter tensor ("segment"), for the ``*_seg`` entry points
+    (include/bde_hip.h): ``ptrs`` (device int64 ``[n_seg * M]``, refreshed every step from ``host``), ``chunks``
+    (device, static: pieces of <= 256 float4 columns of one segment).  ``offsets`` (multiples of 4) / ``numels`` describe
+    the segments on the host."""
+
+    def __init__(self, offsets, numels, m, device):
+        import numpy as np
+        if any(o % 4 for o in offsets):
+            raise BdeKernelError("SegTable: every segment must start on a float4 boundary of the row (FlatLayout(align=4))")
+        self.offsets, self.numels, self.m = list(offsets), list(numels), int(m)
+        self.n_seg = len(self.offsets)
+        rows = []
+        for s, (col0, n) in enumerate(zip(self.offsets, self.numels)):
+            for start in range(0, n, 1024):
+                nflt = min(1024, n - start)
+                rows.append(((col0 + start) // 4, start // 4, s + (nflt << 32), 0))
+        self.n_chunks = len(rows)
+        self.chunks = torch.from_numpy(np.asarray(rows, dtype=np.int64).reshape(-1, 4)).to(device)
+        self.ptrs = torch.zeros(max(1, self.n_seg * self.m), dtype=torch.int64, device=device)
+        on_gpu = torch.device(device).type == "cuda"
+        # host staging, rotated so that a table is never overwritten while its upload may still be in flight
+        self.host = [torch.zeros(max(1, self.n_seg * self.m), dtype=torch.int64) for _ in range(3)]
+        if on_gpu:
+            self.host = [h.pin_memory() for h in self.host]
+        self._events = [None] * len(self.host)
+        self._slot = 0
+
+    def staging(self) -> torch.Tensor:
+        """The host table to fill for the coming step."""
+        ev = self._events[self._slot]
+        if ev is not None:
+            ev.synchronize()
+            self._events[self._slot] = None
+        return self.host[self._slot]
+
+    def upload(self) -> None:
+        """Host table -> device (stream-ordered, asynchronous from pinned memory)."""
+        h = self.host[self._slot]
+        self.ptrs.copy_(h, non_blocking=True)
+        if self.ptrs.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[self._slot] = ev
+        self._slot = (self._slot + 1) % len(self.host)
+
+
 class HipOps:
     """Kernel backend over libbde_hip.so."""
 
@@ -249,26 +331,79 @@ class HipOps:
                                             _ld(P), _ld(G), _ptr(kstat), lr, beta1, beta2, eps, weight_decay, int(step0),
                                             _ptr(ws_next), _stream()), "bde_svgd_fused_adam")
 
+    # ---- gradients read where autograd left them (no copy into the flat rows) ----
+    def seg_table(self, offsets, numels, m, device) -> SegTable:
+        return SegTable(offsets, numels, m, device)
+
+    @_on_device_of
+    def svgd_combine_seg(self, P, seg: SegTable, out, d, kstat):
+        if _ld(out) != _ld(P):
+            raise BdeKernelError("P and out must share one leading dimension")
+        _check(self.lib.bde_svgd_combine_seg(_ptr(P, "P"), seg.ptrs.data_ptr(), seg.chunks.data_ptr(), seg.n_chunks,
+                                             _ptr(out, "out"), P.shape[0], d, _ld(P), _ptr(kstat), _stream()),
+               "bde_svgd_combine_seg")
+
+    @_on_device_of
+    def svgd_fused_sgd_seg(self, P, seg: SegTable, buf, d, kstat, lr, momentum, dampening, weight_decay, nesterov, first,
+                           ws_next=None):
+        _check(self.lib.bde_svgd_fused_sgd_seg(_ptr(P, "P"), seg.ptrs.data_ptr(), seg.chunks.data_ptr(), seg.n_chunks,
+                                               _ptr(buf), P.shape[0], d, _ld(P), _ptr(kstat), lr, momentum, dampening,
+                                               weight_decay, int(nesterov), int(first), _ptr(ws_next), _stream()),
+               "bde_svgd_fused_sgd_seg")
+
+    @_on_device_of
+    def svgd_fused_adam_seg(self, P, seg: SegTable, exp_avg, exp_avg_sq, d, kstat, lr, beta1, beta2, eps, weight_decay,
+                            step0, ws_next=None):
+        _check(self.lib.bde_svgd_fused_adam_seg(_ptr(P, "P"), seg.ptrs.data_ptr(), seg.chunks.data_ptr(), seg.n_chunks,
+                                                _ptr(exp_avg), _ptr(exp_avg_sq), P.shape[0], d, _ld(P), _ptr(kstat), lr,
+                                                beta1, beta2, eps, weight_decay, int(step0), _ptr(ws_next), _stream()),
+               "bde_svgd_fused_adam_seg")
+
+    @_on_device_of
+    def svgd_gather_seg(self, G, seg: SegTable, row0=0, n_rows=None):
+        """Pack the segmented gradients of particles [row0, row0 + n_rows) into the flat rows G [M, ld]: one launch."""
+        n_rows = seg.m - row0 if n_rows is None else n_rows
+        if row0 < 0 or n_rows < 1 or row0 + n_rows > min(seg.m, G.shape[0]):
+            raise BdeKernelError("svgd_gather_seg: rows outside the table / the gradient buffer")
+        # M = the table's particle count (its pointer stride), whatever number of rows G holds
+        _check(self.lib.bde_svgd_gather_seg(seg.ptrs.data_ptr(), seg.chunks.data_ptr(), seg.n_chunks, _ptr(G, "G"),
+                                            seg.m, row0, n_rows, _ld(G), _stream()), "bde_svgd_gather_seg")
+
     # ------------------------------------------------------------ SWAG --
     @_on_device_of
-    def swag_update(self, theta, mean, sq, dev_row, n, d):
-        _check(self.lib.bde_swag_update(_ptr(theta, "theta"), _ptr(mean), _ptr(sq), _ptr(dev_row), int(n), d,
+    def swag_update(self, theta, mean, sq, dev_row, n, d, pieces=None):
+        """``pieces = (log2_piece, piece_stride)``: mean / sq / dev_row are stored in pieces (RowBlock handles)."""
+        lp, ps = pieces or (0, 0)
+        _check(self.lib.bde_swag_update(_ptr(theta, "theta"), _ptr(mean), _ptr(sq), _ptr(dev_row), int(n), d, lp, ps,
                                         _stream()), "bde_swag_update")
 
     @_on_device_of
-    def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0):
+    def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0, pieces=None):
         k = dev.shape[0]
+        lp, ps = pieces or (0, 0)
         _check(self.lib.bde_swag_sample(_ptr(mean), _ptr(sq), _ptr(dev), k, _ld(dev), head, _ptr(eps_w), _ptr(eps_d),
-                                        seed, stream_id, _ptr(out), d, _stream()), "bde_swag_sample")
+                                        seed, stream_id, _ptr(out), d, lp, ps, _stream()), "bde_swag_sample")
 
     @_on_device_of
-    def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0):
+    def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0, pieces=None,
+                            out_pieces=None):
+        """``out``: ``[S, >= d]`` contiguous rows, or (``out_pieces``) the first-piece views ``[S, piece]`` of S rows
+        stored in pieces."""
         k, s = dev.shape[0], out.shape[0]
-        if eps_d is not None and _ld(eps_d) != _ld(out):
-            raise BdeKernelError("eps_d and out must share one leading dimension")
+        lp, ps = pieces or (0, 0)
+        lpo, pso = out_pieces or (0, 0)
         _check(self.lib.bde_swag_sample_batched(_ptr(mean), _ptr(sq), _ptr(dev), k, _ld(dev), head, _ptr(eps_w),
-                                                _ptr(eps_d), seed, stream_id0, _ptr(out), _ld(out), s, d, _stream()),
+                                                _ptr(eps_d), _ld(eps_d) if eps_d is not None else 0, seed, stream_id0,
+                                                _ptr(out), _ld(out), s, d, lp, ps, lpo, pso, _stream()),
                "bde_swag_sample_batched")
+
+    @_on_device_of
+    def swag_copy_row(self, src, dst, d, src_pieces=None, dst_pieces=None):
+        """dst row = src row; either side contiguous or stored in pieces (a RowBlock row handle + its ``pieces``)."""
+        lps, pss = src_pieces or (0, 0)
+        lpd, psd = dst_pieces or (0, 0)
+        _check(self.lib.bde_swag_copy_row(_ptr(src, "src"), lps, pss, _ptr(dst, "dst"), lpd, psd, d, _stream()),
+               "bde_swag_copy_row")
 
     def philox_normal(self, seed, stream_id, eps_w=None, eps_d=None, d=None):
         k = 0 if eps_w is None else eps_w.numel()

@@ -42,7 +42,8 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from .algo import BayesianOptimizer, FlatLayout, adopt_grads, check_params, clear_grads, repoint, _default_ops, _opt_state
+from .algo import (BayesianOptimizer, FlatLayout, adopt_grads, check_params, clear_grads, collect_grads, repoint,
+                   _default_ops, _opt_state)
 from .ops import pad4
 
 
@@ -115,7 +116,9 @@ class SVGDOptimizer(BayesianOptimizer):
         plist = list(self._params())
         check_params(plist, self._ops)
         self._plist = plist
-        self._layout = FlatLayout(plist)
+        # every tensor starts on a float4 boundary of the row, so the update kernels can read a particle's gradients
+        # straight from the tensors autograd produced (no _store_grads copy; see _end_particle)
+        self._layout = FlatLayout(plist, align=4)
         dev = self._params_device()
         m, ld = particle_count, self._layout.ld
         # flat particle / gradient storage; padding stays zero
@@ -125,6 +128,14 @@ class SVGDOptimizer(BayesianOptimizer):
         self._gviews: List[Optional[List[torch.Tensor]]] = [self._layout.views(self._G[i]) for i in range(m)]
         self._ws = self._ops.svgd_ws(m, dev)
         self._kstat = self._ops.svgd_kstat(m, dev)
+        # where the gradients of the current step live (per tensor and particle), the tensors held by reference, and
+        # whether the table describes the step being assembled (step() fills it; a caller that writes the flat
+        # gradient rows itself and calls _posterior_update directly does not)
+        self._seg = self._ops.seg_table(self._layout.offsets, self._layout.numels, m, dev) \
+            if hasattr(self._ops, "seg_table") and m <= 16 else None
+        self._seg_host = None
+        self._retained = [None] * m
+        self._pset = None
         if hasattr(self._ops, "load_code_objects"):
             self._ops.load_code_objects(dev)      # every kernel resident on THIS device before any collective / sharing
 
@@ -250,15 +261,76 @@ class SVGDOptimizer(BayesianOptimizer):
 
         return self._posterior_update(total_loss, grad_scaler)
 
+    def _particle_set(self):
+        """The native object that runs the per-particle loops over its own tensor lists (csrc/host.cpp ParticleSet);
+        None without the host helper.  Rebuilt whenever the particle views change (dimension sharding)."""
+        if self._pset is None:
+            from . import _host
+            native = _host.load()
+            if native is None or not hasattr(native, "ParticleSet"):
+                self._pset = False
+            else:
+                self._pset = native.ParticleSet(self._plist, [v if v is not None else [] for v in self._pviews],
+                                                [v if v is not None else [] for v in self._gviews])
+        return self._pset or None
+
     def _begin_particle(self, particle_idx: int) -> None:
         """_use_particle (svgd.py:120-127) and base_optimizer.zero_grad() (svgd.py:70): the parameters view particle
         ``particle_idx`` and carry no gradient, so backward() hands over the fresh tensors its kernels produce."""
+        pset = self._particle_set()
+        if pset is not None:
+            pset.begin(particle_idx)
+            return
         repoint(self._plist, self._pviews[particle_idx], None)
         clear_grads(self._plist)
 
     def _end_particle(self, particle_idx: int) -> None:
-        """_store_grads (svgd.py:129-133): the particle's gradients move into its row of the flat gradient buffer."""
-        adopt_grads(self._plist, self._gviews[particle_idx])
+        """_store_grads (svgd.py:129-133) without its clones: the tensors autograd just produced are kept BY REFERENCE and
+        their addresses recorded (a gradient the kernels cannot read in place -- missing, strided, unaligned -- is
+        copied / zeroed into the particle's flat gradient row instead, and that address recorded).  The update kernels
+        read the gradients where they are; nothing is copied on the single-GPU path."""
+        if self._seg is None:
+            adopt_grads(self._plist, self._gviews[particle_idx])
+            return
+        if self._seg_host is None:
+            self._seg_host = self._seg.staging()
+        if self._exchange == "alltoall":
+            particle_row = particle_idx - self._local_particles().start
+        else:
+            particle_row = particle_idx
+        pset = self._particle_set()
+        if pset is not None:
+            pset.end(particle_idx, self._seg_host, particle_row, self._seg.m)
+            return
+        self._retained[particle_row] = collect_grads(self._plist, self._gviews[particle_idx], self._seg_host,
+                                                     particle_row, self._seg.m)
+        clear_grads(self._plist)
+
+    def _grads_to_rows(self, G: torch.Tensor, row0: int, n_rows: int) -> None:
+        """The gradients recorded by _end_particle packed into rows [row0, row0 + n_rows) of the flat buffer ``G`` (ONE
+        launch for all of them): what a collective sends and what the small-model kernel reads.  No-op when the caller
+        wrote the flat rows itself."""
+        if self._seg_host is None:
+            return
+        self._seg.upload()
+        self._seg_host = None
+        self._ops.svgd_gather_seg(G, self._seg, row0, n_rows)
+        self._release_grads()
+
+    def _take_segments(self):
+        """The segment table of this step, uploaded, if step() assembled one (then the kernels read the gradients where
+        autograd left them); None when the flat gradient rows hold the gradients."""
+        if self._seg_host is None:
+            return None
+        self._seg.upload()
+        self._seg_host = None
+        return self._seg
+
+    def _release_grads(self) -> None:
+        """After the update has been enqueued the gradient tensors may go back to the allocator (stream-ordered reuse)."""
+        self._retained = [None] * len(self._retained)
+        if self._pset:
+            self._pset.release()
 
     def _posterior_update(self, total_loss, grad_scaler=None):
         """Everything after the forward/backward passes (svgd.py:82-105): gradient exchange (multi-GPU), kernel
@@ -289,10 +361,16 @@ class SVGDOptimizer(BayesianOptimizer):
 
     def _step_replicated(self, total_loss, base, fused, grad_scaler):
         m, d = self.state["__particle_count"], self._layout.d
-        pending = self._start_gradient_exchange(total_loss) if self._world > 1 else None
+        pending = None
+        if self._world > 1:
+            per = m // self._world
+            self._grads_to_rows(self._G, self._rank * per, per)          # own rows packed for the collective: one launch
+            pending = self._start_gradient_exchange(total_loss)
         # The Gram pass and the kernel statistics need only the (replicated) particles: they run while the
         # gradient all-gather is in flight.  (Skipped when the previous fused kernel already left the Gram.)
         single_launch = pending is None and self._single_launch is not False and self._ops.svgd_small_supported(m, d)
+        if single_launch or m > 16:
+            self._grads_to_rows(self._G, 0, m)                           # these kernels read flat rows
         if fused and single_launch:
             # small model on one GPU: statistics, -phi and the M shared-state optimizer applications in ONE launch
             self._fused_apply(base, [(self._P, self._G, d, 0)], single_launch=True)
@@ -305,17 +383,20 @@ class SVGDOptimizer(BayesianOptimizer):
             self._ops.svgd_kstats(self._ws, m, *self._stat_args(), self._kstat)
         if pending is not None:
             total_loss = self._finish_gradient_exchange(pending)
+        seg = self._take_segments()                                      # None: the gradients are in the flat rows
         if fused:
             # ONE pass: -phi in registers, M shared-state optimizer applications, updated particles out
-            self._fused_apply(base, [(self._P, self._G, d, 0)], ws_next=self._ws if self._reuse_gram else None)
+            self._fused_apply(base, [(self._P, self._G, d, 0)], ws_next=self._ws if self._reuse_gram else None, seg=seg)
             self._gram_valid = self._reuse_gram
             self._use_particle(m - 1)    # the reference leaves the model aliased to the last particle
         else:
             self._gram_valid = False
             # svgd.py:86-89: -phi overwrites the gradient rows
             if single_launch:
-                # small model on one GPU: Gram, statistics and combine in ONE persistent launch
+                # small model on one GPU: Gram, statistics and combine by the small-model kernel (two launches)
                 self._ops.svgd_step(self._P, self._G, self._G, d, *self._stat_args(), self._ws, self._kstat)
+            elif seg is not None:
+                self._ops.svgd_combine_seg(self._P, seg, self._G, d, self._kstat)
             elif m <= 16:
                 self._ops.svgd_combine(self._P, self._G, self._G, d, self._kstat)
             else:
@@ -325,13 +406,18 @@ class SVGDOptimizer(BayesianOptimizer):
                 self._ops.svgd_combine(self._P, self._G, self._tmp, d, self._kstat)
                 self._G.copy_(self._tmp)
             self._apply_base_optimizer(base, grad_scaler)
+        self._release_grads()
         return total_loss
 
     def _apply_base_optimizer(self, base, grad_scaler):
         """svgd.py:92-103: hand row i of -phi to the base optimizer as the gradient of particle i, for every i."""
         OptState = _opt_state()
+        pset = self._particle_set()
         for particle_idx in range(self.state["__particle_count"]):
-            repoint(self._plist, self._pviews[particle_idx], self._gviews[particle_idx])
+            if pset is not None:
+                pset.set_grads(particle_idx)
+            else:
+                repoint(self._plist, self._pviews[particle_idx], self._gviews[particle_idx])
             if grad_scaler is not None:
                 self._set_grad_scaler_state(grad_scaler, OptState.UNSCALED, base)
                 grad_scaler.step(base)
@@ -366,6 +452,7 @@ class SVGDOptimizer(BayesianOptimizer):
         m, d = self.state["__particle_count"], self._layout.d
         per = m // self._world
         lo = self._rank * per
+        self._grads_to_rows(self._G, lo, per)                            # own rows packed for the collective: one launch
         self._G[lo:lo + per, d] = total_loss / per
         works = []
         for (c0, c1), stage in zip(self._chunks, self._stage):
@@ -429,6 +516,7 @@ class SVGDOptimizer(BayesianOptimizer):
                 self._pviews[i] = self._gviews[i] = None
                 for param in self._plist:
                     self.state[param].pop(f"particle_{i}", None)
+        self._pset = None                                          # the views changed: the native loops get the new lists
         self._use_particle(lo)
 
     def _all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
@@ -446,6 +534,7 @@ class SVGDOptimizer(BayesianOptimizer):
         import torch.distributed as dist
         m, w, r, sl = self.state["__particle_count"], self._world, self._rank, self._sl
         per = m // w
+        self._grads_to_rows(self._Gown, 0, per)                          # own rows packed for the all-to-all: one launch
         # (1) the slice's Gram block + this rank's loss: one tiny all-gather, issued first
         if self._slice_d > 0:
             self._ops.svgd_gram(self._Ps, self._slice_d, self._ws)
@@ -570,7 +659,7 @@ class SVGDOptimizer(BayesianOptimizer):
         self._fused_state = self.state["__fused"] = st
         return st
 
-    def _fused_apply(self, base, pieces, ws_next=None, advance=True, single_launch=False) -> None:
+    def _fused_apply(self, base, pieces, ws_next=None, advance=True, single_launch=False, seg=None) -> None:
         """-phi and the M sequential base-optimizer applications with shared state in ONE kernel per piece
         (bde_svgd_fused_sgd / bde_svgd_fused_adam); ``pieces`` = (P, G, valid columns, column offset into the state
         buffers).  Hyper-parameters are read from the base optimizer's param_groups every step, so LR schedulers
@@ -587,6 +676,11 @@ class SVGDOptimizer(BayesianOptimizer):
                             g0["dampening"], g0["weight_decay"], g0["nesterov"], st["first"])
                     self._launch_small(self._ops.svgd_step_small_sgd, args)
                     continue
+                if seg is not None:
+                    self._ops.svgd_fused_sgd_seg(P, seg, st["buf"], d, self._kstat, g0["lr"], g0["momentum"],
+                                                 g0["dampening"], g0["weight_decay"], g0["nesterov"], st["first"],
+                                                 ws_next=ws_next)
+                    continue
                 self._ops.svgd_fused_sgd(P, G, st["buf"][c0:], d, self._kstat, g0["lr"], g0["momentum"], g0["dampening"],
                                          g0["weight_decay"], g0["nesterov"], st["first"], ws_next=ws_next)
         elif type(base) is torch.optim.Adam:
@@ -599,6 +693,11 @@ class SVGDOptimizer(BayesianOptimizer):
                     args = (P, G, st["exp_avg"], st["exp_avg_sq"], d, l2, scale, n, self._ws, self._kstat, float(g0["lr"]),
                             g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"])
                     self._launch_small(self._ops.svgd_step_small_adam, args)
+                    continue
+                if seg is not None:
+                    self._ops.svgd_fused_adam_seg(P, seg, st["exp_avg"], st["exp_avg_sq"], d, self._kstat, float(g0["lr"]),
+                                                  g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"],
+                                                  st["step"], ws_next=ws_next)
                     continue
                 self._ops.svgd_fused_adam(P, G, st["exp_avg"][c0:], st["exp_avg_sq"][c0:], d, self._kstat, float(g0["lr"]),
                                           g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"],
@@ -653,16 +752,19 @@ class SVGDOptimizer(BayesianOptimizer):
 
     def _use_particle(self, particle_idx):
         '''Does *not* clone: updates of the model parameters are updates of the particle (svgd.py:120-127)'''
-        repoint(self._plist, self._pviews[particle_idx], None)
+        pset = self._particle_set()
+        if pset is not None:
+            pset.use(particle_idx)
+        else:
+            repoint(self._plist, self._pviews[particle_idx], None)
 
     def get_base_optimizer(self):
         return self.state["__base_optimizer"]
 
     # ---- flat access (bench / multi-GPU tests / checkpoints) -----------
-    @property
-    def particles(self) -> torch.Tensor:
-        """[M, D] view of the flat particle buffer.  With exchange="alltoall" the slices are gathered first
-        (a collective: every rank of the group must read this property)."""
+    def _particle_rows(self) -> torch.Tensor:
+        """``[M, d]`` in the flat row layout (alignment padding included).  With exchange="alltoall" the slices are
+        gathered first (a collective)."""
         self._check_single_launch()
         d = self._layout.d
         if self._exchange != "alltoall":
@@ -672,6 +774,30 @@ class SVGDOptimizer(BayesianOptimizer):
         slices = torch.empty((w, m, sl), dtype=torch.float32, device=self._Ps.device)
         dist.all_gather_into_tensor(slices.view(-1), self._Ps.reshape(-1).clone(), group=self._pg)
         return slices.permute(1, 0, 2).reshape(m, w * sl)[:, :d]
+
+    @property
+    def particles(self) -> torch.Tensor:
+        """The particles as ``[M, D]`` (the parameters' elements in parameter order): a view of the flat buffer when
+        no tensor needed alignment padding, a gathered copy otherwise.  With exchange="alltoall" the slices are gathered
+        first (a collective: every rank of the group must read this property)."""
+        return self._layout.compact(self._particle_rows())
+
+    def set_particles(self, particles: torch.Tensor) -> None:
+        """Overwrite all particles with ``particles [M, D]`` (the layout ``.particles`` returns).  ``.particles`` itself is
+        a copy whenever a tensor needed alignment padding, so in-place edits go through here.  Not available with
+        exchange="alltoall" (load a checkpoint instead)."""
+        self._check_single_launch()
+        if self._exchange == "alltoall":
+            raise NotImplementedError("set_particles with exchange='alltoall': use load_state_dict")
+        m = self.state["__particle_count"]
+        if tuple(particles.shape) != (m, self._layout.n_valid):
+            raise ValueError(f"expected a [{m}, {self._layout.n_valid}] tensor, got {tuple(particles.shape)}")
+        with torch.no_grad():
+            if self._layout.padded:
+                self._P[:, self._layout.valid_index(self._P.device)] = particles.to(self._P.device, torch.float32)
+            else:
+                self._P[:, :self._layout.d] = particles.to(self._P.device, torch.float32)
+        self._gram_valid = False
 
     @property
     def kernel_stats(self) -> dict:
@@ -703,7 +829,7 @@ class SVGDOptimizer(BayesianOptimizer):
             return super().state_dict()
         m, d, ld = self.state["__particle_count"], self._layout.d, self._layout.ld
         full = torch.zeros((m, ld), dtype=torch.float32, device=self._Ps.device)
-        full[:, :d] = self.particles                                        # collective
+        full[:, :d] = self._particle_rows()                                 # collective
         for i in range(m):
             for param, view in zip(self._plist, self._layout.views(full[i])):
                 self.state[param][f"particle_{i}"] = view

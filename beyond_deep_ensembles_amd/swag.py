@@ -8,8 +8,13 @@ sample_parameters / complete_epoch behaviour, integer schedule and
   the moment update reads the weights in place -- the reference flattens them
   with ``parameters_to_vector(...).cpu()`` every update (swag.py:100);
 * ``__mean`` / ``__sq_weights`` stay on the device and ``__deviations`` is a
-  ring ``[K, ld]`` (``__dev_head`` = row the next update overwrites) instead of
-  a CPU ``[D, K]`` matrix that is physically rolled (swag.py:103);
+  ring of K rows (``__dev_head`` = row the next update overwrites) instead of
+  a CPU ``[D, K]`` matrix that is physically rolled (swag.py:103).  The K + 2
+  statistics rows are stored INTERLEAVED in 16 KB pieces (``ops.RowBlock``:
+  ``[piece][row][4096 floats]``), so a pass over them -- every update, every
+  sample -- walks one contiguous region per piece instead of K + 2 streams a row
+  length apart; prefetched samples are stored the same way and served by one
+  streaming copy into the vector the parameters view.  ``mean_vector()`` /
   ``deviations_dk()`` / ``state_dict()`` give the reference's layout back;
 * a posterior sample is one kernel (``bde_swag_sample``) that writes straight
   into a second flat vector the parameters are re-pointed at; restoring the
@@ -30,6 +35,7 @@ from typing import Callable, List, Optional, Tuple
 import torch
 
 from .algo import BayesianOptimizer, FlatLayout, check_params, repoint, _default_ops
+from .ops import RowBlock
 
 
 class SwagOptimizer(BayesianOptimizer):
@@ -64,8 +70,6 @@ class SwagOptimizer(BayesianOptimizer):
         self._layout = FlatLayout(plist)
         dev = self._params_device()
         d, ld, k = self._layout.d, self._layout.ld, deviation_samples
-        # serving a prefetched sample: re-point n_tensors views (~1 us of host time each) or copy the row (8 D bytes)
-        self._copy_is_cheaper = len(plist) * 1e-6 > 8.0 * d / 5e12
 
         # flat training weights; the parameters become views of it
         self._theta = torch.zeros(ld, dtype=torch.float32, device=dev)
@@ -83,11 +87,27 @@ class SwagOptimizer(BayesianOptimizer):
         self.state["__epoch"] = 0
         self.state["__steps_since_swag_start"] = 0
         self.state["__updates"] = 0
-        self.state["__mean"] = self._theta.clone()                              # swag.py:32 (initial weights = sample #1)
-        self.state["__sq_weights"] = self.state["__mean"] ** 2                  # swag.py:33
-        self.state["__deviations"] = torch.zeros((k, ld), dtype=torch.float32, device=dev)   # ring, swag.py:34
+        # rows 0 .. K-1: the deviation ring (swag.py:34), row K: mean (swag.py:32: the initial weights are sample #1),
+        # row K + 1: second moment (swag.py:33) -- interleaved in pieces
+        self._stats = RowBlock(k + 2, d, dev)
+        with torch.no_grad():
+            self._stats.scatter(k, self._theta[:d])
+            self._stats.scatter(k + 1, self._theta[:d] ** 2)
+        self._publish_stats()
         self.state["__dev_head"] = 0
         self.state["__params_dirty"] = False
+
+    def _publish_stats(self) -> None:
+        """The reference's state keys, as (strided) views of the interleaved statistics buffer."""
+        k = self.deviation_samples
+        self.state["__mean"] = self._stats.buf[:, k]
+        self.state["__sq_weights"] = self._stats.buf[:, k + 1]
+        self.state["__deviations"] = self._stats.buf[:, :k]
+
+    def _stat_rows(self):
+        """(mean, sq, ring) row handles for the kernels; pass ``pieces=self._stats.pieces`` with them."""
+        k = self.deviation_samples
+        return self._stats.row(k), self._stats.row(k + 1), self._stats.rows(0, k)
 
     # ------------------------------------------------------------------
     def step(self, forward_closure, backward_closure, grad_scaler=None):
@@ -117,14 +137,15 @@ class SwagOptimizer(BayesianOptimizer):
         if self.rng != "philox" or self.noise_source is not None or n_samples < 2:
             return 0
         n = int(min(n_samples, max(1, max_bytes // (4 * self._layout.ld))))
-        rows = torch.empty((n, self._layout.ld), dtype=torch.float32, device=self._params_device())
         d = self._layout.d
+        rows = RowBlock(n, d, self._params_device())          # the samples, interleaved in pieces like the statistics
+        mean, sq, ring = self._stat_rows()
         with torch.no_grad():
             for lo in range(0, n, 32):
                 hi = min(n, lo + 32)
-                self._ops.swag_sample_batched(self.state["__mean"], self.state["__sq_weights"],
-                                              self.state["__deviations"], self.state["__dev_head"], rows[lo:hi], d,
-                                              seed=self.seed, stream_id0=self._sample_counter + lo)
+                self._ops.swag_sample_batched(mean, sq, ring, self.state["__dev_head"], rows.rows(lo, hi), d,
+                                              seed=self.seed, stream_id0=self._sample_counter + lo,
+                                              pieces=self._stats.pieces, out_pieces=rows.pieces)
         self._prefetched = [rows, 0]
         return n
 
@@ -133,17 +154,12 @@ class SwagOptimizer(BayesianOptimizer):
         self.state["__params_dirty"] = True
         if self._prefetched is not None:
             rows, nxt = self._prefetched
-            if self._copy_is_cheaper:
-                # many tensors: one device copy of the row into the sample vector the parameters already view
-                # (8 D bytes of HBM traffic) beats re-pointing every tensor (~1 us of host time each)
-                with torch.no_grad():
-                    self._sample.copy_(rows[nxt])
-                self._point_at_sample_vector()
-            else:
-                self._layout.point_data(self._plist, rows[nxt])
-                self._points_at = "row"
+            # one streaming copy of the sample's pieces into the contiguous vector the parameters view (8 D bytes)
+            with torch.no_grad():
+                self._ops.swag_copy_row(rows.row(nxt), self._sample, self._layout.d, src_pieces=rows.pieces)
+            self._point_at_sample_vector()
             self._sample_counter += 1
-            self._prefetched = [rows, nxt + 1] if nxt + 1 < rows.shape[0] else None
+            self._prefetched = [rows, nxt + 1] if nxt + 1 < rows.n_rows else None
             return
         d, k = self._layout.d, self.deviation_samples
         eps_w = eps_d = None
@@ -156,10 +172,10 @@ class SwagOptimizer(BayesianOptimizer):
             eps_w = torch.empty(k, dtype=torch.float32, device=dev).normal_()
             eps_d = torch.empty(d, dtype=torch.float32, device=dev).normal_()
             eps_d = self._pad(eps_d)
+        mean, sq, ring = self._stat_rows()
         with torch.no_grad():
-            self._ops.swag_sample(self.state["__mean"], self.state["__sq_weights"], self.state["__deviations"],
-                                  self.state["__dev_head"], self._sample, d, eps_w=eps_w, eps_d=eps_d,
-                                  seed=self.seed, stream_id=self._sample_counter)
+            self._ops.swag_sample(mean, sq, ring, self.state["__dev_head"], self._sample, d, eps_w=eps_w, eps_d=eps_d,
+                                  seed=self.seed, stream_id=self._sample_counter, pieces=self._stats.pieces)
         self._sample_counter += 1
         # vector_to_parameters (swag.py:58): the parameters become views of the sampled vector
         self._point_at_sample_vector()
@@ -204,25 +220,26 @@ class SwagOptimizer(BayesianOptimizer):
                     self.state["__updates"] += 1
                     updates = self.state["__updates"]
                     head = self.state["__dev_head"]
-                    self._ops.swag_update(self._theta, self.state["__mean"], self.state["__sq_weights"],
-                                          self.state["__deviations"][head], updates, self._layout.d)
+                    mean, sq, _ = self._stat_rows()
+                    self._ops.swag_update(self._theta, mean, sq, self._stats.row(head), updates, self._layout.d,
+                                          pieces=self._stats.pieces)
                     self.state["__dev_head"] = (head + 1) % self.deviation_samples
                     self.param_dist = None
                     self._prefetched = None
 
     # ---- reference-layout accessors ------------------------------------
     def mean_vector(self) -> torch.Tensor:
-        return self.state["__mean"][:self._layout.d]
+        return self._stats.gather(self.deviation_samples)
 
     def sq_vector(self) -> torch.Tensor:
-        return self.state["__sq_weights"][:self._layout.d]
+        return self._stats.gather(self.deviation_samples + 1)
 
     def deviations_dk(self) -> torch.Tensor:
         """The deviation matrix in the reference's layout: ``[D, K]``, oldest
         column first, newest last (what swag.py:103-104 maintains by rolling)."""
-        k, d, head = self.deviation_samples, self._layout.d, self.state["__dev_head"]
+        k, head = self.deviation_samples, self.state["__dev_head"]
         order = [(head + c) % k for c in range(k)]
-        return self.state["__deviations"][order, :d].t().contiguous()
+        return self._stats.gather(order).t().contiguous()
 
     def sample_batch(self, n_samples: int, seed: Optional[int] = None, stream_id0: Optional[int] = None) -> torch.Tensor:
         """``n_samples`` posterior samples ``[S, D]`` in one pass over the statistics
@@ -231,12 +248,13 @@ class SwagOptimizer(BayesianOptimizer):
         d, ld = self._layout.d, self._layout.ld
         out = torch.empty((n_samples, ld), dtype=torch.float32, device=self._params_device())
         s0 = self._sample_counter if stream_id0 is None else stream_id0
+        mean, sq, ring = self._stat_rows()
         with torch.no_grad():
             for lo in range(0, n_samples, 32):
                 hi = min(n_samples, lo + 32)
-                self._ops.swag_sample_batched(self.state["__mean"], self.state["__sq_weights"],
-                                              self.state["__deviations"], self.state["__dev_head"], out[lo:hi], d,
-                                              seed=self.seed if seed is None else seed, stream_id0=s0 + lo)
+                self._ops.swag_sample_batched(mean, sq, ring, self.state["__dev_head"], out[lo:hi], d,
+                                              seed=self.seed if seed is None else seed, stream_id0=s0 + lo,
+                                              pieces=self._stats.pieces)
         if stream_id0 is None:
             self._sample_counter += n_samples
         return out[:, :d]
@@ -265,21 +283,18 @@ class SwagOptimizer(BayesianOptimizer):
         self._prefetched = None                          # rows drawn from the old posterior must not be served
         self._sample_counter = int(self.state.pop("__sample_counter", 0))
 
-        def flat(v):
-            out = torch.zeros(ld, dtype=torch.float32, device=dev)
-            out[:d] = v.to(dev).float()[:d]
-            return out
-
-        self.state["__mean"] = flat(self.state["__mean"])
-        self.state["__sq_weights"] = flat(self.state["__sq_weights"])
-        devs = self.state["__deviations"]
-        ring = torch.zeros((k, ld), dtype=torch.float32, device=dev)
+        loaded_mean, loaded_sq, devs = self.state["__mean"], self.state["__sq_weights"], self.state["__deviations"]
+        self._stats = RowBlock(k + 2, d, dev)
+        self._stats.scatter(k, loaded_mean.reshape(-1)[:d])
+        self._stats.scatter(k + 1, loaded_sq.reshape(-1)[:d])
         if devs.dim() == 2 and devs.shape[0] == d and devs.shape[1] == k and not (d == k and "__dev_head" in self.state):
-            ring[:, :d] = devs.to(dev).float().t()          # reference layout [D, K]: column c -> row c, head 0
+            for c in range(k):                                   # reference layout [D, K]: column c -> ring row c, head 0
+                self._stats.scatter(c, devs[:, c])
             self.state["__dev_head"] = 0
         else:
-            ring[:, :d] = devs.to(dev).float()[:, :d]
-        self.state["__deviations"] = ring
+            for r in range(k):                                   # ring rows [K, >= D]
+                self._stats.scatter(r, devs[r, :d])
+        self._publish_stats()
         # re-alias the parameters to the flat weight vector (values come from the model's own state_dict)
         with torch.no_grad():
             torch._foreach_copy_(self._theta_views, [p.detach() for p in self._plist])

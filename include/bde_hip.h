@@ -159,6 +159,43 @@ int bde_svgd_step_small_adam(float* P, const float* G, float* exp_avg, float* ex
                              double beta2, double eps, double weight_decay, int64_t step0, void* ws, float* kstat,
                              int launches, int* abort_flag, void* stream);
 
+/* ---- gradients handed over WITHOUT a copy (the "_store_grads" clones of svgd.py:129-133 removed) ----
+ * The flat row of a particle is the concatenation of its parameter tensors, each starting on a float4 boundary.
+ * Segment s = tensor s = columns [col0_s, col0_s + numel_s) of the row.  seg_ptrs (device memory, n_seg * M
+ * pointers) holds, for segment s and particle j, the address seg_ptrs[s * M + j] of that gradient tensor as autograd
+ * produced it (fp32, contiguous, 16-byte aligned); the caller substitutes the address of the segment inside a flat
+ * gradient row for gradients that are missing / unaligned / strided, after zeroing or copying there.  `chunks`
+ * (device memory, static per layout) lists pieces of at most 256 float4 columns of ONE segment:
+ *   c4    first float4 column of the piece in the flat row         loc4  the same, counted from the segment's start
+ *   seg   segment index                                            nflt  valid floats in the piece (1..1024)
+ * Columns of the row that no chunk covers (alignment padding) are left untouched; they hold zeros.
+ * D (columns in use, padding included) must be a multiple of 4.  Same arithmetic per element as the flat-G entry
+ * points, so results are bit-identical to copying the gradients into G [M, ld] first. */
+typedef struct bde_seg_chunk {
+  int64_t c4;
+  int64_t loc4;
+  int32_t seg;
+  int32_t nflt;
+  int64_t reserved;
+} bde_seg_chunk;
+/* bde_svgd_combine with segmented gradients; out [M, ld] (may be the flat gradient rows the substituted pointers
+ * point into). */
+int bde_svgd_combine_seg(const float* P, const void* const* seg_ptrs, const bde_seg_chunk* chunks, int64_t n_chunks,
+                         float* out, int M, int64_t D, int64_t ld, const float* kstat, void* stream);
+/* bde_svgd_fused_sgd / bde_svgd_fused_adam with segmented gradients (M <= 16; ws_next as there). */
+int bde_svgd_fused_sgd_seg(float* P, const void* const* seg_ptrs, const bde_seg_chunk* chunks, int64_t n_chunks,
+                           float* momentum_buf, int M, int64_t D, int64_t ld, const float* kstat, double lr,
+                           double momentum, double dampening, double weight_decay, int nesterov, int first,
+                           void* ws_next, void* stream);
+int bde_svgd_fused_adam_seg(float* P, const void* const* seg_ptrs, const bde_seg_chunk* chunks, int64_t n_chunks,
+                            float* exp_avg, float* exp_avg_sq, int M, int64_t D, int64_t ld, const float* kstat,
+                            double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step0,
+                            void* ws_next, void* stream);
+/* Pack the segmented gradients of particles [row0, row0 + n_rows) into the flat rows G [M, ld] in ONE launch (what the
+ * collective exchanges and the single-launch kernel read); pieces that already live there are skipped. */
+int bde_svgd_gather_seg(const void* const* seg_ptrs, const bde_seg_chunk* chunks, int64_t n_chunks, float* G, int M,
+                        int row0, int n_rows, int64_t ld, void* stream);
+
 /* Shared-state base-optimizer apply for the M particles, in particle order
  * (svgd.py:92-103 with ONE torch.optim.SGD / Adam whose state is keyed on the
  * model's parameters and therefore shared by all particles).
@@ -200,32 +237,46 @@ int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, float* exp_avg
  * [D, K] matrix that is physically rolled every update (swag.py:103).
  * Logical column c of the reference (0 = oldest ... K-1 = newest) is physical
  * row (head + c) mod K, where `head` is the row the NEXT update overwrites.
- */
+ *
+ * Row storage.  Every statistics row (mean, sq, each ring row) and every output row of the batched sampler is
+ * either contiguous (log2_piece = 0) or cut into PIECES of 2^log2_piece floats (7 <= log2_piece <= 30), piece c of a
+ * row lying piece_stride floats behind its piece c - 1.  The optimizer keeps the K + 2 statistics rows interleaved:
+ * one buffer [n_pieces][K + 2][2^log2_piece], row pointer = address of the row's first piece, ld = 2^log2_piece =
+ * distance between two rows inside a piece, piece_stride = (K + 2) * 2^log2_piece.  A pass over the statistics then
+ * walks one contiguous region per piece instead of K + 2 streams a row length apart (the same shape streams 15 %
+ * faster on MI355X, profiles/r02_layout_probes.txt).  mean, sq and dev share one (log2_piece, piece_stride). */
 
 /* One moment update, n = the already incremented `__updates` counter
  * (swag.py:97-104): mean = (n*mean + theta)/(n+1); sq = (n*sq + theta^2)/(n+1);
- * dev_row[:] = theta - mean_new.  The caller passes dev_row = dev + head*ld and
- * advances head.  Bit-exact with the reference's fp32 CPU arithmetic. */
+ * dev_row[:] = theta - mean_new.  The caller passes dev_row = the ring row `head` and
+ * advances head.  theta is contiguous.  Bit-exact with the reference's fp32 CPU arithmetic. */
 int bde_swag_update(const float* theta, float* mean, float* sq, float* dev_row,
-                    int64_t n, int64_t D, void* stream);
+                    int64_t n, int64_t D, int log2_piece, int64_t piece_stride, void* stream);
 
 /* One posterior sample (swag.py:57,112-114 + LowRankMultivariateNormal.rsample):
  *   out = mean + sum_c dev[col c] * eps_w[c] / sqrt(2 (K-1))
  *              + sqrt(0.5 * (relu(sq - mean^2) + 1e-6)) * eps_d
  * eps_w [K] is indexed by LOGICAL column.  eps_w / eps_d may be NULL: the
  * noise then comes from the in-kernel Philox4x32-10 stream (seed, stream_id),
- * which is independent of the launch geometry. */
+ * element e of the stream being a pure function of (seed, stream_id, e).
+ * out and eps_d are contiguous [D] (out is the vector the model's parameters view). */
 int bde_swag_sample(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
                     const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id,
-                    float* out, int64_t D, void* stream);
+                    float* out, int64_t D, int log2_piece, int64_t piece_stride, void* stream);
 
-/* S posterior samples in one pass over the statistics: out [S, ld_out].
- * The deviation-matrix x noise product [D,K]x[K,S] runs on the f32 MFMA.
- * eps_w [S, K] (logical columns) / eps_d [S, ld_out] may be NULL (Philox
- * streams stream_id0 + s, identical to S calls of bde_swag_sample). */
+/* S <= BDE_MAX_BATCH samples in ONE pass over the statistics (MFMA low-rank product; Philox
+ * streams stream_id0 + s, identical to S calls of bde_swag_sample).  eps_w [S, K] / eps_d [S, ld_eps] (contiguous
+ * rows) may be NULL.  out: S rows ld_out floats apart, stored in pieces (log2_piece_out, piece_stride_out) -- the
+ * optimizer interleaves them like the statistics ([n_pieces][S][2^log2_piece_out]) -- or contiguous. */
 int bde_swag_sample_batched(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
-                            const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id0,
-                            float* out, int64_t ld_out, int S, int64_t D, void* stream);
+                            const float* eps_w, const float* eps_d, int64_t ld_eps, uint64_t seed, uint64_t stream_id0,
+                            float* out, int64_t ld_out, int S, int64_t D, int log2_piece, int64_t piece_stride,
+                            int log2_piece_out, int64_t piece_stride_out, void* stream);
+
+/* dst row = src row, each stored in pieces or contiguous: serving a batched sample (its pieces -> the contiguous
+ * vector the parameters view, one streaming copy), and the accessors / checkpoints (swag.py:32-34's layouts). */
+int bde_swag_copy_row(const float* src, int log2_piece_src, int64_t piece_stride_src, float* dst, int log2_piece_dst,
+                      int64_t piece_stride_dst, int64_t D, void* stream);
 
 /* The Philox normals bde_swag_sample would use, written out (for tests and for
  * callers that want the noise): eps_w [K] and/or eps_d [D] (either may be NULL). */

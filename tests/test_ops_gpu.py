@@ -488,7 +488,181 @@ def test_svgd_single_launch_on_a_shared_device(tmp_path):
     print(f"single launches that gave up with {n_proc} processes sharing the device: {total} / {n_proc * n_iter}")
 
 
+def test_svgd_segmented_gradients_equal_flat_rows(ops):
+    """The *_seg entry points read every particle's gradients from the tensors autograd produced (per-tensor
+    allocations; svgd.py:129-133's clones removed) and must give the BITS of the flat-row entry points fed with the
+    same gradients packed into G [M, ld]: combine, fused SGD / Adam (incl. the next step's Gram partials), and the
+    one-launch packer.  Tensor sizes straddle every boundary: 1 element, numel % 4 != 0, exactly one chunk (1024),
+    several chunks, and gradients the kernels cannot read in place (missing, strided, unaligned) that the collector
+    routes through the flat row."""
+    from beyond_deep_ensembles_amd.algo import FlatLayout, collect_grads
+    torch.manual_seed(33)
+    sizes = [(7,), (1,), (1024,), (33, 31), (4100,), (2, 3, 5), (1027,), (64,), (3000,)]
+    for m in (3, 8, 16):
+        params = [torch.nn.Parameter(torch.randn(s, device=DEV) * 0.05) for s in sizes]
+        lay = FlatLayout(params, align=4)
+        d, ld = lay.d, lay.ld
+        assert lay.padded and d % 4 == 0
+        P = torch.zeros(m, ld, device=DEV)
+        for i in range(m):
+            for v, p in zip(lay.views(P[i]), params):
+                v.copy_(p.detach() + 0.01 * torch.randn_like(p))
+        Gflat = torch.zeros(m, ld, device=DEV)
+        Gfall = torch.zeros(m, ld, device=DEV)                 # the rows the collector falls back to
+        seg = ops.seg_table(lay.offsets, lay.numels, m, DEV)
+        host = seg.staging()
+        retained = []
+        big = torch.randn(5000, device=DEV)
+        for j in range(m):
+            for k, p in enumerate(params):
+                kind = (j + k) % 7
+                if kind == 0:
+                    p.grad = None                                           # missing -> zeros
+                elif kind == 1:
+                    p.grad = big[1:1 + p.numel()].view(p.shape) * 1.0       # fresh, aligned
+                elif kind == 2:
+                    p.grad = big[3:3 + p.numel()].view(p.shape)             # a view at an unaligned address
+                elif kind == 3 and p.dim() == 2:
+                    p.grad = (torch.randn(p.shape[1], p.shape[0], device=DEV) * 0.01).t()   # strided
+                else:
+                    p.grad = torch.randn_like(p) * 0.01
+            for v, p in zip(lay.views(Gflat[j]), params):
+                if p.grad is not None:
+                    v.copy_(p.grad)
+            retained.append(collect_grads(params, lay.views(Gfall[j]), host, j, m))
+        assert any(len(r) < len(params) for r in retained) and all(len(r) > 0 for r in retained)
+        seg.upload()
+        # the packer
+        ops.svgd_gather_seg(Gfall, seg, 0, m)
+        torch.cuda.synchronize()
+        assert torch.equal(Gfall[:, :d], Gflat[:, :d]), m
+        # statistics once
+        ws, ks = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV)
+        ops.svgd_gram(P, d, ws)
+        ops.svgd_kstats(ws, m, 0.01, 1.0, 500.0, -1.0, ks)
+        # re-collect: the packer made every row complete, so point the table at a FRESH fallback buffer again
+        Gfall2 = torch.zeros(m, ld, device=DEV)
+        host = seg.staging()
+        retained = []
+        for j in range(m):
+            for k, p in enumerate(params):
+                v = lay.views(Gflat[j])[k]
+                kind = (j + k) % 7
+                p.grad = None if kind == 0 else (v.clone() if kind != 2 else torch.cat([v.new_zeros(1), v.reshape(-1)])[1:].view(p.shape))
+            retained.append(collect_grads(params, lay.views(Gfall2[j]), host, j, m))
+        seg.upload()
+        out_flat, out_seg = torch.zeros(m, ld, device=DEV), torch.zeros(m, ld, device=DEV)
+        ops.svgd_combine(P, Gflat, out_flat, d, ks)
+        ops.svgd_combine_seg(P, seg, out_seg, d, ks)
+        assert torch.equal(out_seg, out_flat), m
+        # in place on the fallback rows (what the unfused shell does: out = the flat gradient rows)
+        ops.svgd_combine_seg(P, seg, Gfall2, d, ks)
+        assert torch.equal(Gfall2[:, :d], out_flat[:, :d]), m
+        if m > 8:
+            continue
+        # fused SGD / Adam: the table must be rebuilt because the in-place combine consumed the fallback rows
+        for kind in ("sgd", "adam"):
+            Gfall3 = torch.zeros(m, ld, device=DEV)
+            host = seg.staging()
+            retained = []
+            for j in range(m):
+                for k, p in enumerate(params):
+                    v = lay.views(Gflat[j])[k]
+                    p.grad = None if (j + k) % 7 == 0 else v.clone()
+                retained.append(collect_grads(params, lay.views(Gfall3[j]), host, j, m))
+            seg.upload()
+            Pa, Pb = P.clone(), P.clone()
+            s0a, s0b, s1a, s1b = (torch.zeros(ld, device=DEV) for _ in range(4))
+            wa, wb = ops.svgd_ws(m, DEV), ops.svgd_ws(m, DEV)
+            for it in range(2):
+                if kind == "sgd":
+                    ops.svgd_fused_sgd(Pa, Gflat, s0a, d, ks, 0.05, 0.9, 0.0, 3e-4, True, it == 0, ws_next=wa)
+                    ops.svgd_fused_sgd_seg(Pb, seg, s0b, d, ks, 0.05, 0.9, 0.0, 3e-4, True, it == 0, ws_next=wb)
+                else:
+                    ops.svgd_fused_adam(Pa, Gflat, s0a, s1a, d, ks, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m, ws_next=wa)
+                    ops.svgd_fused_adam_seg(Pb, seg, s0b, s1b, d, ks, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m, ws_next=wb)
+            torch.cuda.synchronize()
+            assert torch.equal(Pa, Pb) and torch.equal(s0a, s0b) and torch.equal(s1a, s1b), (m, kind)
+            # the padding columns of the particles and of the state stay zero
+            pad = torch.ones(ld, dtype=torch.bool, device=DEV)
+            pad[lay.valid_index(DEV)] = False
+            assert float(Pb[:, pad].abs().max()) == 0.0 and float(s0b[pad].abs().max()) == 0.0
+            ka, kb = ops.svgd_kstat(m, DEV), ops.svgd_kstat(m, DEV)
+            ops.svgd_kstats(wa, m, 0.01, 1.0, 500.0, -1.0, ka)
+            ops.svgd_kstats(wb, m, 0.01, 1.0, 500.0, -1.0, kb)
+            # Gram partials of the updated particles: the two kernels partition the columns differently (float4 columns
+            # vs chunks), so the partial sums differ in the last bits, the statistics agree to rounding
+            assert torch.allclose(ka[:m * m], kb[:m * m], rtol=0, atol=2e-6), (m, kind)
+
+
 # ------------------------------------------------------------------ SWAG --
+def test_swag_rows_in_pieces_equal_contiguous_rows(ops):
+    """The optimizer keeps the K + 2 statistics rows (and prefetched samples) interleaved in pieces
+    (include/bde_hip.h "Row storage", ops.RowBlock).  Same arithmetic per element: moment update, single sample,
+    batched samples and the row copy must give the BITS of the contiguous-row calls, for sizes below one piece, at
+    piece boundaries, with a D % 4 tail, and for small (128 floats) and the product's (4096 floats) pieces."""
+    from beyond_deep_ensembles_amd.ops import RowBlock
+    torch.manual_seed(41)
+    k, s_n = 5, 7
+    for d in (3, 128, 129, 4096, 4099, 3 * 4096, 70_001):
+        for lp in (7, 12):
+            ld = (d + 63) // 64 * 64
+            theta0 = torch.randn(d) * 0.05
+            mean, sq = padded(theta0), padded(theta0 ** 2)
+            ring = torch.zeros(k, ld, device=DEV)
+            blk = RowBlock(k + 2, d, DEV, log2_piece=lp)
+            blk.scatter(k, theta0)
+            blk.scatter(k + 1, theta0 ** 2)
+            head = 0
+            for n in range(1, 8):
+                th = padded(theta0 + torch.randn(d) * 1e-3 * n)
+                ops.swag_update(th, mean, sq, ring[head], n, d)
+                ops.swag_update(th, blk.row(k), blk.row(k + 1), blk.row(head), n, d, pieces=blk.pieces)
+                head = (head + 1) % k
+            torch.cuda.synchronize()
+            assert torch.equal(blk.gather(k), mean[:d]) and torch.equal(blk.gather(k + 1), sq[:d]), (d, lp)
+            assert torch.equal(blk.gather(list(range(k))), ring[:, :d]), (d, lp)
+            # nothing outside the rows' elements was written (the tail of the last piece stays zero)
+            tail = blk.buf.permute(1, 0, 2).reshape(k + 2, -1)[:, d:]
+            assert tail.numel() == 0 or float(tail.abs().max()) == 0.0
+            # one sample, supplied noise and Philox
+            ew, ed = torch.randn(k, device=DEV), padded(torch.randn(d))
+            a, b = torch.zeros(ld, device=DEV), torch.zeros(ld, device=DEV)
+            ops.swag_sample(mean, sq, ring, head, a, d, eps_w=ew, eps_d=ed)
+            ops.swag_sample(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, b, d, eps_w=ew, eps_d=ed, pieces=blk.pieces)
+            assert torch.equal(a[:d], b[:d]), (d, lp)
+            ops.swag_sample(mean, sq, ring, head, a, d, seed=3, stream_id=11)
+            ops.swag_sample(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, b, d, seed=3, stream_id=11, pieces=blk.pieces)
+            assert torch.equal(a[:d], b[:d]), (d, lp)
+            # batched: contiguous in / contiguous out, pieces in / contiguous out, pieces in / pieces out
+            flat_out, mixed_out = torch.zeros(s_n, ld, device=DEV), torch.zeros(s_n, ld, device=DEV)
+            out_blk = RowBlock(s_n + 2, d, DEV, log2_piece=lp)          # two spare rows: rows(1, 1 + S) is offset on purpose
+            ops.swag_sample_batched(mean, sq, ring, head, flat_out, d, seed=3, stream_id0=11)
+            ops.swag_sample_batched(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, mixed_out, d, seed=3, stream_id0=11,
+                                    pieces=blk.pieces)
+            ops.swag_sample_batched(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, out_blk.rows(1, 1 + s_n), d, seed=3,
+                                    stream_id0=11, pieces=blk.pieces, out_pieces=out_blk.pieces)
+            torch.cuda.synchronize()
+            assert torch.equal(flat_out[:, :d], mixed_out[:, :d]), (d, lp)
+            assert torch.equal(out_blk.gather(list(range(1, 1 + s_n))), flat_out[:, :d]), (d, lp)
+            assert float(out_blk.gather(0).abs().max()) == 0.0 and float(out_blk.gather(s_n + 1).abs().max()) == 0.0
+            assert torch.equal(flat_out[0, :d], a[:d])                                      # stream 11 = the single sample
+            # supplied noise rows (contiguous) with outputs in pieces
+            ewb, edb = torch.randn(s_n, k, device=DEV), torch.zeros(s_n, ld, device=DEV)
+            edb[:, :d] = torch.randn(s_n, d, device=DEV)
+            ops.swag_sample_batched(mean, sq, ring, head, flat_out, d, eps_w=ewb, eps_d=edb)
+            ops.swag_sample_batched(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, out_blk.rows(1, 1 + s_n), d, eps_w=ewb,
+                                    eps_d=edb, pieces=blk.pieces, out_pieces=out_blk.pieces)
+            assert torch.equal(out_blk.gather(list(range(1, 1 + s_n))), flat_out[:, :d]), (d, lp)
+            # the row copy: pieces -> contiguous (serving a prefetched sample) and back
+            got = torch.zeros(ld, device=DEV)
+            ops.swag_copy_row(out_blk.row(3), got, d, src_pieces=out_blk.pieces)
+            assert torch.equal(got[:d], flat_out[2, :d]) and float(got[d:].abs().max() if ld > d else 0.0) == 0.0
+            back = RowBlock(2, d, DEV, log2_piece=lp)
+            ops.swag_copy_row(got, back.row(1), d, dst_pieces=back.pieces)
+            assert torch.equal(back.gather(1), flat_out[2, :d]) and float(back.gather(0).abs().max()) == 0.0
+
+
 def test_swag_update_bit_exact(ops):
     torch.manual_seed(2)
     for d in (1, 5, 64, 1027, 100003):

@@ -283,12 +283,15 @@ def test_swag_prefetch_equals_one_by_one(backend):
     batched = ens.predict(lambda m: m(x).detach().clone(), 7)
     assert torch.allclose(torch.stack(one_by_one), batched, rtol=1e-6, atol=1e-7)
     assert o2._sample_counter == 7 and o2._prefetched is None
-    # a prefetched row is served either by a device copy into the sample vector or by re-pointing the parameters
-    # at the row (whichever the cost model picks for the model's size): both give the same predictions
+    # a prefetched sample (stored in pieces, like the statistics) is served by one copy into the sample vector the
+    # parameters view; sample_batch() hands out the same samples as contiguous rows
     m3, o3, _ = member()
-    o3._copy_is_cheaper = not o2._copy_is_cheaper
-    other = bde.DeepEnsemble([(m3, o3)]).predict(lambda m: m(x).detach().clone(), 7)
-    assert torch.equal(other, batched)
+    rows = o3.sample_batch(7)
+    served = []
+    for s in range(7):
+        o3.use_sample(rows[s])
+        served.append(m3(x).detach().clone())
+    assert torch.allclose(torch.stack(served), batched, rtol=1e-6, atol=1e-7)
     # a training step drops any prefetched rows and restores the training weights
     o2.prefetch_samples(5)
     o2.sample_parameters()
