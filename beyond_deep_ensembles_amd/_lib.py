@@ -59,8 +59,9 @@ SIGNATURES = {
     "bde_swag_sample_batched": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_int64, c_uint64, c_uint64, _P, c_int64,
                                         c_int, c_int64, c_int, c_int64, c_int, c_int64, _P]),
     "bde_swag_copy_row": (c_int, [_P, c_int, c_int64, _P, c_int, c_int64, c_int64, _P]),
-    "bde_philox_normal": (c_int, [c_uint64, c_uint64, _P, c_int, _P, c_int64, _P]),
-    "bde_philox_bits": (c_int, [c_uint64, c_uint64, c_uint32, c_uint64, _P, c_int64, _P]),
+    "bde_swag_philox_rounds": (c_int, []),
+    "bde_philox_normal": (c_int, [c_uint64, c_uint64, _P, c_int, _P, c_int64, c_int, _P]),
+    "bde_philox_bits": (c_int, [c_uint64, c_uint64, c_uint32, c_uint64, _P, c_int64, c_int, _P]),
     "bde_gauss_draw_fwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, c_int64, _P]),
     "bde_gauss_draw_bwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, c_int, c_int64, _P]),
     "bde_reduce_ws_bytes": (c_size_t, []),
@@ -73,10 +74,12 @@ SIGNATURES = {
     "bde_var_operand_bwd": (c_int, [_P, _P, c_int, _P, c_int64, _P]),
     "bde_lrt_linear_supported": (c_int, [c_int, c_int, c_int]),
     "bde_lrt_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "bde_lrt_linear_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int, _P, c_uint64, c_uint64, _P, _P, c_int, c_int, c_int,
+    "bde_lrt_linear_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int, _P, c_uint64, c_uint64, _P, _P, c_int, c_int, c_int,
                                    _P, _P]),
+    "bde_lrt_sigma_cache_wanted": (c_int, [c_int, c_int]),
+    "bde_lrt_sigma_cache": (c_int, [_P, _P, _P, c_int64, _P]),
     "bde_lrt_linear_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "bde_lrt_linear_bwd": (c_int, [_P, c_int64, _P, _P, _P, c_int, _P, _P, _P, c_uint64, c_uint64, _P, _P, _P, _P, _P,
+    "bde_lrt_linear_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_uint64, c_uint64, _P, _P, _P, _P, _P,
                                    c_int, c_int, c_int, _P, _P]),
     "bde_ivon_sample": (c_int, [_P, _P, _P, c_uint64, c_uint64, c_float, c_int, c_int, _P, _P, c_int64, _P]),
     "bde_ivon_update": (c_int, [_P, _P, _P, _P, _P] + [c_float] * 11 + [c_int64, _P]),

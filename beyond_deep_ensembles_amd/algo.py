@@ -46,7 +46,10 @@ class FlatLayout:
         off = (off + align - 1) // align * align
         self.d = off                                   # columns in use, padding included
         self.n_valid = sum(self.numels)                # columns that belong to a parameter
-        self.padded = self.d != self.n_valid
+        # padding BETWEEN tensors (then the parameters' elements are not one contiguous range of the row); padding
+        # only behind the last tensor leaves columns [0, n_valid) exactly the parameters' elements
+        self.padded = any(o != sum(self.numels[:k]) for k, o in enumerate(self.offsets)) if len(self.numels) < 4096 \
+            else self.d != self.n_valid
         self._valid_index = None
         # >= ROW_HEADER spare floats per row, rows 256-byte aligned
         self.ld = pad4(self.d + ROW_HEADER)
@@ -66,7 +69,7 @@ class FlatLayout:
     def compact(self, rows: torch.Tensor) -> torch.Tensor:
         """``rows [..., >= d]`` -> the parameters' elements only ``[..., n_valid]`` (a view when nothing is padded)."""
         if not self.padded:
-            return rows[..., :self.d]
+            return rows[..., :self.n_valid]
         return rows.index_select(-1, self.valid_index(rows.device))
 
     def views(self, row: torch.Tensor) -> List[torch.Tensor]:
@@ -161,23 +164,28 @@ def adopt_grads(params: Sequence[torch.nn.Parameter], views: Sequence[torch.Tens
 
 
 def collect_grads(params: Sequence[torch.nn.Parameter], views: Sequence[torch.Tensor], table: torch.Tensor, j: int,
-                  m: int) -> List[torch.Tensor]:
+                  m: int, zero_addr: int = 0) -> List[torch.Tensor]:
     """``_store_grads`` (``svgd.py:129-133``) without the clones: record WHERE each parameter's gradient lives.
     ``table[i * m + j]`` (host int64; i = parameter, j = particle) receives the address of the gradient tensor autograd
     produced when the update kernels can read it in place (fp32, contiguous, 16-byte aligned, on the views' device);
     otherwise the gradient is copied into -- a missing one zeroes -- its view of the flat gradient row and the view's
-    address is recorded.  Returns the tensors recorded by reference (keep them alive until the update is enqueued)."""
+    address is recorded.  With ``zero_addr`` (the address of a read-only all-zero buffer at least as long as the largest
+    tensor) a MISSING gradient costs nothing: that address is recorded and nothing is written.  Returns the tensors
+    recorded by reference (keep them alive until the update is enqueued)."""
     from . import _host
     native = _host.load()
     if native is not None and hasattr(native, "collect_grads"):
-        return native.collect_grads(params, views, table, int(j), int(m))
+        return native.collect_grads(params, views, table, int(j), int(m), int(zero_addr))
     keep, src, dst, missing = [], [], [], []
     addrs = []
     for p, v in zip(params, views):
         g = p.grad
         addr = v.data_ptr()
         if g is None:
-            missing.append(v)
+            if zero_addr:
+                addr = zero_addr
+            else:
+                missing.append(v)
         elif g.data_ptr() == v.data_ptr():
             pass
         elif g.dtype == torch.float32 and g.layout == torch.strided and g.is_contiguous() and g.device == v.device \

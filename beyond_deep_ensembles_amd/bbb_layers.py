@@ -55,11 +55,33 @@ def _native_nodes(ops):
     return mod if mod is not None and hasattr(mod, "lrt_linear") else None
 
 
-def _lrt_linear(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops):
+def _lrt_linear(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops, w_s2=None, w_ds2=None):
     native = _native_nodes(ops)
     if native is not None:
-        return native.lrt_linear(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id)
-    return _LrtLinear.apply(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops)
+        return native.lrt_linear(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, w_s2, w_ds2)
+    return _LrtLinear.apply(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops, w_s2, w_ds2)
+
+
+class _SigmaCache:
+    """sigma^2 = clamp(softplus(rho)^2, 1e-4) and its rho-derivative of a wide layer's weight matrix, computed ONCE per
+    version of ``rho`` (bde_lrt_sigma_cache) and read by every fused forward / backward of that version: the weights
+    only change at ``base_optimizer.step()``, but a BBB step runs ``mc_samples`` forward and backward passes
+    (``bbb.py:63-67``).  Keyed on the parameter's storage address and autograd version counter, so any in-place change
+    of rho -- an optimizer step, ``load_state_dict``, a manual edit -- refreshes it at the next forward.  A refresh
+    writes NEW tensors: a forward whose backward has not run yet keeps the tensors of its own version."""
+
+    def __init__(self):
+        self.key = None
+        self.s2 = self.ds2 = None
+
+    def get(self, rho: torch.Tensor, ops):
+        key = (rho.data_ptr(), rho._version, tuple(rho.shape))
+        if key != self.key:
+            r = rho.detach().contiguous()
+            s2, ds2 = torch.empty_like(r), torch.empty_like(r)
+            ops.lrt_sigma_cache(r, s2, ds2)
+            self.key, self.s2, self.ds2 = key, s2, ds2
+        return self.s2, self.ds2
 
 
 def _local_reparam(mean, var, eps, seed, stream_id, ops):
@@ -130,7 +152,7 @@ class _LrtLinear(torch.autograd.Function):
     variance and noise)."""
 
     @staticmethod
-    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops):
+    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops, w_s2=None, w_ds2=None):
         x2d = x.reshape(-1, x.shape[-1])
         if x2d.stride(-1) != 1:
             x2d = x2d.contiguous()
@@ -140,15 +162,15 @@ class _LrtLinear(torch.autograd.Function):
         e = None if eps is None else eps.reshape(b, o).contiguous()
         ops.lrt_linear_fwd(x2d.detach(), w_mu.detach().contiguous(), w_rho.detach().contiguous(),
                            None if b_mu is None else b_mu.detach(), None if b_rho is None else b_rho.detach(),
-                           clamp_bias, out, var, eps=e, seed=seed, stream_id=stream_id)
-        ctx.save_for_backward(x2d, w_mu, w_rho, b_rho, var, e)
+                           clamp_bias, out, var, eps=e, seed=seed, stream_id=stream_id, w_s2=w_s2)
+        ctx.save_for_backward(x2d, w_mu, w_rho, b_rho, var, e, w_s2, w_ds2)
         ctx.meta = (clamp_bias, seed, stream_id, ops, x.shape)
         return out.view(x.shape[:-1] + (o,))
 
     @staticmethod
     @once_differentiable          # the kernels produce plain tensors: no double backward
     def backward(ctx, grad_out):
-        x, w_mu, w_rho, b_rho, var, eps = ctx.saved_tensors
+        x, w_mu, w_rho, b_rho, var, eps, w_s2, w_ds2 = ctx.saved_tensors
         clamp_bias, seed, stream_id, ops, x_shape = ctx.meta
         g = grad_out.reshape(var.shape).contiguous()
         g_x = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
@@ -158,8 +180,10 @@ class _LrtLinear(torch.autograd.Function):
             g_bmu, g_brho = torch.empty_like(b_rho), torch.empty_like(b_rho)
         # eps None: the kernel regenerates the forward's in-kernel noise (same element indexing)
         ops.lrt_linear_bwd(x, w_mu.detach().contiguous(), w_rho.detach().contiguous(), None if b_rho is None else b_rho.detach(),
-                           clamp_bias, g, var, g_x, g_wmu, g_wrho, g_bmu, g_brho, eps=eps, seed=seed, stream_id=stream_id)
-        return (None if g_x is None else g_x.view(x_shape)), g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None
+                           clamp_bias, g, var, g_x, g_wmu, g_wrho, g_bmu, g_brho, eps=eps, seed=seed, stream_id=stream_id,
+                           w_s2=w_s2, w_ds2=w_ds2)
+        return (None if g_x is None else g_x.view(x_shape)), g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None, \
+            None, None
 
 
 class _LocalReparamLayer(nn.Module):
@@ -173,6 +197,8 @@ class _LocalReparamLayer(nn.Module):
         self.use_bias = kwargs.get("bias", True)
         self.fused_epilogue = kwargs.get("fused_epilogue", True)     # one HIP pass for mean + sqrt(var) * eps
         self.fused_linear = kwargs.get("fused_linear", True)         # BBBLinear: the whole forward as one fused op
+        self.sigma_cache = kwargs.get("sigma_cache", True)           # wide BBBLinear: sigma^2 once per weight version
+        self._sigma_cache = _SigmaCache()
         self.weight_prior, self.bias_prior = weight_prior, bias_prior
         gp_kwargs = {k: kwargs[k] for k in ("rng", "seed", "_ops") if k in kwargs}
         self.weight = GaussianParameter(weight_shape, **gp_kwargs)
@@ -255,8 +281,12 @@ class BBBLinear(_LocalReparamLayer):
                 eps = None
                 if not (w.rng == "philox" and w.noise_source is None):
                     eps = normal_like(input.new_empty(input.shape[:-1] + (self.out_features,)))
+                ops = w._get_ops()
+                s2 = ds2 = None
+                if self.sigma_cache and ops.lrt_sigma_cache_wanted(self.in_features, self.out_features):
+                    s2, ds2 = self._sigma_cache.get(w.rho, ops)
                 out = _lrt_linear(input, w.mean, w.rho, b.mean if b is not None else None,
-                                  b.rho if b is not None else None, True, eps, w.seed, next(_philox_stream), w._get_ops())
+                                  b.rho if b is not None else None, True, eps, w.seed, next(_philox_stream), ops, s2, ds2)
                 return out / self.mc_sample
             mean = F.linear(input, w.mean, b.mean if b is not None else None)
             var = F.linear(*self._var_operands(input, clamp_bias=True))

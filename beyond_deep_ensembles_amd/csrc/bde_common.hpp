@@ -112,14 +112,22 @@ __device__ __forceinline__ double block_sum(double v, double* smem) {
 // instruction) and two v_bitop3_b32 (hi ^ c ^ key as ONE gfx950 instruction;
 // the compiler emits two v_xor_b32 for the same expression) -- 40 VALU
 // instructions per 128 random bits instead of 59.
+// Rounds: Philox4x32-10 is the published default (and what every draw of the BBB / iVON / layer kernels uses);
+// Philox4x32-7 is the fewest rounds Salmon et al. report as Crush-resistant (it passes BigCrush; the other three are
+// their safety margin).  The SWAG samplers use 7 (kSwagPhiloxRounds): their epilogue generates S x D normals per pass
+// and is co-bound by exactly these multiplies -- 14 instead of 20 v_mad_u64_u32 per 128 bits moved the batched
+// sampler from 0.68 to 0.71 of the HBM peak (profiles/r03_swag_layout_ab.txt).
+constexpr int kPhiloxRounds = 10;
+constexpr int kSwagPhiloxRounds = 7;
 struct Philox {
   static constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
   __device__ __forceinline__ static uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
   }
-  __device__ __forceinline__ static uint4 round10(uint4 c, uint2 k) {
+  template <int ROUNDS>
+  __device__ __forceinline__ static uint4 rounds(uint4 c, uint2 k) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
       const uint64_t p0 = static_cast<uint64_t>(M0) * c.x, p1 = static_cast<uint64_t>(M1) * c.z;
       const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
       const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
@@ -133,11 +141,12 @@ struct Philox {
 
 enum : uint32_t { kDomainDiag = 0x0u, kDomainLowRank = 0x80000000u };
 
+template <int ROUNDS = kPhiloxRounds>
 __device__ __forceinline__ uint4 philox_bits4(uint64_t seed, uint64_t stream_id, uint64_t idx4, uint32_t domain) {
   const uint4 c = make_uint4(static_cast<uint32_t>(idx4), static_cast<uint32_t>(idx4 >> 32),
                              static_cast<uint32_t>(stream_id), static_cast<uint32_t>(stream_id >> 32) ^ domain);
   const uint2 k = make_uint2(static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
-  return Philox::round10(c, k);
+  return Philox::rounds<ROUNDS>(c, k);
 }
 
 // Box-Muller on the 24 high bits of each word.  u0, u2 in [2^-24, 1]: never zero or denormal,
@@ -161,8 +170,9 @@ __device__ __forceinline__ f32x4 box_muller4(uint4 r) {
 }
 
 // Four standard normals for float4 group `idx4` of stream `stream_id`.
+template <int ROUNDS = kPhiloxRounds>
 __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t stream_id, uint64_t idx4, uint32_t domain) {
-  return box_muller4(philox_bits4(seed, stream_id, idx4, domain));
+  return box_muller4(philox_bits4<ROUNDS>(seed, stream_id, idx4, domain));
 }
 
 // softplus(rho) = torch.nn.functional.softplus (beta = 1, threshold = 20; util.py:183) and

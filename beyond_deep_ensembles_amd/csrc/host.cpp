@@ -67,10 +67,12 @@ void adopt_grads(const std::vector<at::Tensor>& params, const std::vector<at::Te
 // lives instead of copying it.  table[i * M + j] (a host int64 tensor, pinned when on a GPU box; i = parameter,
 // j = particle) receives the address of the gradient tensor autograd produced when the update kernels can read it in
 // place (fp32, contiguous, 16-byte aligned, on the views' device); otherwise the gradient is copied into (a missing one
-// zeroes) its view of the flat gradient row and the view's address is recorded.  Returns the tensors recorded by
-// reference: the caller keeps them alive until the update kernel has been enqueued.
+// zeroes) its view of the flat gradient row and the view's address is recorded.  With `zero_addr` != 0 (the address
+// of a read-only all-zero buffer at least as long as the largest tensor) a MISSING gradient costs nothing: that
+// address is recorded and nothing is written.  Returns the tensors recorded by reference: the caller keeps them alive
+// until the update kernel has been enqueued.
 std::vector<at::Tensor> collect_grads(const std::vector<at::Tensor>& params, const std::vector<at::Tensor>& views,
-                                      at::Tensor table, int64_t j, int64_t M) {
+                                      at::Tensor table, int64_t j, int64_t M, int64_t zero_addr) {
   const size_t n = params.size();
   TORCH_CHECK(views.size() == n, "collect_grads: ", n, " parameters but ", views.size(), " views");
   TORCH_CHECK(table.scalar_type() == at::kLong && table.is_contiguous() && !table.is_cuda() &&
@@ -84,7 +86,8 @@ std::vector<at::Tensor> collect_grads(const std::vector<at::Tensor>& params, con
     const at::Tensor& v = views[i];
     int64_t addr = reinterpret_cast<int64_t>(v.data_ptr());
     if (!g.defined()) {
-      missing.push_back(v);
+      if (zero_addr != 0) addr = zero_addr;
+      else missing.push_back(v);
     } else if (g.data_ptr() == v.data_ptr()) {
       // accumulated in place: already where it belongs
     } else if (g.scalar_type() == at::kFloat && g.layout() == at::kStrided && g.is_contiguous() && g.device() == v.device() &&
@@ -180,10 +183,10 @@ class ParticleSet {
     }
   }
 
-  int64_t end(int64_t i, at::Tensor table, int64_t row, int64_t M) {
+  int64_t end(int64_t i, at::Tensor table, int64_t row, int64_t M, int64_t zero_addr) {
     const auto& views = views_of(gviews_, i, "gradient");
     TORCH_CHECK(row >= 0 && row < static_cast<int64_t>(keep_.size()), "ParticleSet.end: row out of range");
-    keep_[row] = collect_grads(params_, views, std::move(table), row, M);
+    keep_[row] = collect_grads(params_, views, std::move(table), row, M, zero_addr);
     for (at::Tensor& p : params_)
       if (p.grad().defined()) p.mutable_grad() = at::Tensor();
     return static_cast<int64_t>(keep_[row].size());
@@ -225,7 +228,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("datas"), py::arg("grads"));
   m.def("clear_grads", &clear_grads, "param.grad = None for a whole parameter list");
   m.def("collect_grads", &collect_grads, "record where the gradients live (no copy); returns the tensors taken by reference",
-        py::arg("params"), py::arg("views"), py::arg("table"), py::arg("j"), py::arg("M"));
+        py::arg("params"), py::arg("views"), py::arg("table"), py::arg("j"), py::arg("M"), py::arg("zero_addr") = 0);
   m.def("adopt_grads", &adopt_grads, "gradients -> flat views (multi-tensor copy/add), views become .grad", py::arg("params"),
         py::arg("views"), py::arg("add"));
 }

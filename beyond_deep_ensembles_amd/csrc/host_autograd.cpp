@@ -35,8 +35,11 @@ at::Tensor opt(const c10::optional<at::Tensor>& t) { return t.has_value() ? *t :
 struct LrtLinear : public torch::autograd::Function<LrtLinear> {
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho,
                             const c10::optional<at::Tensor>& b_mu_, const c10::optional<at::Tensor>& b_rho_,
-                            bool clamp_bias, const c10::optional<at::Tensor>& eps_, int64_t seed, int64_t stream_id) {
+                            bool clamp_bias, const c10::optional<at::Tensor>& eps_, int64_t seed, int64_t stream_id,
+                            const c10::optional<at::Tensor>& w_s2_, const c10::optional<at::Tensor>& w_ds2_) {
     at::Tensor b_mu = opt(b_mu_), b_rho = opt(b_rho_), eps = opt(eps_);
+    // sigma^2 / its rho-derivative of THIS version of w_rho (bde_lrt_sigma_cache), or undefined: on the fly
+    at::Tensor w_s2 = opt(w_s2_), w_ds2 = opt(w_ds2_);
     check_f32_cuda(x, "x");
     check_f32_cuda(w_mu, "w_mu");
     check_f32_cuda(w_rho, "w_rho");
@@ -53,11 +56,14 @@ struct LrtLinear : public torch::autograd::Function<LrtLinear> {
     at::Tensor e;
     if (eps.defined()) e = eps.reshape({B, O}).contiguous();
     const at::Tensor xd = x2d.detach();
-    const int rc = bde_lrt_linear_fwd(ptr(xd), xd.stride(0), ptr(wm), ptr(wr), ptr(b_mu), ptr(b_rho), clamp_bias ? 1 : 0,
+    const int rc = bde_lrt_linear_fwd(ptr(xd), xd.stride(0), ptr(wm), ptr(wr), ptr(w_s2), ptr(b_mu), ptr(b_rho), clamp_bias ? 1 : 0,
                                       ptr(e), static_cast<uint64_t>(seed), static_cast<uint64_t>(stream_id), mptr(out),
                                       mptr(var), B, I, O, ws.data_ptr(), current_stream(x2d));
     TORCH_CHECK(rc == 0, "bde_lrt_linear_fwd failed with code ", rc);
-    ctx->save_for_backward({x2d, w_mu, w_rho, b_rho, var, e});
+    // the cache tensors of THIS weight version are saved like any other operand (a refresh writes new tensors, so a
+    // node always sees the cache of the version its forward ran on; editing rho before the backward trips autograd's
+    // version check on w_rho as it always did)
+    ctx->save_for_backward({x2d, w_mu, w_rho, b_rho, var, e, w_s2, w_ds2});
     ctx->saved_data["clamp_bias"] = clamp_bias;
     ctx->saved_data["seed"] = seed;
     ctx->saved_data["stream_id"] = stream_id;
@@ -72,6 +78,7 @@ struct LrtLinear : public torch::autograd::Function<LrtLinear> {
     check_once_differentiable(grad_outputs);
     const variable_list saved = ctx->get_saved_variables();
     const at::Tensor &x = saved[0], &w_mu = saved[1], &w_rho = saved[2], &b_rho = saved[3], &var = saved[4], &eps = saved[5];
+    const at::Tensor &w_s2 = saved[6], &w_ds2 = saved[7];
     const bool has_bias = ctx->saved_data["has_bias"].toBool();
     c10::DeviceGuard guard(x.device());
     const at::Tensor g = grad_outputs[0].reshape(var.sizes()).contiguous();
@@ -87,13 +94,14 @@ struct LrtLinear : public torch::autograd::Function<LrtLinear> {
     }
     at::Tensor ws = at::empty({static_cast<int64_t>(bde_lrt_linear_bwd_ws_bytes(B, I, O) / 4)}, var.options());
     const at::Tensor xd = x.detach();
-    const int rc = bde_lrt_linear_bwd(ptr(xd), xd.stride(0), ptr(wm), ptr(wr), ptr(br), ctx->saved_data["clamp_bias"].toBool() ? 1 : 0,
+    const int rc = bde_lrt_linear_bwd(ptr(xd), xd.stride(0), ptr(wm), ptr(wr), ptr(w_s2), ptr(w_ds2), ptr(br),
+                                      ctx->saved_data["clamp_bias"].toBool() ? 1 : 0,
                                       ptr(g), ptr(var), ptr(eps), static_cast<uint64_t>(ctx->saved_data["seed"].toInt()),
                                       static_cast<uint64_t>(ctx->saved_data["stream_id"].toInt()), mptr(g_x), mptr(g_wmu),
                                       mptr(g_wrho), mptr(g_bmu), mptr(g_brho), B, I, O, ws.data_ptr(), current_stream(x));
     TORCH_CHECK(rc == 0, "bde_lrt_linear_bwd failed with code ", rc);
     if (g_x.defined()) g_x = g_x.view(ctx->saved_data["x_shape"].toIntVector());
-    return {g_x, g_wmu, g_wrho, g_bmu, g_brho, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    return {g_x, g_wmu, g_wrho, g_bmu, g_brho, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
@@ -165,10 +173,12 @@ void bind_autograd_nodes(py::module_& m) {
   m.def("lrt_linear",
         [](const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho, const c10::optional<at::Tensor>& b_mu,
            const c10::optional<at::Tensor>& b_rho, bool clamp_bias, const c10::optional<at::Tensor>& eps, int64_t seed,
-           int64_t stream_id) { return LrtLinear::apply(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id); },
+           int64_t stream_id, const c10::optional<at::Tensor>& w_s2, const c10::optional<at::Tensor>& w_ds2) {
+          return LrtLinear::apply(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, w_s2, w_ds2);
+        },
         "BBBLinear forward (local reparameterisation) with its fused backward", py::arg("x"), py::arg("w_mu"),
         py::arg("w_rho"), py::arg("b_mu"), py::arg("b_rho"), py::arg("clamp_bias"), py::arg("eps"), py::arg("seed"),
-        py::arg("stream_id"));
+        py::arg("stream_id"), py::arg("w_s2") = py::none(), py::arg("w_ds2") = py::none());
   m.def("local_reparam",
         [](const at::Tensor& mean, const at::Tensor& var, const c10::optional<at::Tensor>& eps, int64_t seed,
            int64_t stream_id) { return LocalReparam::apply(mean, var, eps, seed, stream_id); },

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(kLrtWavesPerWG * 64) void lrt_partial_kernel(
 // per (tile, group) goes to the workspace: 4 x fewer partial bytes than one partial per wave.
 constexpr int kWideChunk = 32, kWideLd = 36, kWideSub = 4;
 
-template <int NB>
+// PRE: `w_rho` is not rho but the cached clamp(softplus(rho)^2, 1e-4) of this weight version (bde_lrt_sigma_cache):
+// same bytes, no transcendental in the loop.
+template <int NB, bool PRE>
 __global__ __launch_bounds__(kWideSub * 64) void lrt_wide_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_mu, const float* __restrict__ w_rho, int B,
     int I, int O, int n_groups, int kgroup, float* __restrict__ ws) {
@@ -168,9 +170,13 @@ __global__ __launch_bounds__(kWideSub * 64) void lrt_wide_kernel(
       f32x4 m, v;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float sp = softplus(q.wr[j][c]);
         m[c] = ok ? q.wm[j][c] : 0.f;
-        v[c] = ok ? fmaxf(sp * sp, kLrtClamp) : 0.f;               // clamp(softplus(rho)^2, 1e-4)
+        if (PRE) {
+          v[c] = ok ? q.wr[j][c] : 0.f;
+        } else {
+          const float sp = softplus(q.wr[j][c]);
+          v[c] = ok ? fmaxf(sp * sp, kLrtClamp) : 0.f;             // clamp(softplus(rho)^2, 1e-4)
+        }
       }
       *reinterpret_cast<f32x4*>(Wm + (8 * j + lr) * kWideLd + lc) = m;
       *reinterpret_cast<f32x4*>(S2 + (8 * j + lr) * kWideLd + lc) = v;
@@ -312,18 +318,50 @@ static inline LrtWidePlan lrt_wide_plan(int I, int O) {
   const int kgroup = ((I + want - 1) / want + unit - 1) / unit * unit;
   return LrtWidePlan{(I + kgroup - 1) / kgroup, kgroup};
 }
-template <int NB>
+template <int NB, bool PRE>
 static int lrt_wide_launch(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, int B, int I, int O,
                            const LrtWidePlan& plan, float* ws, hipStream_t s) {
   constexpr int tile_bytes = kWideSub * (64 + NB * 32) * kWideLd * 4, red_bytes = 3 * 2 * NB * 16 * 64 * 4;
   constexpr int lds_bytes = tile_bytes > red_bytes ? tile_bytes : red_bytes;
-  static int attr_rc = to_err(hipFuncSetAttribute(reinterpret_cast<const void*>(&lrt_wide_kernel<NB>),
+  static int attr_rc = to_err(hipFuncSetAttribute(reinterpret_cast<const void*>(&lrt_wide_kernel<NB, PRE>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   if (attr_rc) return attr_rc;
   const int o_tiles = (O + 31) / 32;
-  hipLaunchKernelGGL((lrt_wide_kernel<NB>), dim3(o_tiles * plan.n_groups), dim3(kWideSub * 64), lds_bytes, s, x, ldx,
+  hipLaunchKernelGGL((lrt_wide_kernel<NB, PRE>), dim3(o_tiles * plan.n_groups), dim3(kWideSub * 64), lds_bytes, s, x, ldx,
                      w_mu, w_rho, B, I, O, plan.n_groups, plan.kgroup, ws);
   return to_err(hipGetLastError());
+}
+
+// sigma^2 = clamp(softplus(rho)^2, 1e-4) and d sigma^2 / d rho = [sigma^2 >= 1e-4] * 2 sigma sigmoid(rho) of a weight
+// matrix, once per weight VERSION: the wide-layer kernels of all Monte-Carlo forward / backward passes of an optimizer
+// step (bbb.py:63-67 runs mc_samples of them between two base_optimizer.step() calls) then read these instead of
+// evaluating softplus / sigmoid per weight per pass.  Same expressions as the kernels: bit-identical results.
+__global__ __launch_bounds__(kBlock) void lrt_sigma_cache_kernel(const float* __restrict__ rho, float* __restrict__ s2,
+                                                                float* __restrict__ ds2, int64_t n) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 r = ld4_nt(rho + 4 * i);
+    f32x4 a, b;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const SoftplusSigmoid sp = softplus_sigmoid(r[c]);
+      const float keep = sp.sp * sp.sp >= kLrtClamp ? 1.f : 0.f;
+      a[c] = fmaxf(sp.sp * sp.sp, kLrtClamp);
+      b[c] = keep * (2.0f * sp.sp * sp.sg);
+    }
+    st4(s2 + 4 * i, a);
+    if (ds2) st4(ds2 + 4 * i, b);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    if (e < n) {
+      const SoftplusSigmoid sp = softplus_sigmoid(rho[e]);
+      const float keep = sp.sp * sp.sp >= kLrtClamp ? 1.f : 0.f;
+      s2[e] = fmaxf(sp.sp * sp.sp, kLrtClamp);
+      if (ds2) ds2[e] = keep * (2.0f * sp.sp * sp.sg);
+    }
+  }
 }
 
 extern "C" int bde_lrt_linear_supported(int B, int I, int O) {
@@ -339,10 +377,19 @@ extern "C" size_t bde_lrt_linear_ws_bytes(int B, int I, int O) {
   return sizeof(float) * static_cast<size_t>(slices) * 2 * b_pad * o_pad;
 }
 
-extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* b_mu,
-                                  const float* b_rho, int clamp_bias_var, const float* eps, uint64_t seed,
-                                  uint64_t stream_id, float* out, float* var_out, int B, int I, int O, void* ws,
-                                  void* stream) {
+extern "C" int bde_lrt_sigma_cache_wanted(int I, int O) { return lrt_wide_shape(I, O) ? 1 : 0; }
+
+extern "C" int bde_lrt_sigma_cache(const float* w_rho, float* s2, float* ds2, int64_t n, void* stream) {
+  if (!w_rho || !s2 || n < 1 || !aligned16(w_rho) || !aligned16(s2) || (ds2 && !aligned16(ds2))) return BDE_ERR_INVALID;
+  hipLaunchKernelGGL(lrt_sigma_cache_kernel, dim3(stream_grid((n + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     w_rho, s2, ds2, n);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* w_s2,
+                                  const float* b_mu, const float* b_rho, int clamp_bias_var, const float* eps,
+                                  uint64_t seed, uint64_t stream_id, float* out, float* var_out, int B, int I, int O,
+                                  void* ws, void* stream) {
   if (!x || !w_mu || !w_rho || !out || !ws || !bde_lrt_linear_supported(B, I, O) || ldx < I) return BDE_ERR_INVALID;
   if ((b_mu == nullptr) != (b_rho == nullptr)) return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -358,9 +405,14 @@ extern "C" int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu
   if (wide) {
     const LrtWidePlan wp = lrt_wide_plan(I, O);
     n_slices = wp.n_groups;
-    rc = nb == 1 ? lrt_wide_launch<1>(x, ldx, w_mu, w_rho, B, I, O, wp, wsf, s)
-                 : nb == 2 ? lrt_wide_launch<2>(x, ldx, w_mu, w_rho, B, I, O, wp, wsf, s)
-                           : lrt_wide_launch<4>(x, ldx, w_mu, w_rho, B, I, O, wp, wsf, s);
+    if (w_s2 && aligned16(w_s2))      // the cached sigma^2 of this weight version instead of rho
+      rc = nb == 1 ? lrt_wide_launch<1, true>(x, ldx, w_mu, w_s2, B, I, O, wp, wsf, s)
+                   : nb == 2 ? lrt_wide_launch<2, true>(x, ldx, w_mu, w_s2, B, I, O, wp, wsf, s)
+                             : lrt_wide_launch<4, true>(x, ldx, w_mu, w_s2, B, I, O, wp, wsf, s);
+    else
+      rc = nb == 1 ? lrt_wide_launch<1, false>(x, ldx, w_mu, w_rho, B, I, O, wp, wsf, s)
+                   : nb == 2 ? lrt_wide_launch<2, false>(x, ldx, w_mu, w_rho, B, I, O, wp, wsf, s)
+                             : lrt_wide_launch<4, false>(x, ldx, w_mu, w_rho, B, I, O, wp, wsf, s);
     if (rc) return rc;
   } else {
     const int units = o_tiles * n_slices;

@@ -92,6 +92,8 @@ __global__ __launch_bounds__(kPrepCols* kPrepRows) void lrt_bwd_prep_kernel(
 }
 
 // Both weight gradients of one 32 x 32 tile of [O, I]: D[m = o][n = i] = sum_b A[o][b] B[b][i].
+// PRE: `w_rho` is the cached chain-rule factor [sigma^2 >= 1e-4] * 2 sigma sigmoid(rho) (bde_lrt_sigma_cache).
+template <bool PRE>
 __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_w_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_rho, const float* __restrict__ g,
     const float* __restrict__ gvar, int B, int I, int O, float* __restrict__ g_wmu, float* __restrict__ g_wrho) {
@@ -147,10 +149,14 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_w_kernel(
     const int oo = ot * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
     if (oo < O) {
       const int64_t idx = static_cast<int64_t>(oo) * I + i;
-      const SoftplusSigmoid sp = softplus_sigmoid(rho[reg]);
-      const float keep = sp.sp * sp.sp >= kLrtBwdClamp ? 1.f : 0.f;
       g_wmu[idx] = accm[reg];
-      g_wrho[idx] = accv[reg] * keep * (2.0f * sp.sp * sp.sg);
+      if (PRE) {
+        g_wrho[idx] = accv[reg] * rho[reg];
+      } else {
+        const SoftplusSigmoid sp = softplus_sigmoid(rho[reg]);
+        const float keep = sp.sp * sp.sp >= kLrtBwdClamp ? 1.f : 0.f;
+        g_wrho[idx] = accv[reg] * keep * (2.0f * sp.sp * sp.sg);
+      }
     }
   }
 }
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_w_kernel(
 // (lanes along i).  Register double buffering: the loads of the next 4 k-steps are issued before the softplus / MFMA
 // work of the current ones.  DIRECT: the slice is all of O and the epilogue writes g_x; otherwise the two partial
 // tiles go to the workspace.
-template <int NB, bool DIRECT>
+// PRE: `w_rho` is the cached clamp(softplus(rho)^2, 1e-4).
+template <int NB, bool DIRECT, bool PRE>
 __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_x_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_mu, const float* __restrict__ w_rho,
     const float* __restrict__ gT, const float* __restrict__ gvT, int B, int I, int O, int n_slices, int oslice,
@@ -203,8 +210,14 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_x_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool w_ok = (ob0 + 2 * u + h < o1) && i_ok;           // rows past the slice / columns past I add zeros
-      const float sg = softplus(cur.wr[u]);
-      const float bm = w_ok ? cur.wm[u] : 0.f, bv = w_ok ? fmaxf(sg * sg, kLrtBwdClamp) : 0.f;
+      float s2;
+      if (PRE) {
+        s2 = cur.wr[u];
+      } else {
+        const float sg = softplus(cur.wr[u]);
+        s2 = fmaxf(sg * sg, kLrtBwdClamp);
+      }
+      const float bm = w_ok ? cur.wm[u] : 0.f, bv = w_ok ? s2 : 0.f;
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
         accm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.ag[u][t], bm, accm[t], 0, 0, 0);
@@ -419,8 +432,8 @@ extern "C" size_t bde_lrt_linear_bwd_ws_bytes(int B, int I, int O) {
   return sizeof(float) * floats;
 }
 
-extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho,
-                                  const float* b_rho, int clamp_bias_var, const float* g, const float* var,
+extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* w_s2,
+                                  const float* w_ds2, const float* b_rho, int clamp_bias_var, const float* g, const float* var,
                                   const float* eps, uint64_t seed, uint64_t stream_id, float* g_x, float* g_wmu,
                                   float* g_wrho, float* g_bmu, float* g_brho, int B, int I, int O, void* ws,
                                   void* stream) {
@@ -448,19 +461,31 @@ extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu
   // Wide layers keep the two kernels: the fused kernel's register set (352 VGPRs at 2 batch tiles, spills at 4) leaves
   // one wave per SIMD and its per-tile chain un-overlapped (4096 x 4096 at batch 64: 303 vs 180 us).
   const bool fused = g_x && nb <= 2 && static_cast<int64_t>(I) * O <= (int64_t{1} << 20);
+  const bool pre = !fused && w_s2 && w_ds2;    // cached sigma^2 / its rho-derivative of this weight version
   if (!fused) {                          // weight gradients: one wave per 32 x 32 tile
     const int64_t w_units = static_cast<int64_t>(i_tiles) * o_tiles;
-    hipLaunchKernelGGL(lrt_bwd_w_kernel, dim3(static_cast<unsigned>((w_units + kLrtBwdWaves - 1) / kLrtBwdWaves)),
-                       dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_rho, g, gvar, B, I, O, g_wmu, g_wrho);
+    const dim3 wgrid(static_cast<unsigned>((w_units + kLrtBwdWaves - 1) / kLrtBwdWaves));
+    if (pre)
+      hipLaunchKernelGGL(lrt_bwd_w_kernel<true>, wgrid, dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_ds2, g, gvar, B, I, O, g_wmu,
+                         g_wrho);
+    else
+      hipLaunchKernelGGL(lrt_bwd_w_kernel<false>, wgrid, dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_rho, g, gvar, B, I, O,
+                         g_wmu, g_wrho);
     rc = to_err(hipGetLastError());
     if (rc || !g_x) return rc;
   }
   const LrtBwdPlan plan = lrt_bwd_plan(I, O);
   const int x_units = i_tiles * plan.n_slices;
   const int xgrid = (x_units + kLrtBwdWaves - 1) / kLrtBwdWaves;
-#define BDE_LRT_X(NB, DIRECT) \
-  hipLaunchKernelGGL((lrt_bwd_x_kernel<NB, DIRECT>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu, w_rho, gT, \
-                     gvT, B, I, O, plan.n_slices, plan.oslice, g_x, part)
+#define BDE_LRT_X(NB, DIRECT)                                                                                              \
+  do {                                                                                                                     \
+    if (pre)                                                                                                               \
+      hipLaunchKernelGGL((lrt_bwd_x_kernel<NB, DIRECT, true>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu,    \
+                         w_s2, gT, gvT, B, I, O, plan.n_slices, plan.oslice, g_x, part);                                   \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((lrt_bwd_x_kernel<NB, DIRECT, false>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu,   \
+                         w_rho, gT, gvT, B, I, O, plan.n_slices, plan.oslice, g_x, part);                                  \
+  } while (0)
 #define BDE_LRT_F(NB, DIRECT) \
   hipLaunchKernelGGL((lrt_bwd_fused_kernel<NB, DIRECT>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu, w_rho, g, \
                      gvar, gT, gvT, B, I, O, plan.n_slices, plan.oslice, g_wmu, g_wrho, g_x, part)

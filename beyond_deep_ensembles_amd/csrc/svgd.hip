@@ -251,8 +251,10 @@ __global__ __launch_bounds__(kBlock) void svgd_combine_seg_kernel(const float* _
                                                                  float* out, int64_t ld,
                                                                  const float* __restrict__ cgT,
                                                                  const float* __restrict__ cpT) {
-  for (int q = blockIdx.x; q < n_chunks; q += gridDim.x) {
-    const SegChunk ch = chunks[q];
+  SegChunk ch = {}, ch_next = {};
+  if (static_cast<int>(blockIdx.x) < n_chunks) ch = chunks[blockIdx.x];
+  for (int q = blockIdx.x; q < n_chunks; q += gridDim.x, ch = ch_next) {
+    if (q + static_cast<int>(gridDim.x) < n_chunks) ch_next = chunks[q + gridDim.x];   // next descriptor in flight early
     const int valid = ch.nflt - 4 * static_cast<int>(threadIdx.x);
     if (valid <= 0) continue;
     const float* const* gp = seg_ptrs + static_cast<int64_t>(ch.seg) * M;

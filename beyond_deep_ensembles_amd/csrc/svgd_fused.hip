@@ -52,12 +52,16 @@ __global__ __launch_bounds__(kBlock) void svgd_fused_kernel(float* __restrict__ 
   const int64_t n_iter = SEG ? static_cast<int64_t>(n_chunks) : n4;
   const int64_t it0 = SEG ? static_cast<int64_t>(blockIdx.x) : static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t it_step = SEG ? static_cast<int64_t>(gridDim.x) : stride;
-  for (int64_t it = it0; it < n_iter; it += it_step) {
+  // SEG: the descriptor of the NEXT chunk is requested before this chunk's work, so that only the (wave-uniform) load
+  // of the M gradient pointers is on an iteration's critical path, and that one overlaps the particle loads
+  SegChunk ch = {}, ch_next = {};
+  if (SEG && it0 < n_iter) ch = chunks[it0];
+  for (int64_t it = it0; it < n_iter; it += it_step, ch = ch_next) {
     int64_t i4 = it, l4 = 0;
     int valid = 4;
     const float* const* gp = nullptr;
     if (SEG) {
-      const SegChunk ch = chunks[it];
+      if (it + it_step < n_iter) ch_next = chunks[it + it_step];
       valid = ch.nflt - 4 * static_cast<int>(threadIdx.x);
       if (valid <= 0) continue;
       gp = seg_ptrs + static_cast<int64_t>(ch.seg) * M;

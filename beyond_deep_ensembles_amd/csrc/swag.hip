@@ -64,9 +64,10 @@ __global__ __launch_bounds__(kBlock) void swag_copy_row_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------- sample --
+template <int ROUNDS>
 __device__ __forceinline__ float lowrank_noise(const float* __restrict__ eps_w, uint64_t seed, uint64_t stream_id, int c) {
   if (eps_w) return eps_w[c];
-  const f32x4 z = philox_normal4(seed, stream_id, static_cast<uint64_t>(c >> 2), kDomainLowRank);
+  const f32x4 z = philox_normal4<ROUNDS>(seed, stream_id, static_cast<uint64_t>(c >> 2), kDomainLowRank);
   return z[c & 3];
 }
 
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
   for (int r = threadIdx.x; r < K; r += blockDim.x) {
     int c = r - head;
     if (c < 0) c += K;
-    w[r] = lowrank_noise(eps_w, seed, stream_id, c) / denom;
+    w[r] = lowrank_noise<kSwagPhiloxRounds>(eps_w, seed, stream_id, c) / denom;
   }
   __syncthreads();
 
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
         const int64_t o = piece_off(4 * c, L);
         const f32x4 m = ld4_nt(mean + o);
         const f32x4 s = ld4_nt(sq + o);
-        const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(c), kDomainDiag) : ld4_nt(eps_d + 4 * c);
+        const f32x4 z = RNG ? philox_normal4<kSwagPhiloxRounds>(seed, stream_id, static_cast<uint64_t>(c), kDomainDiag)
+                            : ld4_nt(eps_d + 4 * c);
         BDE_OUT_ST(out + 4 * c, (m + acc[u]) + diag_std(m, s) * z);
       }
     }
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
       const float m = mean[o], s = sq[o];
       float z;
       if (RNG) {
-        const f32x4 zz = philox_normal4(seed, stream_id, static_cast<uint64_t>(n4), kDomainDiag);
+        const f32x4 zz = philox_normal4<kSwagPhiloxRounds>(seed, stream_id, static_cast<uint64_t>(n4), kDomainDiag);
         z = zz[threadIdx.x & 3];
       } else {
         z = eps_d[e];
@@ -152,17 +154,18 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
 }
 
 // The Philox normals written out (tests; callers that want the noise).
+template <int ROUNDS>
 __global__ __launch_bounds__(kBlock) void philox_normal_kernel(uint64_t seed, uint64_t stream_id, float* __restrict__ eps_w,
                                                               int K, float* __restrict__ eps_d, int64_t D) {
   const int64_t gid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   if (eps_w) {
-    for (int64_t c = gid; c < K; c += stride) eps_w[c] = lowrank_noise(nullptr, seed, stream_id, static_cast<int>(c));
+    for (int64_t c = gid; c < K; c += stride) eps_w[c] = lowrank_noise<ROUNDS>(nullptr, seed, stream_id, static_cast<int>(c));
   }
   if (eps_d) {
     const int64_t n4 = (D + 3) >> 2;
     for (int64_t i = gid; i < n4; i += stride) {
-      const f32x4 z = philox_normal4(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag);
+      const f32x4 z = philox_normal4<ROUNDS>(seed, stream_id, static_cast<uint64_t>(i), kDomainDiag);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (4 * i + j < D) eps_d[4 * i + j] = z[j];
@@ -170,11 +173,12 @@ __global__ __launch_bounds__(kBlock) void philox_normal_kernel(uint64_t seed, ui
   }
 }
 
+template <int ROUNDS>
 __global__ __launch_bounds__(kBlock) void philox_bits_kernel(uint64_t seed, uint64_t stream_id, uint32_t domain,
                                                             uint64_t idx0, uint32_t* __restrict__ out, int64_t n_groups) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < n_groups; g += stride) {
-    const uint4 r = philox_bits4(seed, stream_id, idx0 + static_cast<uint64_t>(g), domain);
+    const uint4 r = philox_bits4<ROUNDS>(seed, stream_id, idx0 + static_cast<uint64_t>(g), domain);
     out[4 * g + 0] = r.x;
     out[4 * g + 1] = r.y;
     out[4 * g + 2] = r.z;
@@ -226,20 +230,31 @@ extern "C" int bde_swag_sample(const float* mean, const float* sq, const float* 
   return to_err(hipGetLastError());
 }
 
+extern "C" int bde_swag_philox_rounds(void) { return kSwagPhiloxRounds; }
+
 extern "C" int bde_philox_normal(uint64_t seed, uint64_t stream_id, float* eps_w, int K, float* eps_d, int64_t D,
-                                 void* stream) {
-  if ((!eps_w && !eps_d) || (eps_w && K < 1) || (eps_d && D < 1)) return BDE_ERR_INVALID;
+                                 int rounds, void* stream) {
+  if ((!eps_w && !eps_d) || (eps_w && K < 1) || (eps_d && D < 1) || (rounds != kPhiloxRounds && rounds != kSwagPhiloxRounds))
+    return BDE_ERR_INVALID;
   const int grid = stream_grid(eps_d ? (D + 3) / 4 : K);
-  hipLaunchKernelGGL(philox_normal_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), seed,
-                     stream_id, eps_w, K, eps_d, D);
+  if (rounds == kPhiloxRounds)
+    hipLaunchKernelGGL(philox_normal_kernel<kPhiloxRounds>, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       seed, stream_id, eps_w, K, eps_d, D);
+  else
+    hipLaunchKernelGGL(philox_normal_kernel<kSwagPhiloxRounds>, dim3(grid), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), seed, stream_id, eps_w, K, eps_d, D);
   return to_err(hipGetLastError());
 }
 
 extern "C" int bde_philox_bits(uint64_t seed, uint64_t stream_id, uint32_t domain, uint64_t idx0, uint32_t* out,
-                               int64_t n_groups, void* stream) {
-  if (!out || n_groups < 1) return BDE_ERR_INVALID;
-  hipLaunchKernelGGL(philox_bits_kernel, dim3(stream_grid(n_groups)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                     seed, stream_id, domain, idx0, out, n_groups);
+                               int64_t n_groups, int rounds, void* stream) {
+  if (!out || n_groups < 1 || (rounds != kPhiloxRounds && rounds != kSwagPhiloxRounds)) return BDE_ERR_INVALID;
+  if (rounds == kPhiloxRounds)
+    hipLaunchKernelGGL(philox_bits_kernel<kPhiloxRounds>, dim3(stream_grid(n_groups)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), seed, stream_id, domain, idx0, out, n_groups);
+  else
+    hipLaunchKernelGGL(philox_bits_kernel<kSwagPhiloxRounds>, dim3(stream_grid(n_groups)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), seed, stream_id, domain, idx0, out, n_groups);
   return to_err(hipGetLastError());
 }
 

@@ -23,7 +23,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ float lowrank_noise_b(const float* __restrict__ eps_w, uint64_t seed, uint64_t stream_id, int c) {
   if (eps_w) return eps_w[c];
-  const f32x4 z = philox_normal4(seed, stream_id, static_cast<uint64_t>(c >> 2), kDomainLowRank);
+  const f32x4 z = philox_normal4<kSwagPhiloxRounds>(seed, stream_id, static_cast<uint64_t>(c >> 2), kDomainLowRank);
   return z[c & 3];
 }
 
@@ -94,8 +94,12 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
       for (int reg = 0; reg < 16; ++reg) {
         const int s = (reg & 3) + 8 * (reg >> 2) + 4 * half;   // C/D row of the 32x32 tile
         if (s < S) {
-          const f32x4 z = RNG ? philox_normal4(seed, stream0 + s, static_cast<uint64_t>(g4), kDomainDiag)
+#ifdef BDE_BATCHED_NO_RNG   // tools/swag_piece_sweep.py only: the memory + MFMA side of the kernel without the noise epilogue
+          const f32x4 z = {1.f, 1.f, 1.f, 1.f};
+#else
+          const f32x4 z = RNG ? philox_normal4<kSwagPhiloxRounds>(seed, stream0 + s, static_cast<uint64_t>(g4), kDomainDiag)
                               : ld4_nt(eps_d + static_cast<int64_t>(s) * ld_eps + 4 * g4);
+#endif
           const f32x4 lr = {acc0[reg], acc1[reg], acc2[reg], acc3[reg]};
           st4_nt(out + static_cast<int64_t>(s) * ld_out + oo, (m + lr) + sd * z);
         }
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
       const float m = mean[so];
       float z;
       if (RNG) {
-        const f32x4 zz = philox_normal4(seed, stream0 + s, static_cast<uint64_t>(n4), kDomainDiag);
+        const f32x4 zz = philox_normal4<kSwagPhiloxRounds>(seed, stream0 + s, static_cast<uint64_t>(n4), kDomainDiag);
         z = zz[k];
       } else {
         z = eps_d[static_cast<int64_t>(s) * ld_eps + e];

@@ -405,7 +405,12 @@ class HipOps:
         _check(self.lib.bde_swag_copy_row(_ptr(src, "src"), lps, pss, _ptr(dst, "dst"), lpd, psd, d, _stream()),
                "bde_swag_copy_row")
 
-    def philox_normal(self, seed, stream_id, eps_w=None, eps_d=None, d=None):
+    @property
+    def swag_philox_rounds(self) -> int:
+        """Philox rounds of the SWAG samplers' in-kernel noise (7; every other draw uses the published default, 10)."""
+        return int(self.lib.bde_swag_philox_rounds())
+
+    def philox_normal(self, seed, stream_id, eps_w=None, eps_d=None, d=None, rounds=10):
         k = 0 if eps_w is None else eps_w.numel()
         n = 0 if eps_d is None else (d if d is not None else eps_d.numel())
         target = eps_d if eps_d is not None else eps_w
@@ -415,13 +420,13 @@ class HipOps:
             raise BdeKernelError("philox_normal: eps_w and eps_d live on different devices")
         pw, pd = _ptr(eps_w, "eps_w"), _ptr(eps_d, "eps_d")
         with torch.cuda.device(target.device):           # the launch goes to the stream of the OUTPUT's device
-            _check(self.lib.bde_philox_normal(seed, stream_id, pw, k, pd, n, _stream()), "bde_philox_normal")
+            _check(self.lib.bde_philox_normal(seed, stream_id, pw, k, pd, n, int(rounds), _stream()), "bde_philox_normal")
 
-    def philox_bits(self, seed, stream_id, n_groups, device, domain=0, idx0=0) -> torch.Tensor:
+    def philox_bits(self, seed, stream_id, n_groups, device, domain=0, idx0=0, rounds=10) -> torch.Tensor:
         """Raw Philox4x32-10 words [n_groups, 4] (int64 holding uint32 values) -- the known-answer hook."""
         out = torch.empty(n_groups * 4, dtype=torch.int32, device=device)
         with torch.cuda.device(out.device):
-            _check(self.lib.bde_philox_bits(seed, stream_id, domain, idx0, out.data_ptr(), n_groups, _stream()),
+            _check(self.lib.bde_philox_bits(seed, stream_id, domain, idx0, out.data_ptr(), n_groups, int(rounds), _stream()),
                    "bde_philox_bits")
         return (out.to(torch.int64) & 0xFFFFFFFF).view(n_groups, 4)
 
@@ -485,8 +490,22 @@ class HipOps:
     def lrt_linear_supported(self, b: int, i: int, o: int) -> bool:
         return bool(self.lib.bde_lrt_linear_supported(b, i, o))
 
+    def lrt_sigma_cache_wanted(self, i: int, o: int) -> bool:
+        """True for layers wide enough that the kernels read a per-weight-version sigma^2 cache instead of evaluating
+        softplus / sigmoid per weight per pass."""
+        return bool(self.lib.bde_lrt_sigma_cache_wanted(i, o))
+
     @_on_device_of
-    def lrt_linear_fwd(self, x, w_mu, w_rho, b_mu, b_rho, clamp_bias_var, out, var_out, eps=None, seed=0, stream_id=0):
+    def lrt_sigma_cache(self, w_rho, s2, ds2=None):
+        """s2 = clamp(softplus(rho)^2, 1e-4), ds2 = [sigma^2 >= 1e-4] * 2 sigma sigmoid(rho): one pass per weight version."""
+        if not (w_rho.is_contiguous() and s2.is_contiguous() and (ds2 is None or ds2.is_contiguous())):
+            raise BdeKernelError("lrt_sigma_cache: contiguous tensors expected")
+        _check(self.lib.bde_lrt_sigma_cache(_ptr(w_rho, "w_rho"), _ptr(s2), _ptr(ds2), w_rho.numel(), _stream()),
+               "bde_lrt_sigma_cache")
+
+    @_on_device_of
+    def lrt_linear_fwd(self, x, w_mu, w_rho, b_mu, b_rho, clamp_bias_var, out, var_out, eps=None, seed=0, stream_id=0,
+                       w_s2=None):
         """Fused local-reparameterisation forward of a mean-field linear layer (bbb_layers.py:61-80): x [B, I] (row
         stride free), w_mu / w_rho [O, I] contiguous, out / var_out / eps [B, O] contiguous."""
         b, i = x.shape
@@ -497,13 +516,13 @@ class HipOps:
         if n == 0:
             raise BdeKernelError(f"lrt_linear_fwd: unsupported shape B={b}, I={i}, O={o}")
         ws = torch.empty(n // 4, dtype=torch.float32, device=x.device)
-        _check(self.lib.bde_lrt_linear_fwd(_ptr(x, "x"), x.stride(0), _ptr(w_mu), _ptr(w_rho), _ptr(b_mu), _ptr(b_rho),
-                                           int(clamp_bias_var), _ptr(eps), seed, stream_id, _ptr(out), _ptr(var_out), b, i,
-                                           o, _ptr(ws), _stream()), "bde_lrt_linear_fwd")
+        _check(self.lib.bde_lrt_linear_fwd(_ptr(x, "x"), x.stride(0), _ptr(w_mu), _ptr(w_rho), _ptr(w_s2), _ptr(b_mu),
+                                           _ptr(b_rho), int(clamp_bias_var), _ptr(eps), seed, stream_id, _ptr(out),
+                                           _ptr(var_out), b, i, o, _ptr(ws), _stream()), "bde_lrt_linear_fwd")
 
     @_on_device_of
     def lrt_linear_bwd(self, x, w_mu, w_rho, b_rho, clamp_bias_var, g, var, g_x, g_wmu, g_wrho, g_bmu, g_brho, eps=None,
-                       seed=0, stream_id=0):
+                       seed=0, stream_id=0, w_s2=None, w_ds2=None):
         """Backward of lrt_linear_fwd (the autograd graph of bbb_layers.py:61-80): g / var / eps [B, O] contiguous,
         g_x [B, I] (None: not wanted), g_wmu / g_wrho [O, I], g_bmu / g_brho [O] (None with b_rho None); all
         outputs are overwritten."""
@@ -516,8 +535,8 @@ class HipOps:
         if n == 0:
             raise BdeKernelError(f"lrt_linear_bwd: unsupported shape B={b}, I={i}, O={o}")
         ws = torch.empty(n // 4, dtype=torch.float32, device=x.device)
-        _check(self.lib.bde_lrt_linear_bwd(_ptr(x, "x"), x.stride(0), _ptr(w_mu), _ptr(w_rho), _ptr(b_rho),
-                                           int(clamp_bias_var), _ptr(g), _ptr(var), _ptr(eps), seed, stream_id, _ptr(g_x),
+        _check(self.lib.bde_lrt_linear_bwd(_ptr(x, "x"), x.stride(0), _ptr(w_mu), _ptr(w_rho), _ptr(w_s2), _ptr(w_ds2),
+                                           _ptr(b_rho), int(clamp_bias_var), _ptr(g), _ptr(var), _ptr(eps), seed, stream_id, _ptr(g_x),
                                            _ptr(g_wmu), _ptr(g_wrho), _ptr(g_bmu), _ptr(g_brho), b, i, o, _ptr(ws),
                                            _stream()), "bde_lrt_linear_bwd")
 

@@ -136,6 +136,8 @@ class SVGDOptimizer(BayesianOptimizer):
         self._seg_host = None
         self._retained = [None] * m
         self._pset = None
+        # what a parameter without a gradient points the kernels at (read-only; nothing is zeroed per step)
+        self._zeros = torch.zeros(max(self._layout.numels) + 4, dtype=torch.float32, device=dev) if self._seg is not None else None
         if hasattr(self._ops, "load_code_objects"):
             self._ops.load_code_objects(dev)      # every kernel resident on THIS device before any collective / sharing
 
@@ -300,10 +302,10 @@ class SVGDOptimizer(BayesianOptimizer):
             particle_row = particle_idx
         pset = self._particle_set()
         if pset is not None:
-            pset.end(particle_idx, self._seg_host, particle_row, self._seg.m)
+            pset.end(particle_idx, self._seg_host, particle_row, self._seg.m, self._zeros.data_ptr())
             return
         self._retained[particle_row] = collect_grads(self._plist, self._gviews[particle_idx], self._seg_host,
-                                                     particle_row, self._seg.m)
+                                                     particle_row, self._seg.m, self._zeros.data_ptr())
         clear_grads(self._plist)
 
     def _grads_to_rows(self, G: torch.Tensor, row0: int, n_rows: int) -> None:
@@ -796,7 +798,7 @@ class SVGDOptimizer(BayesianOptimizer):
             if self._layout.padded:
                 self._P[:, self._layout.valid_index(self._P.device)] = particles.to(self._P.device, torch.float32)
             else:
-                self._P[:, :self._layout.d] = particles.to(self._P.device, torch.float32)
+                self._P[:, :self._layout.n_valid] = particles.to(self._P.device, torch.float32)
         self._gram_valid = False
 
     @property

@@ -278,18 +278,24 @@ int bde_swag_sample_batched(const float* mean, const float* sq, const float* dev
 int bde_swag_copy_row(const float* src, int log2_piece_src, int64_t piece_stride_src, float* dst, int log2_piece_dst,
                       int64_t piece_stride_dst, int64_t D, void* stream);
 
-/* The Philox normals bde_swag_sample would use, written out (for tests and for
- * callers that want the noise): eps_w [K] and/or eps_d [D] (either may be NULL). */
-int bde_philox_normal(uint64_t seed, uint64_t stream_id, float* eps_w, int K, float* eps_d, int64_t D,
+/* In-kernel noise: Philox4x32 (Salmon et al., SC'11) keyed by `seed`, counter = (float4 index, stream id, domain),
+ * normals by Box-Muller on the top 24 bits of each word.  `rounds`: 10 = the published default, used by every draw of
+ * the BBB / iVON / layer kernels; bde_swag_philox_rounds() (= 7, the fewest rounds the paper reports as
+ * Crush-resistant) is what bde_swag_sample / bde_swag_sample_batched use for their S x D normals per pass.
+ *
+ * The normals a kernel would use, written out (for tests and for callers that want the noise): eps_w [K] (the
+ * low-rank weights' domain) and/or eps_d [D] (either may be NULL). */
+int bde_swag_philox_rounds(void);
+int bde_philox_normal(uint64_t seed, uint64_t stream_id, float* eps_w, int K, float* eps_d, int64_t D, int rounds,
                       void* stream);
 
-/* The raw Philox4x32-10 words behind every in-kernel noise draw: for g in [0, n_groups)
- * out[4g .. 4g+3] = Philox4x32-10(counter = (lo32(idx0+g), hi32(idx0+g), lo32(stream_id),
+/* The raw Philox4x32 words behind every in-kernel noise draw: for g in [0, n_groups)
+ * out[4g .. 4g+3] = Philox4x32-<rounds>(counter = (lo32(idx0+g), hi32(idx0+g), lo32(stream_id),
  * hi32(stream_id) ^ domain), key = (lo32(seed), hi32(seed))).  Lets the tests pin the
- * generator against the published Random123 known-answer vectors (domain 0 = the diagonal /
+ * generator against the published Random123 known-answer vectors (10 rounds; domain 0 = the diagonal /
  * element noise, 0x80000000 = the low-rank weights of the SWAG sampler). */
 int bde_philox_bits(uint64_t seed, uint64_t stream_id, uint32_t domain, uint64_t idx0, uint32_t* out,
-                    int64_t n_groups, void* stream);
+                    int64_t n_groups, int rounds, void* stream);
 
 /* ------------------------------------------------- mean-field Gaussian (BBB) --
  * src/algos/util.py:151-183 (GaussianParameter) and bbb.py:18-21 (KL). */
@@ -364,9 +370,18 @@ int bde_var_operand_bwd(const float* g, const float* v, int mode, float* gv, int
  * activation variance the backward pass needs. */
 int bde_lrt_linear_supported(int B, int I, int O);
 size_t bde_lrt_linear_ws_bytes(int B, int I, int O);
-int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* b_mu,
-                       const float* b_rho, int clamp_bias_var, const float* eps, uint64_t seed, uint64_t stream_id,
-                       float* out, float* var_out, int B, int I, int O, void* ws, void* stream);
+int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* w_s2,
+                       const float* b_mu, const float* b_rho, int clamp_bias_var, const float* eps, uint64_t seed,
+                       uint64_t stream_id, float* out, float* var_out, int B, int I, int O, void* ws, void* stream);
+/* sigma^2 cache for WIDE layers (bde_lrt_sigma_cache_wanted(I, O): O * I >= 2^20, I % 4 == 0; there the kernels are
+ * co-bound by the softplus / sigmoid evaluations, the fp32 MFMA and HBM).  The weights only change at
+ * base_optimizer.step(), but BBB runs mc_samples forward + backward passes per step (bbb.py:63-67): one pass
+ *   s2 = clamp(softplus(rho)^2, 1e-4),   ds2 = [sigma^2 >= 1e-4] * 2 sigma sigmoid(rho)      (ds2 may be NULL)
+ * per weight VERSION, then every forward (w_s2) and backward (w_s2, w_ds2) of that version reads these instead of
+ * evaluating the transcendentals per weight per pass -- same bytes read, identical bits.  Pass NULL to compute on
+ * the fly; narrow layers ignore the cache. */
+int bde_lrt_sigma_cache_wanted(int I, int O);
+int bde_lrt_sigma_cache(const float* w_rho, float* s2, float* ds2, int64_t n, void* stream);
 
 /* Backward of bde_lrt_linear_fwd: the autograd graph of bbb_layers.py:61-80 in two launches for layers of up to 2^20
  * weights (one pass over the weights for all three matrix gradients), three or four for larger ones.  With g = d loss / d out [B, O] and
@@ -379,10 +394,10 @@ int bde_lrt_linear_fwd(const float* x, int64_t ldx, const float* w_mu, const flo
  * (b_rho, g_bmu, g_brho all NULL for a bias-free layer).  Every output is OVERWRITTEN (autograd accumulates).
  * Reductions are MFMA tiles and fixed-order sums: bit-reproducible.  ws: bde_lrt_linear_bwd_ws_bytes(B, I, O). */
 size_t bde_lrt_linear_bwd_ws_bytes(int B, int I, int O);
-int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* b_rho,
-                       int clamp_bias_var, const float* g, const float* var, const float* eps, uint64_t seed,
-                       uint64_t stream_id, float* g_x, float* g_wmu, float* g_wrho, float* g_bmu, float* g_brho,
-                       int B, int I, int O, void* ws, void* stream);
+int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu, const float* w_rho, const float* w_s2,
+                       const float* w_ds2, const float* b_rho, int clamp_bias_var, const float* g, const float* var,
+                       const float* eps, uint64_t seed, uint64_t stream_id, float* g_x, float* g_wmu, float* g_wrho,
+                       float* g_bmu, float* g_brho, int B, int I, int O, void* ws, void* stream);
 
 /* ------------------------------------------------------------------ iVON --
  * src/algos/ivorn.py:102-115 (weight-noise draw) and :66-89 (update). */

@@ -25,6 +25,9 @@ import numpy as np
 M0, M1 = 0xD2511F53, 0xCD9E8D57          # round multipliers
 W0, W1 = 0x9E3779B9, 0xBB67AE85          # Weyl key increments (golden ratio, sqrt(3) - 1)
 DOMAIN_DIAG, DOMAIN_LOWRANK = 0x0, 0x80000000
+ROUNDS = 10            # the published default: every draw of the BBB / iVON / layer kernels
+SWAG_ROUNDS = 7        # the SWAG samplers' noise (bde_swag_philox_rounds): the fewest rounds the paper reports as
+                       # Crush-resistant; the same round function and key schedule, three rounds fewer
 
 # (counter[4], key[2]) -> output[4]; Random123 kat_vectors, philox4x32 with 10 rounds
 KAT = [
@@ -51,15 +54,16 @@ def philox4x32(counter: np.ndarray, key, rounds: int = 10) -> np.ndarray:
     return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
 
 
-def stream_bits(seed: int, stream_id: int, n_groups: int, domain: int = DOMAIN_DIAG, idx0: int = 0) -> np.ndarray:
-    """The words ``bde_philox_bits(seed, stream_id, domain, idx0, ..., n_groups)`` must return: ``[n_groups, 4]``."""
+def stream_bits(seed: int, stream_id: int, n_groups: int, domain: int = DOMAIN_DIAG, idx0: int = 0,
+                rounds: int = ROUNDS) -> np.ndarray:
+    """The words ``bde_philox_bits(seed, stream_id, domain, idx0, ..., n_groups, rounds)`` must return: ``[n_groups, 4]``."""
     g = (np.arange(n_groups, dtype=np.uint64) + np.uint64(idx0 & 0xFFFFFFFFFFFFFFFF))
     ctr = np.empty((n_groups, 4), dtype=np.uint64)
     ctr[:, 0] = g & np.uint64(0xFFFFFFFF)
     ctr[:, 1] = g >> np.uint64(32)
     ctr[:, 2] = stream_id & 0xFFFFFFFF
     ctr[:, 3] = ((stream_id >> 32) & 0xFFFFFFFF) ^ domain
-    return philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    return philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF), rounds)
 
 
 def box_muller(bits: np.ndarray) -> np.ndarray:
@@ -76,7 +80,7 @@ def box_muller(bits: np.ndarray) -> np.ndarray:
     return np.stack([r0 * np.cos(a0), r0 * np.sin(a0), r1 * np.cos(a1), r1 * np.sin(a1)], axis=1)
 
 
-def normals(seed: int, stream_id: int, n: int, domain: int = DOMAIN_DIAG) -> np.ndarray:
+def normals(seed: int, stream_id: int, n: int, domain: int = DOMAIN_DIAG, rounds: int = ROUNDS) -> np.ndarray:
     """float64 normals of elements ``0 .. n-1`` of a stream (what ``bde_philox_normal`` writes, before fp32 rounding)."""
     groups = (n + 3) // 4
-    return box_muller(stream_bits(seed, stream_id, groups, domain)).reshape(-1)[:n]
+    return box_muller(stream_bits(seed, stream_id, groups, domain, rounds=rounds)).reshape(-1)[:n]

@@ -11,9 +11,9 @@ from oracle import bde_oracle as O
 from oracle import philox as PH
 
 
-def _philox(seed, stream_id, n, domain=PH.DOMAIN_DIAG):
+def _philox(seed, stream_id, n, domain=PH.DOMAIN_DIAG, rounds=PH.ROUNDS):
     """The in-kernel noise of rng="philox" (csrc/bde_common.hpp), evaluated by the numpy checker."""
-    return torch.from_numpy(PH.normals(int(seed), int(stream_id), int(n), domain)).float()
+    return torch.from_numpy(PH.normals(int(seed), int(stream_id), int(n), domain, rounds)).float()
 
 
 def pad4(n, mult=64):
@@ -234,7 +234,8 @@ class OracleOps:
     def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0, pieces=None):
         k = dev.shape[0]
         if eps_w is None:
-            eps_w, eps_d = _philox(seed, stream_id, k, PH.DOMAIN_LOWRANK), _philox(seed, stream_id, d)
+            eps_w = _philox(seed, stream_id, k, PH.DOMAIN_LOWRANK, PH.SWAG_ROUNDS)       # the samplers' 7-round streams
+            eps_d = _philox(seed, stream_id, d, rounds=PH.SWAG_ROUNDS)
         out[:d] = O.swag_sample(self._get_row(mean, pieces, d), self._get_row(sq, pieces, d),
                                 self._logical(dev, head, d, pieces), eps_w, eps_d[:d])
 
@@ -307,12 +308,14 @@ class OracleOps:
             else:
                 gmean[:n] = g
 
-    def philox_normal(self, seed, stream_id, eps_w=None, eps_d=None, d=None):
+    swag_philox_rounds = PH.SWAG_ROUNDS
+
+    def philox_normal(self, seed, stream_id, eps_w=None, eps_d=None, d=None, rounds=PH.ROUNDS):
         if eps_w is not None:
-            eps_w.copy_(_philox(seed, stream_id, eps_w.numel(), PH.DOMAIN_LOWRANK))
+            eps_w.copy_(_philox(seed, stream_id, eps_w.numel(), PH.DOMAIN_LOWRANK, rounds))
         if eps_d is not None:
             n = d if d is not None else eps_d.numel()
-            eps_d[:n] = _philox(seed, stream_id, n)
+            eps_d[:n] = _philox(seed, stream_id, n, rounds=rounds)
 
     def local_reparam_fwd(self, mean, var, out, n, eps=None, seed=0, stream_id=0):
         if eps is None:
@@ -345,7 +348,17 @@ class OracleOps:
     def lrt_linear_supported(self, b, i, o):
         return 1 <= b <= 128
 
-    def lrt_linear_fwd(self, x, w_mu, w_rho, b_mu, b_rho, clamp_bias_var, out, var_out, eps=None, seed=0, stream_id=0):
+    def lrt_sigma_cache_wanted(self, i, o):
+        return i % 4 == 0 and i >= 512 and i * o >= (1 << 20)
+
+    def lrt_sigma_cache(self, w_rho, s2, ds2=None):
+        sp = torch.nn.functional.softplus(w_rho)
+        s2.copy_((sp ** 2).clamp(min=1e-4))
+        if ds2 is not None:
+            ds2.copy_((sp ** 2 >= 1e-4).float() * 2 * sp * torch.sigmoid(w_rho))
+
+    def lrt_linear_fwd(self, x, w_mu, w_rho, b_mu, b_rho, clamp_bias_var, out, var_out, eps=None, seed=0, stream_id=0,
+                       w_s2=None):
         # bbb_layers.py:70-80 with torch ops
         sw = torch.nn.functional.softplus(w_rho)
         mean = torch.nn.functional.linear(x, w_mu, b_mu)
@@ -362,7 +375,7 @@ class OracleOps:
         out.copy_(mean + torch.sqrt(var) * eps)
 
     def lrt_linear_bwd(self, x, w_mu, w_rho, b_rho, clamp_bias_var, g, var, g_x, g_wmu, g_wrho, g_bmu, g_brho, eps=None,
-                       seed=0, stream_id=0):
+                       seed=0, stream_id=0, w_s2=None, w_ds2=None):
         # torch autograd over the forward lines (bbb_layers.py:70-80)
         if eps is None:
             eps = _philox(seed, stream_id, g.numel()).view(g.shape)

@@ -290,9 +290,10 @@ def test_multiswag_densenet121_fanout_eight_ranks_one_device(tmp_path):
         member = int(np.searchsorted(starts, unit, side="right") - 1)
         s = unit - int(starts[member])
         opt = ens.optimizers[member]
-        eps_w = torch.from_numpy(PH.normals(opt.seed, s, K, PH.DOMAIN_LOWRANK)).float()
-        head = PH.box_muller(PH.stream_bits(opt.seed, s, PROBE_HEAD // 4)).reshape(-1)
-        tail = PH.box_muller(PH.stream_bits(opt.seed, s, (D121 + 3) // 4 - g_tail0, idx0=g_tail0)).reshape(-1)
+        rd = PH.SWAG_ROUNDS                                             # the samplers' noise streams
+        eps_w = torch.from_numpy(PH.normals(opt.seed, s, K, PH.DOMAIN_LOWRANK, rounds=rd)).float()
+        head = PH.box_muller(PH.stream_bits(opt.seed, s, PROBE_HEAD // 4, rounds=rd)).reshape(-1)
+        tail = PH.box_muller(PH.stream_bits(opt.seed, s, (D121 + 3) // 4 - g_tail0, idx0=g_tail0, rounds=rd)).reshape(-1)
         tail = tail[(D121 - PROBE_TAIL) - 4 * g_tail0:][:PROBE_TAIL]
         mean, sq, dk = opt.mean_vector(), opt.sq_vector(), opt.deviations_dk()
         for sl, eps, cols in ((slice(0, PROBE_HEAD), head, slice(0, PROBE_HEAD)),

@@ -762,7 +762,8 @@ def test_philox_streams(ops):
     ring = torch.randn(kk, ldd, device=DEV) * 1e-3
     o1, o2 = torch.zeros(ldd, device=DEV), torch.zeros(ldd, device=DEV)
     ew, ed = torch.zeros(kk, device=DEV), torch.zeros(ldd, device=DEV)
-    ops.philox_normal(99, 5, eps_w=ew, eps_d=ed, d=dd)
+    assert ops.swag_philox_rounds == 7
+    ops.philox_normal(99, 5, eps_w=ew, eps_d=ed, d=dd, rounds=ops.swag_philox_rounds)    # the samplers' 7-round streams
     ops.swag_sample(mean, sq, ring, 3, o1, dd, seed=99, stream_id=5)
     ops.swag_sample(mean, sq, ring, 3, o2, dd, eps_w=ew, eps_d=ed)
     assert torch.equal(o1[:dd], o2[:dd])
@@ -1238,6 +1239,41 @@ def test_var_operand_kernels(ops):
                 assert gv[1].item() == 0.0 and out[1].item() == pytest.approx(1e-4)
             if mode == 2 and n > 2:
                 assert gv[1].item() != 0.0
+
+
+def test_lrt_sigma_cache_is_bit_identical(ops):
+    """Wide layers: sigma^2 = clamp(softplus(rho)^2, 1e-4) and its rho-derivative computed ONCE per weight version
+    (bde_lrt_sigma_cache) and read by the fused forward / backward instead of evaluating softplus / sigmoid per weight per
+    pass.  Same expressions, so outputs and all five gradients equal the on-the-fly kernels bit for bit; narrow layers
+    ignore the cache."""
+    torch.manual_seed(29)
+    for b, i, o in [(64, 1024, 1100), (128, 2048, 700), (20, 640, 2000), (33, 4096, 512), (16, 256, 64)]:
+        wide = ops.lrt_sigma_cache_wanted(i, o)
+        assert wide == (i * o >= (1 << 20))
+        x = torch.randn(b, i, device=DEV)
+        x[0, :3] = 0.0
+        w_mu, w_rho = torch.randn(o, i, device=DEV) * 0.1, torch.randn(o, i, device=DEV) * 1.5 - 3.0
+        w_rho[0, :4] = -8.0                                            # below the clamp: the mask of the chain rule
+        b_mu, b_rho = torch.randn(o, device=DEV) * 0.1, torch.randn(o, device=DEV) - 3.0
+        s2, ds2 = torch.empty_like(w_rho), torch.empty_like(w_rho)
+        ops.lrt_sigma_cache(w_rho, s2, ds2)
+        sp = torch.nn.functional.softplus(w_rho.double())
+        assert (s2.double() - (sp ** 2).clamp(min=1e-4)).abs().max().item() <= 3e-7 * float((sp ** 2).max())
+        want_ds2 = (sp ** 2 >= 1e-4).double() * 2 * sp * torch.sigmoid(w_rho.double())
+        assert (ds2.double() - want_ds2).abs().max().item() <= 1e-6 * float(want_ds2.abs().max()) + 1e-9
+        outs = []
+        for cached in (False, True):
+            out, var = torch.empty(b, o, device=DEV), torch.empty(b, o, device=DEV)
+            ops.lrt_linear_fwd(x, w_mu, w_rho, b_mu, b_rho, True, out, var, seed=5, stream_id=2, w_s2=s2 if cached else None)
+            g = torch.randn(b, o, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+            gs = [torch.empty(b, i, device=DEV), torch.empty_like(w_mu), torch.empty_like(w_rho), torch.empty_like(b_mu),
+                  torch.empty_like(b_rho)]
+            ops.lrt_linear_bwd(x, w_mu, w_rho, b_rho, True, g, var, *gs, seed=5, stream_id=2,
+                               w_s2=s2 if cached else None, w_ds2=ds2 if cached else None)
+            outs.append([out, var] + gs)
+        torch.cuda.synchronize()
+        for name, a, c in zip(("out", "var", "g_x", "g_wmu", "g_wrho", "g_bmu", "g_brho"), *outs):
+            assert torch.equal(a, c), (b, i, o, name)
 
 
 def test_lrt_linear_random_shapes(ops):

@@ -1,5 +1,7 @@
-"""The in-kernel noise generator (rng="philox") is the published Philox4x32-10: the numpy checker reproduces the
-Random123 known-answer vectors (CPU), and the HIP kernels reproduce the checker word for word (GPU)."""
+"""The in-kernel noise generator (rng="philox") is the published Philox4x32: the numpy checker reproduces the
+Random123 known-answer vectors at the default 10 rounds (CPU), and the HIP kernels reproduce the checker word for word
+(GPU) -- at 10 rounds (every draw of the BBB / iVON / layer kernels) and at the 7 rounds of the SWAG samplers (same
+round function and key schedule, three rounds fewer)."""
 import numpy as np
 import pytest
 import torch
@@ -16,8 +18,10 @@ def test_checker_reproduces_random123_known_answers():
 
 
 def test_checker_normals_are_standard():
-    z = PH.normals(1234, 0, 1 << 18)
-    assert abs(z.mean()) < 6e-3 and abs(z.var() - 1) < 1e-2 and abs((z ** 4).mean() - 3) < 0.1
+    for rounds in (PH.ROUNDS, PH.SWAG_ROUNDS):
+        z = PH.normals(1234, 0, 1 << 18, rounds=rounds)
+        assert abs(z.mean()) < 6e-3 and abs(z.var() - 1) < 1e-2 and abs((z ** 4).mean() - 3) < 0.1
+        assert abs(np.mean(z[1:] * z[:-1])) < 6e-3 and abs(np.mean(z[4:] * z[:-4])) < 6e-3     # neighbours / next group
     assert np.abs(z).max() < 5.78                                    # sqrt(2 * 24 ln 2): 24-bit radius uniforms
     w = PH.normals(1234, 0, 64, PH.DOMAIN_LOWRANK)
     assert not np.allclose(z[:64], w)                                # the two domains are different streams
@@ -36,9 +40,11 @@ def test_kernel_words_equal_the_known_answers_and_the_checker():
         assert [int(x) for x in got] == list(want), (counter, key)
     for seed, stream, domain, idx0, n in [(0, 0, 0, 0, 1000), (987654321987, 5, PH.DOMAIN_LOWRANK, 0, 777),
                                          (1 << 40, (1 << 33) + 7, 0, (1 << 32) - 100, 4096)]:
-        got = ops.philox_bits(seed, stream, n, dev, domain=domain, idx0=idx0).cpu().numpy()
-        want = PH.stream_bits(seed, stream, n, domain, idx0).astype(np.int64)
-        np.testing.assert_array_equal(got, want)
+        for rounds in (PH.ROUNDS, PH.SWAG_ROUNDS):
+            got = ops.philox_bits(seed, stream, n, dev, domain=domain, idx0=idx0, rounds=rounds).cpu().numpy()
+            want = PH.stream_bits(seed, stream, n, domain, idx0, rounds=rounds).astype(np.int64)
+            np.testing.assert_array_equal(got, want)
+    assert ops.swag_philox_rounds == PH.SWAG_ROUNDS
 
 
 @pytest.mark.gpu
@@ -50,8 +56,9 @@ def test_kernel_normals_equal_the_checker_transform():
     dev = "cuda:0"
     d, k = 100003, 37
     e, w = torch.zeros(d, device=dev), torch.zeros(k, device=dev)
-    ops.philox_normal(4242, 11, eps_w=w, eps_d=e)
-    want_e = PH.normals(4242, 11, d)
-    want_w = PH.normals(4242, 11, k, PH.DOMAIN_LOWRANK)
-    assert np.abs(e.cpu().numpy().astype(np.float64) - want_e).max() < 4e-6
-    assert np.abs(w.cpu().numpy().astype(np.float64) - want_w).max() < 4e-6
+    for rounds in (PH.ROUNDS, PH.SWAG_ROUNDS):
+        ops.philox_normal(4242, 11, eps_w=w, eps_d=e, rounds=rounds)
+        want_e = PH.normals(4242, 11, d, rounds=rounds)
+        want_w = PH.normals(4242, 11, k, PH.DOMAIN_LOWRANK, rounds=rounds)
+        assert np.abs(e.cpu().numpy().astype(np.float64) - want_e).max() < 4e-6
+        assert np.abs(w.cpu().numpy().astype(np.float64) - want_w).max() < 4e-6

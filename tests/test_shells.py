@@ -1307,3 +1307,55 @@ def test_svgd_shell_recovers_from_an_abandoned_single_launch():
     assert got_opt._small_launches == 2 and got_opt._small_pending is None
     assert torch.equal(got_p, clean_p)
     assert got_l == clean_l
+
+
+def test_bbb_linear_sigma_cache_follows_the_weights(backend):
+    """A wide BBBLinear keeps sigma^2 of its weight matrix per weight VERSION: computed at the first forward, reused by
+    the following forwards / backwards (bbb.py:63-67 runs mc_samples of them per step), recomputed after ANY in-place
+    change of rho (an optimizer step, a manual edit).  Outputs and gradients equal the layer without the cache."""
+    ops, dev = backend
+    torch.manual_seed(17)
+    prior = bde.GaussianPrior(0, 1.0)
+    layers = [bde.BBBLinear(1024, 1100, prior, prior, rng="philox", seed=4, _ops=ops, sigma_cache=c).to(dev) for c in (True, False)]
+    layers[1].load_state_dict(layers[0].state_dict())
+    calls = []
+    real = ops.lrt_sigma_cache
+
+    def counted(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    ops.lrt_sigma_cache = counted
+    try:
+        import beyond_deep_ensembles_amd.util as U
+        import itertools
+        x = torch.randn(8, 1024, device=dev)
+
+        def run(layer, stream0):
+            U._philox_stream = itertools.count(stream0)
+            import beyond_deep_ensembles_amd.bbb_layers as BL
+            BL._philox_stream = U._philox_stream
+            outs = []
+            for _ in range(2):                                   # two Monte-Carlo passes on one weight version
+                out = layer(x)
+                grads = torch.autograd.grad(out.pow(2).sum(), [layer.weight.mean, layer.weight.rho])
+                outs.append((out.detach(), grads[0], grads[1]))
+            return outs
+        a, b = run(layers[0], 100), run(layers[1], 100)
+        assert len(calls) == 1                                    # one cache pass for two forwards + two backwards
+        for (o1, g1, r1), (o2, g2, r2) in zip(a, b):
+            assert torch.equal(o1, o2) and torch.equal(g1, g2) and torch.equal(r1, r2)
+        with torch.no_grad():                                     # any in-place change of rho is a new version
+            for layer in layers:
+                layer.weight.rho.add_(0.25)
+        a, b = run(layers[0], 200), run(layers[1], 200)
+        assert len(calls) == 2
+        for (o1, g1, r1), (o2, g2, r2) in zip(a, b):
+            assert torch.equal(o1, o2) and torch.equal(g1, g2) and torch.equal(r1, r2)
+        # weights edited between a forward and ITS backward: autograd refuses (the saved rho changed), cache or not
+        out_old = layers[0](x)
+        with torch.no_grad():
+            layers[0].weight.rho.sub_(0.1)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            torch.autograd.grad(out_old.pow(2).sum(), [layers[0].weight.mean])
+    finally:
+        ops.lrt_sigma_cache = real
