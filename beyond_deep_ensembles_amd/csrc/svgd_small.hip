@@ -32,10 +32,11 @@
 // other processes or streams can hold CUs, and two such launches could each be partly resident and wait for the
 // rest.  Therefore the wait is BOUNDED and the launch decides as ONE unit whether the update happens:
 //   * the polling wave gives up after `timeout` ticks of the 100 MHz wall clock (default 2 ms);
-//   * the outcome of a launch is ONE 64-bit word of the workspace, (stamp, status), written by compare-and-swap: the
-//     first workgroup that sees all arrivals proposes (want, COMMIT), the first that times out proposes (want, ABORT);
-//     whoever loses the CAS follows the winner.  So either every workgroup runs phase 2 or none does -- an aborted
-//     launch leaves P, the optimizer state and `out` untouched;
+//   * the outcome of a launch is ONE 64-bit word of the workspace, (stamp, status), written by compare-and-swap against
+//     its value at launch start: workgroup 0 proposes (want, COMMIT) once it has seen all arrivals, whoever times out
+//     proposes (want, ABORT); exactly one proposal wins, everybody reads the outcome in the same load that polls the
+//     counters and follows it.  So either every workgroup runs phase 2 or none does -- an aborted launch leaves P, the
+//     optimizer state and `out` untouched;
 //   * ABORT is sticky: later workgroups of that launch, and later single launches on the workspace, see it when they
 //     start and return at once (they do not arrive, so the counters stay consistent); an aborting workgroup also sets
 //     the caller's `abort_flag` word (host-visible memory), which is how the caller learns that it must redo the update;
@@ -286,40 +287,56 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
 
   // ---------------- hand-off: wave 0 polls the 8 shard counters (one 8-lane load per poll), for a bounded time ----------------
   if (phase == kSmallSingle && wave == 0) {
-    const unsigned* ctr = words + kWsArriveWord + 32 * (lane & (kWsShards - 1));
+    // ONE load per poll brings the 8 shard counters (lanes 0-7) AND the outcome word (lanes 8, 9: stamp, status)
+    const unsigned* poll_ptr = lane < kWsShards ? words + kWsArriveWord + 32 * lane
+                                                : words + kWsStateWord + (lane == kWsShards + 1 ? 1 : 0);
     const unsigned want = arrived_before + static_cast<unsigned>(nwg);
-    bool all_here = false;
-    if (!poisoned && timeout_ticks != 0u) {
-      const unsigned long long t_start = wall_clock64();
-      unsigned polls = 0;
-      do {
-        const unsigned c = (lane < kWsShards) ? __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        unsigned total = 0;
+    const unsigned long long commit_word = static_cast<unsigned long long>(want) | (static_cast<unsigned long long>(kSmallCommit) << 32);
+    const unsigned long long abort_word = static_cast<unsigned long long>(want) | (static_cast<unsigned long long>(kSmallAbort) << 32);
+    // The launch decides as ONE unit through the outcome word.  COMMIT is proposed by workgroup 0 alone, once it has
+    // seen every arrival (one uncontended compare-and-swap per launch -- 238 workgroups proposing it cost 5 us of
+    // serialised atomics); everybody else sees the decision in the poll that follows.  ABORT is proposed by whoever runs
+    // out of time.  Both are compare-and-swaps against the value the word had when the launch started, so exactly one
+    // proposal wins and the loser follows it.
+    int decision = 0;
+    if (poisoned || timeout_ticks == 0u) decision = -1;                  // nothing to wait for: propose ABORT right away
+    const unsigned long long t_start = wall_clock64();
+    unsigned polls = 0;
+    while (decision == 0) {
+      const unsigned c = (lane < kWsShards + 2) ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      unsigned total = 0;
 #pragma unroll
-        for (int sh = 0; sh < kWsShards; ++sh) total += __builtin_amdgcn_readlane(c, sh);
-        all_here = static_cast<int>(total - want) >= 0;            // difference: immune to uint32 wrap-around
-        if (all_here) break;
+      for (int sh = 0; sh < kWsShards; ++sh) total += __builtin_amdgcn_readlane(c, sh);
+      const unsigned stamp = __builtin_amdgcn_readlane(c, kWsShards), status = __builtin_amdgcn_readlane(c, kWsShards + 1);
+      if (status == kSmallAbort) {
+        decision = static_cast<int>(kSmallAbort);
+      } else if (status == kSmallCommit && stamp == want) {
+        decision = static_cast<int>(kSmallCommit);
+      } else if (static_cast<int>(total - want) >= 0 && blockIdx.x == 0) {   // difference: immune to uint32 wrap-around
+        unsigned long long cur = state_seen;
+        if (lane == 0 && __hip_atomic_compare_exchange_strong(state, &cur, commit_word, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT))
+          cur = commit_word;
+        const unsigned st = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur >> 32));
+        decision = st == kSmallCommit ? static_cast<int>(kSmallCommit) : static_cast<int>(kSmallAbort);
+      } else {
         // the clock is read on every 8th unsuccessful poll (~1 us apart): workgroups that cannot become resident
         // together must not wait for each other forever
-        if ((++polls & 7u) == 0u && wall_clock64() - t_start > static_cast<unsigned long long>(timeout_ticks)) break;
-        __builtin_amdgcn_s_sleep(4);
-      } while (true);
-    }
-    // ONE outcome per launch: propose COMMIT (all arrived) or ABORT (timed out / abandoned workspace) by compare-and-swap
-    // on the outcome word; a lost CAS returns what another workgroup of this launch decided, and that is followed
-    int decision = static_cast<int>(kSmallAbort);
-    if (!poisoned) {
-      const unsigned long long proposed = static_cast<unsigned long long>(want) |
-                                          (static_cast<unsigned long long>(all_here ? kSmallCommit : kSmallAbort) << 32);
-      unsigned long long cur = state_seen;
-      if (lane == 0) {
-        if (__hip_atomic_compare_exchange_strong(state, &cur, proposed, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT))
-          cur = proposed;
+        if ((++polls & 7u) == 0u && wall_clock64() - t_start > static_cast<unsigned long long>(timeout_ticks)) decision = -1;
+        else __builtin_amdgcn_s_sleep(4);
       }
-      const unsigned stamp = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur));
-      const unsigned status = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur >> 32));
-      if (status == kSmallCommit && stamp == want) decision = static_cast<int>(kSmallCommit);
+    }
+    if (decision < 0) {                                                  // out of time (or abandoned workspace): propose ABORT
+      decision = static_cast<int>(kSmallAbort);
+      if (!poisoned) {
+        unsigned long long cur = state_seen;
+        if (lane == 0 && __hip_atomic_compare_exchange_strong(state, &cur, abort_word, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT))
+          cur = abort_word;
+        const unsigned st = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur >> 32));
+        const unsigned sm = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur));
+        if (st == kSmallCommit && sm == want) decision = static_cast<int>(kSmallCommit);   // workgroup 0 was faster: all are here
+      }
     }
     if (lane == 0) {
       s_decision = decision;

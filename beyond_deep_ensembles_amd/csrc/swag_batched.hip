@@ -33,7 +33,7 @@ template <bool RNG>
 __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
     const float* __restrict__ mean, const float* __restrict__ sq, const float* __restrict__ dev, int K, int64_t ld,
     int head, const float* __restrict__ eps_w, const float* __restrict__ eps_d, int64_t ld_eps, uint64_t seed,
-    uint64_t stream0, float* __restrict__ out, int64_t ld_out, int S, int64_t D, RowPieces L, RowPieces Lo) {
+    uint64_t stream0, float* __restrict__ out, int64_t ld_out, int S, int64_t D, RowPiecesRt L, RowPiecesRt Lo) {
   extern __shared__ __attribute__((aligned(16))) float w[];   // [K + (K & 1)][32]: weight of ring row r for sample s
   const int kpad = K + (K & 1);
   const int ksteps = kpad >> 1;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
     const int64_t g4 = t * 32 + j;                            // this lane's float4 group
     const bool ok = g4 < n4;
     // a tile is 128 consecutive parameters and a piece a multiple of that, so a tile lies inside ONE piece
-    const int64_t so = piece_off(4 * g4, L), oo = piece_off(4 * g4, Lo);
+    const int64_t so = piece_off_rt(4 * g4, L), oo = piece_off_rt(4 * g4, Lo);
     const float* col = dev + so;
     f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
     // The whole [K, 128] slab of the ring is requested before the first MFMA waits on it: a
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
     for (int idx = threadIdx.x; idx < rem * S; idx += blockDim.x) {
       const int s = idx / rem, k = idx % rem;
       const int64_t e = (n4 << 2) + k;
-      const int64_t so = piece_off(e, L);
+      const int64_t so = piece_off_rt(e, L);
       float acc = 0.f;
       for (int r = 0; r < K; ++r) acc = __builtin_fmaf(dev[static_cast<int64_t>(r) * ld + so], w[r * 32 + s], acc);
       const float m = mean[so];
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
       } else {
         z = eps_d[static_cast<int64_t>(s) * ld_eps + e];
       }
-      out[static_cast<int64_t>(s) * ld_out + piece_off(e, Lo)] =
+      out[static_cast<int64_t>(s) * ld_out + piece_off_rt(e, Lo)] =
           (m + acc) + __builtin_sqrtf(0.5f * (fmaxf(sq[so] - m * m, 0.0f) + 1e-6f)) * z;
     }
   }
@@ -145,7 +145,7 @@ extern "C" int bde_swag_sample_batched(const float* mean, const float* sq, const
       (log2_piece_out == 0 ? ld_out < D : ld_out < (int64_t{1} << log2_piece_out)) ||
       (eps_d && (ld_eps < D || (ld_eps & 3))))
     return BDE_ERR_INVALID;
-  const RowPieces L{log2_piece, piece_stride}, Lo{log2_piece_out, piece_stride_out};
+  const RowPiecesRt L{log2_piece, piece_stride}, Lo{log2_piece_out, piece_stride_out};
   if (!aligned16(mean) || !aligned16(sq) || !aligned16(dev) || !aligned16(out) || (eps_d && !aligned16(eps_d)))
     return BDE_ERR_INVALID;
   const int64_t n_tiles = ((D >> 2) + 31) / 32;

@@ -131,6 +131,9 @@ class SegTable:
                 nflt = min(1024, n - start)
                 rows.append(((col0 + start) // 4, start // 4, s + (nflt << 32), 0))
         self.n_chunks = len(rows)
+        # flat columns [start, end) each piece covers, for callers that pack a COLUMN RANGE of the rows (piece_range)
+        self.piece_start = np.asarray([4 * r[0] for r in rows], dtype=np.int64)
+        self.piece_end = self.piece_start + np.asarray([r[2] >> 32 for r in rows], dtype=np.int64)
         self.chunks = torch.from_numpy(np.asarray(rows, dtype=np.int64).reshape(-1, 4)).to(device)
         self.ptrs = torch.zeros(max(1, self.n_seg * self.m), dtype=torch.int64, device=device)
         on_gpu = torch.device(device).type == "cuda"
@@ -140,6 +143,17 @@ class SegTable:
             self.host = [h.pin_memory() for h in self.host]
         self._events = [None] * len(self.host)
         self._slot = 0
+
+    def piece_range(self, c0: int, c1: int):
+        """Indices [q0, q1) of the pieces that intersect flat columns [c0, c1) (pieces are sorted by column)."""
+        import numpy as np
+        q0 = int(np.searchsorted(self.piece_end, c0, side="right"))
+        q1 = int(np.searchsorted(self.piece_start, c1, side="left"))
+        return q0, max(q0, q1)
+
+    def upload_again(self) -> None:
+        """Re-send the host table being filled (more entries are valid now) without closing the step's staging slot."""
+        self.ptrs.copy_(self.host[self._slot], non_blocking=True)
 
     def staging(self) -> torch.Tensor:
         """The host table to fill for the coming step."""
@@ -360,13 +374,19 @@ class HipOps:
                "bde_svgd_fused_adam_seg")
 
     @_on_device_of
-    def svgd_gather_seg(self, G, seg: SegTable, row0=0, n_rows=None):
-        """Pack the segmented gradients of particles [row0, row0 + n_rows) into the flat rows G [M, ld]: one launch."""
+    def svgd_gather_seg(self, G, seg: SegTable, row0=0, n_rows=None, pieces=None):
+        """Pack the segmented gradients of particles [row0, row0 + n_rows) into the flat rows G [M, ld]: one launch.
+        ``pieces = (q0, q1)`` restricts it to those pieces of the table (``SegTable.piece_range``: a column range)."""
         n_rows = seg.m - row0 if n_rows is None else n_rows
+        q0, q1 = pieces if pieces is not None else (0, seg.n_chunks)
+        if not 0 <= q0 <= q1 <= seg.n_chunks:
+            raise BdeKernelError("svgd_gather_seg: piece range outside the table")
+        if q0 == q1:
+            return
         if row0 < 0 or n_rows < 1 or row0 + n_rows > min(seg.m, G.shape[0]):
             raise BdeKernelError("svgd_gather_seg: rows outside the table / the gradient buffer")
         # M = the table's particle count (its pointer stride), whatever number of rows G holds
-        _check(self.lib.bde_svgd_gather_seg(seg.ptrs.data_ptr(), seg.chunks.data_ptr(), seg.n_chunks, _ptr(G, "G"),
+        _check(self.lib.bde_svgd_gather_seg(seg.ptrs.data_ptr(), seg.chunks.data_ptr() + 32 * q0, q1 - q0, _ptr(G, "G"),
                                             seg.m, row0, n_rows, _ld(G), _stream()), "bde_svgd_gather_seg")
 
     # ------------------------------------------------------------ SWAG --

@@ -84,6 +84,11 @@ class SVGDOptimizer(BayesianOptimizer):
           exchange            "allgather" (replicated particles, gradient rows gathered) or "alltoall"
                               (dimension-sharded particles and optimizer state; needs fuse_base_optimizer)
           exchange_chunks     "allgather" only: pipeline the gather and the update over this many column chunks
+          overlap_backward    with exchange_chunks > 1: start the gather of a column chunk as soon as the LAST local
+                              particle's backward pass has produced the gradients of every tensor in it (chunks leave
+                              in a fixed order, last chunk first -- the order backward fills them), so the exchange
+                              overlaps the rest of that backward pass like DDP's gradient buckets.  Needs one backward
+                              call per closure; ignored while a GradScaler is active (its unscale pass runs after backward)
           fuse_base_optimizer apply a torch.optim.SGD / Adam base optimizer inside the update kernel (one pass over
                               P and G that writes the updated particles; -phi is never materialised).  "auto": fused
                               exactly when that is indistinguishable from particle_count calls of base.step() -- a
@@ -93,16 +98,19 @@ class SVGDOptimizer(BayesianOptimizer):
           reuse_gram          with fuse_base_optimizer: the fused kernel also emits the Gram partials of the updated
                               particles, so the next step skips the Gram pass.  Only valid while nothing but this
                               optimizer modifies the particles between two steps (call invalidate_gram() otherwise).
-          single_launch       None (default): small models on one GPU run the whole update with the small-model kernel
-                              (bde_svgd_step_small*) -- with a fused base optimizer as ONE persistent launch whose
-                              in-kernel hand-off waits a bounded time; if that launch ever gives up (device shared with
-                              other work), the update is redone as two ordinary launches of the same kernel (identical
-                              results) and stays that way.  "two": always two launches.  False: the staged kernels
+          single_launch       None (default) / "two": small models on one GPU run the whole update with the small-model kernel
+                              (bde_svgd_step_small*) as TWO ordinary launches (Gram partials; everything after).  True:
+                              with a fused base optimizer, as ONE persistent launch whose in-kernel hand-off waits a
+                              bounded time -- for a device this process has to itself; if that launch ever gives up
+                              (device shared with other work), the update is redone as two launches (identical results)
+                              and stays that way.  With the wait bounded and the outcome agreed between the workgroups
+                              the single launch is no faster than the two (14.3 vs 14.7 us at ResNet-20 size; the
+                              unbounded round-2 kernel took 10.7), hence the default.  False: the staged kernels
     '''
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
                  kernel_grad_scale=1.0, *, process_group=None, exchange="allgather", exchange_chunks=1,
-                 fuse_base_optimizer=False, reuse_gram=False, single_launch=None, _ops=None):
+                 overlap_backward=False, fuse_base_optimizer=False, reuse_gram=False, single_launch=None, _ops=None):
         # one param group per tensor, like the reference (svgd.py:50): groups distinguish tensors, not particles
         super().__init__([{"params": p} for p in params], {})
         self._ops = _ops or _default_ops()
@@ -174,7 +182,7 @@ class SVGDOptimizer(BayesianOptimizer):
         self._single_launch = single_launch
         # the persistent single launch (bounded in-kernel wait): its outcome is checked before anything reads or
         # overwrites what it worked on -- see _check_single_launch
-        self._small_launches = 2 if single_launch == "two" else 1
+        self._small_launches = 1 if single_launch is True else 2
         self._small_flag = None
         self._small_pending = None
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
@@ -192,6 +200,71 @@ class SVGDOptimizer(BayesianOptimizer):
             self._stage = [torch.zeros((m, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in self._chunks]
         if self._exchange == "alltoall":
             self._init_dimension_sharding()
+        self._ov = None                                   # state of an overlapped exchange while a backward pass runs
+        self._overlap = bool(overlap_backward) and self._chunks is not None and self._seg is not None
+        if self._overlap:
+            self._init_overlap()
+
+    # ---- chunked all-gather overlapped with the last local particle's backward pass -------------------------
+    def _init_overlap(self):
+        """Which tensors a column chunk needs, which table pieces cover it, and one post-accumulate hook per tensor."""
+        offs, nums = self._layout.offsets, self._layout.numels
+        self._chunk_tensors = [[k for k, (o, n) in enumerate(zip(offs, nums)) if o < c1 and o + n > c0]
+                               for c0, c1 in self._chunks]
+        self._tensor_chunks = [[] for _ in offs]
+        for c, ks in enumerate(self._chunk_tensors):
+            for k in ks:
+                self._tensor_chunks[k].append(c)
+        self._chunk_pieces = [self._seg.piece_range(c0, c1) for c0, c1 in self._chunks]
+        for k, p in enumerate(self._plist):
+            p.register_post_accumulate_grad_hook(lambda param, k=k: self._grad_ready(k, param))
+
+    def _begin_overlap(self, particle_idx: int, loss_sum: torch.Tensor) -> None:
+        """Called between the forward and the backward pass of the last local particle."""
+        per = self.state["__particle_count"] // self._world
+        if self._seg_host is None:
+            self._seg_host = self._seg.staging()
+        self._ov = {"row": particle_idx, "pending": [len(ks) for ks in self._chunk_tensors], "seen": set(),
+                    "next": len(self._chunks) - 1, "works": [None] * len(self._chunks), "loss": loss_sum / per}
+
+    def _grad_ready(self, k: int, param) -> None:
+        """Post-accumulate hook of tensor k: record where its gradient lives; chunks whose tensors are all in leave."""
+        ov = self._ov
+        if ov is None or k in ov["seen"]:
+            return
+        ov["seen"].add(k)
+        g, view = param.grad, self._gviews[ov["row"]][k]
+        addr = view.data_ptr()
+        if g is not None and g.data_ptr() != addr:
+            if g.dtype == torch.float32 and g.layout == torch.strided and g.is_contiguous() and g.device == view.device \
+                    and g.numel() == view.numel() and g.data_ptr() % 16 == 0:
+                addr = g.data_ptr()
+            else:
+                with torch.no_grad():
+                    view.copy_(g)
+        self._seg_host[k * self._seg.m + ov["row"]] = addr
+        for c in self._tensor_chunks[k]:
+            ov["pending"][c] -= 1
+        self._launch_ready_chunks()
+
+    def _launch_ready_chunks(self, force: bool = False) -> None:
+        """Chunks leave strictly in descending order (the same order on every rank), each as soon as it is complete."""
+        import torch.distributed as dist
+        ov = self._ov
+        m, d = self.state["__particle_count"], self._layout.d
+        per = m // self._world
+        lo = self._rank * per
+        while ov["next"] >= 0 and (force or ov["pending"][ov["next"]] == 0):
+            c = ov["next"]
+            ov["next"] -= 1
+            (c0, c1), stage = self._chunks[c], self._stage[c]
+            with torch.no_grad():
+                self._seg.upload_again()
+                self._ops.svgd_gather_seg(self._G, self._seg, lo, per, pieces=self._chunk_pieces[c])
+                if c0 <= d < c1:
+                    self._G[lo:lo + per, d] = ov["loss"]               # the loss rides in the spare floats of the row
+                send = self._G[lo, c0:c1] if per == 1 else self._G[lo:lo + per, c0:c1].contiguous().view(-1)
+                ov["works"][c] = dist.all_gather_into_tensor(stage.view(-1), send, group=self._pg, async_op=True)
 
     @staticmethod
     def _fusable(base, plist, particle_count) -> bool:
@@ -256,6 +329,8 @@ class SVGDOptimizer(BayesianOptimizer):
             self._begin_particle(particle_idx)
             loss = forward_closure()
             total_loss += loss.detach()
+            if self._overlap and particle_idx == self._local_particles()[-1] and not self._scaler_active(grad_scaler):
+                self._begin_overlap(particle_idx, total_loss)
             backward_closure(loss)
             if not self._prepare_and_check_grads(grad_scaler, base):
                 return None
@@ -303,10 +378,12 @@ class SVGDOptimizer(BayesianOptimizer):
         pset = self._particle_set()
         if pset is not None:
             pset.end(particle_idx, self._seg_host, particle_row, self._seg.m, self._zeros.data_ptr())
-            return
-        self._retained[particle_row] = collect_grads(self._plist, self._gviews[particle_idx], self._seg_host,
-                                                     particle_row, self._seg.m, self._zeros.data_ptr())
-        clear_grads(self._plist)
+        else:
+            self._retained[particle_row] = collect_grads(self._plist, self._gviews[particle_idx], self._seg_host,
+                                                         particle_row, self._seg.m, self._zeros.data_ptr())
+            clear_grads(self._plist)
+        if self._ov is not None:
+            self._launch_ready_chunks(force=True)         # tensors without a gradient: their chunks leave now
 
     def _grads_to_rows(self, G: torch.Tensor, row0: int, n_rows: int) -> None:
         """The gradients recorded by _end_particle packed into rows [row0, row0 + n_rows) of the flat buffer ``G`` (ONE
@@ -454,13 +531,20 @@ class SVGDOptimizer(BayesianOptimizer):
         m, d = self.state["__particle_count"], self._layout.d
         per = m // self._world
         lo = self._rank * per
-        self._grads_to_rows(self._G, lo, per)                            # own rows packed for the collective: one launch
-        self._G[lo:lo + per, d] = total_loss / per
-        works = []
-        for (c0, c1), stage in zip(self._chunks, self._stage):
-            # a row chunk is contiguous; several own rows are packed first (1/W of the data)
-            send = self._G[lo, c0:c1] if per == 1 else self._G[lo:lo + per, c0:c1].contiguous().view(-1)
-            works.append(dist.all_gather_into_tensor(stage.view(-1), send, group=self._pg, async_op=True))
+        if self._ov is not None:
+            # the chunks left while the last backward pass was still running (_grad_ready / _end_particle)
+            works, self._ov = self._ov["works"], None
+            self._seg.upload()                               # closes the step's staging slot
+            self._seg_host = None
+            self._release_grads()
+        else:
+            self._grads_to_rows(self._G, lo, per)                        # own rows packed for the collective: one launch
+            self._G[lo:lo + per, d] = total_loss / per
+            works = []
+            for (c0, c1), stage in zip(self._chunks, self._stage):
+                # a row chunk is contiguous; several own rows are packed first (1/W of the data)
+                send = self._G[lo, c0:c1] if per == 1 else self._G[lo:lo + per, c0:c1].contiguous().view(-1)
+                works.append(dist.all_gather_into_tensor(stage.view(-1), send, group=self._pg, async_op=True))
         self._ops.svgd_gram(self._P, d, self._ws)            # needs the particles only: hidden behind the exchange
         self._ops.svgd_kstats(self._ws, m, *self._stat_args(), self._kstat)
         self._gram_valid = False

@@ -239,7 +239,8 @@ int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, float* exp_avg
  * row (head + c) mod K, where `head` is the row the NEXT update overwrites.
  *
  * Row storage.  Every statistics row (mean, sq, each ring row) and every output row of the batched sampler is
- * either contiguous (log2_piece = 0) or cut into PIECES of 2^log2_piece floats (7 <= log2_piece <= 30), piece c of a
+ * either contiguous (log2_piece = 0) or cut into PIECES of 2^log2_piece floats (log2_piece = 12, or 7 for tests: the
+ * piece size is a compile-time parameter of the kernels -- as a runtime value it cost the sampler 20 %), piece c of a
  * row lying piece_stride floats behind its piece c - 1.  The optimizer keeps the K + 2 statistics rows interleaved:
  * one buffer [n_pieces][K + 2][2^log2_piece], row pointer = address of the row's first piece, ld = 2^log2_piece =
  * distance between two rows inside a piece, piece_stride = (K + 2) * 2^log2_piece.  A pass over the statistics then

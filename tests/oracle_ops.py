@@ -79,12 +79,18 @@ class OracleOps:
                 G[j, col0:col0 + n] = src
         return G
 
-    def svgd_gather_seg(self, G, seg, row0=0, n_rows=None):
+    def svgd_gather_seg(self, G, seg, row0=0, n_rows=None, pieces=None):
+        import ctypes
         n_rows = seg.m - row0 if n_rows is None else n_rows
-        rows = range(row0, row0 + n_rows)
-        got = self._seg_rows(seg, G.shape[1], rows)
-        for j in rows:
-            G[j] = got[j]
+        q0, q1 = pieces if pieces is not None else (0, seg.n_chunks)
+        table = seg.chunks.view(-1, 4)
+        for q in range(q0, q1):                                   # piece by piece, like the kernel
+            c4, loc4, packed = int(table[q, 0]), int(table[q, 1]), int(table[q, 2])
+            s, nflt = packed & 0xFFFFFFFF, packed >> 32
+            for j in range(row0, row0 + n_rows):
+                addr = int(seg.ptrs[s * seg.m + j]) + 16 * loc4
+                src = torch.frombuffer((ctypes.c_float * nflt).from_address(addr), dtype=torch.float32)
+                G[j, 4 * c4:4 * c4 + nflt] = src
 
     def svgd_combine_seg(self, P, seg, out, d, kstat):
         self.svgd_combine(P, self._seg_rows(seg, P.shape[1], range(seg.m)), out, d, kstat)

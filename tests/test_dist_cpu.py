@@ -62,9 +62,18 @@ def _svgd_worker(rank, world, port, m, fuse, kw, out_dir):
             fwd_calls[0] += 1
             return orig(*a, **k)
         model.forward = counting_forward
+        early = []
+        if dict(kw).get("overlap_backward"):
+            end = opt._end_particle
+
+            def spying_end(idx):                      # how many chunks had already left when backward returned
+                if opt._ov is not None:
+                    early.append(sum(w is not None for w in opt._ov["works"]))
+                return end(idx)
+            opt._end_particle = spying_end
         losses = _run_steps(model, opt)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=opt.particles.numpy(), losses=np.array(losses),
-                 fwd=np.array(fwd_calls[0]))
+                 fwd=np.array(fwd_calls[0]), early=np.array(early))
     finally:
         dist.destroy_process_group()
 
@@ -74,8 +83,11 @@ def _svgd_worker(rank, world, port, m, fuse, kw, out_dir):
     (4, False, {"exchange_chunks": 3}), (4, True, {"exchange_chunks": 2}), (2, True, {"exchange_chunks": 4, "base": "adam"}),
     (4, True, {"exchange": "alltoall"}), (2, True, {"exchange": "alltoall"}), (4, True, {"exchange": "alltoall", "base": "adam"}),
     (2, True, {"exchange": "alltoall", "tiny": True}), (4, False, {"exchange_chunks": 7, "tiny": True}),
+    (4, True, {"exchange_chunks": 3, "overlap_backward": True}), (2, False, {"exchange_chunks": 4, "overlap_backward": True}),
+    (2, True, {"exchange_chunks": 5, "overlap_backward": True, "base": "adam"}),
 ], ids=["allgather", "allgather_fused", "pipelined", "pipelined_fused", "pipelined_fused_adam", "alltoall_2per",
-        "alltoall_1per", "alltoall_adam", "alltoall_empty_slice", "pipelined_more_chunks_than_columns"])
+        "alltoall_1per", "alltoall_adam", "alltoall_empty_slice", "pipelined_more_chunks_than_columns",
+        "overlap_fused_2per", "overlap_unfused_1per", "overlap_fused_adam_1per"])
 def test_svgd_sharded_equals_single_process(tmp_path, m, fuse, kw):
     """One exchange of gradient rows (all-gather, chunk-pipelined all-gather, or the dimension-sharded all-to-all
     pair) + the deterministic update reproduces the single-process trajectory, with identical particles on all ranks."""
@@ -89,6 +101,10 @@ def test_svgd_sharded_equals_single_process(tmp_path, m, fuse, kw):
     np.testing.assert_array_equal(r0["losses"], r1["losses"])
     # each rank ran forward/backward only for its own M/W particles
     assert int(r0["fwd"]) == 3 * m // world and int(r1["fwd"]) == 3 * m // world
+    if kw.get("overlap_backward"):
+        # chunk gathers left WHILE the last local particle's backward pass was running (every step, both ranks)
+        for r in (r0, r1):
+            assert len(r["early"]) == 3 and all(int(n) >= 1 for n in r["early"]), r["early"]
     # single-process run from rank 0's initial state
     torch.set_num_threads(1)
     model, opt = _make(100, m, OracleOps(), fuse=fuse, base=kw.get("base", "sgd"), tiny=kw.get("tiny", False))

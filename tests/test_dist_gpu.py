@@ -97,6 +97,8 @@ SVGD_CASES = [
     ("fused_adam", 2, {"fuse_base_optimizer": True, "base": "adam"}),
     ("pipelined", 4, {"exchange_chunks": 3}),
     ("pipelined_fused", 4, {"exchange_chunks": 2, "fuse_base_optimizer": True}),
+    ("pipelined_overlap_fused", 4, {"exchange_chunks": 3, "fuse_base_optimizer": True, "overlap_backward": True}),
+    ("pipelined_overlap_unfused_1per", 2, {"exchange_chunks": 4, "overlap_backward": True}),
     ("alltoall_2per", 4, {"exchange": "alltoall", "fuse_base_optimizer": True}),
     ("alltoall_1per_adam", 2, {"exchange": "alltoall", "fuse_base_optimizer": True, "base": "adam"}),
 ]
@@ -110,7 +112,7 @@ def _check_svgd(tmp_path, backend, name, m, kw):
     np.testing.assert_array_equal(r0["losses"], r1["losses"])
     assert int(r0["fwd"]) == 4 * m // world and int(r1["fwd"]) == 4 * m // world
     # the single-process HIP run from rank 0's initial state (no process group; same kernels)
-    single_kw = {k: v for k, v in kw.items() if k not in ("exchange", "exchange_chunks")}
+    single_kw = {k: v for k, v in kw.items() if k not in ("exchange", "exchange_chunks", "overlap_backward")}
     model, opt = _make_svgd(100, m, torch.device("cuda", 0), **single_kw)
     losses = _run_steps(model, opt, torch.device("cuda", 0))
     np.testing.assert_allclose(r0["particles"], opt.particles.cpu().numpy(), rtol=2e-5, atol=2e-6)

@@ -60,6 +60,9 @@ def flat(ts):
     ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "staged"),
     ("adam_wd", lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2), "staged_fused"),
     ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "staged_reuse_gram"),
+    # ONE persistent launch with the bounded in-kernel hand-off (single_launch=True) instead of the default two launches
+    ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "one_launch"),
+    ("adam", lambda ps: torch.optim.Adam(ps, lr=1e-3), "one_launch"),
 ])
 def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
     ops, dev = backend
@@ -80,7 +83,8 @@ def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
                             l2_reg=float(g["l2_reg"]), kernel_grad_scale=float(g["scale"]),
                             fuse_base_optimizer=fuse not in (False, "staged"),
                             reuse_gram=fuse in ("reuse_gram", "staged_reuse_gram"),
-                            single_launch=False if str(fuse).startswith("staged") else None, _ops=ops)
+                            single_launch=False if str(fuse).startswith("staged") else (True if fuse == "one_launch" else None),
+                            _ops=ops)
     fuse = fuse not in (False, "staged")
     assert torch.equal(opt.particles.cpu(), init.cpu())
     for i in range(m):      # reference state keys (svgd.py:57)
@@ -546,8 +550,11 @@ def test_grad_scaler_path_matches_unscaled(backend, algo):
             opt = bde.SVGDOptimizer(params, lambda: None, torch.optim.SGD(params, lr=0.05, momentum=0.9),
                                     particle_count=3, dataset_size=16, l2_reg=0.01, _ops=ops)
             with torch.no_grad():       # distinct particles without touching the RNG
-                opt.particles[1] += 0.01
-                opt.particles[2] -= 0.02
+                moved = opt.particles.clone()
+                moved[1] += 0.01
+                moved[2] -= 0.02
+                opt.set_particles(moved)
+                assert not torch.equal(opt.particles[0], opt.particles[1])
         elif algo == "swag":
             opt = bde.SwagOptimizer(params, torch.optim.SGD(params, lr=0.05), update_interval=1, deviation_samples=3, _ops=ops)
         elif algo == "bbb":
@@ -1270,7 +1277,7 @@ def test_bbb_group_draw_is_never_stale(backend):
 
 @pytest.mark.gpu
 def test_svgd_shell_recovers_from_an_abandoned_single_launch():
-    """Small model, fused base optimizer: the update is ONE persistent launch with a bounded in-kernel wait.  When such
+    """Small model, fused base optimizer, single_launch=True: the update is ONE persistent launch with a bounded in-kernel wait.  When such
     a launch gives up (forced here by a zero bound), the optimizer notices on its next entry, redoes the update as two
     launches of the same kernel from the untouched gradients and optimizer state, warns once and never uses single
     launches again -- and the trajectory is bit-identical to the undisturbed run (svgd.py:65-105 semantics unchanged)."""
@@ -1284,7 +1291,7 @@ def test_svgd_shell_recovers_from_an_abandoned_single_launch():
         params = list(model.parameters())
         base = torch.optim.SGD(params, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)
         opt = bde.SVGDOptimizer(params, lambda: bde.reset_model_params(model), base, particle_count=5, dataset_size=64,
-                                l2_reg=0.01, fuse_base_optimizer=True)
+                                l2_reg=0.01, fuse_base_optimizer=True, single_launch=True)
         g = torch.Generator().manual_seed(5)
         x, y = torch.randn(64, 13, generator=g).to(dev), torch.randn(64, 1, generator=g).to(dev)
         losses, caught = [], []

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for the round: kernel traces of bench.py (exact default command and the main loop alone) with
 # the JSON of the SAME runs, PMC passes (traffic, MFMA busy, VALU activity), summaries.  Run from the repo root on the GPU box.
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/prof_$R; mkdir -p $O
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 export PYTHONDONTWRITEBYTECODE=1
@@ -14,6 +14,15 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$tag -o p -- python3 bench.py --gpus 1 --steps 3 --warmup 1 --blocks 1 --no-cpu-baseline --no-config-extras > $O/pmc_$tag.json 2> $O/pmc_$tag.err; echo "pmc $tag rc=$?"
 done
+# (d) the wide BBBLinear kernels at 4096 x 4096, batch 64 (tools/lrt_bench.py): kernel trace + the same counter groups
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_lrt -o t -- python3 tools/lrt_bench.py 64x4096x4096 > $O/lrt_bench_under_rocprof.txt 2> $O/lrt_trace.err; echo "trace_lrt rc=$?"
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"; do
+  tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --output-format csv -d $O/lrtpmc_$tag -o p -- python3 tools/lrt_bench.py 64x4096x4096 > /dev/null 2> $O/lrtpmc_$tag.err; echo "lrt pmc $tag rc=$?"
+done
+BDE_PMC_LRT_SHAPE=64x4096x4096 python3 tools/pmc_summary.py $O/pmc_lrt_summary.json $O/lrtpmc_*/ ; echo "lrt summary rc=$?"
+for f in $(find $O/trace_lrt -name "*kernel_stats.csv"); do mkdir -p $O/keep; cp $f $O/keep/lrt_kernel_stats.csv; done
+rm -rf $O/trace_lrt $O/lrtpmc_*/
 echo "--- sizes before pruning"; du -sh $O/* | sort -h | tail -12; find $O -type f -size +1M | head -20
 f=$(find $O/pmc_FETCH_SIZE -name "*counter_collection*" | head -1); echo "counter file: $f"; head -2 "$f" | cut -c1-600
 python3 tools/pmc_summary.py $O/pmc_summary.json $O/pmc_*/ ; echo "summary rc=$?"

@@ -17,13 +17,31 @@ def short(name):
     return name.replace("bde::", "")
 
 
+LRT = os.environ.get("BDE_PMC_LRT_SHAPE")          # "BxIxO" when the passes ran tools/lrt_bench.py on ONE shape
+
+
 def algorithmic(kernel, grid):
     """Algorithmic bytes of one launch at ResNet-50 size; None when the launch is not that size."""
+    if LRT and kernel.startswith("lrt_"):
+        b, i, o = (int(v) for v in LRT.split("x"))
+        w = 4 * i * o
+        if kernel.startswith("lrt_wide_kernel"):
+            return 2 * w + 4 * b * i                                      # W_mu, W_rho (or the cached sigma^2) once + x
+        if kernel.startswith("lrt_bwd_w_kernel"):
+            return 3 * w + 4 * b * (i + 2 * o)                            # rho (or d sigma^2) read, two gradients written
+        if kernel.startswith("lrt_bwd_x_kernel"):
+            return 2 * w + 8 * o * 64                                     # W_mu, W_rho (or sigma^2) once + the transposed g copies
+        if kernel.startswith("lrt_sigma_cache_kernel"):
+            return 3 * w
+        return None
     big = grid >= 200_000          # every ResNet-50-size launch of this library uses >= 1024 workgroups of 256
     if not big:
         return None
     table = {"svgd_gram_kernel<2>": 4 * M * D50, "svgd_combine_kernel<8, true>": 12 * M * D50,
-             "svgd_fused_kernel<8, 0, true>": (12 * M + 8) * D50, "svgd_fused_kernel<8, 0, false>": (12 * M + 8) * D50,
+             "svgd_combine_seg_kernel<8>": 12 * M * D50,
+             "svgd_fused_kernel<8, 0, true, false>": (12 * M + 8) * D50, "svgd_fused_kernel<8, 0, false, false>": (12 * M + 8) * D50,
+             "svgd_fused_kernel<8, 0, true, true>": (12 * M + 8) * D50, "svgd_fused_kernel<8, 0, false, true>": (12 * M + 8) * D50,
+             "svgd_gather_seg_kernel": 8 * M * D50, "swag_copy_row_kernel": 8 * D50,
              "svgd_apply_sgd_kernel": (12 * M + 8) * D50,
              "swag_update_kernel": 24 * D50, "swag_sample_kernel<true>": 4 * D50 * (K + 3),
              "swag_sample_batched_kernel<true>": 4 * D50 * (K + 2 + S),
@@ -42,7 +60,8 @@ def main():
             with open(f) as fh:
                 for row in csv.DictReader(fh):
                     k = short(row["Kernel_Name"])
-                    if not ("svgd" in k or "swag" in k or "gauss" in k or "ivon" in k or "local_reparam" in k or "philox" in k):
+                    if not ("svgd" in k or "swag" in k or "gauss" in k or "ivon" in k or "local_reparam" in k or "philox" in k
+                            or "lrt_" in k):
                         continue
                     g = int(row["Grid_Size"])
                     key = (k, g >= 200_000)
