@@ -303,13 +303,12 @@ def torch_gpu_baseline(P, G, d, dev):
     return out
 
 
-def shell_step_ms(dev, steps=10):
+def shell_step_ms(dev, steps=10, n_tensors=161, d=D_RESNET50):
     """End-to-end SVGDOptimizer.step() over 161 parameter tensors totalling ResNet-50 size with NULL closures
     (forward returns a constant, backward does nothing): what is timed is the shell's host logic (re-pointing the
     views, gradient hand-over) + the kernels + the fused base optimizer -- "step minus closures" with nothing to
     subtract.  tools/shell_bench.py has the variants (unfused, Adam, closures with real gradients)."""
     import beyond_deep_ensembles_amd as bde
-    n_tensors, d = 161, D_RESNET50
     sizes = [d // n_tensors] * (n_tensors - 1)
     sizes.append(d - sum(sizes))
     params = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in sizes]
@@ -335,7 +334,7 @@ def shell_step_ms(dev, steps=10):
     return {"shell_plus_kernels_ms": round(t_step * 1e3, 3), "tensors": n_tensors, "particles": M,
             "native_host_helper": _host.load() is not None,
             "what": "SVGDOptimizer(fuse_base_optimizer=True, reuse_gram=True).step with null closures: host logic "
-                    "of the shell + kernels + fused SGD for 8 particles x 161 tensors"}
+                    f"of the shell + kernels + fused SGD for 8 particles x {n_tensors} tensors, D = {d}"}
 
 
 class _ManyGrads(torch.autograd.Function):
@@ -1000,7 +999,9 @@ def main():
                 res["extra"] = extras(ops, dev, quick=False)
                 try:
                     res["extra"]["svgd_shell_step_ms"] = shell_step_ms(dev)
+                    res["extra"]["svgd_shell_step_densenet121_ms"] = shell_step_ms(dev, n_tensors=364, d=D_DENSENET)
                     log(f"  svgd_shell_step_ms {res['extra']['svgd_shell_step_ms']}")
+                    log(f"  svgd_shell_step_densenet121_ms {res['extra']['svgd_shell_step_densenet121_ms']}")
                 except Exception as e:
                     log(f"  svgd_shell_step_ms skipped: {e}")
                 try:

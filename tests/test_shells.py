@@ -287,8 +287,16 @@ def test_swag_prefetch_equals_one_by_one(backend):
     batched = ens.predict(lambda m: m(x).detach().clone(), 7)
     assert torch.allclose(torch.stack(one_by_one), batched, rtol=1e-6, atol=1e-7)
     assert o2._sample_counter == 7 and o2._prefetched is None
-    # a prefetched sample (stored in pieces, like the statistics) is served by one copy into the sample vector the
-    # parameters view; sample_batch() hands out the same samples as contiguous rows
+    # small models keep prefetched samples as contiguous rows, served by a device copy into the sample vector or by
+    # re-pointing the parameters at the row (whichever the cost model picks): same predictions either way
+    m4, o4, _ = member()
+    o4._copy_is_cheaper = not o2._copy_is_cheaper
+    assert torch.equal(bde.DeepEnsemble([(m4, o4)]).predict(lambda m: m(x).detach().clone(), 7), batched)
+    # large models store them in pieces, like the statistics, and serve them by one streaming copy
+    m5, o5, _ = member()
+    o5._PIECES_FROM = 0
+    assert torch.equal(bde.DeepEnsemble([(m5, o5)]).predict(lambda m: m(x).detach().clone(), 7), batched)
+    # sample_batch() hands out the same samples as contiguous rows
     m3, o3, _ = member()
     rows = o3.sample_batch(7)
     served = []
