@@ -999,14 +999,17 @@ def main():
                 res["extra"] = extras(ops, dev, quick=False)
                 try:
                     res["extra"]["svgd_shell_step_ms"] = shell_step_ms(dev)
-                    res["extra"]["svgd_shell_step_densenet121_ms"] = shell_step_ms(dev, n_tensors=364, d=D_DENSENET)
                     log(f"  svgd_shell_step_ms {res['extra']['svgd_shell_step_ms']}")
-                    log(f"  svgd_shell_step_densenet121_ms {res['extra']['svgd_shell_step_densenet121_ms']}")
+                    if not args.no_config_extras:       # other sizes: kept out of the PMC passes (one size per kernel there)
+                        res["extra"]["svgd_shell_step_densenet121_ms"] = shell_step_ms(dev, n_tensors=364, d=D_DENSENET)
+                        log(f"  svgd_shell_step_densenet121_ms {res['extra']['svgd_shell_step_densenet121_ms']}")
                 except Exception as e:
                     log(f"  svgd_shell_step_ms skipped: {e}")
                 try:
                     res["extra"]["svgd_shell_step_real_grads_ms"] = shell_step_real_grads_ms(dev)
-                    res["extra"]["svgd_shell_step_real_grads_densenet121_ms"] = shell_step_real_grads_ms(dev, 364, D_DENSENET)
+                    if not args.no_config_extras:
+                        res["extra"]["svgd_shell_step_real_grads_densenet121_ms"] = \
+                            shell_step_real_grads_ms(dev, 364, D_DENSENET)
                     log(f"  svgd_shell_step_real_grads_ms {res['extra']['svgd_shell_step_real_grads_ms']}")
                 except Exception as e:
                     log(f"  svgd_shell_step_real_grads_ms skipped: {type(e).__name__}: {e}")
