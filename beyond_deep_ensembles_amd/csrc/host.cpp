@@ -11,6 +11,20 @@
 
 namespace {
 
+// param.data = view.  All particle views of one parameter live in ONE storage with ONE shape (rows of the flat
+// particle buffer), so switching particle is a change of the parameter's storage offset: one store instead of
+// set_data()'s shallow copy of the whole TensorImpl (0.45 us per tensor on the GPU box: 8 x 161 of them were 0.58 ms
+// of a ResNet-50 SVGD step).  Anything else (first use, a parameter the caller re-pointed elsewhere) takes set_data().
+inline void point_at(at::Tensor& p, const at::Tensor& view) {
+  c10::TensorImpl* pi = p.unsafeGetTensorImpl();
+  const c10::TensorImpl* vi = view.unsafeGetTensorImpl();
+  if (pi->storage().unsafeGetStorageImpl() == vi->storage().unsafeGetStorageImpl() && pi->allow_tensor_metadata_change() &&
+      pi->dtype() == vi->dtype() && pi->sizes() == vi->sizes() && pi->strides() == vi->strides())
+    pi->set_storage_offset(vi->storage_offset());
+  else
+    p.set_data(view);
+}
+
 // param[i].data = datas[i] (if given); param[i].grad = grads[i] (if given; None clears).
 void repoint(const std::vector<at::Tensor>& params, const c10::optional<std::vector<at::Tensor>>& datas,
              const c10::optional<std::vector<at::Tensor>>& grads) {
@@ -71,8 +85,10 @@ void adopt_grads(const std::vector<at::Tensor>& params, const std::vector<at::Te
 // of a read-only all-zero buffer at least as long as the largest tensor) a MISSING gradient costs nothing: that
 // address is recorded and nothing is written.  Returns the tensors recorded by reference: the caller keeps them alive
 // until the update kernel has been enqueued.
+// `take`: the gradients are also detached from the parameters (param.grad = None afterwards; the ones recorded by
+// reference are MOVED out of the parameter, no reference-count traffic).
 std::vector<at::Tensor> collect_grads(const std::vector<at::Tensor>& params, const std::vector<at::Tensor>& views,
-                                      at::Tensor table, int64_t j, int64_t M, int64_t zero_addr) {
+                                      at::Tensor table, int64_t j, int64_t M, int64_t zero_addr, bool take) {
   const size_t n = params.size();
   TORCH_CHECK(views.size() == n, "collect_grads: ", n, " parameters but ", views.size(), " views");
   TORCH_CHECK(table.scalar_type() == at::kLong && table.is_contiguous() && !table.is_cuda() &&
@@ -82,21 +98,23 @@ std::vector<at::Tensor> collect_grads(const std::vector<at::Tensor>& params, con
   std::vector<at::Tensor> keep, src, dst, missing;
   keep.reserve(n);
   for (size_t i = 0; i < n; ++i) {
-    const at::Tensor& g = params[i].grad();
+    at::Tensor& g = params[i].mutable_grad();      // the slot itself (Tensor::grad() adds a leaf check per call)
     const at::Tensor& v = views[i];
     int64_t addr = reinterpret_cast<int64_t>(v.data_ptr());
     if (!g.defined()) {
       if (zero_addr != 0) addr = zero_addr;
       else missing.push_back(v);
     } else if (g.data_ptr() == v.data_ptr()) {
-      // accumulated in place: already where it belongs
+      if (take) g = at::Tensor();                  // accumulated in place: already where it belongs
     } else if (g.scalar_type() == at::kFloat && g.layout() == at::kStrided && g.is_contiguous() && g.device() == v.device() &&
                g.numel() == v.numel() && (reinterpret_cast<uintptr_t>(g.data_ptr()) & 15u) == 0) {
       addr = reinterpret_cast<int64_t>(g.data_ptr());
-      keep.push_back(g);
+      if (take) keep.push_back(std::move(g));      // leaves param.grad undefined
+      else keep.push_back(g);
     } else {
       src.push_back(g);
       dst.push_back(v);
+      if (take) g = at::Tensor();
     }
     t[static_cast<int64_t>(i) * M + j] = addr;
   }
@@ -132,9 +150,19 @@ class Layout {
   void point_data(const std::vector<at::Tensor>& params, const at::Tensor& row) const {
     TORCH_CHECK(params.size() == offsets_.size(), "Layout.point_data: ", offsets_.size(), " tensors in the layout but ",
                 params.size(), " parameters");
+    const c10::StorageImpl* storage = row.unsafeGetTensorImpl()->storage().unsafeGetStorageImpl();
+    const int64_t row0 = row.storage_offset();
+    const bool row_ok = row.dim() == 1 && row.stride(0) == 1;
     for (size_t i = 0; i < offsets_.size(); ++i) {
       at::Tensor p = params[i];
-      p.set_data(row.narrow(0, offsets_[i], numels_[i]).view(shapes_[i]));
+      c10::TensorImpl* pi = p.unsafeGetTensorImpl();
+      // already a contiguous view of this shape in the row's storage (another row of the same buffer): move the offset
+      if (row_ok && pi->storage().unsafeGetStorageImpl() == storage && pi->allow_tensor_metadata_change() &&
+          pi->dtype() == row.dtype() && pi->is_contiguous() && pi->sizes() == c10::IntArrayRef(shapes_[i]) &&
+          offsets_[i] + numels_[i] <= row.numel())
+        pi->set_storage_offset(row0 + offsets_[i]);
+      else
+        p.set_data(row.narrow(0, offsets_[i], numels_[i]).view(shapes_[i]));
     }
   }
 
@@ -162,15 +190,16 @@ class ParticleSet {
 
   void use(int64_t i) {
     const auto& views = views_of(pviews_, i, "particle");
-    for (size_t k = 0; k < params_.size(); ++k) params_[k].set_data(views[k]);
+    for (size_t k = 0; k < params_.size(); ++k) point_at(params_[k], views[k]);
   }
 
   void begin(int64_t i) {
     const auto& views = views_of(pviews_, i, "particle");
     for (size_t k = 0; k < params_.size(); ++k) {
       at::Tensor& p = params_[k];
-      p.set_data(views[k]);
-      if (p.grad().defined()) p.mutable_grad() = at::Tensor();
+      point_at(p, views[k]);
+      at::Tensor& g = p.mutable_grad();
+      if (g.defined()) g = at::Tensor();
     }
   }
 
@@ -178,7 +207,7 @@ class ParticleSet {
     const auto& pv = views_of(pviews_, i, "particle");
     const auto& gv = views_of(gviews_, i, "gradient");
     for (size_t k = 0; k < params_.size(); ++k) {
-      params_[k].set_data(pv[k]);
+      point_at(params_[k], pv[k]);
       params_[k].mutable_grad() = gv[k];
     }
   }
@@ -186,12 +215,13 @@ class ParticleSet {
   int64_t end(int64_t i, at::Tensor table, int64_t row, int64_t M, int64_t zero_addr) {
     const auto& views = views_of(gviews_, i, "gradient");
     TORCH_CHECK(row >= 0 && row < static_cast<int64_t>(keep_.size()), "ParticleSet.end: row out of range");
-    keep_[row] = collect_grads(params_, views, std::move(table), row, M, zero_addr);
-    for (at::Tensor& p : params_)
-      if (p.grad().defined()) p.mutable_grad() = at::Tensor();
+    keep_[row] = collect_grads(params_, views, std::move(table), row, M, zero_addr, /*take=*/true);
     return static_cast<int64_t>(keep_[row].size());
   }
 
+  // (Handing the tensors to a worker thread instead was measured: the 8 x 161 frees, 0.28 ms, leave this thread, but the
+  // closures get slower by as much -- allocator lock and, for gradients with Python wrappers, the interpreter lock --
+  // and the step takes the same time: profiles/r03_shell_host_profile_release_ab.txt.)
   void release() {
     for (auto& k : keep_) k.clear();
   }
@@ -228,7 +258,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("datas"), py::arg("grads"));
   m.def("clear_grads", &clear_grads, "param.grad = None for a whole parameter list");
   m.def("collect_grads", &collect_grads, "record where the gradients live (no copy); returns the tensors taken by reference",
-        py::arg("params"), py::arg("views"), py::arg("table"), py::arg("j"), py::arg("M"), py::arg("zero_addr") = 0);
+        py::arg("params"), py::arg("views"), py::arg("table"), py::arg("j"), py::arg("M"), py::arg("zero_addr") = 0,
+        py::arg("take") = false);
   m.def("adopt_grads", &adopt_grads, "gradients -> flat views (multi-tensor copy/add), views become .grad", py::arg("params"),
         py::arg("views"), py::arg("add"));
 }

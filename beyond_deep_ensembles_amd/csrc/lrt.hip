@@ -26,6 +26,20 @@ namespace bde {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// tools/lrt_ab.py only (never defined in the product build): where the time of the wide-layer kernels goes.
+//   BDE_EXP_NOMFMA   the matrix products replaced by one VALU FMA each (memory + LDS + issue side alone)
+//   BDE_EXP_ALIAS    every tile reads / writes the FIRST tile's rows of the weight-shaped arrays (no HBM stream)
+#ifdef BDE_EXP_NOMFMA
+#define BDE_MFMA32(a, b, c) ([&] { auto c_ = (c); c_[0] = __builtin_fmaf((a), (b), c_[0]); return c_; }())
+#else
+#define BDE_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#endif
+#ifdef BDE_EXP_ALIAS
+#define BDE_EXP_ROW(r) ((r) & 31)
+#else
+#define BDE_EXP_ROW(r) (r)
+#endif
+
 constexpr int kLrtMinKSlice = 64;     // columns of W per wave at least (8 k-steps of 8)
 constexpr int kLrtTargetWaves = 2048; // (o-tile, K-slice) units wanted: 2 waves per SIMD on 256 CUs
 constexpr int kLrtWavesPerWG = 4;
@@ -98,8 +112,8 @@ __global__ __launch_bounds__(kLrtWavesPerWG * 64) void lrt_partial_kernel(
         const float a = cur.xs[t][c];
         const bool xok = (t * 32 + r < B) && (k < k1) && (ALIGNED || k + c < k1);
         const float a2 = xok ? fmaxf(a * a, kLrtClamp) : 0.f;     // clamp(x^2, 1e-4)
-        accm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bm, accm[t], 0, 0, 0);
-        accv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bv, accv[t], 0, 0, 0);
+        accm[t] = BDE_MFMA32(a, bm, accm[t]);
+        accv[t] = BDE_MFMA32(a2, bv, accv[t]);
       }
     }
     cur = nxt;
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(kWideSub * 64) void lrt_wide_kernel(
     const int col = (kc + lc < k1) ? kc + lc : k0;                 // past the slice: any valid address, masked at the stash
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = min(ot * 32 + 8 * j + lr, O - 1);
+      const int row = BDE_EXP_ROW(min(ot * 32 + 8 * j + lr, O - 1));
       q.wm[j] = ld4(w_mu + static_cast<int64_t>(row) * I + col);
       q.wr[j] = ld4(w_rho + static_cast<int64_t>(row) * I + col);
     }
@@ -198,8 +212,8 @@ __global__ __launch_bounds__(kWideSub * 64) void lrt_wide_kernel(
         const f32x4 a = *reinterpret_cast<const f32x4*>(X + (t * 32 + r) * kWideLd + 8 * q + 4 * h);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          accm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], bm[c], accm[t], 0, 0, 0);
-          accv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(a[c] * a[c], kLrtClamp), bv[c], accv[t], 0, 0, 0);
+          accm[t] = BDE_MFMA32(a[c], bm[c], accm[t]);
+          accv[t] = BDE_MFMA32(fmaxf(a[c] * a[c], kLrtClamp), bv[c], accv[t]);
         }
       }
     }

@@ -26,6 +26,20 @@ namespace bde {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// tools/lrt_ab.py only (never defined in the product build): where the time of the wide-layer kernels goes.
+//   BDE_EXP_NOMFMA   the matrix products replaced by one VALU FMA each (memory + LDS + issue side alone)
+//   BDE_EXP_ALIAS    every tile reads / writes the FIRST tile's rows of the weight-shaped arrays (no HBM stream)
+#ifdef BDE_EXP_NOMFMA
+#define BDE_MFMA32(a, b, c) ([&] { auto c_ = (c); c_[0] = __builtin_fmaf((a), (b), c_[0]); return c_; }())
+#else
+#define BDE_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#endif
+#ifdef BDE_EXP_ALIAS
+#define BDE_EXP_ROW(r) ((r) & 31)
+#else
+#define BDE_EXP_ROW(r) (r)
+#endif
+
 constexpr float kLrtBwdClamp = 1e-4f;   // bbb_layers.py:66-67,71
 constexpr int kLrtBwdWaves = 4;         // waves per workgroup (independent units)
 #ifndef BDE_LRT_BWD_WU
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_w_kernel(
   float rho[16];
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
-    const int oo = min(ot * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, O - 1);
+    const int oo = BDE_EXP_ROW(min(ot * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, O - 1));
     rho[reg] = w_rho[static_cast<int64_t>(oo) * I + ic];
   }
   constexpr int U = BDE_LRT_BWD_WU;                                // k-steps (of 2 batch rows) per operand set
@@ -138,8 +152,8 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_w_kernel(
       const bool b_ok = 2 * (s0 + u) + h < B;                      // rows past B: clamped loads, zero operands
       const float xv = cur.xv[u];
       const float bx = (b_ok && i_ok) ? xv : 0.f, bx2 = (b_ok && i_ok) ? fmaxf(xv * xv, kLrtBwdClamp) : 0.f;
-      accm = __builtin_amdgcn_mfma_f32_32x32x2f32(o_ok ? cur.ag[u] : 0.f, bx, accm, 0, 0, 0);
-      accv = __builtin_amdgcn_mfma_f32_32x32x2f32(o_ok ? cur.av[u] : 0.f, bx2, accv, 0, 0, 0);
+      accm = BDE_MFMA32(o_ok ? cur.ag[u] : 0.f, bx, accm);
+      accv = BDE_MFMA32(o_ok ? cur.av[u] : 0.f, bx2, accv);
     }
     cur = nxt;
   }
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_w_kernel(
   for (int reg = 0; reg < 16; ++reg) {
     const int oo = ot * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
     if (oo < O) {
-      const int64_t idx = static_cast<int64_t>(oo) * I + i;
+      const int64_t idx = static_cast<int64_t>(BDE_EXP_ROW(oo)) * I + i;
       g_wmu[idx] = accm[reg];
       if (PRE) {
         g_wrho[idx] = accv[reg] * rho[reg];
@@ -191,8 +205,8 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_x_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int oc = min(ob0 + 2 * u + h, o1 - 1);
-      q.wm[u] = w_mu[static_cast<int64_t>(oc) * I + ic];
-      q.wr[u] = w_rho[static_cast<int64_t>(oc) * I + ic];
+      q.wm[u] = w_mu[static_cast<int64_t>(BDE_EXP_ROW(oc)) * I + ic];
+      q.wr[u] = w_rho[static_cast<int64_t>(BDE_EXP_ROW(oc)) * I + ic];
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
         q.ag[u][t] = gT[static_cast<int64_t>(oc) * b_pad + t * 32 + r];
@@ -220,8 +234,8 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_x_kernel(
       const float bm = w_ok ? cur.wm[u] : 0.f, bv = w_ok ? s2 : 0.f;
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
-        accm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.ag[u][t], bm, accm[t], 0, 0, 0);
-        accv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.av[u][t], bv, accv[t], 0, 0, 0);
+        accm[t] = BDE_MFMA32(cur.ag[u][t], bm, accm[t]);
+        accv[t] = BDE_MFMA32(cur.av[u][t], bv, accv[t]);
       }
     }
     cur = nxt;
@@ -313,8 +327,8 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_fused_kernel(
         const bool a_ok = oa_ok && (2 * (u0 + u) + h < B);
         const float xv = xs[u0 + u];
         const float x2 = (2 * (u0 + u) + h < B && i_ok) ? fmaxf(xv * xv, kLrtBwdClamp) : 0.f;
-        accwm = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ok ? ag[u] : 0.f, xv, accwm, 0, 0, 0);
-        accwv = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ok ? av[u] : 0.f, x2, accwv, 0, 0, 0);
+        accwm = BDE_MFMA32(a_ok ? ag[u] : 0.f, xv, accwm);
+        accwv = BDE_MFMA32(a_ok ? av[u] : 0.f, x2, accwv);
       }
     }
     // dX k-steps + the dW epilogue, 4 rows of transposed-copy operands in flight at a time
@@ -341,8 +355,8 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_fused_kernel(
         const float bm = w_ok ? wm[s] : 0.f, bv = w_ok ? fmaxf(s2, kLrtBwdClamp) : 0.f;
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
-          accxm[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(agT[q][t], bm, accxm[t], 0, 0, 0);
-          accxv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(avT[q][t], bv, accxv[t], 0, 0, 0);
+          accxm[t] = BDE_MFMA32(agT[q][t], bm, accxm[t]);
+          accxv[t] = BDE_MFMA32(avT[q][t], bv, accxv[t]);
         }
         if (w_ok) {
           const int64_t idx = static_cast<int64_t>(row) * I + i;

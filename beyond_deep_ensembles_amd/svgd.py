@@ -323,12 +323,17 @@ class SVGDOptimizer(BayesianOptimizer):
         OptState = _opt_state()
         base = self.state["__base_optimizer"]
         m, d = self.state["__particle_count"], self._layout.d
-        total_loss = torch.tensor(0.0, device=self._params_device())
+        total_loss = None
         for particle_idx in self._local_particles():
             self._set_grad_scaler_state(grad_scaler, OptState.READY, base)
             self._begin_particle(particle_idx)
             loss = forward_closure()
-            total_loss += loss.detach()
+            # svgd.py:66,72: total_loss = tensor(0.0); total_loss += loss.  0 + x == x bit for bit, so the first loss starts
+            # the sum (no host-to-device copy of a constant, one launch less per step)
+            if total_loss is None:
+                total_loss = loss.detach().to(device=self._params_device(), dtype=torch.float32, copy=True)
+            else:
+                total_loss += loss.detach()
             if self._overlap and particle_idx == self._local_particles()[-1] and not self._scaler_active(grad_scaler):
                 self._begin_overlap(particle_idx, total_loss)
             backward_closure(loss)

@@ -1374,3 +1374,47 @@ def test_bbb_linear_sigma_cache_follows_the_weights(backend):
             torch.autograd.grad(out_old.pow(2).sum(), [layers[0].weight.mean])
     finally:
         ops.lrt_sigma_cache = real
+
+
+def test_particle_set_of_the_host_helper():
+    """csrc/host.cpp ParticleSet: begin()/use() re-point the parameters by moving the storage offset when they already
+    view a row of the particle buffer and by set_data() otherwise (same result either way); end() hands the gradients
+    over by reference and detaches them from the parameters; release() lets go of them."""
+    from beyond_deep_ensembles_amd import _host
+    native = _host.load()
+    assert native is not None, "lib/_bde_host.so is missing or does not load: run __graft_entry__.build()"
+    torch.manual_seed(5)
+    shapes, m = [(3, 4), (5,), (), (2, 1, 3)], 3
+    numels = [int(np.prod(s)) for s in shapes]
+    offs = np.concatenate([[0], np.cumsum([(n + 3) // 4 * 4 for n in numels])]).tolist()
+    ld = offs[-1]
+    P, G = torch.randn(m, ld), torch.zeros(m, ld)
+    params = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    views = lambda buf: [[buf[i, o:o + n].view(s) for o, n, s in zip(offs, numels, shapes)] for i in range(m)]
+    pv, gv = views(P), views(G)
+    ps = native.ParticleSet(params, pv, gv)
+    table = torch.zeros(len(params) * m, dtype=torch.int64)
+    weak = []
+    for _ in range(3):
+        for i in (1, 0, 2, 2, 1):                       # first call: set_data(); later ones: the offset moves
+            ps.begin(i)
+            for p, v, s in zip(params, pv[i], shapes):
+                assert p.data_ptr() == v.data_ptr() and p.shape == torch.Size(s) and torch.equal(p.data, v) and p.grad is None
+            loss = sum((p * (k + 1.0)).sum() for k, p in enumerate(params[:-1]))      # the last tensor gets no gradient
+            loss.backward()
+            grads = [p.grad for p in params[:-1]]
+            assert ps.end(i, table, i, m, 0) == len(grads)
+            assert all(p.grad is None for p in params)
+            t = table.view(len(params), m)
+            assert [int(t[k, i]) for k in range(len(grads))] == [g.data_ptr() for g in grads]
+            assert int(t[len(params) - 1, i]) == gv[i][-1].data_ptr()                # missing: its (zeroed) flat view
+            for k, g in enumerate(grads):
+                assert torch.equal(g, torch.full(shapes[k], k + 1.0))
+            import weakref
+            weak.append(weakref.ref(grads[0]))
+            del grads
+        params[1].data = torch.randn(5)                 # the caller re-pointed a parameter elsewhere: set_data() again
+        ps.use(2)
+        assert params[1].data_ptr() == pv[2][1].data_ptr() and torch.equal(params[1].data, pv[2][1])
+        ps.release()
+    assert all(w() is None for w in weak)

@@ -11,7 +11,7 @@ import bench
 dev = torch.device("cuda", 0)
 
 
-def profile(n_tensors, d, fuse=True, steps=20):
+def profile(n_tensors, d, fuse=True, steps=20, producer="python node"):
     sizes = [d // n_tensors] * (n_tensors - 1)
     sizes.append(d - sum(sizes))
     params = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in sizes]
@@ -48,7 +48,10 @@ def profile(n_tensors, d, fuse=True, steps=20):
 
     def fwd():
         t0 = time.perf_counter()
-        out = bench._ManyGrads.apply(cs, *params)
+        if producer == "python node":     # ONE Python autograd node: its gradients carry Python wrapper objects
+            out = bench._ManyGrads.apply(cs, *params)
+        else:                             # per-tensor C++ nodes (mul, sum), like a model: no Python objects on the gradients
+            out = torch.stack([t.sum() for t in torch._foreach_mul(params, cs)]).sum()
         t_f[0] += time.perf_counter() - t0
         return out
 
@@ -69,7 +72,7 @@ def profile(n_tensors, d, fuse=True, steps=20):
     wall = (time.perf_counter() - t0) / steps
     for n, fn in saved.items():
         setattr(S, n, fn)
-    print(f"{n_tensors} tensors, D = {d}, fused = {fuse}: step {wall*1e3:.3f} ms wall ({host*1e3:.3f} ms until the last "
+    print(f"{n_tensors} tensors, D = {d}, fused = {fuse}, gradients from {producer}: step {wall*1e3:.3f} ms wall ({host*1e3:.3f} ms until the last "
           f"launch was issued); closures {t_f[0]/steps*1e3:.3f} ms host; step() itself (not in any row below, "
           f"_release_grads / _take_segments / _check_single_launch are inside _posterior_update) "
           f"{(host - t_f[0]/steps - sum(v for k, v in acc.items() if k in ('_posterior_update', '_begin_particle', '_end_particle', '_prepare_and_check_grads', '_set_grad_scaler_state', '_local_particles'))/steps)*1e3:.3f} ms")
@@ -80,5 +83,7 @@ def profile(n_tensors, d, fuse=True, steps=20):
 
 for fuse in (True, False):
     profile(161, 23_880_950, fuse)
+profile(161, 23_880_950, True)
+profile(161, 23_880_950, True, producer="C++ nodes")
 profile(364, 6_955_906, True)
 profile(65, 273_610, True)
