@@ -261,6 +261,141 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_x_kernel(
   }
 }
 
+// The same input gradient with 16-byte loads (I % 4 == 0, O % 4 == 0; up to 64 batch rows).  lrt_bwd_x_kernel issues six
+// 4-byte loads per pair of weight rows; here a wave walks its O-slice in chunks of 16 weight rows:
+//   * W_mu / sigma^2 rows arrive as float4s, 8 rows x 128 bytes per instruction, and are parked in a per-wave LDS tile;
+//     the B operand (lane = input column, one row per k) is read back with conflict-free 4-byte LDS reads;
+//   * the A operand comes straight from g / gvar [B, O] as float4s along o (no transposed copies): k-step (j, c) of a
+//     chunk multiplies rows 8 j + c (lanes 0-31) and 8 j + 4 + c (lanes 32-63);
+//   * the next chunk's loads are in flight while the current chunk's 16 NB products run.
+// 12 memory instructions per 16 rows instead of 48 (NB = 2), and the prep kernel skips the transposed copies.  Worth
+// 2-5 % of the backward at 4096 x 4096 (profiles/r03_lrt_limiter_experiments.txt: the wide kernels are bound by how
+// well operand waits and the fp32 matrix pipe overlap, not by the count of memory instructions).  Same partial /
+// finish scheme as lrt_bwd_x_kernel.
+constexpr int kX4Rows = 16, kX4Ld = 36;
+#ifndef BDE_LRT_BWD_X4
+#define BDE_LRT_BWD_X4 1
+#endif
+#ifndef BDE_LRT_X4_WAVES
+#define BDE_LRT_X4_WAVES 2      // waves per SIMD the register allocation aims for
+#endif
+
+template <int NB, bool DIRECT, bool PRE>
+__global__ __launch_bounds__(kLrtBwdWaves * 64, BDE_LRT_X4_WAVES) void lrt_bwd_x4_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_mu, const float* __restrict__ w_rho,
+    const float* __restrict__ g, const float* __restrict__ gvar, int B, int I, int O, int n_slices, int oslice,
+    float* __restrict__ g_x, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float tiles[kLrtBwdWaves][2 * kX4Rows * kX4Ld];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i_tiles = (I + 31) >> 5;
+  const int unit = blockIdx.x * kLrtBwdWaves + wave;
+  if (unit >= i_tiles * n_slices) return;                          // (no workgroup barrier below: waves are independent)
+  const int sl = unit / i_tiles, it = unit % i_tiles;
+  const int r = lane & 31, h = lane >> 5;
+  const int lr = lane >> 3, lc = 4 * (lane & 7);                   // row layout of the W loads: row 8 p + lr, columns lc .. lc + 3
+  const int i = it * 32 + r;
+  const bool i_ok = i < I;
+  const int colw = min(it * 32 + lc, I - 4);                       // columns past I: any valid address (never stored)
+  const int o0 = sl * oslice, o1 = min(O, o0 + oslice);
+  constexpr int b_pad = NB * 32;
+  float* tile = tiles[wave];
+  bool b_ok[NB];
+  int64_t arow[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    b_ok[t] = t * 32 + r < B;                                      // rows past B: clamped loads, zero operands
+    arow[t] = static_cast<int64_t>(min(t * 32 + r, B - 1)) * O;
+  }
+
+  struct Stage {
+    f32x4 wm[2], wr[2], ag[NB][2], av[NB][2];
+  };
+  auto gload = [&](Stage& q, int oc0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int64_t row = static_cast<int64_t>(BDE_EXP_ROW(min(oc0 + 8 * p + lr, O - 1))) * I + colw;
+      q.wm[p] = ld4(w_mu + row);
+      q.wr[p] = ld4(w_rho + row);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int oc = min(oc0 + 8 * j + 4 * h, O - 4);              // past the slice: the W rows are zero, any finite A will do
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        q.ag[t][j] = ld4(g + arow[t] + oc);
+        q.av[t][j] = ld4(gvar + arow[t] + oc);
+      }
+    }
+  };
+  auto stash = [&](const Stage& q, int oc0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const bool ok = oc0 + 8 * p + lr < o1;                       // rows past the slice add zeros
+      f32x4 m, v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        m[c] = ok ? q.wm[p][c] : 0.f;
+        if (PRE) {
+          v[c] = ok ? q.wr[p][c] : 0.f;
+        } else {
+          const float sg = softplus(q.wr[p][c]);
+          v[c] = ok ? fmaxf(sg * sg, kLrtBwdClamp) : 0.f;
+        }
+      }
+      *reinterpret_cast<f32x4*>(tile + (8 * p + lr) * kX4Ld + lc) = m;
+      *reinterpret_cast<f32x4*>(tile + (kX4Rows + 8 * p + lr) * kX4Ld + lc) = v;
+    }
+  };
+  f32x16 accm[NB], accv[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) accm[t] = accv[t] = f32x16{};
+  Stage st;
+  gload(st, o0);
+  for (int oc0 = o0; oc0 < o1; oc0 += kX4Rows) {
+    stash(st, oc0);
+    f32x4 ag[NB][2], av[NB][2];
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ag[t][j] = st.ag[t][j];
+        av[t][j] = st.av[t][j];
+      }
+    if (oc0 + kX4Rows < o1) gload(st, oc0 + kX4Rows);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int krow = 8 * j + 4 * h + c;
+        const float bm = tile[krow * kX4Ld + r], bv = tile[(kX4Rows + krow) * kX4Ld + r];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          accm[t] = BDE_MFMA32(b_ok[t] ? ag[t][j][c] : 0.f, bm, accm[t]);
+          accv[t] = BDE_MFMA32(b_ok[t] ? av[t][j][c] : 0.f, bv, accv[t]);
+        }
+      }
+  }
+  if (!i_ok) return;
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int b = t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (DIRECT) {
+        if (b < B) {
+          const float xv = x[static_cast<int64_t>(b) * ldx + i];
+          const float keep = xv * xv >= kLrtBwdClamp ? 1.f : 0.f;
+          g_x[static_cast<int64_t>(b) * I + i] = accm[t][reg] + accv[t][reg] * keep * (2.0f * xv);
+        }
+      } else {
+        float* base = part + static_cast<int64_t>(sl) * 2 * b_pad * I;
+        base[static_cast<int64_t>(b) * I + i] = accm[t][reg];
+        base[static_cast<int64_t>(b_pad + b) * I + i] = accv[t][reg];
+      }
+    }
+  }
+}
+
 // Weight gradients AND input gradient in ONE pass over the weights (layers up to 2^20 weights, batch <= 64): a
 // wave owns 32 input columns and an O-slice and walks the slice in tiles of 32 rows.  Per tile the rows of W_mu / W_rho
 // are read ONCE and softplus / sigmoid evaluated ONCE per element, serving both products:
@@ -420,11 +555,15 @@ struct LrtBwdPlan {
 #ifndef BDE_LRT_BWD_TARGET_WAVES
 #define BDE_LRT_BWD_TARGET_WAVES 2048
 #endif
-static inline LrtBwdPlan lrt_bwd_plan(int I, int O) {
+
+#ifndef BDE_LRT_BWD_X4_TARGET_WAVES
+#define BDE_LRT_BWD_X4_TARGET_WAVES 1024   // lrt_bwd_x4_kernel: one wave per SIMD and half the partials beat two (A/B: 73 vs 78 us)
+#endif
+static inline LrtBwdPlan lrt_bwd_plan(int I, int O, int target_waves = BDE_LRT_BWD_TARGET_WAVES) {
   // slices are whole 32-row tiles (the fused kernel's dW tiles must not straddle two slices)
   const int i_tiles = (I + 31) / 32, o_tiles = (O + 31) / 32;
   if (o_tiles < 4) return LrtBwdPlan{1, o_tiles * 32};
-  int want = (BDE_LRT_BWD_TARGET_WAVES + i_tiles - 1) / i_tiles;
+  int want = (target_waves + i_tiles - 1) / i_tiles;
   if (want > o_tiles) want = o_tiles;
   if (want < 1) want = 1;
   const int oslice = (o_tiles + want - 1) / want * 32;
@@ -461,7 +600,16 @@ extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu
   float* gvT = gT + pad64(static_cast<size_t>(O) * b_pad);
   float* part = gvT + pad64(static_cast<size_t>(O) * b_pad);
   const int pgrid = (O + kPrepCols - 1) / kPrepCols;
-  float* gT_arg = g_x ? gT : nullptr;                                // no input gradient wanted: no transposed copies
+  const int i_tiles = (I + 31) / 32, o_tiles = (O + 31) / 32;
+  // One pass over the weights for layers up to 2^20 weights (the reference's sizes: 23 vs 38 us at the iWildCam head).
+  // Wide layers keep the two kernels: the fused kernel's register set (352 VGPRs at 2 batch tiles, spills at 4) leaves
+  // one wave per SIMD and its per-tile chain un-overlapped (4096 x 4096 at batch 64: 303 vs 180 us).
+  const bool fused = g_x && nb <= 2 && static_cast<int64_t>(I) * O <= (int64_t{1} << 20);
+  const bool pre = !fused && w_s2 && w_ds2;    // cached sigma^2 / its rho-derivative of this weight version
+  // input gradient with 16-byte loads: float4-addressable rows of the weights and of g / gvar
+  const bool x4 = g_x && !fused && BDE_LRT_BWD_X4 && nb <= 2 && (I % 4 == 0) && (O % 4 == 0) && aligned16(w_mu) &&
+                  aligned16(pre ? w_s2 : w_rho) && aligned16(g) && aligned16(gvar);
+  float* gT_arg = (g_x && !x4) ? gT : nullptr;                       // the transposed copies: lrt_bwd_x_kernel's A operand
   if (eps)
     hipLaunchKernelGGL(lrt_bwd_prep_kernel<false>, dim3(pgrid), dim3(kPrepCols * kPrepRows), 0, s, g, var, eps, seed,
                        stream_id, b_rho, clamp_bias_var, gvar, gT_arg, gvT, g_bmu, g_brho, B, b_pad, O);
@@ -470,12 +618,6 @@ extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu
                        stream_id, b_rho, clamp_bias_var, gvar, gT_arg, gvT, g_bmu, g_brho, B, b_pad, O);
   int rc = to_err(hipGetLastError());
   if (rc) return rc;
-  const int i_tiles = (I + 31) / 32, o_tiles = (O + 31) / 32;
-  // One pass over the weights for layers up to 2^20 weights (the reference's sizes: 23 vs 38 us at the iWildCam head).
-  // Wide layers keep the two kernels: the fused kernel's register set (352 VGPRs at 2 batch tiles, spills at 4) leaves
-  // one wave per SIMD and its per-tile chain un-overlapped (4096 x 4096 at batch 64: 303 vs 180 us).
-  const bool fused = g_x && nb <= 2 && static_cast<int64_t>(I) * O <= (int64_t{1} << 20);
-  const bool pre = !fused && w_s2 && w_ds2;    // cached sigma^2 / its rho-derivative of this weight version
   if (!fused) {                          // weight gradients: one wave per 32 x 32 tile
     const int64_t w_units = static_cast<int64_t>(i_tiles) * o_tiles;
     const dim3 wgrid(static_cast<unsigned>((w_units + kLrtBwdWaves - 1) / kLrtBwdWaves));
@@ -488,7 +630,7 @@ extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu
     rc = to_err(hipGetLastError());
     if (rc || !g_x) return rc;
   }
-  const LrtBwdPlan plan = lrt_bwd_plan(I, O);
+  const LrtBwdPlan plan = x4 ? lrt_bwd_plan(I, O, BDE_LRT_BWD_X4_TARGET_WAVES) : lrt_bwd_plan(I, O);   // (never more slices: ws_bytes)
   const int x_units = i_tiles * plan.n_slices;
   const int xgrid = (x_units + kLrtBwdWaves - 1) / kLrtBwdWaves;
 #define BDE_LRT_X(NB, DIRECT)                                                                                              \
@@ -504,7 +646,19 @@ extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu
   hipLaunchKernelGGL((lrt_bwd_fused_kernel<NB, DIRECT>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu, w_rho, g, \
                      gvar, gT, gvT, B, I, O, plan.n_slices, plan.oslice, g_wmu, g_wrho, g_x, part)
   const bool direct = plan.n_slices == 1;
-  if (!fused) {
+#define BDE_LRT_X4(NB, DIRECT)                                                                                             \
+  do {                                                                                                                     \
+    if (pre)                                                                                                               \
+      hipLaunchKernelGGL((lrt_bwd_x4_kernel<NB, DIRECT, true>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu,   \
+                         w_s2, g, gvar, B, I, O, plan.n_slices, plan.oslice, g_x, part);                                   \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((lrt_bwd_x4_kernel<NB, DIRECT, false>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu,  \
+                         w_rho, g, gvar, B, I, O, plan.n_slices, plan.oslice, g_x, part);                                  \
+  } while (0)
+  if (x4) {
+    if (nb == 1) { if (direct) BDE_LRT_X4(1, true); else BDE_LRT_X4(1, false); }
+    else { if (direct) BDE_LRT_X4(2, true); else BDE_LRT_X4(2, false); }
+  } else if (!fused) {
     if (nb == 1) { if (direct) BDE_LRT_X(1, true); else BDE_LRT_X(1, false); }
     else if (nb == 2) { if (direct) BDE_LRT_X(2, true); else BDE_LRT_X(2, false); }
     else { if (direct) BDE_LRT_X(4, true); else BDE_LRT_X(4, false); }
@@ -514,6 +668,7 @@ extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu
     if (direct) BDE_LRT_F(2, true); else BDE_LRT_F(2, false);
   }
 #undef BDE_LRT_X
+#undef BDE_LRT_X4
 #undef BDE_LRT_F
   rc = to_err(hipGetLastError());
   if (rc || plan.n_slices == 1) return rc;
