@@ -273,6 +273,10 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_x_kernel(
 // well operand waits and the fp32 matrix pipe overlap, not by the count of memory instructions).  Same partial /
 // finish scheme as lrt_bwd_x_kernel.
 constexpr int kX4Rows = 16, kX4Ld = 36;
+#ifndef BDE_LRT_X4_FULL_ROWS
+#define BDE_LRT_X4_FULL_ROWS 16
+#endif
+constexpr int kX4FullRows = BDE_LRT_X4_FULL_ROWS;   // FULL variant: rows per chunk (two chunks per trip of its loop)
 #ifndef BDE_LRT_BWD_X4
 #define BDE_LRT_BWD_X4 1
 #endif
@@ -280,15 +284,21 @@ constexpr int kX4Rows = 16, kX4Ld = 36;
 #define BDE_LRT_X4_WAVES 2      // waves per SIMD the register allocation aims for
 #endif
 
-template <int NB, bool DIRECT, bool PRE>
-__global__ __launch_bounds__(kLrtBwdWaves * 64, BDE_LRT_X4_WAVES) void lrt_bwd_x4_kernel(
+// FULL: B % 32 == 0, I % 32 == 0, O % 32 == 0 (slices are whole 32-row tiles): no padding anywhere, and the product loop
+// is written so that it carries next to no vector instructions besides the products -- on this chip they do not run in
+// the shadow of the fp32 MFMA, each costs 6-10 % of a product (tools/mfma_rate.hip): every address is a wave-uniform base
+// (scalar unit) + a per-lane 32-bit offset computed once, no masks, no register copies (two operand sets alternate).
+template <int NB, bool DIRECT, bool PRE, bool FULL>
+__global__ __launch_bounds__(kLrtBwdWaves * 64, FULL ? 1 : BDE_LRT_X4_WAVES) void lrt_bwd_x4_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_mu, const float* __restrict__ w_rho,
     const float* __restrict__ g, const float* __restrict__ gvar, int B, int I, int O, int n_slices, int oslice,
     float* __restrict__ g_x, float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float tiles[kLrtBwdWaves][2 * kX4Rows * kX4Ld];
+  __shared__ __attribute__((aligned(16))) float tiles[kLrtBwdWaves][2 * (FULL ? kX4FullRows : kX4Rows) * kX4Ld];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i_tiles = (I + 31) >> 5;
-  const int unit = blockIdx.x * kLrtBwdWaves + wave;
+  // (readfirstlane: the wave index is uniform, but only this tells the compiler -- slice bounds, the loop counter and
+  // the row offsets then live in scalar registers)
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * kLrtBwdWaves + wave);
   if (unit >= i_tiles * n_slices) return;                          // (no workgroup barrier below: waves are independent)
   const int sl = unit / i_tiles, it = unit % i_tiles;
   const int r = lane & 31, h = lane >> 5;
@@ -307,6 +317,97 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64, BDE_LRT_X4_WAVES) void lrt_bwd_x
     arow[t] = static_cast<int64_t>(min(t * 32 + r, B - 1)) * O;
   }
 
+  f32x16 accm[NB], accv[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) accm[t] = accv[t] = f32x16{};
+  if constexpr (FULL) {
+    constexpr int RF = kX4FullRows, PW = RF / 8;                     // rows per chunk, 8-row groups per chunk
+    struct WOps {
+      f32x4 wm[PW], wr[PW];
+    };
+    struct AOps {
+      f32x4 ag[NB][PW], av[NB][PW];
+    };
+    // per-lane offsets (elements), computed once; the chunk's row offset is wave-uniform
+    const unsigned w_off = static_cast<unsigned>(lr) * static_cast<unsigned>(I) + static_cast<unsigned>(it * 32 + lc);
+    unsigned a_off[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) a_off[t] = static_cast<unsigned>(t * 32 + r) * static_cast<unsigned>(O) + 4u * h;
+    const int o_last = o1 - RF;                               // requests past the slice re-read its last chunk (unused)
+    auto request_w = [&](WOps& q, int oc0) {
+      oc0 = min(oc0, o_last);
+#pragma unroll
+      for (int p = 0; p < PW; ++p) {
+        const int64_t rows = static_cast<int64_t>(BDE_EXP_ROW(oc0 + 8 * p)) * I;       // uniform
+        q.wm[p] = ld4(&(w_mu + rows)[w_off]);                                           // scalar base + 32-bit lane offset
+        q.wr[p] = ld4(&(w_rho + rows)[w_off]);
+      }
+    };
+    auto request_a = [&](AOps& q, int oc0) {
+      oc0 = min(oc0, o_last);
+#pragma unroll
+      for (int j = 0; j < PW; ++j)
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          q.ag[t][j] = ld4(&(g + (oc0 + 8 * j))[a_off[t]]);
+          q.av[t][j] = ld4(&(gvar + (oc0 + 8 * j))[a_off[t]]);
+        }
+    };
+    auto park = [&](const WOps& q) {
+#pragma unroll
+      for (int p = 0; p < PW; ++p) {
+        *reinterpret_cast<f32x4*>(tile + (8 * p + lr) * kX4Ld + lc) = q.wm[p];
+        if (PRE) {
+          *reinterpret_cast<f32x4*>(tile + (RF + 8 * p + lr) * kX4Ld + lc) = q.wr[p];
+        } else {
+          f32x4 v;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float sg = softplus(q.wr[p][c]);
+            v[c] = fmaxf(sg * sg, kLrtBwdClamp);
+          }
+          *reinterpret_cast<f32x4*>(tile + (RF + 8 * p + lr) * kX4Ld + lc) = v;
+        }
+      }
+    };
+    auto products = [&](const AOps& q) {
+#pragma unroll
+      for (int j = 0; j < PW; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int krow = 8 * j + 4 * h + c;
+          const float bm = tile[krow * kX4Ld + r], bv = tile[(RF + krow) * kX4Ld + r];
+#pragma unroll
+          for (int t = 0; t < NB; ++t) {
+            accm[t] = BDE_MFMA32(q.ag[t][j][c], bm, accm[t]);
+            accv[t] = BDE_MFMA32(q.av[t][j][c], bv, accv[t]);
+          }
+        }
+    };
+    // Weight rows (HBM) are requested TWO chunks ahead, the A operands (g / gvar: 1 MB each, L2) one chunk ahead; the
+    // sched_barriers keep the compiler from sinking a request below the stash that waits for the previous one.
+    auto step = [&](WOps& w, AOps& a_now, AOps& a_next, int oc0) {
+      park(w);                                                     // chunk oc0's weight rows -> LDS tile
+      __builtin_amdgcn_sched_barrier(0);
+      request_w(w, oc0 + 2 * RF);
+      request_a(a_next, oc0 + RF);
+      __builtin_amdgcn_sched_barrier(0);
+      products(a_now);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    WOps w0, w1;
+    AOps a0, a1;
+    // (the prologue issues its requests in the order a trip leaves them outstanding -- w0, a1, w1, a0 -- so that the
+    // waits at the top of the loop can be counted instead of "everything"; a1's first request is a dummy)
+    request_w(w0, o0);
+    request_a(a1, o0);
+    request_w(w1, o0 + RF);
+    request_a(a0, o0);
+    for (int oc0 = o0; oc0 < o1; oc0 += 2 * RF) {             // slices are whole 32-row tiles: two chunks per trip
+      step(w0, a0, a1, oc0);
+      step(w1, a1, a0, oc0 + RF);
+    }
+  } else {
   struct Stage {
     f32x4 wm[2], wr[2], ag[NB][2], av[NB][2];
   };
@@ -346,9 +447,6 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64, BDE_LRT_X4_WAVES) void lrt_bwd_x
       *reinterpret_cast<f32x4*>(tile + (kX4Rows + 8 * p + lr) * kX4Ld + lc) = v;
     }
   };
-  f32x16 accm[NB], accv[NB];
-#pragma unroll
-  for (int t = 0; t < NB; ++t) accm[t] = accv[t] = f32x16{};
   Stage st;
   gload(st, o0);
   for (int oc0 = o0; oc0 < o1; oc0 += kX4Rows) {
@@ -374,6 +472,7 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64, BDE_LRT_X4_WAVES) void lrt_bwd_x
           accv[t] = BDE_MFMA32(b_ok[t] ? av[t][j][c] : 0.f, bv, accv[t]);
         }
       }
+  }
   }
   if (!i_ok) return;
 #pragma unroll
@@ -646,14 +745,20 @@ extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu
   hipLaunchKernelGGL((lrt_bwd_fused_kernel<NB, DIRECT>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu, w_rho, g, \
                      gvar, gT, gvT, B, I, O, plan.n_slices, plan.oslice, g_wmu, g_wrho, g_x, part)
   const bool direct = plan.n_slices == 1;
+  const bool x4_full = (B % 32 == 0) && (I % 32 == 0) && (O % 32 == 0) && (plan.oslice % (2 * kX4FullRows) == 0) &&
+                       static_cast<int64_t>(std::max(I, B)) * O < (int64_t{1} << 30);   // 32-bit per-lane offsets
+#define BDE_LRT_X4_(NB, DIRECT, PRE, FULL)                                                                                 \
+  hipLaunchKernelGGL((lrt_bwd_x4_kernel<NB, DIRECT, PRE, FULL>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu,  \
+                     (PRE) ? w_s2 : w_rho, g, gvar, B, I, O, plan.n_slices, plan.oslice, g_x, part)
 #define BDE_LRT_X4(NB, DIRECT)                                                                                             \
   do {                                                                                                                     \
-    if (pre)                                                                                                               \
-      hipLaunchKernelGGL((lrt_bwd_x4_kernel<NB, DIRECT, true>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu,   \
-                         w_s2, g, gvar, B, I, O, plan.n_slices, plan.oslice, g_x, part);                                   \
-    else                                                                                                                   \
-      hipLaunchKernelGGL((lrt_bwd_x4_kernel<NB, DIRECT, false>), dim3(xgrid), dim3(kLrtBwdWaves * 64), 0, s, x, ldx, w_mu,  \
-                         w_rho, g, gvar, B, I, O, plan.n_slices, plan.oslice, g_x, part);                                  \
+    if (pre) {                                                                                                             \
+      if (x4_full) BDE_LRT_X4_(NB, DIRECT, true, true);                                                                    \
+      else BDE_LRT_X4_(NB, DIRECT, true, false);                                                                           \
+    } else {                                                                                                               \
+      if (x4_full) BDE_LRT_X4_(NB, DIRECT, false, true);                                                                   \
+      else BDE_LRT_X4_(NB, DIRECT, false, false);                                                                          \
+    }                                                                                                                      \
   } while (0)
   if (x4) {
     if (nb == 1) { if (direct) BDE_LRT_X4(1, true); else BDE_LRT_X4(1, false); }
@@ -669,6 +774,7 @@ extern "C" int bde_lrt_linear_bwd(const float* x, int64_t ldx, const float* w_mu
   }
 #undef BDE_LRT_X
 #undef BDE_LRT_X4
+#undef BDE_LRT_X4_
 #undef BDE_LRT_F
   rc = to_err(hipGetLastError());
   if (rc || plan.n_slices == 1) return rc;

@@ -1145,7 +1145,9 @@ def test_lrt_linear_backward(ops):
     dev = lambda t: None if t is None else t.to(DEV)
     for b, i, o, bias, clamp_bias in [(16, 13, 50, True, True), (5, 50, 1, True, True), (16, 2048, 182, True, True),
                                       (128, 300, 70, False, True), (33, 64, 32, True, False), (1, 7, 3, True, True),
-                                      (96, 1000, 200, True, True), (64, 2100, 520, True, True), (70, 129, 33, True, True)]:
+                                      (96, 1000, 200, True, True), (64, 2100, 520, True, True), (70, 129, 33, True, True),
+                                      # tile-aligned wide layers: the mask-free variants of the two gradient kernels
+                                      (64, 1056, 1024, True, True), (32, 2048, 544, False, True)]:
         x = torch.randn(b, i)
         x[0, : min(i, 3)] = 0.0                                       # x^2 below the clamp: no gradient through it
         w_mu, w_rho = torch.randn(o, i) * 0.1, torch.randn(o, i) * 1.5 - 3.0
