@@ -31,6 +31,8 @@ def algorithmic(kernel, grid):
             return 3 * w + 4 * b * (i + 2 * o)                            # rho (or d sigma^2) read, two gradients written
         if kernel.startswith("lrt_bwd_x_kernel"):
             return 2 * w + 8 * o * 64                                     # W_mu, W_rho (or sigma^2) once + the transposed g copies
+        if kernel.startswith("lrt_bwd_x4_kernel"):
+            return 2 * w + 8 * b * o                                      # W_mu, W_rho (or sigma^2) once + g, gvar
         if kernel.startswith("lrt_sigma_cache_kernel"):
             return 3 * w
         return None
