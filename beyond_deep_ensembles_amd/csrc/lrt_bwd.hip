@@ -119,7 +119,11 @@ __global__ __launch_bounds__(kLrtBwdWaves * 64) void lrt_bwd_w_kernel(
   const int r = lane & 31, h = lane >> 5;
   const int o = ot * 32 + r, i = it * 32 + r;
   const bool o_ok = o < O, i_ok = i < I;
+#ifdef BDE_EXP_ALIAS_OPS   // tools/lrt_ab.py only: every tile reads the FIRST tile's operands (L1 hits instead of L2 traffic)
+  const int oc = r, ic = r;
+#else
   const int oc = o_ok ? o : O - 1, ic = i_ok ? i : I - 1;         // clamped: every load is unconditional
+#endif
   // the rho rows of the epilogue (C layout: lane = column i, rows o = ot*32 + (reg & 3) + 8 (reg >> 2) + 4 h) are
   // requested first and arrive while the products run
   float rho[16];
