@@ -550,6 +550,27 @@ def config_extras(dev):
                                              "weights_GBps": round(28.0 * fi * fo / t_f / 1e9, 1),
                                              "what": "BBBLinear forward + backward (all five gradients): 2 + 3..4 launches, "
                                                      "28*O*I algorithmic bytes, vs autograd over the reference's op sequence"}
+        if name == "mlp_4096x4096_b64":
+            # the C-ABI ops alone (kernels, preallocated outputs), with the sigma^2 cache of the weight version
+            ops = layer._ops if hasattr(layer, "_ops") else None
+            from beyond_deep_ensembles_amd.ops import HipOps
+            ops = ops or HipOps()
+            wm, wr, bm, br = (t.detach() for t in (layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho))
+            o_, v_ = torch.empty(bsz, fo, device=dev), torch.empty(bsz, fo, device=dev)
+            gg = torch.randn(bsz, fo, device=dev)
+            gx_, gwm_, gwr_ = torch.empty_like(xin), torch.empty_like(wm), torch.empty_like(wr)
+            gbm_, gbr_ = torch.empty_like(bm), torch.empty_like(br)
+            s2_, ds2_ = torch.empty_like(wr), torch.empty_like(wr)
+            t_c = time_loop(lambda: ops.lrt_sigma_cache(wr, s2_, ds2_), 30)
+            t_kf = time_loop(lambda: ops.lrt_linear_fwd(xin, wm, wr, bm, br, True, o_, v_, seed=1, stream_id=2, w_s2=s2_), 50)
+            t_kb = time_loop(lambda: ops.lrt_linear_bwd(xin, wm, wr, br, True, gg, v_, gx_, gwm_, gwr_, gbm_, gbr_, seed=1,
+                                                        stream_id=2, w_s2=s2_, w_ds2=ds2_), 50)
+            out["bbb_linear_kernels_" + name] = {
+                "ms": round((t_kf + t_kb) * 1e3, 4), "fwd_us": round(t_kf * 1e6, 1), "bwd_us": round(t_kb * 1e6, 1),
+                "sigma_cache_us": round(t_c * 1e6, 1), "B": bsz, "I": fi, "O": fo,
+                "what": "bde_lrt_linear_fwd / bde_lrt_linear_bwd alone (2 / 4 launches, preallocated outputs) with the "
+                        "sigma^2 cache of the weight version (bde_lrt_sigma_cache: once per base_optimizer.step)"}
+            del o_, v_, gg, gx_, gwm_, gwr_, s2_, ds2_
         del layer
 
     # ---- a BBBConv2d layer of the CIFAR ResNet-20 (BASELINE configs[1] model family: 3x3, 16 -> 16 channels, 32x32, batch 128):
