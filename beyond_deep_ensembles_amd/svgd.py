@@ -94,7 +94,10 @@ class SVGDOptimizer(BayesianOptimizer):
                               exactly when that is indistinguishable from particle_count calls of base.step() -- a
                               plain torch.optim.SGD / Adam (not a subclass) over exactly this optimizer's parameters,
                               one set of hyper-parameters, no amsgrad / maximize / capturable / differentiable, no
-                              step hooks, particle_count <= 16 -- and the torch loop otherwise
+                              step hooks, particle_count <= 64 -- and the torch loop otherwise.  Up to 16 particles:
+                              one pass; 17 to 64 (single GPU or exchange="allgather" without chunks): the blocked
+                              update kernel writes -phi, then ONE launch applies the base optimizer to all
+                              particles in order with its shared state
           reuse_gram          with fuse_base_optimizer: the fused kernel also emits the Gram partials of the updated
                               particles, so the next step skips the Gram pass.  Only valid while nothing but this
                               optimizer modifies the particles between two steps (call invalidate_gram() otherwise).
@@ -175,8 +178,6 @@ class SVGDOptimizer(BayesianOptimizer):
                 self._exchange = exchange
         if fuse_base_optimizer == "auto":
             fuse_base_optimizer = self._fusable(base_optimizer, plist, particle_count)
-        if fuse_base_optimizer and particle_count > 16:
-            warnings.warn("fuse_base_optimizer needs particle_count <= 16 (single-tile kernels); running unfused")
         if single_launch not in (None, True, False, "two"):
             raise ValueError("single_launch must be None, True, False or 'two'")
         self._single_launch = single_launch
@@ -186,6 +187,10 @@ class SVGDOptimizer(BayesianOptimizer):
         self._small_flag = None
         self._small_pending = None
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
+        # 17 <= particle_count <= 64: -phi by the blocked update kernel, then ONE launch applies the base optimizer to all
+        # particles in order with its shared state (bde_svgd_apply_sgd / adam) instead of particle_count torch steps
+        self._fuse_staged = bool(fuse_base_optimizer) and 16 < particle_count <= 64 and exchange != "alltoall" and \
+            int(exchange_chunks) <= 1
         self._fused_decision = None
         self._tmp = None
         self._fused_state = None
@@ -269,7 +274,7 @@ class SVGDOptimizer(BayesianOptimizer):
     @staticmethod
     def _fusable(base, plist, particle_count) -> bool:
         """fuse_base_optimizer="auto": True iff the in-kernel SGD / Adam applications are the base optimizer's own."""
-        if type(base) not in (torch.optim.SGD, torch.optim.Adam) or particle_count > 16:
+        if type(base) not in (torch.optim.SGD, torch.optim.Adam) or particle_count > 64:
             return False
         groups = base.param_groups
         if {id(p) for g in groups for p in g["params"]} != {id(p) for p in plist}:
@@ -424,7 +429,7 @@ class SVGDOptimizer(BayesianOptimizer):
         base = self.state["__base_optimizer"]
         m = self.state["__particle_count"]
         with torch.no_grad():
-            fused = self._fuse and (grad_scaler is None or not grad_scaler.is_enabled())
+            fused = (self._fuse or self._fuse_staged) and (grad_scaler is None or not grad_scaler.is_enabled())
             if self._fused_decision is None:
                 self._fused_decision = fused
             elif self._fused_decision != fused:
@@ -435,7 +440,8 @@ class SVGDOptimizer(BayesianOptimizer):
             elif self._chunks is not None:
                 total_loss = self._step_pipelined(total_loss, base, fused, grad_scaler)
             else:
-                total_loss = self._step_replicated(total_loss, base, fused, grad_scaler)
+                total_loss = self._step_replicated(total_loss, base, fused and self._fuse, grad_scaler,
+                                                   staged_apply=fused and self._fuse_staged)
         return total_loss / m
 
     # ---- replicated particles: one gather (or none), then the update ----------------------------------------
@@ -443,7 +449,7 @@ class SVGDOptimizer(BayesianOptimizer):
         return (float(self.state["__l2_reg"]), float(self.state["__kernel_grad_scale"]),
                 float(self.state["__dataset_size"]), -1.0)
 
-    def _step_replicated(self, total_loss, base, fused, grad_scaler):
+    def _step_replicated(self, total_loss, base, fused, grad_scaler, staged_apply=False):
         m, d = self.state["__particle_count"], self._layout.d
         pending = None
         if self._world > 1:
@@ -488,8 +494,14 @@ class SVGDOptimizer(BayesianOptimizer):
                 if self._tmp is None:
                     self._tmp = torch.zeros_like(self._G)
                 self._ops.svgd_combine(self._P, self._G, self._tmp, d, self._kstat)
-                self._G.copy_(self._tmp)
-            self._apply_base_optimizer(base, grad_scaler)
+                if not staged_apply:
+                    self._G.copy_(self._tmp)
+            if staged_apply:
+                # > 16 particles with a fusable base optimizer: its particle_count applications in ONE launch
+                self._fused_apply(base, [(self._P, self._tmp if m > 16 else self._G, d, 0)], staged=True)
+                self._use_particle(m - 1)
+            else:
+                self._apply_base_optimizer(base, grad_scaler)
         self._release_grads()
         return total_loss
 
@@ -750,7 +762,7 @@ class SVGDOptimizer(BayesianOptimizer):
         self._fused_state = self.state["__fused"] = st
         return st
 
-    def _fused_apply(self, base, pieces, ws_next=None, advance=True, single_launch=False, seg=None) -> None:
+    def _fused_apply(self, base, pieces, ws_next=None, advance=True, single_launch=False, seg=None, staged=False) -> None:
         """-phi and the M sequential base-optimizer applications with shared state in ONE kernel per piece
         (bde_svgd_fused_sgd / bde_svgd_fused_adam); ``pieces`` = (P, G, valid columns, column offset into the state
         buffers).  Hyper-parameters are read from the base optimizer's param_groups every step, so LR schedulers
@@ -761,6 +773,10 @@ class SVGDOptimizer(BayesianOptimizer):
                 raise RuntimeError("fuse_base_optimizer: maximize=True is not supported")
             st = self._fused_buffers(base, "sgd")
             for P, G, d, c0 in pieces:
+                if staged:                           # G holds -phi already (blocked update): the applications alone
+                    self._ops.svgd_apply_sgd(P, G, st["buf"][c0:], d, g0["lr"], g0["momentum"], g0["dampening"],
+                                             g0["weight_decay"], g0["nesterov"], st["first"])
+                    continue
                 if single_launch:
                     l2, scale, n, _ = self._stat_args()
                     args = (P, G, st["buf"], d, l2, scale, n, self._ws, self._kstat, g0["lr"], g0["momentum"],
@@ -779,6 +795,10 @@ class SVGDOptimizer(BayesianOptimizer):
                 raise RuntimeError("fuse_base_optimizer: amsgrad / maximize are not supported")
             st = self._fused_buffers(base, "adam")
             for P, G, d, c0 in pieces:
+                if staged:
+                    self._ops.svgd_apply_adam(P, G, st["exp_avg"][c0:], st["exp_avg_sq"][c0:], d, float(g0["lr"]),
+                                              g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"])
+                    continue
                 if single_launch:
                     l2, scale, n, _ = self._stat_args()
                     args = (P, G, st["exp_avg"], st["exp_avg_sq"], d, l2, scale, n, self._ws, self._kstat, float(g0["lr"]),

@@ -126,7 +126,8 @@ def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
 
 
 def test_svgd_many_particles(backend):
-    """particle_count > 16 (blocked path; fused options silently fall back to the base optimizer loop)."""
+    """particle_count > 16: the blocked update kernel, then (fuse_base_optimizer) ONE launch that applies the base optimizer
+    to all particles in order with its shared state -- the same trajectory as the reference's loop of base.step() calls."""
     ops, dev = backend
     torch.manual_seed(3)
     model = nn.Linear(7, 2).to(dev)
@@ -1176,8 +1177,9 @@ def test_svgd_fuse_auto_eligibility(backend):
         model = make_mlp().to(dev)
         ps = list(model.parameters())
         base = make_base(ps)
-        return bde.SVGDOptimizer(ps, lambda: bde.reset_model_params(model), base, particle_count=kw.pop("m", 4),
-                                 dataset_size=32, fuse_base_optimizer="auto", _ops=ops, **kw)._fuse
+        opt = bde.SVGDOptimizer(ps, lambda: bde.reset_model_params(model), base, particle_count=kw.pop("m", 4),
+                                dataset_size=32, fuse_base_optimizer="auto", _ops=ops, **kw)
+        return opt._fuse or opt._fuse_staged
 
     class MySGD(torch.optim.SGD):
         pass
@@ -1190,7 +1192,7 @@ def test_svgd_fuse_auto_eligibility(backend):
     assert not decide(lambda ps: torch.optim.SGD([{"params": ps[:2], "lr": 0.1}, {"params": ps[2:], "lr": 0.01}], lr=0.1))
     assert decide(lambda ps: torch.optim.SGD([{"params": ps[:2]}, {"params": ps[2:]}], lr=0.1))
     assert not decide(lambda ps: torch.optim.SGD(ps[:2], lr=0.1))                 # not the same parameter set
-    assert not decide(lambda ps: torch.optim.SGD(ps, lr=0.1), m=20)              # > 16 particles: blocked path
+    assert decide(lambda ps: torch.optim.SGD(ps, lr=0.1), m=20)                  # 17..64 particles: blocked update + one apply launch
 
     def hooked(ps):
         base = torch.optim.SGD(ps, lr=0.1)
@@ -1418,3 +1420,36 @@ def test_particle_set_of_the_host_helper():
         assert params[1].data_ptr() == pv[2][1].data_ptr() and torch.equal(params[1].data, pv[2][1])
         ps.release()
     assert all(w() is None for w in weak)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
+def test_svgd_many_particles_one_apply_launch_equals_the_optimizer_loop(backend, kind):
+    """17..64 particles with a fusable base optimizer: blocked update + ONE bde_svgd_apply_* launch == particle_count
+    calls of base.step() with its shared state (svgd.py:92-103), including what ends up in base.state."""
+    ops, dev = backend
+
+    def run(fuse):
+        torch.manual_seed(11)
+        model = make_mlp().to(dev)
+        ps = list(model.parameters())
+        base = torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4) if kind == "sgd" else \
+            torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2)
+        opt = bde.SVGDOptimizer(ps, lambda: bde.reset_model_params(model), base, particle_count=20, dataset_size=64,
+                                l2_reg=0.01, fuse_base_optimizer=fuse, _ops=ops)
+        assert opt._fuse_staged == fuse and not opt._fuse
+        torch.manual_seed(12)
+        x, y = torch.randn(16, 13, device=dev), torch.randn(16, 1, device=dev)
+        losses = [float(opt.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())) for _ in range(3)]
+        sd = opt.state_dict()
+        return opt.particles.clone(), losses, base, ps, sd
+    pa, la, base_a, ps_a, sd_a = run(True)
+    pb, lb, base_b, ps_b, _ = run(False)
+    np.testing.assert_allclose(pa.cpu().numpy(), pb.cpu().numpy(), rtol=3e-5, atol=3e-6)
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    key = "momentum_buffer" if kind == "sgd" else "exp_avg"
+    for qa, qb in zip(ps_a, ps_b):                         # the shared optimizer state, where torch keeps it
+        np.testing.assert_allclose(base_a.state[qa][key].cpu().numpy(), base_b.state[qb][key].cpu().numpy(), rtol=3e-5, atol=1e-6)
+    if kind == "adam":
+        # (the fused paths keep ONE shared counter; the per-parameter step tensors are refreshed when the state is taken)
+        assert int(base_a.state_dict()["state"][0]["step"]) == int(base_b.state_dict()["state"][0]["step"]) == 60
+    assert "particle_19" in sd_a["state"][0]
