@@ -85,9 +85,10 @@ def _svgd_worker(rank, world, port, m, fuse, kw, out_dir):
     (2, True, {"exchange": "alltoall", "tiny": True}), (4, False, {"exchange_chunks": 7, "tiny": True}),
     (4, True, {"exchange_chunks": 3, "overlap_backward": True}), (2, False, {"exchange_chunks": 4, "overlap_backward": True}),
     (2, True, {"exchange_chunks": 5, "overlap_backward": True, "base": "adam"}),
+    (20, True, {"base": "adam"}),
 ], ids=["allgather", "allgather_fused", "pipelined", "pipelined_fused", "pipelined_fused_adam", "alltoall_2per",
         "alltoall_1per", "alltoall_adam", "alltoall_empty_slice", "pipelined_more_chunks_than_columns",
-        "overlap_fused_2per", "overlap_unfused_1per", "overlap_fused_adam_1per"])
+        "overlap_fused_2per", "overlap_unfused_1per", "overlap_fused_adam_1per", "allgather_20_particles_one_apply_launch"])
 def test_svgd_sharded_equals_single_process(tmp_path, m, fuse, kw):
     """One exchange of gradient rows (all-gather, chunk-pipelined all-gather, or the dimension-sharded all-to-all
     pair) + the deterministic update reproduces the single-process trajectory, with identical particles on all ranks."""
