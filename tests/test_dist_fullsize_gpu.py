@@ -23,6 +23,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from tests.spawn_one_device import spawn_ranks
+
 pytestmark = pytest.mark.gpu
 
 M = 8
@@ -153,7 +155,7 @@ def single_process():
 @pytest.mark.parametrize("mode", list(MODES))
 def test_svgd_resnet50_sharded_one_device(tmp_path, single_process, mode, world):
     single, oracle = single_process
-    mp.spawn(_svgd_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_svgd_worker, lambda: (world, _free_port(), mode, str(tmp_path)), world)
     ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     r0 = ranks[0]
     for r in ranks[1:]:                                          # replicas bit-identical across ranks (whole matrix)
@@ -268,7 +270,7 @@ def test_multiswag_densenet121_fanout_eight_ranks_one_device(tmp_path):
     from oracle import bde_oracle as O
     from oracle import philox as PH
     world = 8
-    mp.spawn(_predict_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_predict_worker, lambda: (world, _free_port(), str(tmp_path)), world)
     preds = [np.load(tmp_path / f"pred{r}.npz") for r in range(world)]
     for r, p in enumerate(preds):
         np.testing.assert_array_equal(preds[0]["out"], p["out"])

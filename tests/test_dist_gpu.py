@@ -16,6 +16,8 @@ import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
+
+from tests.spawn_one_device import spawn_ranks
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -106,7 +108,7 @@ SVGD_CASES = [
 
 def _check_svgd(tmp_path, backend, name, m, kw):
     world = 2
-    mp.spawn(_svgd_worker, args=(world, _free_port(), backend, m, tuple(kw.items()), str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_svgd_worker, lambda: (world, _free_port(), backend, m, tuple(kw.items()), str(tmp_path)), world)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     np.testing.assert_array_equal(r0["particles"], r1["particles"])          # replicas stay bit-identical
     np.testing.assert_array_equal(r0["losses"], r1["losses"])
@@ -178,7 +180,7 @@ def _predict_worker(rank, world, port, backend, kind, out_dir):
 def test_predict_distributed_hip_two_ranks_one_device(tmp_path, kind):
     import beyond_deep_ensembles_amd as bde
     world = 2
-    mp.spawn(_predict_worker, args=(world, _free_port(), "gloo", kind, str(tmp_path)), nprocs=world, join=True)
+    spawn_ranks(_predict_worker, lambda: (world, _free_port(), "gloo", kind, str(tmp_path)), world)
     a, b = np.load(tmp_path / "pred0.npz"), np.load(tmp_path / "pred1.npz")
     np.testing.assert_array_equal(a["out"], b["out"])
     assert a["out"].shape[0] == 13
@@ -216,5 +218,5 @@ def test_reference_checkpoint_resumes_on_two_ranks_one_device(tmp_path, kw):
     """tests/ckpt_resume.py with the real kernels: reference-written checkpoint -> 2 ranks -> step -> state_dict()
     (collective in alltoall mode) -> fresh optimizer -> step; both steps == the reference's own next steps."""
     from tests.ckpt_resume import check
-    mp.spawn(_resume_worker, args=(2, _free_port(), "gloo", tuple(kw.items()), str(tmp_path)), nprocs=2, join=True)
+    spawn_ranks(_resume_worker, lambda: (2, _free_port(), "gloo", tuple(kw.items()), str(tmp_path)), 2)
     check(str(tmp_path))

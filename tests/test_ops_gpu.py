@@ -475,7 +475,8 @@ def test_svgd_single_launch_on_a_shared_device(tmp_path):
     writes nothing and is redone as two launches of the same kernel)."""
     import torch.multiprocessing as mp
     n_proc, n_iter = 5, 300
-    mp.spawn(_shared_device_worker, args=(n_iter, str(tmp_path)), nprocs=n_proc, join=True)
+    from tests.spawn_one_device import spawn_ranks
+    spawn_ranks(_shared_device_worker, lambda: (n_iter, str(tmp_path)), n_proc)
     _shared_device_worker(99, n_iter, str(tmp_path))                   # solo, in this process
     solo = np.load(tmp_path / "shared99.npz")
     assert int(solo["gave_up"]) == 0
