@@ -90,11 +90,14 @@ class SVGDOptimizer(BayesianOptimizer):
                               overlaps the rest of that backward pass like DDP's gradient buckets.  Needs one backward
                               call per closure; ignored while a GradScaler is active (its unscale pass runs after backward)
           fuse_base_optimizer apply a torch.optim.SGD / Adam base optimizer inside the update kernel (one pass over
-                              P and G that writes the updated particles; -phi is never materialised).  "auto": fused
+                              P and G that writes the updated particles; -phi is never materialised).  "auto" (the
+                              DEFAULT: what the reference's constructor call gets): fused
                               exactly when that is indistinguishable from particle_count calls of base.step() -- a
                               plain torch.optim.SGD / Adam (not a subclass) over exactly this optimizer's parameters,
-                              one set of hyper-parameters, no amsgrad / maximize / capturable / differentiable, no
-                              step hooks, particle_count <= 64 -- and the torch loop otherwise.  Up to 16 particles:
+                              one set of hyper-parameters, no amsgrad / maximize / capturable / differentiable /
+                              decoupled_weight_decay, no step hooks, particle_count <= 64 (and, for 17..64 particles,
+                              no chunked or dimension-sharded exchange) -- and the torch loop (False) otherwise; an
+                              enabled GradScaler keeps the torch loop as well.  Up to 16 particles:
                               one pass; 17 to 64 (single GPU or exchange="allgather" without chunks): the blocked
                               update kernel writes -phi, then ONE launch applies the base optimizer to all
                               particles in order with its shared state
@@ -113,7 +116,7 @@ class SVGDOptimizer(BayesianOptimizer):
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
                  kernel_grad_scale=1.0, *, process_group=None, exchange="allgather", exchange_chunks=1,
-                 overlap_backward=False, fuse_base_optimizer=False, reuse_gram=False, single_launch=None, _ops=None):
+                 overlap_backward=False, fuse_base_optimizer="auto", reuse_gram=False, single_launch=None, _ops=None):
         # one param group per tensor, like the reference (svgd.py:50): groups distinguish tensors, not particles
         super().__init__([{"params": p} for p in params], {})
         self._ops = _ops or _default_ops()
@@ -283,7 +286,8 @@ class SVGDOptimizer(BayesianOptimizer):
         if any(g[k] != groups[0][k] for g in groups[1:] for k in keys):
             return False
         g0 = groups[0]
-        if any(g0.get(flag, False) for flag in ("amsgrad", "maximize", "capturable", "differentiable")):
+        if any(g0.get(flag, False) for flag in ("amsgrad", "maximize", "capturable", "differentiable",
+                                                "decoupled_weight_decay")):
             return False
         if any(torch.is_tensor(g0.get(k)) for k in ("lr", "momentum", "weight_decay", "eps")):
             return False
@@ -791,8 +795,11 @@ class SVGDOptimizer(BayesianOptimizer):
                 self._ops.svgd_fused_sgd(P, G, st["buf"][c0:], d, self._kstat, g0["lr"], g0["momentum"], g0["dampening"],
                                          g0["weight_decay"], g0["nesterov"], st["first"], ws_next=ws_next)
         elif type(base) is torch.optim.Adam:
-            if g0.get("amsgrad", False) or g0.get("maximize", False):
-                raise RuntimeError("fuse_base_optimizer: amsgrad / maximize are not supported")
+            if g0.get("amsgrad", False) or g0.get("maximize", False) or g0.get("decoupled_weight_decay", False):
+                # the kernels apply torch.optim.Adam's COUPLED decay (g += wd * theta); AdamW-style decay would be a
+                # different update, so it is refused rather than silently replaced (fuse_base_optimizer="auto" keeps the
+                # torch loop for such an optimizer)
+                raise RuntimeError("fuse_base_optimizer: amsgrad / maximize / decoupled_weight_decay are not supported")
             st = self._fused_buffers(base, "adam")
             for P, G, d, c0 in pieces:
                 if staged:

@@ -63,6 +63,10 @@ def flat(ts):
     # ONE persistent launch with the bounded in-kernel hand-off (single_launch=True) instead of the default two launches
     ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "one_launch"),
     ("adam", lambda ps: torch.optim.Adam(ps, lr=1e-3), "one_launch"),
+    # the reference's OWN constructor call, no extra keyword (experiments/iwildcam/models.py:120): fuse_base_optimizer="auto"
+    ("adam", lambda ps: torch.optim.Adam(ps, lr=1e-3), "default"),
+    ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "default"),
+    ("adam_wd", lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2), "default"),
 ])
 def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
     ops, dev = backend
@@ -79,12 +83,13 @@ def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
         set_flat(params, init[k[0]])
 
     base = make_opt(model.parameters())
+    extra = {} if fuse == "default" else dict(
+        fuse_base_optimizer=fuse not in (False, "staged"), reuse_gram=fuse in ("reuse_gram", "staged_reuse_gram"),
+        single_launch=False if str(fuse).startswith("staged") else (True if fuse == "one_launch" else None))
     opt = bde.SVGDOptimizer(model.parameters(), reset, base, particle_count=m, dataset_size=64,
-                            l2_reg=float(g["l2_reg"]), kernel_grad_scale=float(g["scale"]),
-                            fuse_base_optimizer=fuse not in (False, "staged"),
-                            reuse_gram=fuse in ("reuse_gram", "staged_reuse_gram"),
-                            single_launch=False if str(fuse).startswith("staged") else (True if fuse == "one_launch" else None),
-                            _ops=ops)
+                            l2_reg=float(g["l2_reg"]), kernel_grad_scale=float(g["scale"]), _ops=ops, **extra)
+    if fuse == "default":
+        assert opt._fuse and not opt._reuse_gram     # plain SGD / Adam over the model's parameters: fused by default
     fuse = fuse not in (False, "staged")
     assert torch.equal(opt.particles.cpu(), init.cpu())
     for i in range(m):      # reference state keys (svgd.py:57)
@@ -1178,7 +1183,7 @@ def test_svgd_fuse_auto_eligibility(backend):
         ps = list(model.parameters())
         base = make_base(ps)
         opt = bde.SVGDOptimizer(ps, lambda: bde.reset_model_params(model), base, particle_count=kw.pop("m", 4),
-                                dataset_size=32, fuse_base_optimizer="auto", _ops=ops, **kw)
+                                dataset_size=32, _ops=ops, **kw)            # "auto" is the default
         return opt._fuse or opt._fuse_staged
 
     class MySGD(torch.optim.SGD):
@@ -1188,6 +1193,8 @@ def test_svgd_fuse_auto_eligibility(backend):
     assert not decide(lambda ps: torch.optim.AdamW(ps, lr=1e-3))
     assert not decide(lambda ps: MySGD(ps, lr=0.1))
     assert not decide(lambda ps: torch.optim.Adam(ps, lr=1e-3, amsgrad=True))
+    # torch >= 2.7: Adam(decoupled_weight_decay=True) is AdamW's update; the kernels apply the coupled decay
+    assert not decide(lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2, decoupled_weight_decay=True))
     assert not decide(lambda ps: torch.optim.SGD(ps, lr=0.1, maximize=True))
     assert not decide(lambda ps: torch.optim.SGD([{"params": ps[:2], "lr": 0.1}, {"params": ps[2:], "lr": 0.01}], lr=0.1))
     assert decide(lambda ps: torch.optim.SGD([{"params": ps[:2]}, {"params": ps[2:]}], lr=0.1))
