@@ -13,10 +13,9 @@ _LAZY = {
     "BayesianOptimizer": ".algo", "LastLayerBayesianOptimizer": ".algo",
     "SVGDOptimizer": ".svgd", "rbf": ".svgd",
     "SwagOptimizer": ".swag",
-    "BBBOptimizer": ".bbb", "GaussianPrior": ".bbb",
+    "BBBOptimizer": ".bbb", "GaussianPrior": ".bbb", "MixturePrior": ".bbb",
     "GaussianParameter": ".util", "normal_like": ".util", "reset_model_params": ".util",
     "iVONOptimizer": ".ivon",
-    "Rank1Linear": ".rank1", "Rank1Conv2D": ".rank1", "make_module_rank1": ".rank1",
     "BBBLinear": ".bbb_layers", "BBBConv2d": ".bbb_layers", "make_module_bbb": ".bbb_layers",
     "DeepEnsemble": ".ensemble",
     "HipOps": ".ops",

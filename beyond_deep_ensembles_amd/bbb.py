@@ -42,6 +42,11 @@ class GaussianPrior:
         return per_weight.sum()
 
 
+def _invalidate_sigma_caches() -> None:
+    from .bbb_layers import invalidate_sigma_caches
+    invalidate_sigma_caches()
+
+
 class MixturePrior:
     """Scale mixture of two zero-mean Gaussians (API of ``src/algos/bbb.py:23-37``); its
     "KL" is the negative clamped log-density of the means, evaluated with torch autograd."""
@@ -218,6 +223,7 @@ class BBBOptimizer(BayesianOptimizer):
             p.grad = None
         for fg in self._groups:
             fg.invalidate_draw()                        # a group-wide weight draw never outlives a step
+        _invalidate_sigma_caches()                      # nor does a layer's cached sigma^2 (rho.data edits between steps)
         pi = self.kl_rescaling / self.dataset_size
         scale_dev = None
         if grad_scaler is not None and grad_scaler.is_enabled():
@@ -288,8 +294,15 @@ class BBBOptimizer(BayesianOptimizer):
                 self.state["__base_optimizer"].step()
         for fg in self._groups:
             fg.invalidate_draw()
+        _invalidate_sigma_caches()
 
         return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for fg in self._groups:
+            fg.invalidate_draw()
+        _invalidate_sigma_caches()
 
     def sample_parameters(self):
         '''The parameters sample themselves'''

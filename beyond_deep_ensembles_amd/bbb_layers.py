@@ -68,20 +68,36 @@ class _SigmaCache:
     only change at ``base_optimizer.step()``, but a BBB step runs ``mc_samples`` forward and backward passes
     (``bbb.py:63-67``).  Keyed on the parameter's storage address and autograd version counter, so any in-place change
     of rho -- an optimizer step, ``load_state_dict``, a manual edit -- refreshes it at the next forward.  A refresh
-    writes NEW tensors: a forward whose backward has not run yet keeps the tensors of its own version."""
+    writes NEW tensors: a forward whose backward has not run yet keeps the tensors of its own version.
+
+    Writes through ``rho.data`` (``rho.data.fill_()``, a custom optimizer written the way the reference writes ``.data``)
+    keep the address AND the version counter; for those the key also carries a process-wide epoch that
+    ``BBBOptimizer.step`` advances when it begins and ends and ``BBBOptimizer.load_state_dict`` advances once
+    (``invalidate_sigma_caches``), and a layer can drop its own cache (``layer.invalidate_sigma_cache()``): code that edits
+    ``rho.data`` BETWEEN two forward passes of one step has to call one of the two."""
+
+    epoch = 0
 
     def __init__(self):
         self.key = None
         self.s2 = self.ds2 = None
 
+    def drop(self) -> None:
+        self.key = None
+
     def get(self, rho: torch.Tensor, ops):
-        key = (rho.data_ptr(), rho._version, tuple(rho.shape))
+        key = (rho.data_ptr(), rho._version, tuple(rho.shape), _SigmaCache.epoch)
         if key != self.key:
             r = rho.detach().contiguous()
             s2, ds2 = torch.empty_like(r), torch.empty_like(r)
             ops.lrt_sigma_cache(r, s2, ds2)
             self.key, self.s2, self.ds2 = key, s2, ds2
         return self.s2, self.ds2
+
+
+def invalidate_sigma_caches() -> None:
+    """Every layer's cached sigma^2 is recomputed at its next forward (cheap: one pass per wide layer)."""
+    _SigmaCache.epoch += 1
 
 
 def _local_reparam(mean, var, eps, seed, stream_id, ops):
@@ -199,6 +215,7 @@ class _LocalReparamLayer(nn.Module):
         self.fused_linear = kwargs.get("fused_linear", True)         # BBBLinear: the whole forward as one fused op
         self.sigma_cache = kwargs.get("sigma_cache", True)           # wide BBBLinear: sigma^2 once per weight version
         self._sigma_cache = _SigmaCache()
+        self.invalidate_sigma_cache = self._sigma_cache.drop
         self.weight_prior, self.bias_prior = weight_prior, bias_prior
         gp_kwargs = {k: kwargs[k] for k in ("rng", "seed", "_ops") if k in kwargs}
         self.weight = GaussianParameter(weight_shape, **gp_kwargs)

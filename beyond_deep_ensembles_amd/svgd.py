@@ -87,8 +87,10 @@ class SVGDOptimizer(BayesianOptimizer):
           overlap_backward    with exchange_chunks > 1: start the gather of a column chunk as soon as the LAST local
                               particle's backward pass has produced the gradients of every tensor in it (chunks leave
                               in a fixed order, last chunk first -- the order backward fills them), so the exchange
-                              overlaps the rest of that backward pass like DDP's gradient buckets.  Needs one backward
-                              call per closure; ignored while a GradScaler is active (its unscale pass runs after backward)
+                              overlaps the rest of that backward pass like DDP's gradient buckets.  backward_closure
+                              must call backward() exactly once and must not touch the gradients afterwards (clipping,
+                              scaling, accumulation: a RuntimeError says so); ignored while a GradScaler is active (its
+                              unscale pass runs after backward)
           fuse_base_optimizer apply a torch.optim.SGD / Adam base optimizer inside the update kernel (one pass over
                               P and G that writes the updated particles; -phi is never materialised).  "auto" (the
                               DEFAULT: what the reference's constructor call gets): fused
@@ -232,7 +234,7 @@ class SVGDOptimizer(BayesianOptimizer):
         per = self.state["__particle_count"] // self._world
         if self._seg_host is None:
             self._seg_host = self._seg.staging()
-        self._ov = {"row": particle_idx, "pending": [len(ks) for ks in self._chunk_tensors], "seen": set(),
+        self._ov = {"row": particle_idx, "pending": [len(ks) for ks in self._chunk_tensors], "seen": {},
                     "next": len(self._chunks) - 1, "works": [None] * len(self._chunks), "loss": loss_sum / per}
 
     def _grad_ready(self, k: int, param) -> None:
@@ -240,8 +242,9 @@ class SVGDOptimizer(BayesianOptimizer):
         ov = self._ov
         if ov is None or k in ov["seen"]:
             return
-        ov["seen"].add(k)
         g, view = param.grad, self._gviews[ov["row"]][k]
+        # what left on the wire: the gradient tensor as it is NOW (checked again when backward has returned)
+        ov["seen"][k] = (g.data_ptr(), g._version) if g is not None else None
         addr = view.data_ptr()
         if g is not None and g.data_ptr() != addr:
             if g.dtype == torch.float32 and g.layout == torch.strided and g.is_contiguous() and g.device == view.device \
@@ -383,6 +386,8 @@ class SVGDOptimizer(BayesianOptimizer):
         if self._seg is None:
             adopt_grads(self._plist, self._gviews[particle_idx])
             return
+        if self._ov is not None:
+            self._check_overlap_grads()
         if self._seg_host is None:
             self._seg_host = self._seg.staging()
         if self._exchange == "alltoall":
@@ -398,6 +403,27 @@ class SVGDOptimizer(BayesianOptimizer):
             clear_grads(self._plist)
         if self._ov is not None:
             self._launch_ready_chunks(force=True)         # tensors without a gradient: their chunks leave now
+
+    def _check_overlap_grads(self) -> None:
+        """overlap_backward: the chunks of the last local particle left while its backward pass was still running, each
+        carrying the gradients as they were when autograd produced them.  A closure that touches the gradients AFTER
+        ``backward()`` -- clip_grad_norm_, manual scaling, a second backward that accumulates -- would change them
+        behind the exchange (the earlier local particles, collected after their closures, WOULD carry such edits): that
+        is refused loudly instead of producing an inconsistent -phi.  A rank-local silent redo is not an option: the
+        ranks must issue the same sequence of collectives."""
+        for k, sent in self._ov["seen"].items():
+            g = self._plist[k].grad
+            now = (g.data_ptr(), g._version) if g is not None else None
+            if now != sent:
+                for work in self._ov["works"]:
+                    if work is not None:
+                        work.wait()                  # nothing of this step stays in flight behind the exception
+                self._ov = None
+                raise RuntimeError(
+                    f"SVGDOptimizer(overlap_backward=True): the gradient of parameter {k} changed after its column chunk "
+                    "had been sent (in-place edit, clipping, or a second backward pass inside backward_closure).  With "
+                    "overlap_backward the closure must call backward() exactly once and leave the gradients alone "
+                    "afterwards; use overlap_backward=False otherwise")
 
     def _grads_to_rows(self, G: torch.Tensor, row0: int, n_rows: int) -> None:
         """The gradients recorded by _end_particle packed into rows [row0, row0 + n_rows) of the flat buffer ``G`` (ONE

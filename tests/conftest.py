@@ -31,3 +31,14 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return load
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The several-ranks-on-one-device harness (tests/spawn_one_device.py) re-runs its ranks once on the HIP runtime's
+    HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION queue abort; every such event is reported here so that it is visible in the
+    tail of the test log (and in gpurun_out/one_device_retries.log on the GPU box)."""
+    from tests import spawn_one_device
+    terminalreporter.write_line(f"one-device harness: {len(spawn_one_device.RETRIES)} rank re-run(s) on "
+                                f"{spawn_one_device.FAULT_TEXT}")
+    for when, nprocs, line in spawn_one_device.RETRIES:
+        terminalreporter.write_line(f"  {when} nprocs={nprocs} {line}")

@@ -114,6 +114,39 @@ def test_svgd_sharded_equals_single_process(tmp_path, m, fuse, kw):
     np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=1e-6)
 
 
+def _overlap_edit_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.oracle_ops import OracleOps
+        torch.set_num_threads(1)
+        model, opt = _make(100 + rank, 2, OracleOps(), pg=dist.group.WORLD, fuse=True, exchange_chunks=3, overlap_backward=True)
+        x, y = torch.randn(16, 13), torch.randn(16, 1)
+
+        def backward_then_clip(loss):
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1e-3)      # edits the gradients behind the exchange
+        try:
+            opt.step(lambda: F.mse_loss(model(x), y), backward_then_clip)
+            msg = "no error"
+        except RuntimeError as e:
+            msg = str(e)
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlap_backward_refuses_gradients_edited_after_backward(tmp_path):
+    """with overlap_backward the last local particle's chunks leave inside backward(); a closure that clips /
+    scales / accumulates afterwards would change the gradients behind the exchange -> a clear error on every rank."""
+    mp.spawn(_overlap_edit_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        msg = (tmp_path / f"rank{r}.txt").read_text()
+        assert "changed after its column chunk had been sent" in msg, msg
+
+
 def _swag_member(seed, ops):
     import beyond_deep_ensembles_amd as bde
     torch.manual_seed(seed)

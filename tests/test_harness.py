@@ -1,0 +1,37 @@
+"""The several-ranks-on-one-device harness itself (tests/spawn_one_device.py): it retries ONLY the HIP runtime's
+HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION queue abort, once, and counts it; any other abort fails."""
+import os
+import sys
+
+import pytest
+from torch.multiprocessing.spawn import ProcessExitedException
+
+from tests import spawn_one_device as sod
+
+
+def _worker(rank, marker, say_fault):
+    if rank == 1 and not os.path.exists(marker):
+        open(marker, "w").close()
+        if say_fault:
+            sys.stderr.write(":0:rocdevice.cpp :3676: Callback: Queue 0x1 aborting with error : "
+                             "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION: The agent attempted to execute an illegal shader "
+                             "instruction. code: 0x2a\n")
+            sys.stderr.flush()
+        os.abort()
+
+
+def test_retries_exactly_the_runtime_queue_abort_once(tmp_path, monkeypatch):
+    monkeypatch.setattr(sod, "RETRIES", [])
+    with pytest.warns(UserWarning, match="HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION"):
+        sod.spawn_ranks(_worker, lambda: (str(tmp_path / "a"), True), 2)
+    assert len(sod.RETRIES) == 1 and "rocdevice.cpp" in sod.RETRIES[0][2]
+    # a second event in the same session is not tolerated
+    with pytest.raises(RuntimeError, match="more than the one"):
+        sod.spawn_ranks(_worker, lambda: (str(tmp_path / "b"), True), 2)
+
+
+def test_any_other_abort_fails(tmp_path, monkeypatch):
+    monkeypatch.setattr(sod, "RETRIES", [])
+    with pytest.raises(ProcessExitedException):
+        sod.spawn_ranks(_worker, lambda: (str(tmp_path / "c"), False), 2)
+    assert sod.RETRIES == []

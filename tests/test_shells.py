@@ -812,15 +812,34 @@ def test_svgd_fused_reuse_gram_tracks_unfused_over_many_steps(backend):
     np.testing.assert_allclose(runs[1].numpy(), runs[0].numpy(), rtol=2e-3, atol=2e-5)
 
 
-def test_rank1_layers_reproduce_reference_trajectory(golden, backend):
-    """bde.Rank1Linear (the caller of GaussianParameter.sample(), rank1.py:51-52) + BBBOptimizer(components=2)
-    against the trajectory of the reference's Rank1Linear + BBBOptimizer, draws replayed."""
+class _ScaledLinear(nn.Module):
+    """Test helper, not product: a caller of ``GaussianParameter.sample()`` shaped like the reference's Rank1Linear
+    (rank1.py:9-80, out of scope per SURVEY section 2) -- ``y = W (x * s) * r + b`` with ``components`` (s, r, b) sets used
+    round robin -- so that its parameter names match the fixture written from the reference's layer."""
+
+    def __init__(self, n_in, n_out, components, ops):
+        super().__init__()
+        self.layer = nn.Linear(n_in, n_out, bias=False)
+        self.s = nn.ModuleList([bde.GaussianParameter(n_in, _ops=ops) for _ in range(components)])
+        self.r = nn.ModuleList([bde.GaussianParameter(n_out, _ops=ops) for _ in range(components)])
+        self.bias = nn.Parameter(torch.zeros((components, n_out)))
+        self.components, self.component_counter = components, 0
+
+    def forward(self, x):
+        c = self.component_counter
+        out = self.layer(x * self.s[c].sample()) * self.r[c].sample() + self.bias[c]
+        self.component_counter = (c + 1) % self.components
+        return out
+
+
+def test_bbb_components_and_sample_callers_reproduce_reference_trajectory(golden, backend):
+    """BBBOptimizer(components=2, l2_scale) (bbb.py:75-80) over layers that call GaussianParameter.sample() per forward
+    (util.py:170-171), against the trajectory of the reference's BBBOptimizer over its own rank-1 layers, draws replayed."""
     ops, dev = backend
     g = golden("rank1.npz")
     tape = [T(g[f"eps_{i}"]) for i in range(int(g["n_eps"]))]
     prior = bde.GaussianPrior(0, 1.0)
-    model = nn.Sequential(bde.Rank1Linear(13, 20, prior, components=2, _ops=ops), nn.ReLU(),
-                          bde.Rank1Linear(20, 1, prior, components=2, _ops=ops)).to(dev)
+    model = nn.Sequential(_ScaledLinear(13, 20, 2, ops), nn.ReLU(), _ScaledLinear(20, 1, 2, ops)).to(dev)
     for m in model.modules():
         if isinstance(m, bde.GaussianParameter):
             m.noise_source = lambda rho: tape.pop(0).to(rho.device)
@@ -840,10 +859,6 @@ def test_rank1_layers_reproduce_reference_trajectory(golden, backend):
         assert abs(float(loss.detach()) - g["losses"][t]) <= 1e-5 * abs(g["losses"][t])
         np.testing.assert_allclose(flat(params).cpu().numpy(), g["traj"][t], rtol=2e-4, atol=2e-5)
     assert not tape and model[0].component_counter == 0
-    conv = bde.Rank1Conv2D(3, 4, 3, prior, padding=1, components=3, _ops=ops).to(dev)
-    assert conv(torch.randn(2, 3, 6, 6, device=dev)).shape == (2, 4, 6, 6) and conv.component_counter == 1
-    net = nn.Sequential(nn.Conv2d(3, 4, 3), nn.Flatten(), nn.Linear(4, 2)).to(dev)
-    assert bde.make_module_rank1(net, prior, components=2, _ops=ops) == 2
 
 
 # ------------------------------------------- BBB round-2 fixtures (bbb2.npz) --
@@ -860,7 +875,7 @@ def test_bbb_mixture_prior_trajectory(golden, backend):
     optimizer-level zero_grad (bbb.py:60) must clear the rho gradients every step -- they only receive the data
     term, so a missed clear shows up as a drifting trajectory (4 steps, SGD with momentum)."""
     ops, dev = backend
-    from beyond_deep_ensembles_amd.bbb import MixturePrior
+    MixturePrior = bde.MixturePrior              # exported like the reference's src.algos.bbb.MixturePrior (bbb.py:23)
     g = golden("bbb2.npz")
     tape = [T(g[f"d_eps_{i}"]) for i in range(int(g["d_n_eps"]))]
     model = nn.Sequential(SampledLinear(13, 20, tape, ops), nn.ReLU(), SampledLinear(20, 1, tape, ops)).to(dev)
@@ -1381,6 +1396,24 @@ def test_bbb_linear_sigma_cache_follows_the_weights(backend):
             layers[0].weight.rho.sub_(0.1)
         with pytest.raises(RuntimeError, match="modified by an inplace operation"):
             torch.autograd.grad(out_old.pow(2).sum(), [layers[0].weight.mean])
+        # a write through rho.data keeps address AND version counter; the layer's own invalidate call, the
+        # process-wide one BBBOptimizer.step / load_state_dict issue, and nothing else, refresh the cache then
+        for layer in layers:
+            layer.weight.rho.data.fill_(-2.0)
+        n0 = len(calls)
+        layers[0].invalidate_sigma_cache()
+        a, b = run(layers[0], 300), run(layers[1], 300)
+        assert len(calls) == n0 + 1
+        for (o1, g1, r1), (o2, g2, r2) in zip(a, b):
+            assert torch.equal(o1, o2) and torch.equal(g1, g2) and torch.equal(r1, r2)
+        for layer in layers:
+            layer.weight.rho.data.fill_(-1.0)
+        opt = bde.BBBOptimizer(layers[0].parameters(), torch.optim.SGD(layers[0].parameters(), lr=0.0), prior, dataset_size=8,
+                               _ops=ops)
+        opt.step(lambda: layers[0](x).pow(2).mean(), lambda l: l.backward())     # begins and ends with an invalidation
+        a, b = run(layers[0], 400), run(layers[1], 400)
+        for (o1, g1, r1), (o2, g2, r2) in zip(a, b):
+            assert torch.equal(o1, o2) and torch.equal(g1, g2) and torch.equal(r1, r2)
     finally:
         ops.lrt_sigma_cache = real
 
