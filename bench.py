@@ -337,6 +337,22 @@ def shell_step_ms(dev, steps=10, n_tensors=161, d=D_RESNET50):
                     f"of the shell + kernels + fused SGD for 8 particles x {n_tensors} tensors, D = {d}"}
 
 
+def resnet50_shapes(n_classes=182):
+    """The 161 parameter tensors of the reference's iWildCam model (torchvision ResNet-50 + a 182-class head,
+    experiments/iwildcam/models.py:21-22,170-176) in parameters() order, written out analytically (torchvision is not
+    installed here): 23,880,950 elements, from 64-element batch-norm vectors to the 2.36 M-element 3x3 convolutions."""
+    shapes = [(64, 3, 7, 7), (64,), (64,)]
+    inpl = 64
+    for planes, blocks in ((64, 3), (128, 4), (256, 6), (512, 3)):
+        for b in range(blocks):
+            shapes += [(planes, inpl, 1, 1), (planes,), (planes,), (planes, planes, 3, 3), (planes,), (planes,),
+                       (4 * planes, planes, 1, 1), (4 * planes,), (4 * planes,)]
+            if b == 0:
+                shapes += [(4 * planes, inpl, 1, 1), (4 * planes,), (4 * planes,)]
+            inpl = 4 * planes
+    return shapes + [(n_classes, 2048), (n_classes,)]
+
+
 class _ManyGrads(torch.autograd.Function):
     """loss = sum_i <p_i, c_i> as ONE autograd node with n_tensors inputs whose backward hands out n_tensors FRESH,
     separately allocated gradient tensors (c_i * grad_out through one multi-tensor launch) -- what a real model's
@@ -352,25 +368,45 @@ class _ManyGrads(torch.autograd.Function):
         return (None,) + tuple(torch._foreach_mul(ctx.cs, grad_out))
 
 
-def shell_step_real_grads_ms(dev, n_tensors=161, d=D_RESNET50, steps=20, fuse=True):
+def shell_step_real_grads_ms(dev, n_tensors=161, d=D_RESNET50, steps=20, fuse=True, ctor="opt_in", particles=M):
     """SVGDOptimizer.step() with REAL gradients: every particle's backward produces n_tensors fresh gradient tensors
     (one pre-built autograd node, _ManyGrads).  ONE loop of whole steps is timed; inside it the closures carry their
     own host timers, so the optimizer's host time = step host time - closure host time of the SAME steps (never
     negative), and HIP events around the posterior update give its GPU time.  No gradient is copied: the kernels read
-    the tensors autograd produced (svgd.py:129-133's clones removed)."""
+    the tensors autograd produced (svgd.py:129-133's clones removed).
+
+    ctor = "opt_in": round 3's figure -- equal-sized tensors, nesterov SGD, fuse_base_optimizer=True, reuse_gram=True.
+    ctor = "reference": the optimizer built EXACTLY as the reference builds it (experiments/iwildcam/models.py:120 with
+    iwildcam.yaml:214-221): ``SVGDOptimizer(model.parameters(), reset_model, Adam(model.parameters(), lr=3e-5,
+    weight_decay=0), particle_count=..., l2_reg=0.0, dataset_size=129809, kernel_grad_scale=1.0)`` -- no extra keyword --
+    over the 161 tensors of the iWildCam ResNet-50 in their real shapes; reset_model re-initialises the head only.
+    ctor = "reference_unfused": the same with fuse_base_optimizer=False (particle_count x torch Adam.step per step, the
+    reference's own cost structure, svgd.py:99-103)."""
     import beyond_deep_ensembles_amd as bde
-    sizes = [d // n_tensors] * (n_tensors - 1)
-    sizes.append(d - sum(sizes))
-    params = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in sizes]
-    cs = [torch.randn(s, device=dev) * 0.01 for s in sizes]
-    base = torch.optim.SGD(params, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=3e-4)
+    if ctor == "opt_in":
+        sizes = [d // n_tensors] * (n_tensors - 1)
+        sizes.append(d - sum(sizes))
+        shapes = [(n,) for n in sizes]
+    else:
+        shapes = resnet50_shapes()
+        n_tensors, d = len(shapes), sum(int(torch.Size(sh).numel()) for sh in shapes)
+    params = [torch.nn.Parameter(torch.randn(sh, device=dev) * 0.05) for sh in shapes]
+    cs = [torch.randn(sh, device=dev) * 0.01 for sh in shapes]
 
     def reset():
         with torch.no_grad():
             for p in params[-2:]:
                 p.normal_(0, 0.05)
-    opt = bde.SVGDOptimizer(params, reset, base, particle_count=M, dataset_size=DATASET_SIZE, fuse_base_optimizer=fuse,
-                            reuse_gram=fuse)
+    if ctor == "opt_in":
+        base = torch.optim.SGD(params, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=3e-4)
+        opt = bde.SVGDOptimizer(params, reset, base, particle_count=particles, dataset_size=DATASET_SIZE,
+                                fuse_base_optimizer=fuse, reuse_gram=fuse)
+    else:
+        svgd_cfg = dict(particle_count=particles, l2_reg=0.0, dataset_size=129809, kernel_grad_scale=1.0)   # iwildcam.yaml:217-221
+        base_cfg = dict(lr=0.00003, weight_decay=0)                                                          # iwildcam.yaml:214-216
+        extra_kw = {"fuse_base_optimizer": False} if ctor == "reference_unfused" else {}
+        opt = bde.SVGDOptimizer(iter(params), reset, torch.optim.Adam(iter(params), **base_cfg), **svgd_cfg, **extra_kw)
+        fuse = bool(opt._fuse)
     t_closures = [0.0]
 
     def fwd():
@@ -410,11 +446,11 @@ def shell_step_real_grads_ms(dev, n_tensors=161, d=D_RESNET50, steps=20, fuse=Tr
     wall = (time.perf_counter() - t0) / steps
     clos = t_closures[0] / steps
     gpu = sum(a.elapsed_time(b) for a, b in ev) / steps
-    del opt, params, cs, base
+    del opt, params, cs
     torch.cuda.empty_cache()
     return {"step_ms": round(wall * 1e3, 3), "step_host_ms": round(host * 1e3, 3), "closures_host_ms": round(clos * 1e3, 3),
             "optimizer_host_ms": round((host - clos) * 1e3, 3), "optimizer_gpu_ms": round(gpu, 3),
-            "tensors": n_tensors, "particles": M, "fused": fuse,
+            "tensors": n_tensors, "particles": particles, "fused": fuse, "constructor": ctor,
             "what": "SVGDOptimizer.step with real gradients (8 backward passes producing n_tensors fresh tensors each), one "
                     "timed loop: host time of the whole step, of the closures inside it, their difference = the "
                     "optimizer's own host time (re-pointing, gradient hand-over by reference, launches), and the GPU time "
@@ -751,7 +787,7 @@ def multi_gpu_mode(kind, args, dist, dev, rank, world, d):
     base = torch.optim.SGD([theta], lr=1e-12, momentum=0.9, nesterov=True, weight_decay=3e-4)
     kw = {"alltoall": dict(exchange="alltoall"), "pipelined": dict(exchange_chunks=args.chunks), "allgather": {}}[kind]
     opt = bde.SVGDOptimizer([theta], reset, base, particle_count=M, dataset_size=DATASET_SIZE,
-                            process_group=dist.group.WORLD, fuse_base_optimizer=True, **kw)
+                            process_group=dist.group.WORLD, fuse_base_optimizer=True, _force_exchange=(world == 1), **kw)
     del rows
     g = torch.Generator(device=dev).manual_seed(1234 + rank)          # own gradient rows differ per rank
     for i in opt._local_particles():
@@ -829,7 +865,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # launched by torch.distributed.run (RANK / MASTER_ADDR set): a process group even with ONE rank, so that
+    # `torchrun --nproc-per-node 1 bench.py --gpus 1` drives barriers, the MAX reduction and extra.rccl_one_rank over RCCL
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("BDE_BENCH_BACKEND", "nccl")
@@ -848,7 +887,7 @@ def main():
     per = M // world
     exchange_used, exchange_note = "none", None
     phases = None
-    if world > 1 and os.environ.get("BDE_BENCH_BACKEND", "nccl") != "nccl":
+    if dist is not None and os.environ.get("BDE_BENCH_BACKEND", "nccl") != "nccl":
         exchange_note = "smoke run: all ranks share one device over " + os.environ["BDE_BENCH_BACKEND"] + \
                         " (exchange times are host-staged copies, not xGMI)"
 
@@ -1032,8 +1071,32 @@ def main():
                         res["extra"]["svgd_shell_step_real_grads_densenet121_ms"] = \
                             shell_step_real_grads_ms(dev, 364, D_DENSENET)
                     log(f"  svgd_shell_step_real_grads_ms {res['extra']['svgd_shell_step_real_grads_ms']}")
+                    # the drop-in a user of the reference actually gets: the reference's own constructor call
+                    ref_ctor = {"m8": shell_step_real_grads_ms(dev, ctor="reference"),
+                                "m8_fuse_base_optimizer_false": shell_step_real_grads_ms(dev, ctor="reference_unfused", steps=6),
+                                "m5_reference_particle_count": shell_step_real_grads_ms(dev, ctor="reference", particles=5)}
+                    base_step = res["extra"]["svgd_shell_step_real_grads_ms"]["step_ms"]
+                    ref_ctor["m8_vs_opt_in_step"] = round(ref_ctor["m8"]["step_ms"] / base_step, 3)
+                    ref_ctor["what"] = ("SVGDOptimizer built exactly as experiments/iwildcam/models.py:120 builds it (Adam lr 3e-5, "
+                                        "no extra keyword -> fuse_base_optimizer='auto'), real ResNet-50 tensor shapes, real "
+                                        "gradients; m8_vs_opt_in_step = its step time / svgd_shell_step_real_grads_ms.step_ms "
+                                        "(fused nesterov SGD + reuse_gram, opt-in keywords)")
+                    res["extra"]["svgd_reference_constructor_step"] = ref_ctor
+                    log(f"  svgd_reference_constructor_step {ref_ctor}")
                 except Exception as e:
                     log(f"  svgd_shell_step_real_grads_ms skipped: {type(e).__name__}: {e}")
+                if dist is not None:
+                    # one rank under torch.distributed.run: the product's multi-GPU update forced through the RCCL
+                    # collectives (all_gather_into_tensor in place, the chunk pipeline, all_to_all_single)
+                    one = {}
+                    for kind in ("allgather", "pipelined", "alltoall"):
+                        one[kind] = multi_gpu_mode(kind, args, dist, dev, rank, world, d)
+                        one[kind].pop("_blocks", None)
+                    one["what"] = ("world size 1 over " + os.environ.get("BDE_BENCH_BACKEND", "nccl") + ": SVGDOptimizer("
+                                   "process_group=WORLD, _force_exchange=True)._posterior_update -- every collective of the "
+                                   "multi-GPU step executes (self-exchange, no wire); exchange_ms is launch + copy cost")
+                    res["extra"]["rccl_one_rank"] = one
+                    log(f"  rccl_one_rank {one}")
                 try:
                     res["extra"]["other_shell_steps_ms"] = other_shell_steps_ms(dev)
                     log(f"  other_shell_steps_ms {res['extra']['other_shell_steps_ms']}")

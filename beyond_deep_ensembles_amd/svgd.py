@@ -118,7 +118,8 @@ class SVGDOptimizer(BayesianOptimizer):
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
                  kernel_grad_scale=1.0, *, process_group=None, exchange="allgather", exchange_chunks=1,
-                 overlap_backward=False, fuse_base_optimizer="auto", reuse_gram=False, single_launch=None, _ops=None):
+                 overlap_backward=False, fuse_base_optimizer="auto", reuse_gram=False, single_launch=None, _ops=None,
+                 _force_exchange=False):
         # one param group per tensor, like the reference (svgd.py:50): groups distinguish tensors, not particles
         super().__init__([{"params": p} for p in params], {})
         self._ops = _ops or _default_ops()
@@ -172,6 +173,10 @@ class SVGDOptimizer(BayesianOptimizer):
         self._world, self._rank = 1, 0
         self._exchange = "allgather"
         self._chunks = None
+        # does the update go through the collectives?  A group of ONE rank normally does not (nothing to exchange);
+        # ``_force_exchange`` (tests / bench only) sends it through them anyway, so that the RCCL code paths -- the
+        # in-place all_gather_into_tensor, all_to_all_single, the chunk pipeline -- execute on a single-GPU box
+        self._sharded = False
         if process_group is not None:
             import torch.distributed as dist
             self._world, self._rank = dist.get_world_size(process_group), dist.get_rank(process_group)
@@ -179,7 +184,8 @@ class SVGDOptimizer(BayesianOptimizer):
                 raise ValueError(f"particle_count ({particle_count}) must be a multiple of the group size ({self._world})")
             # identical particles on every rank whatever the local RNG state was
             dist.broadcast(self._P, src=dist.get_global_rank(process_group, 0), group=process_group)
-            if self._world > 1:
+            self._sharded = self._world > 1 or bool(_force_exchange)
+            if self._sharded:
                 self._exchange = exchange
         if fuse_base_optimizer == "auto":
             fuse_base_optimizer = self._fusable(base_optimizer, plist, particle_count)
@@ -204,7 +210,7 @@ class SVGDOptimizer(BayesianOptimizer):
         if int(exchange_chunks) > 1 and particle_count > 16:
             raise ValueError("exchange_chunks > 1 (pipelined all-gather) needs particle_count <= 16: the blocked update "
                              "for more particles re-reads all gradient rows per pass and cannot consume a staged chunk")
-        if self._exchange == "allgather" and self._world > 1 and int(exchange_chunks) > 1:
+        if self._exchange == "allgather" and self._sharded and int(exchange_chunks) > 1:
             clen = pad4((ld + int(exchange_chunks) - 1) // int(exchange_chunks))
             self._chunks = [(c0, min(ld, c0 + clen)) for c0 in range(0, ld, clen)]
             self._stage = [torch.zeros((m, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in self._chunks]
@@ -482,7 +488,7 @@ class SVGDOptimizer(BayesianOptimizer):
     def _step_replicated(self, total_loss, base, fused, grad_scaler, staged_apply=False):
         m, d = self.state["__particle_count"], self._layout.d
         pending = None
-        if self._world > 1:
+        if self._sharded:
             per = m // self._world
             self._grads_to_rows(self._G, self._rank * per, per)          # own rows packed for the collective: one launch
             pending = self._start_gradient_exchange(total_loss)

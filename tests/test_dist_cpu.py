@@ -114,6 +114,31 @@ def test_svgd_sharded_equals_single_process(tmp_path, m, fuse, kw):
     np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=1e-6)
 
 
+def _forced_worker(rank, world, port, m, fuse, kw, out_dir):
+    _svgd_worker(rank, world, port, m, fuse, kw, out_dir)
+
+
+@pytest.mark.parametrize("m,fuse,kw", [
+    (4, False, {}), (4, True, {}), (4, True, {"exchange_chunks": 3}), (2, True, {"exchange_chunks": 3, "overlap_backward": True}),
+    (4, True, {"exchange": "alltoall"}), (2, True, {"exchange": "alltoall", "base": "adam"}),
+], ids=["allgather", "allgather_fused", "pipelined_fused", "overlap_fused", "alltoall", "alltoall_adam"])
+def test_svgd_group_of_one_rank_with_forced_exchange(tmp_path, m, fuse, kw):
+    """``_force_exchange=True``: a process group of ONE rank still goes through the collectives (the switch that lets a
+    single-GPU box execute the RCCL branches, tests/test_dist_gpu.py); the result is the single-process trajectory."""
+    from tests.oracle_ops import OracleOps
+    forced = dict(kw, _force_exchange=True)
+    mp.spawn(_forced_worker, args=(1, _free_port(), m, fuse, tuple(forced.items()), str(tmp_path)), nprocs=1, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    assert int(r0["fwd"]) == 3 * m
+    if kw.get("overlap_backward"):
+        assert len(r0["early"]) == 3 and all(int(n) >= 1 for n in r0["early"])
+    torch.set_num_threads(1)
+    model, opt = _make(100, m, OracleOps(), fuse=fuse, base=kw.get("base", "sgd"))
+    losses = _run_steps(model, opt)
+    np.testing.assert_allclose(r0["particles"], opt.particles.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=1e-6)
+
+
 def _overlap_edit_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

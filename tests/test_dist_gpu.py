@@ -132,6 +132,47 @@ def test_svgd_sharded_hip_rccl(tmp_path, name, m, kw):
     _check_svgd(tmp_path, "nccl", name, m, kw)
 
 
+# ------------------------------------------------------------------ RCCL on ONE GPU: a group of one rank, exchange forced --
+def _check_svgd_rccl_world1(tmp_path, name, m, kw):
+    """The build and the driver's test box have ONE GPU, so the N >= 2 RCCL tests above skip there.  This runs the SAME
+    product code over the nccl (= RCCL) backend with a process group of ONE rank and ``_force_exchange=True``, which
+    sends the update through the collectives although there is nobody to exchange with: the in-place
+    ``all_gather_into_tensor`` without gloo's clone, ``all_to_all_single`` (both directions), the chunk pipeline with
+    its staging buffers, the overlapped buckets.  The result must equal the update without a process group -- bit for
+    bit for the replicated exchanges (same kernels on the same rows), to 2e-6 for the dimension-sharded one (its Gram is
+    reduced slice-wise through fp64 blocks)."""
+    kw = dict(kw, _force_exchange=True)
+    spawn_ranks(_svgd_worker, lambda: (1, _free_port(), "nccl", m, tuple(kw.items()), str(tmp_path)), 1)
+    r0 = np.load(tmp_path / "rank0.npz")
+    assert int(r0["fwd"]) == 4 * m
+    single_kw = {k: v for k, v in kw.items() if k not in ("exchange", "exchange_chunks", "overlap_backward", "_force_exchange")}
+    model, opt = _make_svgd(100, m, torch.device("cuda", 0), **single_kw)
+    losses = _run_steps(model, opt, torch.device("cuda", 0))
+    if kw.get("exchange") == "alltoall":
+        np.testing.assert_allclose(r0["particles"], opt.particles.cpu().numpy(), rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=2e-6)
+    else:
+        np.testing.assert_array_equal(r0["particles"], opt.particles.cpu().numpy())
+        np.testing.assert_array_equal(r0["losses"], np.array(losses))
+
+
+@pytest.mark.parametrize("name,m,kw", SVGD_CASES, ids=[c[0] for c in SVGD_CASES])
+def test_svgd_rccl_one_rank_forced_exchange(tmp_path, name, m, kw):
+    _check_svgd_rccl_world1(tmp_path, name, m, kw)
+
+
+def test_predict_distributed_rccl_one_rank(tmp_path):
+    """DeepEnsemble.predict_distributed over nccl with a group of one rank: its all-gather runs on RCCL."""
+    import beyond_deep_ensembles_amd as bde
+    spawn_ranks(_predict_worker, lambda: (1, _free_port(), "nccl", "swag", str(tmp_path)), 1)
+    a = np.load(tmp_path / "pred0.npz")
+    dev = torch.device("cuda", 0)
+    ens = bde.DeepEnsemble(_members(dev, "swag"))
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(1)).to(dev)
+    want = ens.predict(lambda m: m(x).detach(), 13).cpu().numpy()
+    np.testing.assert_array_equal(a["out"], want)
+
+
 # ------------------------------------------------------------------ MultiX fan-out --
 def _members(dev, kind="swag"):
     import beyond_deep_ensembles_amd as bde

@@ -130,6 +130,74 @@ def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
     assert opt.get_base_optimizer() is base
 
 
+@pytest.mark.parametrize("variant", ["default_adam", "unfused_adam", "default_sgd", "reuse_gram_sgd"])
+def test_svgd_streaming_path_through_the_shell(backend, variant):
+    """SVGDOptimizer.step on a multi-tensor model ABOVE the small-model kernel's limit (D = 669,482 >
+    524,288: 2048 -> 300 -> 182 MLP, 4 tensors), 5 particles (the reference's particle_count, iwildcam.yaml:218), three
+    steps: the three-launch streaming path (Gram -> statistics -> segmented combine / fused update reading the gradients
+    where autograd left them), default constructor (fused) and fuse_base_optimizer=False.  Checked per step against the
+    oracle from the SAME particles and gradients: -phi by oracle.svgd_phi, then particle_count shared-state applications
+    of a CPU torch optimizer (oracle.svgd_apply_shared_optimizer, svgd.py:92-103), in fp32 (= the reference's
+    arithmetic) and in fp64 (the anchor): |ours - fp64| <= max(2 |ref32 - fp64|, 3e-6 max|step|)."""
+    import oracle.bde_oracle as O
+    ops, dev = backend
+    torch.manual_seed(21)
+    model = nn.Sequential(nn.Linear(2048, 300), nn.Tanh(), nn.Linear(300, 182)).to(dev)
+    params = list(model.parameters())
+    m, n_data, l2 = 5, 129809.0, 1e-5
+
+    def make_base(ps):
+        if variant.endswith("adam"):
+            return torch.optim.Adam(ps, lr=1e-3, eps=1e-6, weight_decay=1e-2)
+        return torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)
+    base = make_base(params)
+    kw = {"unfused_adam": dict(fuse_base_optimizer=False), "reuse_gram_sgd": dict(fuse_base_optimizer=True, reuse_gram=True)}.get(variant, {})
+    opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=m,
+                            dataset_size=n_data, l2_reg=l2, _ops=ops, **kw)
+    assert not ops.svgd_small_supported(m, opt._layout.d)          # the streaming path, not the small-model kernel
+    assert bool(opt._fuse) == (variant != "unfused_adam")
+    shapes = [tuple(p.shape) for p in params]
+    numels = [p.numel() for p in params]
+
+    def split(row):
+        return [t.view(sh) for t, sh in zip(row.split(numels), shapes)]
+    # the oracle's two tracks: CPU model parameters + a CPU base optimizer whose state all particles share
+    tracks = {}
+    for dt in (torch.float32, torch.float64):
+        cpu_params = [torch.nn.Parameter(torch.zeros(sh, dtype=dt)) for sh in shapes]
+        tracks[dt] = (cpu_params, make_base(cpu_params))
+    x, y = torch.randn(48, 2048, device=dev), torch.randint(0, 182, (48,), device=dev)
+    grads = []
+
+    def backward(loss):
+        loss.backward()
+        grads.append(torch.cat([p.grad.detach().reshape(-1) for p in params]).cpu())
+    for t in range(3):
+        xb, yb = x[t * 16:(t + 1) * 16], y[t * 16:(t + 1) * 16]
+        before = opt.particles.cpu().clone()
+        grads.clear()
+        loss = opt.step(lambda: F.cross_entropy(model(xb), yb), backward)
+        assert torch.isfinite(loss)
+        G = torch.stack(grads)
+        after = opt.particles.cpu()
+        want = {}
+        for dt, (cpu_params, cpu_base) in tracks.items():
+            P = before.to(dt).clone()
+            neg_phi = -O.svgd_phi(P, G.to(dt), l2, 1.0, n_data)
+            rows = [split(P[i]) for i in range(m)]
+            O.svgd_apply_shared_optimizer(rows, [split(neg_phi[i]) for i in range(m)], cpu_params, cpu_base)
+            want[dt] = P
+        step_size = float((want[torch.float64] - before.double()).abs().max())
+        err_ref = float((want[torch.float32].double() - want[torch.float64]).abs().max())
+        err = float((after.double() - want[torch.float64]).abs().max())
+        assert step_size > 0
+        assert err <= max(2 * err_ref, 3e-6 * step_size), (variant, t, err, err_ref, step_size)
+    # the model aliases the last particle afterwards (svgd.py:96) and the shared optimizer advanced M times per step (Q5)
+    np.testing.assert_array_equal(flat(params).cpu().numpy(), opt.particles[m - 1].cpu().numpy())
+    if variant.endswith("adam"):
+        assert float(base.state_dict()["state"][0]["step"]) == 3 * m
+
+
 def test_svgd_many_particles(backend):
     """particle_count > 16: the blocked update kernel, then (fuse_base_optimizer) ONE launch that applies the base optimizer
     to all particles in order with its shared state -- the same trajectory as the reference's loop of base.step() calls."""
