@@ -86,17 +86,70 @@ def time_loop(fn, iters, warm=3):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+class StreamProbes:
+    """bench_probe/libbde_bench_probe.so (bench-only): a no-arithmetic kernel with the read / write / read-modify-write
+    SHAPE of a product kernel, run on the SAME tensors right beside it.  frac_of_probe = kernel rate / probe rate."""
+
+    def __init__(self):
+        import ctypes
+        self.lib = None
+        path = os.path.join(ROOT, "bench_probe", "libbde_bench_probe.so")
+        if os.path.exists(path):
+            self.lib = ctypes.CDLL(path)
+            c = ctypes
+            self.lib.bde_bench_probe.restype = c.c_int
+            self.lib.bde_bench_probe.argtypes = [c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_int64, c.c_int, c.c_int64,
+                                                 c.c_void_p, c.c_int64, c.c_int, c.c_int64, c.c_void_p, c.c_int64, c.c_int64,
+                                                 c.c_void_p]
+
+    @staticmethod
+    def _rows(tensors):
+        """(base pointer, floats between consecutive rows) of 1..n row tensors: one 2-D tensor, or separately allocated
+        vectors (then the distance between the first two; any further ones are assumed equally spaced)."""
+        if tensors is None:
+            return 0, 0
+        if torch.is_tensor(tensors):
+            return tensors.data_ptr(), (tensors.stride(0) if tensors.dim() == 2 else 0)
+        ptrs = [t.data_ptr() for t in tensors]
+        step = (ptrs[1] - ptrs[0]) // 4 if len(ptrs) > 1 else 0
+        assert all(b - a == 4 * step for a, b in zip(ptrs, ptrs[1:])), "probe rows must be equally spaced"
+        return ptrs[0], step
+
+    def run(self, shape, n, rd=None, wr=None, rw=None, nt_store=False, rd_pieces=None, wr_pieces=None):
+        """One launch of the (n_read, n_write, n_rmw) probe over n floats per row."""
+        rp, rl = self._rows(rd)
+        wp, wl = self._rows(wr)
+        mp, ml = self._rows(rw)
+        rlp, rps = rd_pieces if rd_pieces else (0, 0)          # RowBlock.pieces = (log2_piece, piece_stride)
+        wlp, wps = wr_pieces if wr_pieces else (0, 0)
+        rc = self.lib.bde_bench_probe(shape[0], shape[1], shape[2], int(nt_store), rp, rl, rlp, rps, wp, wl, wlp, wps, mp, ml, n,
+                                      torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, (shape, rc)
+
+
 def extras(ops, dev, quick):
-    """Secondary hot-path kernels: seconds per launch, algorithmic GB/s, fraction of the 8 TB/s HBM peak."""
+    """Secondary hot-path kernels: seconds per launch, algorithmic GB/s, fraction of the 8 TB/s HBM peak, and -- round 4 --
+    beside every streaming kernel a no-arithmetic probe of the same read / write shape on the same tensors
+    (probe_GBps, frac_of_probe = kernel rate / probe rate; StreamProbes)."""
     out = {}
     it = 10 if quick else 20
+    probes = StreamProbes()
 
-    def rec(name, t, nbytes, unit_count=None, unit=None):
+    def rec(name, t, nbytes, unit_count=None, unit=None, probe=None, probe_iters=None):
         e = {"ms": round(t * 1e3, 4), "GBps": round(nbytes / t / 1e9, 1), "hbm_frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4)}
         if unit_count is not None:
             e[unit] = round(unit_count / t, 1)
+        if probe is not None and probes.lib is not None:
+            shape, n = probe["shape"], probe["n"]
+            assert 4 * n * (shape[0] + shape[1] + 2 * shape[2]) == nbytes, (name, shape, nbytes)
+            kw = {k: v for k, v in probe.items() if k not in ("shape", "n")}
+            tp = time_loop(lambda: probes.run(shape, n, **kw), probe_iters or it)
+            e["probe_shape"] = "R%d W%d RMW%d" % shape
+            e["probe_GBps"] = round(nbytes / tp / 1e9, 1)
+            e["frac_of_probe"] = round(tp / t, 4)
         out[name] = e
-        log(f"  {name:34s} {t*1e3:9.3f} ms {nbytes/t/1e9:8.1f} GB/s {e['hbm_frac']*100:5.1f}%")
+        log(f"  {name:34s} {t*1e3:9.3f} ms {nbytes/t/1e9:8.1f} GB/s {e['hbm_frac']*100:5.1f}%"
+            + (f"   probe {e['probe_GBps']:8.1f} GB/s  of probe {e['frac_of_probe']:.3f}" if "frac_of_probe" in e else ""))
 
     d = D_RESNET50
     ld = pad_ld(d)
@@ -105,7 +158,7 @@ def extras(ops, dev, quick):
     P, G = make_svgd_inputs(d, dev, 1234)
     outb = torch.empty_like(G)
     ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
-    rec("svgd_gram_M8_resnet50", time_loop(lambda: ops.svgd_gram(P, d, ws), it), 4 * M * d)
+    rec("svgd_gram_M8_resnet50", time_loop(lambda: ops.svgd_gram(P, d, ws), it), 4 * M * d, probe=dict(shape=(8, 0, 0), n=d, rd=P))
     rec("svgd_combine_M8_resnet50", time_loop(lambda: ops.svgd_combine(P, G, outb, d, ks), it), 12 * M * d)
     rec("svgd_combine_inplace_M8_resnet50", time_loop(lambda: ops.svgd_combine(P, outb, outb, d, ks), it), 12 * M * d)
     buf = torch.zeros(ld, device=dev)
@@ -129,60 +182,96 @@ def extras(ops, dev, quick):
     rec("svgd_step_M8_resnet20", time_loop(lambda: ops.svgd_step(P2, G2, o2, d20, 3e-4, 1.0, 50000.0, -1.0, ws, ks), 50),
         16 * M * d20, 1, "steps_per_s")
     b2 = torch.zeros(pad_ld(d20), device=dev)
-    flag = ops.small_abort_flag()
-    for launches in (1, 2):
-        t = time_loop(lambda: ops.svgd_step_small_sgd(P2, G2, b2, d20, 3e-4, 1.0, 50000.0, ws, ks, 1e-12, 0.9, 0.0, 3e-4,
-                                                      True, False, launches=launches, abort_flag=flag), 50)
-        rec(f"svgd_full_step_fused_sgd_M8_resnet20_{launches}_launch{'es' if launches > 1 else ''}", t,
-            (12 * M + 8) * d20, 1, "steps_per_s")
-    out["svgd_full_step_fused_sgd_M8_resnet20_1_launch"]["gave_up"] = int(flag[0])
+    t = time_loop(lambda: ops.svgd_step_small_sgd(P2, G2, b2, d20, 3e-4, 1.0, 50000.0, ws, ks, 1e-12, 0.9, 0.0, 3e-4,
+                                                  True, False), 50)
+    rec("svgd_full_step_fused_sgd_M8_resnet20_2_launches", t, (12 * M + 8) * d20, 1, "steps_per_s")
     del P2, G2, o2, b2
-    # --- SWAG: the statistics as the optimizer keeps them (K + 2 rows interleaved in 16 KB pieces, ops.RowBlock) and,
-    # beside it, the same kernels on contiguous rows a row length apart (round 2's layout)
+    # --- SWAG: contiguous rows ([K + 2, ld]: ring rows, then mean, then second moment) and the same statistics with the
+    # rows interleaved in 16 KB pieces (ops.RowBlock); timed INTERLEAVED, several rounds, min and median of both
     from beyond_deep_ensembles_amd.ops import RowBlock
-    mean = torch.randn(ld, device=dev, generator=g) * 0.05
-    sq = mean * mean + 1e-4
-    ring = torch.randn(K_SWAG, ld, device=dev, generator=g) * 1e-3
+    stat = torch.randn(K_SWAG + 2, ld, device=dev, generator=g) * 1e-3
+    stat[K_SWAG] = torch.randn(ld, device=dev, generator=g) * 0.05
+    stat[K_SWAG + 1] = stat[K_SWAG] * stat[K_SWAG] + 1e-4
+    ring, mean, sq = stat[:K_SWAG], stat[K_SWAG], stat[K_SWAG + 1]
     theta = torch.randn(ld, device=dev, generator=g) * 0.05
     o = torch.empty(ld, device=dev)
     blk = RowBlock(K_SWAG + 2, d, dev)
     blk.buf.copy_(torch.randn(blk.buf.shape, device=dev, generator=g) * 1e-3)
     bm, bs, br = blk.row(K_SWAG), blk.row(K_SWAG + 1), blk.rows(0, K_SWAG)
-    rec("swag_update_resnet50", time_loop(lambda: ops.swag_update(theta, bm, bs, blk.row(3), 5, d, pieces=blk.pieces), it), 24 * d)
-    rec("swag_update_resnet50_contiguous_rows", time_loop(lambda: ops.swag_update(theta, mean, sq, ring[3], 5, d), it), 24 * d)
-    t = time_loop(lambda: ops.swag_sample(bm, bs, br, 3, o, d, seed=1, stream_id=2, pieces=blk.pieces), it)
-    rec("swag_sample_K20_resnet50", t, 4 * d * (K_SWAG + 3), 1, "samples_per_s")
+    rec("swag_update_resnet50", time_loop(lambda: ops.swag_update(theta, mean, sq, ring[3], 5, d), it), 24 * d,
+        probe=dict(shape=(1, 1, 2), n=d, rd=theta, wr=ring[3], rw=[mean, sq]))
+    rec("swag_update_resnet50_rows_in_pieces", time_loop(lambda: ops.swag_update(theta, bm, bs, blk.row(3), 5, d, pieces=blk.pieces), it), 24 * d)
     t = time_loop(lambda: ops.swag_sample(mean, sq, ring, 3, o, d, seed=1, stream_id=2), it)
-    rec("swag_sample_K20_resnet50_contiguous_rows", t, 4 * d * (K_SWAG + 3), 1, "samples_per_s")
+    rec("swag_sample_K20_resnet50", t, 4 * d * (K_SWAG + 3), 1, "samples_per_s", probe=dict(shape=(22, 1, 0), n=d, rd=stat, wr=o))
+    t = time_loop(lambda: ops.swag_sample(bm, bs, br, 3, o, d, seed=1, stream_id=2, pieces=blk.pieces), it)
+    rec("swag_sample_K20_resnet50_rows_in_pieces", t, 4 * d * (K_SWAG + 3), 1, "samples_per_s",
+        probe=dict(shape=(22, 1, 0), n=d, rd=blk.rows(0, K_SWAG + 2), wr=o, rd_pieces=blk.pieces))
+    # batched sampler: layout A/B, interleaved 5 x, same allocation state, with the same-shape probe in the same rounds
     oblk = RowBlock(S_SWAG, d, dev)
-    t = time_loop(lambda: ops.swag_sample_batched(bm, bs, br, 3, oblk.rows(0, S_SWAG), d, seed=1, stream_id0=0,
-                                                  pieces=blk.pieces, out_pieces=oblk.pieces), max(3, it // 2))
-    rec("swag_sample_batched_K20_S30_resnet50", t, 4 * d * (K_SWAG + 2 + S_SWAG), S_SWAG, "samples_per_s")
-    rec("swag_serve_prefetched_sample_resnet50", time_loop(lambda: ops.swag_copy_row(oblk.row(7), o, d, src_pieces=oblk.pieces), it),
-        8 * d, 1, "samples_per_s")
-    del oblk
     ob = torch.empty(S_SWAG, ld, device=dev)
-    t = time_loop(lambda: ops.swag_sample_batched(mean, sq, ring, 3, ob, d, seed=1, stream_id0=0), max(3, it // 2))
-    rec("swag_sample_batched_K20_S30_resnet50_contiguous_rows", t, 4 * d * (K_SWAG + 2 + S_SWAG), S_SWAG, "samples_per_s")
-    del ob, ring, blk, bm, bs, br
+    nb = 4 * d * (K_SWAG + 2 + S_SWAG)
+    arms = {
+        "contiguous": lambda: ops.swag_sample_batched(mean, sq, ring, 3, ob, d, seed=1, stream_id0=0),
+        "pieces": lambda: ops.swag_sample_batched(bm, bs, br, 3, oblk.rows(0, S_SWAG), d, seed=1, stream_id0=0, pieces=blk.pieces,
+                                                  out_pieces=oblk.pieces),
+    }
+    if probes.lib is not None:
+        arms["probe_contiguous"] = lambda: probes.run((22, 30, 0), d, rd=stat, wr=ob, nt_store=True)
+        arms["probe_pieces"] = lambda: probes.run((22, 30, 0), d, rd=blk.rows(0, K_SWAG + 2), wr=oblk.rows(0, S_SWAG), nt_store=True,
+                                                  rd_pieces=blk.pieces, wr_pieces=oblk.pieces)
+    for fn in arms.values():
+        time_loop(fn, 3)
+    times = {k: [] for k in arms}
+    for _ in range(3 if quick else 5):
+        for k, fn in arms.items():
+            times[k].append(time_loop(fn, 6, warm=1))
+    for arm in ("contiguous", "pieces"):
+        ts = sorted(times[arm])
+        name = "swag_sample_batched_K20_S30_resnet50" + ("" if arm == "contiguous" else "_rows_in_pieces")
+        rec(name, ts[len(ts) // 2], nb, S_SWAG, "samples_per_s")
+        e = out[name]
+        e["ms_min"], e["ms_all_rounds"] = round(ts[0] * 1e3, 4), [round(x * 1e3, 4) for x in times[arm]]
+        e["hbm_frac_best_round"] = round(nb / ts[0] / 1e9 / HBM_PEAK_GBS, 4)
+        if "probe_" + arm in times:
+            tp = sorted(times["probe_" + arm])
+            e["probe_shape"], e["probe_GBps"] = "R22 W30 RMW0", round(nb / tp[len(tp) // 2] / 1e9, 1)
+            e["frac_of_probe"] = round(tp[len(tp) // 2] / ts[len(ts) // 2], 4)
+        e["timing"] = "median of interleaved rounds (contiguous, pieces, and their probes in turn, 6 launches each)"
+    rec("swag_serve_prefetched_sample_resnet50", time_loop(lambda: ops.swag_copy_row(ob[7], o, d), it), 8 * d, 1, "samples_per_s",
+        probe=dict(shape=(1, 1, 0), n=d, rd=ob[7], wr=o))
+    del oblk, ob, ring, blk, bm, bs, br, stat
     # --- BBB
+    mean = torch.randn(ld, device=dev, generator=g) * 0.05
     rho = torch.full((ld,), -3.0, device=dev)
     w = torch.empty(ld, device=dev)
     gm, gr = torch.zeros(ld, device=dev), torch.zeros(ld, device=dev)
     rws, kl = ops.reduce_ws(dev), torch.zeros(1, device=dev)
-    rec("bbb_draw_fwd_resnet50", time_loop(lambda: ops.gauss_draw_fwd(mean, rho, w, d, seed=1, stream_id=0), it), 12 * d)
-    rec("bbb_draw_bwd_resnet50", time_loop(lambda: ops.gauss_draw_bwd(w, rho, gm, gr, d, seed=1, stream_id=0, accumulate=True), it), 24 * d)
+    rec("bbb_draw_fwd_resnet50", time_loop(lambda: ops.gauss_draw_fwd(mean, rho, w, d, seed=1, stream_id=0), it), 12 * d,
+        probe=dict(shape=(2, 1, 0), n=d, rd=[mean, rho], wr=w))
+    rec("bbb_draw_bwd_resnet50", time_loop(lambda: ops.gauss_draw_bwd(w, rho, gm, gr, d, seed=1, stream_id=0, accumulate=True), it), 24 * d,
+        probe=dict(shape=(2, 0, 2), n=d, rd=[w, rho], rw=[gm, gr]))
     # the KL row is the ACCUMULATE form (mu, rho read; gmu, grho read-modify-write) = 24 B/param
-    rec("bbb_kl_fwd_bwd_resnet50", time_loop(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, d, rws, kl_out=kl, gmean=gm, grho=gr, accumulate=True), it), 24 * d)
-    rec("bbb_kl_fwd_bwd_overwrite_resnet50", time_loop(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, d, rws, kl_out=kl, gmean=gm, grho=gr), it), 16 * d)
+    rec("bbb_kl_fwd_bwd_resnet50", time_loop(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, d, rws, kl_out=kl, gmean=gm, grho=gr, accumulate=True), it), 24 * d,
+        probe=dict(shape=(2, 0, 2), n=d, rd=[mean, rho], rw=[gm, gr]))
+    rec("bbb_kl_fwd_bwd_overwrite_resnet50", time_loop(lambda: ops.gauss_kl(mean, rho, 0.0, 1.0, d, rws, kl_out=kl, gmean=gm, grho=gr), it), 16 * d,
+        probe=dict(shape=(2, 2, 0), n=d, rd=[mean, rho], wr=[gm, gr]))
     var = torch.rand(ld, device=dev) + 1e-4
-    rec("bbb_local_reparam_epilogue_fwd_resnet50", time_loop(lambda: ops.local_reparam_fwd(mean, var, w, d, seed=1, stream_id=0), it), 12 * d)
+    rec("bbb_local_reparam_epilogue_fwd_resnet50", time_loop(lambda: ops.local_reparam_fwd(mean, var, w, d, seed=1, stream_id=0), it), 12 * d,
+        probe=dict(shape=(2, 1, 0), n=d, rd=[mean, var], wr=w))
     # --- iVON
     prec = torch.full((ld,), 100.0 / DATASET_SIZE, device=dev)
     ds, mom = torch.zeros(ld, device=dev), torch.zeros(ld, device=dev)
-    rec("ivon_sample_resnet50", time_loop(lambda: ops.ivon_sample(mean, prec, w, ds, d, DATASET_SIZE, first=False, seed=1, stream_id=0), it), 20 * d)
-    rec("ivon_update_resnet50", time_loop(lambda: ops.ivon_update(mean, mom, prec, ds, gm, d, lam=100.0 / DATASET_SIZE, n_eff=DATASET_SIZE, mc=2,
-                                                                   beta1=0.9, beta2=0.999, t=1, lr=1e-12, damping=1e-3), it), 32 * d)
+    rec("ivon_sample_resnet50", time_loop(lambda: ops.ivon_sample(mean, prec, w, ds, d, DATASET_SIZE, first=False, seed=1, stream_id=0), it), 20 * d,
+        probe=dict(shape=(2, 1, 1), n=d, rd=[mean, prec], wr=w, rw=ds))
+    st3 = torch.zeros(3, ld, device=dev)                     # mean / momentum / precision as rows of one tensor (probe: equal spacing)
+    st3[0], st3[2] = mean, prec
+    mean2, mom, prec = st3[0], st3[1], st3[2]
+    rec("ivon_update_resnet50", time_loop(lambda: ops.ivon_update(mean2, mom, prec, ds, gm, d, lam=100.0 / DATASET_SIZE, n_eff=DATASET_SIZE, mc=2,
+                                                                   beta1=0.9, beta2=0.999, t=1, lr=1e-12, damping=1e-3), it), 32 * d,
+        probe=dict(shape=(2, 0, 3), n=d, rd=[ds, gm], rw=[mean2, mom, prec]))
+    out["probe_note"] = ("probe_GBps / frac_of_probe: a no-arithmetic kernel with the SAME number of read / written / "
+                         "read-modify-written rows on the SAME tensors (bench_probe/probe.hip), timed right beside the kernel: "
+                         "frac_of_probe = kernel rate / probe rate; the probe walks its rows at the kernel's own addresses")
     return out
 
 

@@ -15,6 +15,8 @@
 // c, so that a lane ends up with 4 CONSECUTIVE parameters of one sample in
 // (acc0[reg] .. acc3[reg]) and the epilogue stores float4s, 512 B contiguous
 // per sample row.
+#include <cstdlib>
+
 #include "bde_common.hpp"
 
 namespace bde {
@@ -130,6 +132,174 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the same tile, software-pipelined through the LDS-DMA.
+//
+// The register kernel above runs load -> MFMA -> epilogue per tile and wave; a wave in its epilogue (16 x (Philox +
+// Box-Muller + 512-byte store), ~80 VALU instructions each) has nothing in flight, so with 3 waves per SIMD only about a
+// third of them keep memory busy (~40 KB in flight per CU against the ~64 KB that 8 TB/s x ~2 us of loaded latency
+// need).  Holding the NEXT tile's ring rows in registers during the epilogue would cost 40 more VGPRs on a kernel that sits
+// at its 168-register budget.  global_load_lds_dwordx4 has no register destination: each wave owns an 11 KB LDS slab
+// ([20 ring rows + mean + sq][128 floats], lane-linear = exactly the order its lanes read the MFMA B operand back with
+// ds_read_b128), and the slab of tile t+1 (or of the next 20-row chunk of this tile, K > 20) is requested as soon as
+// tile t's operands sit in registers -- BEFORE its 40 MFMAs and its whole epilogue.  Every wave then has 11 KB in
+// flight all the time (132 KB per CU).  No barrier: a slab is private to its wave, the only waits are the wave's own
+// s_waitcnt vmcnt (DMA landed) and lgkmcnt (operands read before the slab is refilled).  hipcc does not order a ds_read
+// behind an LDS-DMA in flight (checked in the ISA), so those waits are explicit.
+//
+// The epilogue runs two independent Philox chains per trip (the 64-bit multiplies of one chain fill the latency of the
+// other's) and reads mean / second moment from the slab as well, so there is no ordinary global load inside the loop
+// (hipcc would drain the DMA queue with vmcnt(0) at its first use).
+constexpr int kSlabRows = 2 * kBatchCH + 2;            // 20 ring rows + mean + sq
+constexpr int kSlabFloats = kSlabRows * 128;
+
+// 64 lanes x 16 bytes: lane l's source is base + off_bytes[l], its destination lds_uniform_base + 16 l (the LDS
+// address of an LDS-DMA is wave-uniform + lane * size).  Uniform 64-bit base + 32-bit lane offset = the saddr form of
+// the instruction: ONE VGPR of addressing for all rows of a tile.
+__device__ __forceinline__ void dma16(const float* __restrict__ base_uniform, uint32_t off_bytes, float* lds_uniform_base) {
+  const char* src = reinterpret_cast<const char*>(base_uniform) + off_bytes;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                   (__attribute__((address_space(3))) void*)(lds_uniform_base), 16, 0, 2 /* nt */);
+}
+
+template <bool RNG, int ROUNDS, bool SINGLE>
+__global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_dma_kernel(
+    const float* __restrict__ mean, const float* __restrict__ sq, const float* __restrict__ dev, int K, int64_t ld,
+    int head, const float* __restrict__ eps_w, const float* __restrict__ eps_d, int64_t ld_eps, uint64_t seed,
+    uint64_t stream0, float* __restrict__ out, int64_t ld_out, int S, int64_t D, RowPiecesRt L, RowPiecesRt Lo) {
+  extern __shared__ __attribute__((aligned(16))) float w[];   // [kpad][32] weights, then one slab per wave
+  const int kpad = K + (K & 1);
+  const int ksteps = kpad >> 1;                               // SINGLE: ksteps <= kBatchCH (one slab per tile)
+  const float denom = __builtin_sqrtf(2.0f * static_cast<float>(K - 1));   // swag.py:113
+  for (int idx = threadIdx.x; idx < kpad * 32; idx += blockDim.x) {
+    const int r = idx >> 5, s = idx & 31;
+    float v = 0.f;
+    if (r < K && s < S) {
+      int c = r - head;
+      if (c < 0) c += K;
+      v = lowrank_noise_b(eps_w ? eps_w + static_cast<int64_t>(s) * K : nullptr, seed, stream0 + s, c) / denom;
+    }
+    w[idx] = v;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, half = lane >> 5;
+  float* slab = w + kpad * 32 + wave * kSlabFloats;          // wave-uniform
+  const float* my = slab + 4 * lane;                          // where this lane's float4 of a row pair lands
+  const int64_t n4 = D >> 2;                                  // full float4 groups
+  const int64_t n_tiles = (n4 + 31) / 32;                     // 32 float4 = 128 parameters per tile
+  const int64_t waves_total = static_cast<int64_t>(gridDim.x) * (kBlock / 64);
+  const uint32_t row_bytes = static_cast<uint32_t>(ld) * 4u;  // ld < 2^30 floats (checked by the launcher)
+
+  // Request the slab of (tile, chunk c0): ring rows 2 (c0 + u) + half, u < kBatchCH, and with chunk 0 mean | sq.  All
+  // addressing is a wave-uniform base (tile, row pair) + ONE per-lane byte offset: (half, float4 j) -- lanes past the
+  // end of the vector (last tile) read the last valid float4 instead; their columns are never stored.  The odd row K
+  // of an odd K re-reads row K - 1 (its weight is zero).
+  auto request = [&](int64_t tile, int c0) {
+    const int64_t e0 = tile * 128;                                            // uniform
+    const int jlast = static_cast<int>(min<int64_t>(31, n4 - 1 - tile * 32));  // uniform
+    const uint32_t joff = 16u * static_cast<uint32_t>(min(j, jlast));
+    const float* base = dev + piece_off_rt(e0, L);                            // uniform
+#pragma unroll
+    for (int u = 0; u < kBatchCH; ++u) {
+      if (c0 + u < ksteps) {                                                  // wave-uniform
+        const int r0 = 2 * (c0 + u);
+        const uint32_t lane_off = (r0 + 1 < K) ? joff + (half ? row_bytes : 0u) : joff;
+        dma16(base + static_cast<int64_t>(r0) * ld, lane_off, slab + u * 256);
+      }
+    }
+    if (c0 == 0) dma16(half ? sq + piece_off_rt(e0, L) : mean + piece_off_rt(e0, L), joff, slab + kBatchCH * 256);
+  };
+
+  int64_t t = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
+  if (t < n_tiles) request(t, 0);
+  for (; t < n_tiles; t += waves_total) {
+    const int64_t g4 = t * 32 + j;                            // this lane's float4 group
+    const bool ok = g4 < n4;
+    f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
+    f32x4 m = {}, q = {};
+    for (int c0 = 0; c0 < (SINGLE ? 1 : ksteps); c0 += kBatchCH) {
+      f32x4 b[kBatchCH];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this chunk's slab has landed
+#pragma unroll
+      for (int u = 0; u < kBatchCH; ++u) b[u] = *reinterpret_cast<const f32x4*>(my + u * 256);
+      if (SINGLE || c0 == 0) {
+        m = *reinterpret_cast<const f32x4*>(slab + kBatchCH * 256 + 4 * j);
+        q = *reinterpret_cast<const f32x4*>(slab + kBatchCH * 256 + 128 + 4 * j);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // operands in registers: the slab may be refilled
+      if (!SINGLE && c0 + kBatchCH < ksteps) request(t, c0 + kBatchCH);
+      else if (t + waves_total < n_tiles) request(t + waves_total, 0);
+#pragma unroll
+      for (int u = 0; u < kBatchCH; ++u) {
+        if (c0 + u < ksteps) {                                // wave-uniform
+          const float a = w[(2 * (c0 + u) + half) * 32 + j];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][1], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][2], acc2, 0, 0, 0);
+          acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][3], acc3, 0, 0, 0);
+        }
+      }
+    }
+    if (ok) {
+      const int64_t oo = piece_off_rt(4 * g4, Lo);
+      const f32x4 v = q - m * m;
+      f32x4 sd;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sd[c] = __builtin_sqrtf(0.5f * (fmaxf(v[c], 0.0f) + 1e-6f));   // swag.py:112
+      // two samples (= two independent Philox chains) per trip; rolled: all 16 chains at once cost > 240 VGPRs
+#pragma unroll 1
+      for (int reg = 0; reg < 16; reg += 2) {
+        const int s0 = (reg & 3) + 8 * (reg >> 2) + 4 * half;  // C/D rows of the 32x32 tile: reg and reg + 1
+        f32x4 z0, z1;
+#ifdef BDE_BATCHED_NO_RNG
+        z0 = z1 = f32x4{1.f, 1.f, 1.f, 1.f};
+#else
+        if (RNG) {
+          z0 = philox_normal4<ROUNDS>(seed, stream0 + s0, static_cast<uint64_t>(g4), kDomainDiag);
+          z1 = philox_normal4<ROUNDS>(seed, stream0 + s0 + 1, static_cast<uint64_t>(g4), kDomainDiag);
+        } else {
+          z0 = s0 < S ? ld4_nt(eps_d + static_cast<int64_t>(s0) * ld_eps + 4 * g4) : f32x4{};
+          z1 = s0 + 1 < S ? ld4_nt(eps_d + static_cast<int64_t>(s0 + 1) * ld_eps + 4 * g4) : f32x4{};
+        }
+#endif
+        // both chains complete BEFORE the (lane-masked) stores: otherwise the compiler sinks each chain into the branch
+        // of its own store and they run one after the other
+        asm volatile("" : "+v"(z0), "+v"(z1));
+        const f32x4 lr0 = {acc0[reg], acc1[reg], acc2[reg], acc3[reg]};
+        const f32x4 lr1 = {acc0[reg + 1], acc1[reg + 1], acc2[reg + 1], acc3[reg + 1]};
+        if (s0 < S) st4_nt(out + static_cast<int64_t>(s0) * ld_out + oo, (m + lr0) + sd * z0);
+        if (s0 + 1 < S) st4_nt(out + static_cast<int64_t>(s0 + 1) * ld_out + oo, (m + lr1) + sd * z1);
+      }
+    }
+  }
+
+  // the D % 4 tail parameters: plain dot products (block 0 only)
+  if (blockIdx.x == 0) {
+    const int rem = static_cast<int>(D - (n4 << 2));
+    for (int idx = threadIdx.x; idx < rem * S; idx += blockDim.x) {
+      const int s = idx / rem, k = idx % rem;
+      const int64_t e = (n4 << 2) + k;
+      const int64_t so = piece_off_rt(e, L);
+      float acc = 0.f;
+      for (int r = 0; r < K; ++r) acc = __builtin_fmaf(dev[static_cast<int64_t>(r) * ld + so], w[r * 32 + s], acc);
+      const float mm = mean[so];
+      float z;
+      if (RNG) {
+        const f32x4 zz = philox_normal4<ROUNDS>(seed, stream0 + s, static_cast<uint64_t>(n4), kDomainDiag);
+        z = zz[k];
+      } else {
+        z = eps_d[static_cast<int64_t>(s) * ld_eps + e];
+      }
+      out[static_cast<int64_t>(s) * ld_out + piece_off_rt(e, Lo)] =
+          (mm + acc) + __builtin_sqrtf(0.5f * (fmaxf(sq[so] - mm * mm, 0.0f) + 1e-6f)) * z;
+    }
+  }
+}
+
 }  // namespace bde
 
 using namespace bde;
@@ -155,6 +325,26 @@ extern "C" int bde_swag_sample_batched(const float* mean, const float* sq, const
   const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, kCUs * 12)));
   const size_t lds = sizeof(float) * static_cast<size_t>(K + (K & 1)) * 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // EXPERIMENT SWITCH (round 4 A/B, read per call): 0: register kernel, 1: LDS-DMA kernel, 2: LDS-DMA where one slab holds all K rows
+  const char* env_variant = std::getenv("BDE_BATCHED_KERNEL");
+  const int variant = env_variant ? std::atoi(env_variant) : 2;
+  if ((variant == 1 || (variant == 2 && (K + (K & 1)) / 2 <= kBatchCH)) && (D >> 2) >= 1 && ld < (int64_t{1} << 30)) {
+    const size_t lds_dma = lds + sizeof(float) * (kBlock / 64) * kSlabFloats;
+    const bool single = (K + (K & 1)) / 2 <= kBatchCH;
+#define BDE_LAUNCH_DMA(RNG_, SINGLE_)                                                                                        \
+  do {                                                                                                                       \
+    auto kern = swag_sample_batched_dma_kernel<RNG_, kSwagPhiloxRounds, SINGLE_>;                                            \
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+        static_cast<int>(sizeof(float) * ((BDE_MAX_RANK + 1) * 32 + (kBlock / 64) * kSlabFloats))) == hipSuccess;             \
+    if (!attr_ok) return BDE_ERR_INVALID;                                                                                     \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds_dma, s, mean, sq, dev, K, ld, head, eps_w, eps_d, ld_eps, seed,   \
+                       stream_id0, out, ld_out, S, D, L, Lo);                                                                \
+  } while (0)
+    if (eps_d) { if (single) BDE_LAUNCH_DMA(false, true); else BDE_LAUNCH_DMA(false, false); }
+    else { if (single) BDE_LAUNCH_DMA(true, true); else BDE_LAUNCH_DMA(true, false); }
+#undef BDE_LAUNCH_DMA
+    return to_err(hipGetLastError());
+  }
   if (eps_d)
     hipLaunchKernelGGL(swag_sample_batched_kernel<false>, dim3(grid), dim3(kBlock), lds, s, mean, sq, dev, K, ld, head,
                        eps_w, eps_d, ld_eps, seed, stream_id0, out, ld_out, S, D, L, Lo);

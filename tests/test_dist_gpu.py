@@ -146,10 +146,15 @@ def _check_svgd_rccl_world1(tmp_path, name, m, kw):
     r0 = np.load(tmp_path / "rank0.npz")
     assert int(r0["fwd"]) == 4 * m
     single_kw = {k: v for k, v in kw.items() if k not in ("exchange", "exchange_chunks", "overlap_backward", "_force_exchange")}
-    model, opt = _make_svgd(100, m, torch.device("cuda", 0), **single_kw)
+    # single_launch=False: the streaming kernels (Gram -> statistics -> combine / fused), which the sharded update always
+    # runs -- this model is small enough for the small-model kernel, whose Gram partials sum in another (fixed) order
+    model, opt = _make_svgd(100, m, torch.device("cuda", 0), single_launch=False, **single_kw)
     losses = _run_steps(model, opt, torch.device("cuda", 0))
-    if kw.get("exchange") == "alltoall":
-        np.testing.assert_allclose(r0["particles"], opt.particles.cpu().numpy(), rtol=2e-6, atol=2e-7)
+    if kw.get("exchange") == "alltoall" or kw.get("reuse_gram"):
+        # alltoall: Gram reduced slice-wise through fp64 blocks; reuse_gram: the next step's Gram partials come out of the
+        # fused kernel, whose flat-row form (sharded) and segmented form (single process) sum them chunk-wise in different
+        # fixed orders -- 1-ulp differences in the statistics
+        np.testing.assert_allclose(r0["particles"], opt.particles.cpu().numpy(), rtol=1e-5, atol=2e-7)
         np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=2e-6)
     else:
         np.testing.assert_array_equal(r0["particles"], opt.particles.cpu().numpy())
