@@ -120,7 +120,7 @@ class StreamProbes:
         rp, rl = self._rows(rd)
         wp, wl = self._rows(wr)
         mp, ml = self._rows(rw)
-        rlp, rps = rd_pieces if rd_pieces else (0, 0)          # RowBlock.pieces = (log2_piece, piece_stride)
+        rlp, rps = rd_pieces if rd_pieces else (0, 0)          # (log2_piece, piece_stride): rows interleaved in pieces
         wlp, wps = wr_pieces if wr_pieces else (0, 0)
         rc = self.lib.bde_bench_probe(shape[0], shape[1], shape[2], int(nt_store), rp, rl, rlp, rps, wp, wl, wlp, wps, mp, ml, n,
                                       torch.cuda.current_stream().cuda_stream)
@@ -186,60 +186,51 @@ def extras(ops, dev, quick):
                                                   True, False), 50)
     rec("svgd_full_step_fused_sgd_M8_resnet20_2_launches", t, (12 * M + 8) * d20, 1, "steps_per_s")
     del P2, G2, o2, b2
-    # --- SWAG: contiguous rows ([K + 2, ld]: ring rows, then mean, then second moment) and the same statistics with the
-    # rows interleaved in 16 KB pieces (ops.RowBlock); timed INTERLEAVED, several rounds, min and median of both
-    from beyond_deep_ensembles_amd.ops import RowBlock
+    # --- SWAG: the K + 2 statistics rows are the rows of one [K + 2, ld] buffer (ring rows, then mean, then second moment)
     stat = torch.randn(K_SWAG + 2, ld, device=dev, generator=g) * 1e-3
     stat[K_SWAG] = torch.randn(ld, device=dev, generator=g) * 0.05
     stat[K_SWAG + 1] = stat[K_SWAG] * stat[K_SWAG] + 1e-4
     ring, mean, sq = stat[:K_SWAG], stat[K_SWAG], stat[K_SWAG + 1]
     theta = torch.randn(ld, device=dev, generator=g) * 0.05
     o = torch.empty(ld, device=dev)
-    blk = RowBlock(K_SWAG + 2, d, dev)
-    blk.buf.copy_(torch.randn(blk.buf.shape, device=dev, generator=g) * 1e-3)
-    bm, bs, br = blk.row(K_SWAG), blk.row(K_SWAG + 1), blk.rows(0, K_SWAG)
     rec("swag_update_resnet50", time_loop(lambda: ops.swag_update(theta, mean, sq, ring[3], 5, d), it), 24 * d,
         probe=dict(shape=(1, 1, 2), n=d, rd=theta, wr=ring[3], rw=[mean, sq]))
-    rec("swag_update_resnet50_rows_in_pieces", time_loop(lambda: ops.swag_update(theta, bm, bs, blk.row(3), 5, d, pieces=blk.pieces), it), 24 * d)
     t = time_loop(lambda: ops.swag_sample(mean, sq, ring, 3, o, d, seed=1, stream_id=2), it)
     rec("swag_sample_K20_resnet50", t, 4 * d * (K_SWAG + 3), 1, "samples_per_s", probe=dict(shape=(22, 1, 0), n=d, rd=stat, wr=o))
-    t = time_loop(lambda: ops.swag_sample(bm, bs, br, 3, o, d, seed=1, stream_id=2, pieces=blk.pieces), it)
-    rec("swag_sample_K20_resnet50_rows_in_pieces", t, 4 * d * (K_SWAG + 3), 1, "samples_per_s",
-        probe=dict(shape=(22, 1, 0), n=d, rd=blk.rows(0, K_SWAG + 2), wr=o, rd_pieces=blk.pieces))
-    # batched sampler: layout A/B, interleaved 5 x, same allocation state, with the same-shape probe in the same rounds
-    oblk = RowBlock(S_SWAG, d, dev)
+    # batched sampler and its same-shape probe INTERLEAVED (5 rounds of 6 launches each, same allocation state); beside
+    # them the probe on round 3's layout (rows interleaved in 16 KB pieces, [piece][row][4096 floats]): what the
+    # silicon gives each layout without any arithmetic -- the layout question of VERDICT r3 #3, in driver-visible data
     ob = torch.empty(S_SWAG, ld, device=dev)
     nb = 4 * d * (K_SWAG + 2 + S_SWAG)
-    arms = {
-        "contiguous": lambda: ops.swag_sample_batched(mean, sq, ring, 3, ob, d, seed=1, stream_id0=0),
-        "pieces": lambda: ops.swag_sample_batched(bm, bs, br, 3, oblk.rows(0, S_SWAG), d, seed=1, stream_id0=0, pieces=blk.pieces,
-                                                  out_pieces=oblk.pieces),
-    }
+    arms = {"kernel": lambda: ops.swag_sample_batched(mean, sq, ring, 3, ob, d, seed=1, stream_id0=0)}
     if probes.lib is not None:
-        arms["probe_contiguous"] = lambda: probes.run((22, 30, 0), d, rd=stat, wr=ob, nt_store=True)
-        arms["probe_pieces"] = lambda: probes.run((22, 30, 0), d, rd=blk.rows(0, K_SWAG + 2), wr=oblk.rows(0, S_SWAG), nt_store=True,
-                                                  rd_pieces=blk.pieces, wr_pieces=oblk.pieces)
+        npc = (d + 4095) // 4096
+        pin = torch.zeros(npc, K_SWAG + 2, 4096, device=dev)
+        pout = torch.empty(npc, S_SWAG, 4096, device=dev)
+        arms["probe"] = lambda: probes.run((22, 30, 0), d, rd=stat, wr=ob, nt_store=True)
+        arms["probe_rows_in_pieces"] = lambda: probes.run((22, 30, 0), d, rd=pin[0], wr=pout[0], nt_store=True,
+                                                          rd_pieces=(12, (K_SWAG + 2) * 4096), wr_pieces=(12, S_SWAG * 4096))
     for fn in arms.values():
         time_loop(fn, 3)
     times = {k: [] for k in arms}
     for _ in range(3 if quick else 5):
         for k, fn in arms.items():
             times[k].append(time_loop(fn, 6, warm=1))
-    for arm in ("contiguous", "pieces"):
-        ts = sorted(times[arm])
-        name = "swag_sample_batched_K20_S30_resnet50" + ("" if arm == "contiguous" else "_rows_in_pieces")
-        rec(name, ts[len(ts) // 2], nb, S_SWAG, "samples_per_s")
-        e = out[name]
-        e["ms_min"], e["ms_all_rounds"] = round(ts[0] * 1e3, 4), [round(x * 1e3, 4) for x in times[arm]]
-        e["hbm_frac_best_round"] = round(nb / ts[0] / 1e9 / HBM_PEAK_GBS, 4)
-        if "probe_" + arm in times:
-            tp = sorted(times["probe_" + arm])
-            e["probe_shape"], e["probe_GBps"] = "R22 W30 RMW0", round(nb / tp[len(tp) // 2] / 1e9, 1)
-            e["frac_of_probe"] = round(tp[len(tp) // 2] / ts[len(ts) // 2], 4)
-        e["timing"] = "median of interleaved rounds (contiguous, pieces, and their probes in turn, 6 launches each)"
-    rec("swag_serve_prefetched_sample_resnet50", time_loop(lambda: ops.swag_copy_row(ob[7], o, d), it), 8 * d, 1, "samples_per_s",
+    ts = sorted(times["kernel"])
+    rec("swag_sample_batched_K20_S30_resnet50", ts[len(ts) // 2], nb, S_SWAG, "samples_per_s")
+    e = out["swag_sample_batched_K20_S30_resnet50"]
+    e["ms_min"], e["ms_all_rounds"] = round(ts[0] * 1e3, 4), [round(x * 1e3, 4) for x in times["kernel"]]
+    e["hbm_frac_best_round"] = round(nb / ts[0] / 1e9 / HBM_PEAK_GBS, 4)
+    e["timing"] = "median of 5 interleaved rounds (kernel, probe, probe on rows in pieces; 6 launches each)"
+    if "probe" in times:
+        tp, tq = sorted(times["probe"]), sorted(times["probe_rows_in_pieces"])
+        e["probe_shape"], e["probe_GBps"] = "R22 W30 RMW0", round(nb / tp[len(tp) // 2] / 1e9, 1)
+        e["frac_of_probe"] = round(tp[len(tp) // 2] / ts[len(ts) // 2], 4)
+        e["probe_rows_in_pieces_GBps"] = round(nb / tq[len(tq) // 2] / 1e9, 1)
+        del pin, pout
+    rec("swag_serve_prefetched_sample_resnet50", time_loop(lambda: o.copy_(ob[7]), it), 8 * d, 1, "samples_per_s",
         probe=dict(shape=(1, 1, 0), n=d, rd=ob[7], wr=o))
-    del oblk, ob, ring, blk, bm, bs, br, stat
+    del ob, ring, stat
     # --- BBB
     mean = torch.randn(ld, device=dev, generator=g) * 0.05
     rho = torch.full((ld,), -3.0, device=dev)
@@ -1031,18 +1022,15 @@ def main():
         torch.cuda.empty_cache()
         ld = pad_ld(d)
         gsw = torch.Generator(device=dev).manual_seed(99 + rank)
-        from beyond_deep_ensembles_amd.ops import RowBlock
-        blk = RowBlock(K_SWAG + 2, d, dev)                      # the optimizer's layout: rows interleaved in 16 KB pieces
-        blk.buf.copy_(torch.randn(blk.buf.shape, device=dev, generator=gsw) * 1e-3)
-        blk.buf[:, K_SWAG + 1] += 1e-4
-        bm, bs, br = blk.row(K_SWAG), blk.row(K_SWAG + 1), blk.rows(0, K_SWAG)
+        stat = torch.randn(K_SWAG + 2, ld, device=dev, generator=gsw) * 1e-3     # ring rows, mean, second moment
+        stat[K_SWAG + 1] += 1e-4
+        bm, bs, br = stat[K_SWAG], stat[K_SWAG + 1], stat[:K_SWAG]
         o1 = torch.empty(ld, device=dev)
-        ob = RowBlock(S_SWAG, d, dev)
+        ob = torch.empty(S_SWAG, ld, device=dev)
         if dist:
             dist.barrier()
-        t_single = time_loop(lambda: ops.swag_sample(bm, bs, br, 3, o1, d, seed=1, stream_id=2, pieces=blk.pieces), 20)
-        t_batch = time_loop(lambda: ops.swag_sample_batched(bm, bs, br, 3, ob.rows(0, S_SWAG), d, seed=1, stream_id0=0,
-                                                            pieces=blk.pieces, out_pieces=ob.pieces), 8)
+        t_single = time_loop(lambda: ops.swag_sample(bm, bs, br, 3, o1, d, seed=1, stream_id=2), 20)
+        t_batch = time_loop(lambda: ops.swag_sample_batched(bm, bs, br, 3, ob, d, seed=1, stream_id0=0), 8)
         rates = torch.tensor([1.0 / t_single, S_SWAG / t_batch], device=dev, dtype=torch.float64)
         if dist:
             dist.all_reduce(rates, op=dist.ReduceOp.SUM)
@@ -1050,7 +1038,7 @@ def main():
                 "K": K_SWAG, "D": d, "scaling": "weak (independent posterior samples on every GPU)",
                 "per_sample_hbm_frac_rank0": round(4 * d * (K_SWAG + 3) / t_single / 1e9 / HBM_PEAK_GBS, 4),
                 "batched_hbm_frac_rank0": round(4 * d * (K_SWAG + 2 + S_SWAG) / t_batch / 1e9 / HBM_PEAK_GBS, 4)}
-        del blk, bm, bs, br, o1, ob
+        del stat, bm, bs, br, o1, ob
         out = None
 
     if rank == 0:

@@ -53,12 +53,10 @@ SIGNATURES = {
     "bde_svgd_fused_adam_seg": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int, c_int64, c_int64, _P, c_double, c_double,
                                         c_double, c_double, c_double, c_int64, _P, _P]),
     "bde_svgd_gather_seg": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, _P]),
-    "bde_swag_update": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int, c_int64, _P]),
-    "bde_swag_sample": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64, c_int, c_int64,
-                                _P]),
+    "bde_swag_update": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P]),
+    "bde_swag_sample": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_swag_sample_batched": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_int64, c_uint64, c_uint64, _P, c_int64,
-                                        c_int, c_int64, c_int, c_int64, c_int, c_int64, _P]),
-    "bde_swag_copy_row": (c_int, [_P, c_int, c_int64, _P, c_int, c_int64, c_int64, _P]),
+                                        c_int, c_int64, _P]),
     "bde_swag_philox_rounds": (c_int, []),
     "bde_philox_normal": (c_int, [c_uint64, c_uint64, _P, c_int, _P, c_int64, c_int, _P]),
     "bde_philox_bits": (c_int, [c_uint64, c_uint64, c_uint32, c_uint64, _P, c_int64, c_int, _P]),
@@ -72,6 +70,8 @@ SIGNATURES = {
     "bde_local_reparam_bwd": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_var_operand_fwd": (c_int, [_P, c_int, _P, c_int64, _P]),
     "bde_var_operand_bwd": (c_int, [_P, _P, c_int, _P, c_int64, _P]),
+    "bde_conv_lrt_supported": (c_int, [c_int] * 11),
+    "bde_conv_lrt_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_uint64, c_uint64, _P, _P] + [c_int] * 11 + [_P]),
     "bde_lrt_linear_supported": (c_int, [c_int, c_int, c_int]),
     "bde_lrt_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "bde_lrt_linear_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int, _P, c_uint64, c_uint64, _P, _P, c_int, c_int, c_int,

@@ -57,44 +57,6 @@ __device__ __forceinline__ f32x4 ld4_nt(const float* __restrict__ p) {
   return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
 }
 
-// ---- rows stored in pieces ------------------------------------------------
-// A "row" of D floats is either contiguous (log2_piece = 0) or cut into pieces of 2^log2_piece floats with piece c at
-// offset c * piece_stride from the row's first piece: the SWAG statistics keep their K + 2 rows INTERLEAVED that way
-// ([piece][row][2^log2_piece floats]: one contiguous region per piece instead of K + 2 streams a row length apart).
-// The piece size is a COMPILE-TIME parameter of the kernels (LOG2 = 0: contiguous, 7: 128 floats -- the tests' small
-// size --, 12: 4096 floats = 16 KB, what the optimizer uses): with the piece size a runtime value the unbatched sampler
-// lost 20 % (0.785 -> 0.655 of the HBM peak at identical instruction mixes, profiles/r03_swag_single_sampler_bisect.txt).
-constexpr int kPieceSmall = 7, kPieceLarge = 12;
-// Offset (in floats) of element e of a row stored in pieces of 2^LOG2 floats, piece c at c * piece_stride from the
-// row's first piece; pieces are multiples of 4 floats, so a float4 never straddles two.
-template <int LOG2>
-__device__ __forceinline__ int64_t piece_off(int64_t e, int64_t piece_stride) {
-  if constexpr (LOG2 == 0) return e;
-  else return (e >> LOG2) * piece_stride + (e & ((int64_t{1} << LOG2) - 1));
-}
-// The batched sampler is the exception: it keeps the piece size a RUNTIME value.  Its register budget (168 VGPRs = 3
-// waves per SIMD) is exhausted, the compile-time 4096-float variants spilled 6-8 VGPRs to scratch (1.07 vs 0.92 ms),
-// and one uniform branch per 128-parameter tile is free there (profiles/r03_swag_single_sampler_bisect.txt).
-struct RowPiecesRt {
-  int log2_piece;          // 0: contiguous row
-  int64_t piece_stride;    // floats from one piece of a row to its next piece
-};
-__device__ __forceinline__ int64_t piece_off_rt(int64_t e, RowPiecesRt L) {
-  if (L.log2_piece == 0) return e;
-  return (e >> L.log2_piece) * L.piece_stride + (e & ((int64_t{1} << L.log2_piece) - 1));
-}
-static inline bool pieces_ok(int log2_piece, int64_t piece_stride) {
-  return log2_piece == 0 || ((log2_piece == kPieceSmall || log2_piece == kPieceLarge) &&
-                             piece_stride >= (int64_t{1} << log2_piece) && (piece_stride & 3) == 0);
-}
-// run `body(std::integral_constant<int, LOG2>)` for the runtime piece size (validated by pieces_ok)
-#define BDE_DISPATCH_PIECE(log2_piece, NAME, ...)                                   \
-  do {                                                                              \
-    if ((log2_piece) == 0) { constexpr int NAME = 0; __VA_ARGS__; }                 \
-    else if ((log2_piece) == bde::kPieceSmall) { constexpr int NAME = bde::kPieceSmall; __VA_ARGS__; } \
-    else { constexpr int NAME = bde::kPieceLarge; __VA_ARGS__; }                    \
-  } while (0)
-
 // ---- reductions ---------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

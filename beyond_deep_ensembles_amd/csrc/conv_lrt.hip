@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
         float z;
         if (RNG) {
           const f32x4 zz = philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag);
-          z = zz[e & 3];
+          const int c = static_cast<int>(e & 3);
+          z = c == 0 ? zz.x : c == 1 ? zz.y : c == 2 ? zz.z : zz.w;
         } else {
           z = eps[e];
         }

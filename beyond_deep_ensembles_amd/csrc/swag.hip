@@ -4,7 +4,8 @@
 // The reference keeps mean/sq/deviations on the CPU, copies the flattened
 // weights GPU->CPU every update, physically rolls a [D, K] matrix, and ships
 // everything back to the device to sample.  Here the statistics stay in HBM,
-// the deviation matrix is a [K, ld] ring (one coalesced row per iterate) and
+// the deviation matrix is a [K, ld] ring (one coalesced row per iterate; rows a leading dimension apart -- round 3's
+// interleaved 16 KB pieces did not win in any bench.py record and are gone) and
 // both operations are single streaming passes:
 //   update : 24 B / parameter   (theta r, mean rw, sq rw, one ring row w)
 //   sample : 4 (K + 3) B / parameter with in-kernel Philox noise
@@ -18,15 +19,14 @@ namespace bde {
 // ---------------------------------------------------------------- update --
 // Bit-exact with the reference's CPU fp32 arithmetic: separately rounded
 // multiply, add and IEEE divide (this file is built with -ffp-contract=off).
-template <int LP>
 __global__ __launch_bounds__(kBlock) void swag_update_kernel(const float* __restrict__ theta,
                                                             float* __restrict__ mean, float* __restrict__ sq,
                                                             float* __restrict__ dev_row, float n, float np1,
-                                                            int64_t D, int64_t pstride) {
+                                                            int64_t D) {
   const int64_t n4 = D >> 2;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const int64_t o = piece_off<LP>(4 * i, pstride);
+    const int64_t o = 4 * i;
     const f32x4 t = ld4_nt(theta + 4 * i);
     f32x4 m = ld4(mean + o);
     f32x4 s = ld4(sq + o);
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void swag_update_kernel(const float* __rest
   if (blockIdx.x == 0) {
     const int64_t e = (n4 << 2) + threadIdx.x;
     if (e < D) {
-      const int64_t o = piece_off<LP>(e, pstride);
+      const int64_t o = e;
       const float t = theta[e];
       const float m = (n * mean[o] + t) / np1;
       const float s = (n * sq[o] + t * t) / np1;
@@ -47,21 +47,6 @@ __global__ __launch_bounds__(kBlock) void swag_update_kernel(const float* __rest
       sq[o] = s;
       dev_row[o] = t - m;
     }
-  }
-}
-
-// One row re-laid out: dst (pieces Ld) = src (pieces Ls); either side may be contiguous.  The consumer of a batched
-// sample (its pieces -> the contiguous vector the parameters view), and the accessors / checkpoints.
-template <int LPS, int LPD>
-__global__ __launch_bounds__(kBlock) void swag_copy_row_kernel(const float* __restrict__ src, int64_t ps_src,
-                                                              float* __restrict__ dst, int64_t ps_dst, int64_t D) {
-  const int64_t n4 = D >> 2;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride)
-    st4(dst + piece_off<LPD>(4 * i, ps_dst), ld4_nt(src + piece_off<LPS>(4 * i, ps_src)));
-  if (blockIdx.x == 0) {
-    const int64_t e = (n4 << 2) + threadIdx.x;
-    if (e < D) dst[piece_off<LPD>(e, ps_dst)] = src[piece_off<LPS>(e, ps_src)];
   }
 }
 
@@ -82,14 +67,14 @@ __device__ __forceinline__ f32x4 diag_std(f32x4 m, f32x4 s) {
   return r;
 }
 
-template <bool RNG, int LP>
+template <bool RNG>
 __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __restrict__ mean,
                                                             const float* __restrict__ sq,
                                                             const float* __restrict__ dev, int K, int64_t ld,
                                                             int head, const float* __restrict__ eps_w,
                                                             const float* __restrict__ eps_d, uint64_t seed,
                                                             uint64_t stream_id, float* __restrict__ out,
-                                                            int64_t D, int64_t pstride) {
+                                                            int64_t D) {
   __shared__ float w[BDE_MAX_RANK];   // noise weight of each PHYSICAL ring row
   const float denom = __builtin_sqrtf(2.0f * static_cast<float>(K - 1));   // swag.py:113
   for (int r = threadIdx.x; r < K; r += blockDim.x) {
@@ -113,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
     for (int u = 0; u < U; ++u) {
       acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int64_t c = i + u * stride;
-      off[u] = piece_off<LP>(4 * (c < n4 ? c : i), pstride);
+      off[u] = 4 * (c < n4 ? c : i);
     }
 #pragma unroll 5
     for (int r = 0; r < K; ++r) {
@@ -144,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void swag_sample_kernel(const float* __rest
     const int64_t e = (n4 << 2) + threadIdx.x;
     if (e < D) {
       float acc = 0.f;
-      const int64_t o = piece_off<LP>(e, pstride);
+      const int64_t o = e;
       for (int r = 0; r < K; ++r) acc = __builtin_fmaf(dev[static_cast<int64_t>(r) * ld + o], w[r], acc);
       const float m = mean[o], s = sq[o];
       float z;
@@ -196,51 +181,30 @@ __global__ __launch_bounds__(kBlock) void philox_bits_kernel(uint64_t seed, uint
 
 using namespace bde;
 
-extern "C" int bde_swag_update(const float* theta, float* mean, float* sq, float* dev_row, int64_t n, int64_t D,
-                               int log2_piece, int64_t piece_stride, void* stream) {
-  if (!theta || !mean || !sq || !dev_row || D <= 0 || n < 1 || !pieces_ok(log2_piece, piece_stride)) return BDE_ERR_INVALID;
+extern "C" int bde_swag_update(const float* theta, float* mean, float* sq, float* dev_row, int64_t n, int64_t D, void* stream) {
+  if (!theta || !mean || !sq || !dev_row || D <= 0 || n < 1) return BDE_ERR_INVALID;
   if (!aligned16(theta) || !aligned16(mean) || !aligned16(sq) || !aligned16(dev_row)) return BDE_ERR_INVALID;
   const int grid = stream_grid((D + 3) / 4);
-  BDE_DISPATCH_PIECE(log2_piece, LP,
-                     hipLaunchKernelGGL(swag_update_kernel<LP>, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                                        theta, mean, sq, dev_row, static_cast<float>(n), static_cast<float>(n + 1), D,
-                                        piece_stride));
-  return to_err(hipGetLastError());
-}
-
-extern "C" int bde_swag_copy_row(const float* src, int log2_piece_src, int64_t piece_stride_src, float* dst,
-                                 int log2_piece_dst, int64_t piece_stride_dst, int64_t D, void* stream) {
-  if (!src || !dst || D <= 0 || !aligned16(src) || !aligned16(dst) || !pieces_ok(log2_piece_src, piece_stride_src) ||
-      !pieces_ok(log2_piece_dst, piece_stride_dst))
-    return BDE_ERR_INVALID;
-  const int grid = stream_grid((D + 3) / 4);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  BDE_DISPATCH_PIECE(log2_piece_src, LPS,
-                     BDE_DISPATCH_PIECE(log2_piece_dst, LPD,
-                                        hipLaunchKernelGGL((swag_copy_row_kernel<LPS, LPD>), dim3(grid), dim3(kBlock), 0, s, src,
-                                                           piece_stride_src, dst, piece_stride_dst, D)));
+  hipLaunchKernelGGL(swag_update_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream), theta, mean, sq, dev_row,
+                     static_cast<float>(n), static_cast<float>(n + 1), D);
   return to_err(hipGetLastError());
 }
 
 extern "C" int bde_swag_sample(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
                                const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id, float* out,
-                               int64_t D, int log2_piece, int64_t piece_stride, void* stream) {
-  if (!mean || !sq || !dev || !out || D <= 0 || K < 1 || K > BDE_MAX_RANK || !pieces_ok(log2_piece, piece_stride))
-    return BDE_ERR_INVALID;
-  if (head < 0 || head >= K || (ld & 3) || (log2_piece == 0 ? ld < D : ld < (int64_t{1} << log2_piece))) return BDE_ERR_INVALID;
-
+                               int64_t D, void* stream) {
+  if (!mean || !sq || !dev || !out || D <= 0 || K < 1 || K > BDE_MAX_RANK) return BDE_ERR_INVALID;
+  if (head < 0 || head >= K || (ld & 3) || ld < D) return BDE_ERR_INVALID;
   if (!aligned16(mean) || !aligned16(sq) || !aligned16(dev) || !aligned16(out) || (eps_d && !aligned16(eps_d)))
     return BDE_ERR_INVALID;
   const int grid = stream_grid((D + 3) / 4);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (eps_d)
-    BDE_DISPATCH_PIECE(log2_piece, LP,
-                       hipLaunchKernelGGL((swag_sample_kernel<false, LP>), dim3(grid), dim3(kBlock), 0, s, mean, sq, dev, K, ld,
-                                          head, eps_w, eps_d, seed, stream_id, out, D, piece_stride));
+    hipLaunchKernelGGL(swag_sample_kernel<false>, dim3(grid), dim3(kBlock), 0, s, mean, sq, dev, K, ld, head, eps_w, eps_d, seed,
+                       stream_id, out, D);
   else
-    BDE_DISPATCH_PIECE(log2_piece, LP,
-                       hipLaunchKernelGGL((swag_sample_kernel<true, LP>), dim3(grid), dim3(kBlock), 0, s, mean, sq, dev, K, ld,
-                                          head, eps_w, eps_d, seed, stream_id, out, D, piece_stride));
+    hipLaunchKernelGGL(swag_sample_kernel<true>, dim3(grid), dim3(kBlock), 0, s, mean, sq, dev, K, ld, head, eps_w, eps_d, seed,
+                       stream_id, out, D);
   return to_err(hipGetLastError());
 }
 
@@ -276,5 +240,5 @@ extern "C" int bde_philox_bits(uint64_t seed, uint64_t stream_id, uint32_t domai
 // first launch of one of its kernels).  Internal to the library (not exported).
 extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_swag(void) {
   hipFuncAttributes attr;
-  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::swag_update_kernel<bde::kPieceLarge>)));
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::swag_update_kernel)));
 }

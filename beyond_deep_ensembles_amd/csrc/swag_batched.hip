@@ -15,8 +15,6 @@
 // c, so that a lane ends up with 4 CONSECUTIVE parameters of one sample in
 // (acc0[reg] .. acc3[reg]) and the epilogue stores float4s, 512 B contiguous
 // per sample row.
-#include <cstdlib>
-
 #include "bde_common.hpp"
 
 namespace bde {
@@ -35,7 +33,7 @@ template <bool RNG>
 __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
     const float* __restrict__ mean, const float* __restrict__ sq, const float* __restrict__ dev, int K, int64_t ld,
     int head, const float* __restrict__ eps_w, const float* __restrict__ eps_d, int64_t ld_eps, uint64_t seed,
-    uint64_t stream0, float* __restrict__ out, int64_t ld_out, int S, int64_t D, RowPiecesRt L, RowPiecesRt Lo) {
+    uint64_t stream0, float* __restrict__ out, int64_t ld_out, int S, int64_t D) {
   extern __shared__ __attribute__((aligned(16))) float w[];   // [K + (K & 1)][32]: weight of ring row r for sample s
   const int kpad = K + (K & 1);
   const int ksteps = kpad >> 1;
@@ -61,8 +59,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave; t < n_tiles; t += waves_total) {
     const int64_t g4 = t * 32 + j;                            // this lane's float4 group
     const bool ok = g4 < n4;
-    // a tile is 128 consecutive parameters and a piece a multiple of that, so a tile lies inside ONE piece
-    const int64_t so = piece_off_rt(4 * g4, L), oo = piece_off_rt(4 * g4, Lo);
+    const int64_t so = 4 * g4, oo = 4 * g4;
     const float* col = dev + so;
     f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
     // The whole [K, 128] slab of the ring is requested before the first MFMA waits on it: a
@@ -115,7 +112,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
     for (int idx = threadIdx.x; idx < rem * S; idx += blockDim.x) {
       const int s = idx / rem, k = idx % rem;
       const int64_t e = (n4 << 2) + k;
-      const int64_t so = piece_off_rt(e, L);
+      const int64_t so = e;
       float acc = 0.f;
       for (int r = 0; r < K; ++r) acc = __builtin_fmaf(dev[static_cast<int64_t>(r) * ld + so], w[r * 32 + s], acc);
       const float m = mean[so];
@@ -126,7 +123,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
       } else {
         z = eps_d[static_cast<int64_t>(s) * ld_eps + e];
       }
-      out[static_cast<int64_t>(s) * ld_out + piece_off_rt(e, Lo)] =
+      out[static_cast<int64_t>(s) * ld_out + e] =
           (m + acc) + __builtin_sqrtf(0.5f * (fmaxf(sq[so] - m * m, 0.0f) + 1e-6f)) * z;
     }
   }
@@ -142,8 +139,8 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_kernel(
 // need).  Holding the NEXT tile's ring rows in registers during the epilogue would cost 40 more VGPRs on a kernel that sits
 // at its 168-register budget.  global_load_lds_dwordx4 has no register destination: each wave owns an 11 KB LDS slab
 // ([20 ring rows + mean + sq][128 floats], lane-linear = exactly the order its lanes read the MFMA B operand back with
-// ds_read_b128), and the slab of tile t+1 (or of the next 20-row chunk of this tile, K > 20) is requested as soon as
-// tile t's operands sit in registers -- BEFORE its 40 MFMAs and its whole epilogue.  Every wave then has 11 KB in
+// ds_read_b128), and the slab of tile t+1 is requested as soon as tile t's operands sit in registers -- BEFORE its 40
+// MFMAs and its whole epilogue (K <= 20: one slab per tile; more ring rows run the register kernel above).  Every wave then has 11 KB in
 // flight all the time (132 KB per CU).  No barrier: a slab is private to its wave, the only waits are the wave's own
 // s_waitcnt vmcnt (DMA landed) and lgkmcnt (operands read before the slab is refilled).  hipcc does not order a ds_read
 // behind an LDS-DMA in flight (checked in the ISA), so those waits are explicit.
@@ -163,14 +160,14 @@ __device__ __forceinline__ void dma16(const float* __restrict__ base_uniform, ui
                                    (__attribute__((address_space(3))) void*)(lds_uniform_base), 16, 0, 2 /* nt */);
 }
 
-template <bool RNG, int ROUNDS, bool SINGLE>
+template <bool RNG, int ROUNDS>
 __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_dma_kernel(
     const float* __restrict__ mean, const float* __restrict__ sq, const float* __restrict__ dev, int K, int64_t ld,
     int head, const float* __restrict__ eps_w, const float* __restrict__ eps_d, int64_t ld_eps, uint64_t seed,
-    uint64_t stream0, float* __restrict__ out, int64_t ld_out, int S, int64_t D, RowPiecesRt L, RowPiecesRt Lo) {
+    uint64_t stream0, float* __restrict__ out, int64_t ld_out, int S, int64_t D) {
   extern __shared__ __attribute__((aligned(16))) float w[];   // [kpad][32] weights, then one slab per wave
   const int kpad = K + (K & 1);
-  const int ksteps = kpad >> 1;                               // SINGLE: ksteps <= kBatchCH (one slab per tile)
+  const int ksteps = kpad >> 1;                               // <= kBatchCH: one slab holds all ring rows of a tile
   const float denom = __builtin_sqrtf(2.0f * static_cast<float>(K - 1));   // swag.py:113
   for (int idx = threadIdx.x; idx < kpad * 32; idx += blockDim.x) {
     const int r = idx >> 5, s = idx & 31;
@@ -194,15 +191,16 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_dma_kernel(
   const int64_t waves_total = static_cast<int64_t>(gridDim.x) * (kBlock / 64);
   const uint32_t row_bytes = static_cast<uint32_t>(ld) * 4u;  // ld < 2^30 floats (checked by the launcher)
 
-  // Request the slab of (tile, chunk c0): ring rows 2 (c0 + u) + half, u < kBatchCH, and with chunk 0 mean | sq.  All
+  // Request the slab of a tile: ring rows 2 u + half, u < ksteps, then mean | sq.  All
   // addressing is a wave-uniform base (tile, row pair) + ONE per-lane byte offset: (half, float4 j) -- lanes past the
   // end of the vector (last tile) read the last valid float4 instead; their columns are never stored.  The odd row K
   // of an odd K re-reads row K - 1 (its weight is zero).
-  auto request = [&](int64_t tile, int c0) {
+  auto request = [&](int64_t tile) {
+    constexpr int c0 = 0;
     const int64_t e0 = tile * 128;                                            // uniform
     const int jlast = static_cast<int>(min<int64_t>(31, n4 - 1 - tile * 32));  // uniform
     const uint32_t joff = 16u * static_cast<uint32_t>(min(j, jlast));
-    const float* base = dev + piece_off_rt(e0, L);                            // uniform
+    const float* base = dev + e0;                                             // uniform
 #pragma unroll
     for (int u = 0; u < kBatchCH; ++u) {
       if (c0 + u < ksteps) {                                                  // wave-uniform
@@ -211,28 +209,26 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_dma_kernel(
         dma16(base + static_cast<int64_t>(r0) * ld, lane_off, slab + u * 256);
       }
     }
-    if (c0 == 0) dma16(half ? sq + piece_off_rt(e0, L) : mean + piece_off_rt(e0, L), joff, slab + kBatchCH * 256);
+    dma16(half ? sq + e0 : mean + e0, joff, slab + kBatchCH * 256);
   };
 
   int64_t t = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave;
-  if (t < n_tiles) request(t, 0);
+  if (t < n_tiles) request(t);
   for (; t < n_tiles; t += waves_total) {
     const int64_t g4 = t * 32 + j;                            // this lane's float4 group
     const bool ok = g4 < n4;
     f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
     f32x4 m = {}, q = {};
-    for (int c0 = 0; c0 < (SINGLE ? 1 : ksteps); c0 += kBatchCH) {
+    {
+      constexpr int c0 = 0;
       f32x4 b[kBatchCH];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this chunk's slab has landed
 #pragma unroll
       for (int u = 0; u < kBatchCH; ++u) b[u] = *reinterpret_cast<const f32x4*>(my + u * 256);
-      if (SINGLE || c0 == 0) {
-        m = *reinterpret_cast<const f32x4*>(slab + kBatchCH * 256 + 4 * j);
-        q = *reinterpret_cast<const f32x4*>(slab + kBatchCH * 256 + 128 + 4 * j);
-      }
+      m = *reinterpret_cast<const f32x4*>(slab + kBatchCH * 256 + 4 * j);
+      q = *reinterpret_cast<const f32x4*>(slab + kBatchCH * 256 + 128 + 4 * j);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // operands in registers: the slab may be refilled
-      if (!SINGLE && c0 + kBatchCH < ksteps) request(t, c0 + kBatchCH);
-      else if (t + waves_total < n_tiles) request(t + waves_total, 0);
+      if (t + waves_total < n_tiles) request(t + waves_total);
 #pragma unroll
       for (int u = 0; u < kBatchCH; ++u) {
         if (c0 + u < ksteps) {                                // wave-uniform
@@ -245,7 +241,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_dma_kernel(
       }
     }
     if (ok) {
-      const int64_t oo = piece_off_rt(4 * g4, Lo);
+      const int64_t oo = 4 * g4;
       const f32x4 v = q - m * m;
       f32x4 sd;
 #pragma unroll
@@ -283,7 +279,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_dma_kernel(
     for (int idx = threadIdx.x; idx < rem * S; idx += blockDim.x) {
       const int s = idx / rem, k = idx % rem;
       const int64_t e = (n4 << 2) + k;
-      const int64_t so = piece_off_rt(e, L);
+      const int64_t so = e;
       float acc = 0.f;
       for (int r = 0; r < K; ++r) acc = __builtin_fmaf(dev[static_cast<int64_t>(r) * ld + so], w[r * 32 + s], acc);
       const float mm = mean[so];
@@ -294,7 +290,7 @@ __global__ __launch_bounds__(kBlock, 3) void swag_sample_batched_dma_kernel(
       } else {
         z = eps_d[static_cast<int64_t>(s) * ld_eps + e];
       }
-      out[static_cast<int64_t>(s) * ld_out + piece_off_rt(e, Lo)] =
+      out[static_cast<int64_t>(s) * ld_out + e] =
           (mm + acc) + __builtin_sqrtf(0.5f * (fmaxf(sq[so] - mm * mm, 0.0f) + 1e-6f)) * z;
     }
   }
@@ -306,51 +302,38 @@ using namespace bde;
 
 extern "C" int bde_swag_sample_batched(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
                                        const float* eps_w, const float* eps_d, int64_t ld_eps, uint64_t seed,
-                                       uint64_t stream_id0, float* out, int64_t ld_out, int S, int64_t D, int log2_piece,
-                                       int64_t piece_stride, int log2_piece_out, int64_t piece_stride_out, void* stream) {
+                                       uint64_t stream_id0, float* out, int64_t ld_out, int S, int64_t D, void* stream) {
   if (!mean || !sq || !dev || !out || D <= 0 || K < 1 || K > BDE_MAX_RANK || S < 1 || S > BDE_MAX_BATCH)
     return BDE_ERR_INVALID;
-  if (!pieces_ok(log2_piece, piece_stride) || !pieces_ok(log2_piece_out, piece_stride_out)) return BDE_ERR_INVALID;
-  if (head < 0 || head >= K || (ld & 3) || (ld_out & 3) || (log2_piece == 0 ? ld < D : ld < (int64_t{1} << log2_piece)) ||
-      (log2_piece_out == 0 ? ld_out < D : ld_out < (int64_t{1} << log2_piece_out)) ||
-      (eps_d && (ld_eps < D || (ld_eps & 3))))
+  if (head < 0 || head >= K || (ld & 3) || (ld_out & 3) || ld < D || ld_out < D || (eps_d && (ld_eps < D || (ld_eps & 3))))
     return BDE_ERR_INVALID;
-  const RowPiecesRt L{log2_piece, piece_stride}, Lo{log2_piece_out, piece_stride_out};
   if (!aligned16(mean) || !aligned16(sq) || !aligned16(dev) || !aligned16(out) || (eps_d && !aligned16(eps_d)))
     return BDE_ERR_INVALID;
   const int64_t n_tiles = ((D >> 2) + 31) / 32;
-  // 12 workgroups of 4 waves per CU = the 3 waves per SIMD that 168 VGPRs allow: the grid-stride loop keeps every one of
-  // them busy (4 per CU, one wave per SIMD, left the load -> MFMA -> Philox epilogue chain of a tile un-overlapped:
-  // 1.02 -> 0.98 ms with in-kernel noise, 1.70 -> 1.43 ms with supplied noise; tools/kexp5.hip batched)
+  // 12 workgroups of 4 waves per CU = 3 waves per SIMD (the register budget of both kernels): the grid-stride loop keeps
+  // every one of them busy
   const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, kCUs * 12)));
   const size_t lds = sizeof(float) * static_cast<size_t>(K + (K & 1)) * 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // EXPERIMENT SWITCH (round 4 A/B, read per call): 0: register kernel, 1: LDS-DMA kernel, 2: LDS-DMA where one slab holds all K rows
-  const char* env_variant = std::getenv("BDE_BATCHED_KERNEL");
-  const int variant = env_variant ? std::atoi(env_variant) : 2;
-  if ((variant == 1 || (variant == 2 && (K + (K & 1)) / 2 <= kBatchCH)) && (D >> 2) >= 1 && ld < (int64_t{1} << 30)) {
+  // K <= 20 (one 20-row slab per tile; BASELINE's K): the LDS-DMA pipelined kernel.  More ring rows: the register kernel
+  // (a multi-slab DMA variant spilled at the 168-register budget and lost 7 % to it, profiles/r04_swag_batched_ab.txt).
+  // mean + 127 floats past a partial last tile stay inside the row (ld >= D; the DMA clamps its lanes to the last float4).
+  if ((K + (K & 1)) / 2 <= kBatchCH && (D >> 2) >= 1 && ld < (int64_t{1} << 30)) {
     const size_t lds_dma = lds + sizeof(float) * (kBlock / 64) * kSlabFloats;
-    const bool single = (K + (K & 1)) / 2 <= kBatchCH;
-#define BDE_LAUNCH_DMA(RNG_, SINGLE_)                                                                                        \
-  do {                                                                                                                       \
-    auto kern = swag_sample_batched_dma_kernel<RNG_, kSwagPhiloxRounds, SINGLE_>;                                            \
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-        static_cast<int>(sizeof(float) * ((BDE_MAX_RANK + 1) * 32 + (kBlock / 64) * kSlabFloats))) == hipSuccess;             \
-    if (!attr_ok) return BDE_ERR_INVALID;                                                                                     \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds_dma, s, mean, sq, dev, K, ld, head, eps_w, eps_d, ld_eps, seed,   \
-                       stream_id0, out, ld_out, S, D, L, Lo);                                                                \
-  } while (0)
-    if (eps_d) { if (single) BDE_LAUNCH_DMA(false, true); else BDE_LAUNCH_DMA(false, false); }
-    else { if (single) BDE_LAUNCH_DMA(true, true); else BDE_LAUNCH_DMA(true, false); }
-#undef BDE_LAUNCH_DMA
+    if (eps_d)
+      hipLaunchKernelGGL((swag_sample_batched_dma_kernel<false, kSwagPhiloxRounds>), dim3(grid), dim3(kBlock), lds_dma, s, mean,
+                         sq, dev, K, ld, head, eps_w, eps_d, ld_eps, seed, stream_id0, out, ld_out, S, D);
+    else
+      hipLaunchKernelGGL((swag_sample_batched_dma_kernel<true, kSwagPhiloxRounds>), dim3(grid), dim3(kBlock), lds_dma, s, mean,
+                         sq, dev, K, ld, head, eps_w, eps_d, ld_eps, seed, stream_id0, out, ld_out, S, D);
     return to_err(hipGetLastError());
   }
   if (eps_d)
     hipLaunchKernelGGL(swag_sample_batched_kernel<false>, dim3(grid), dim3(kBlock), lds, s, mean, sq, dev, K, ld, head,
-                       eps_w, eps_d, ld_eps, seed, stream_id0, out, ld_out, S, D, L, Lo);
+                       eps_w, eps_d, ld_eps, seed, stream_id0, out, ld_out, S, D);
   else
     hipLaunchKernelGGL(swag_sample_batched_kernel<true>, dim3(grid), dim3(kBlock), lds, s, mean, sq, dev, K, ld, head,
-                       eps_w, eps_d, ld_eps, seed, stream_id0, out, ld_out, S, D, L, Lo);
+                       eps_w, eps_d, ld_eps, seed, stream_id0, out, ld_out, S, D);
   return to_err(hipGetLastError());
 }
 

@@ -1,8 +1,9 @@
 #include "bde_common.hpp"
-extern "C" int bde_version(void) { return 301; /* 0.3.1: segmented gradients (*_seg), SWAG rows stored in pieces, bde_swag_copy_row */ }
+extern "C" int bde_version(void) { return 400; /* 0.4.0: contiguous SWAG rows again (pieces layout and bde_swag_copy_row gone), LDS-DMA batched sampler, bde_conv_lrt_* */ }
 extern "C" const char* bde_arch(void) { return "gfx950"; }
 
 extern "C" {
+int bde_internal_load_conv_lrt(void);
 int bde_internal_load_gauss(void);
 int bde_internal_load_ivon(void);
 int bde_internal_load_lrt(void);
@@ -19,7 +20,7 @@ int bde_internal_load_swag_batched(void);
 // the device with other processes calls this first, from one thread, so that no kernel's first launch coincides with
 // them (profiles/r03_first_launch_*.txt).  Idempotent, cheap after the first call; needs a visible device.
 extern "C" int bde_init(void) {
-  int (*const loaders[])(void) = {bde_internal_load_gauss,      bde_internal_load_ivon,       bde_internal_load_lrt,
+  int (*const loaders[])(void) = {bde_internal_load_conv_lrt,   bde_internal_load_gauss,      bde_internal_load_ivon,       bde_internal_load_lrt,
                                   bde_internal_load_lrt_bwd,    bde_internal_load_svgd,       bde_internal_load_svgd_fused,
                                   bde_internal_load_svgd_small, bde_internal_load_swag,       bde_internal_load_swag_batched};
   for (auto load : loaders) {

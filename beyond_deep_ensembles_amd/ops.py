@@ -78,41 +78,6 @@ def pad4(n: int, mult: int = 64) -> int:
     return (n + mult - 1) // mult * mult
 
 
-class RowBlock:
-    """``n_rows`` rows of ``d`` floats stored INTERLEAVED in pieces of ``2 ** log2_piece`` floats: one buffer
-    ``[n_pieces, n_rows, piece]`` (include/bde_hip.h, "Row storage").  ``row(r)`` / ``rows(a, b)`` are the handles the
-    kernels take (views of the rows' first pieces; the distance between two rows inside a piece is ``piece``), and
-    ``pieces = (log2_piece, piece_stride)`` goes with them.  ``gather`` / ``scatter`` move one row to / from a contiguous
-    vector with plain torch indexing (accessors and checkpoints; the hot paths use bde_swag_copy_row)."""
-
-    LOG2_PIECE = 12          # 4096 floats = 16 KB per row and piece: the sweet spot of the layout probes (r02)
-
-    def __init__(self, n_rows: int, d: int, device, log2_piece: int = LOG2_PIECE):
-        self.n_rows, self.d, self.log2_piece = int(n_rows), int(d), int(log2_piece)
-        self.piece = 1 << self.log2_piece
-        self.n_pieces = max(1, (self.d + self.piece - 1) // self.piece)
-        self.buf = torch.zeros((self.n_pieces, self.n_rows, self.piece), dtype=torch.float32, device=device)
-        self.pieces = (self.log2_piece, self.n_rows * self.piece)
-
-    def row(self, r: int) -> torch.Tensor:
-        return self.buf[0, r]
-
-    def rows(self, a: int, b: int) -> torch.Tensor:
-        return self.buf[0, a:b]
-
-    def gather(self, r) -> torch.Tensor:
-        """Row(s) ``r`` (an index, a list of indices or a slice) as contiguous ``[d]`` / ``[n, d]`` copies."""
-        if isinstance(r, int):
-            return self.buf[:, r].reshape(-1)[:self.d]
-        sel = self.buf[:, r]                                         # [n_pieces, n, piece]
-        return sel.permute(1, 0, 2).reshape(sel.shape[1], -1)[:, :self.d]
-
-    def scatter(self, r: int, vec: torch.Tensor) -> None:
-        full = torch.zeros(self.n_pieces * self.piece, dtype=torch.float32, device=self.buf.device)
-        full[:self.d] = vec.to(self.buf.device).float().reshape(-1)[:self.d]
-        self.buf[:, r] = full.view(self.n_pieces, self.piece)
-
-
 class SegTable:
     """Where the gradients of the M particles live, per parameter tensor ("segment"), for the ``*_seg`` entry points
     (include/bde_hip.h): ``ptrs`` (device int64 ``[n_seg * M]``, refreshed every step from ``host``), ``chunks``
@@ -391,39 +356,24 @@ class HipOps:
 
     # ------------------------------------------------------------ SWAG --
     @_on_device_of
-    def swag_update(self, theta, mean, sq, dev_row, n, d, pieces=None):
-        """``pieces = (log2_piece, piece_stride)``: mean / sq / dev_row are stored in pieces (RowBlock handles)."""
-        lp, ps = pieces or (0, 0)
-        _check(self.lib.bde_swag_update(_ptr(theta, "theta"), _ptr(mean), _ptr(sq), _ptr(dev_row), int(n), d, lp, ps,
-                                        _stream()), "bde_swag_update")
+    def swag_update(self, theta, mean, sq, dev_row, n, d):
+        _check(self.lib.bde_swag_update(_ptr(theta, "theta"), _ptr(mean), _ptr(sq), _ptr(dev_row), int(n), d, _stream()),
+               "bde_swag_update")
 
     @_on_device_of
-    def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0, pieces=None):
+    def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0):
         k = dev.shape[0]
-        lp, ps = pieces or (0, 0)
         _check(self.lib.bde_swag_sample(_ptr(mean), _ptr(sq), _ptr(dev), k, _ld(dev), head, _ptr(eps_w), _ptr(eps_d),
-                                        seed, stream_id, _ptr(out), d, lp, ps, _stream()), "bde_swag_sample")
+                                        seed, stream_id, _ptr(out), d, _stream()), "bde_swag_sample")
 
     @_on_device_of
-    def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0, pieces=None,
-                            out_pieces=None):
-        """``out``: ``[S, >= d]`` contiguous rows, or (``out_pieces``) the first-piece views ``[S, piece]`` of S rows
-        stored in pieces."""
+    def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0):
+        """``out``: ``[S, >= d]`` contiguous rows."""
         k, s = dev.shape[0], out.shape[0]
-        lp, ps = pieces or (0, 0)
-        lpo, pso = out_pieces or (0, 0)
         _check(self.lib.bde_swag_sample_batched(_ptr(mean), _ptr(sq), _ptr(dev), k, _ld(dev), head, _ptr(eps_w),
                                                 _ptr(eps_d), _ld(eps_d) if eps_d is not None else 0, seed, stream_id0,
-                                                _ptr(out), _ld(out), s, d, lp, ps, lpo, pso, _stream()),
+                                                _ptr(out), _ld(out), s, d, _stream()),
                "bde_swag_sample_batched")
-
-    @_on_device_of
-    def swag_copy_row(self, src, dst, d, src_pieces=None, dst_pieces=None):
-        """dst row = src row; either side contiguous or stored in pieces (a RowBlock row handle + its ``pieces``)."""
-        lps, pss = src_pieces or (0, 0)
-        lpd, psd = dst_pieces or (0, 0)
-        _check(self.lib.bde_swag_copy_row(_ptr(src, "src"), lps, pss, _ptr(dst, "dst"), lpd, psd, d, _stream()),
-               "bde_swag_copy_row")
 
     @property
     def swag_philox_rounds(self) -> int:
@@ -506,6 +456,21 @@ class HipOps:
             raise BdeKernelError("var_operand_bwd: contiguous tensors expected")
         _check(self.lib.bde_var_operand_bwd(_ptr(g, "g"), _ptr(v), mode, _ptr(gv), v.numel(), _stream()),
                "bde_var_operand_bwd")
+
+    def conv_lrt_supported(self, x_shape, w_shape, stride, padding) -> bool:
+        n, c, h, w = (int(v) for v in x_shape)
+        o, c2, kh, kw = (int(v) for v in w_shape)
+        return c == c2 and bool(self.lib.bde_conv_lrt_supported(n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0],
+                                                                 padding[1]))
+
+    @_on_device_of
+    def conv_lrt_fwd(self, x, w_mu, w_s2, b_mu, b_var, stride, padding, out, var_out, eps=None, seed=0, stream_id=0):
+        """BBBConv2d forward (bbb_layers.py:146-154) in one launch; all tensors contiguous fp32 NCHW / OIHW."""
+        n, c, h, w = x.shape
+        o, _, kh, kw = w_mu.shape
+        _check(self.lib.bde_conv_lrt_fwd(_ptr(x, "x"), _ptr(w_mu), _ptr(w_s2), _ptr(b_mu), _ptr(b_var), _ptr(eps), seed,
+                                         stream_id, _ptr(out), _ptr(var_out), n, c, h, w, o, kh, kw, stride[0], stride[1],
+                                         padding[0], padding[1], _stream()), "bde_conv_lrt_fwd")
 
     def lrt_linear_supported(self, b: int, i: int, o: int) -> bool:
         return bool(self.lib.bde_lrt_linear_supported(b, i, o))

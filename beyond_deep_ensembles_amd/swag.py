@@ -10,12 +10,9 @@ sample_parameters / complete_epoch behaviour, integer schedule and
 * ``__mean`` / ``__sq_weights`` stay on the device and ``__deviations`` is a
   ring of K rows (``__dev_head`` = row the next update overwrites) instead of
   a CPU ``[D, K]`` matrix that is physically rolled (swag.py:103).  The K + 2
-  statistics rows are stored INTERLEAVED in 16 KB pieces (``ops.RowBlock``:
-  ``[piece][row][4096 floats]``), so a pass over them -- every update, every
-  sample -- walks one contiguous region per piece instead of K + 2 streams a row
-  length apart; prefetched samples are stored the same way and served by one
-  streaming copy into the vector the parameters view.  ``mean_vector()`` /
-  ``deviations_dk()`` / ``state_dict()`` give the reference's layout back;
+  statistics rows are the rows of ONE ``[K + 2, ld]`` buffer (ring rows, mean,
+  second moment).  ``mean_vector()`` / ``deviations_dk()`` / ``state_dict()``
+  give the reference's layout back;
 * a posterior sample is one kernel (``bde_swag_sample``) that writes straight
   into a second flat vector the parameters are re-pointed at; restoring the
   training weights (swag.py:76-82) is a pointer swap, not a clone;
@@ -35,7 +32,6 @@ from typing import Callable, List, Optional, Tuple
 import torch
 
 from .algo import BayesianOptimizer, FlatLayout, check_params, repoint, _default_ops
-from .ops import RowBlock
 
 
 class SwagOptimizer(BayesianOptimizer):
@@ -90,26 +86,26 @@ class SwagOptimizer(BayesianOptimizer):
         self.state["__steps_since_swag_start"] = 0
         self.state["__updates"] = 0
         # rows 0 .. K-1: the deviation ring (swag.py:34), row K: mean (swag.py:32: the initial weights are sample #1),
-        # row K + 1: second moment (swag.py:33) -- interleaved in pieces
-        self._stats = RowBlock(k + 2, d, dev)
+        # row K + 1: second moment (swag.py:33)
+        self._stats = torch.zeros((k + 2, ld), dtype=torch.float32, device=dev)
         with torch.no_grad():
-            self._stats.scatter(k, self._theta[:d])
-            self._stats.scatter(k + 1, self._theta[:d] ** 2)
+            self._stats[k, :d] = self._theta[:d]
+            self._stats[k + 1, :d] = self._theta[:d] ** 2
         self._publish_stats()
         self.state["__dev_head"] = 0
         self.state["__params_dirty"] = False
 
     def _publish_stats(self) -> None:
-        """The reference's state keys, as (strided) views of the interleaved statistics buffer."""
+        """The reference's state keys, as views of the statistics buffer (``__deviations``: the ring rows ``[K, ld]``)."""
         k = self.deviation_samples
-        self.state["__mean"] = self._stats.buf[:, k]
-        self.state["__sq_weights"] = self._stats.buf[:, k + 1]
-        self.state["__deviations"] = self._stats.buf[:, :k]
+        self.state["__mean"] = self._stats[k]
+        self.state["__sq_weights"] = self._stats[k + 1]
+        self.state["__deviations"] = self._stats[:k]
 
     def _stat_rows(self):
-        """(mean, sq, ring) row handles for the kernels; pass ``pieces=self._stats.pieces`` with them."""
+        """(mean, sq, ring) for the kernels."""
         k = self.deviation_samples
-        return self._stats.row(k), self._stats.row(k + 1), self._stats.rows(0, k)
+        return self._stats[k], self._stats[k + 1], self._stats[:k]
 
     # ------------------------------------------------------------------
     def step(self, forward_closure, backward_closure, grad_scaler=None):
@@ -141,46 +137,30 @@ class SwagOptimizer(BayesianOptimizer):
         n = int(min(n_samples, max(1, max_bytes // (4 * self._layout.ld))))
         d = self._layout.d
         mean, sq, ring = self._stat_rows()
-        # Large models: the samples are stored in pieces like the statistics (what makes the batched pass 5-9 % faster)
-        # and served by one streaming copy.  Small models (< 2^20 parameters) are launch-bound, the layout buys them
-        # nothing: contiguous rows, served by a plain device copy or by re-pointing the parameters (see sample_parameters).
-        in_pieces = d >= self._PIECES_FROM
-        rows = RowBlock(n, d, self._params_device()) if in_pieces else \
-            torch.empty((n, self._layout.ld), dtype=torch.float32, device=self._params_device())
+        rows = torch.empty((n, self._layout.ld), dtype=torch.float32, device=self._params_device())
         with torch.no_grad():
             for lo in range(0, n, 32):
                 hi = min(n, lo + 32)
-                self._ops.swag_sample_batched(mean, sq, ring, self.state["__dev_head"],
-                                              rows.rows(lo, hi) if in_pieces else rows[lo:hi], d,
-                                              seed=self.seed, stream_id0=self._sample_counter + lo,
-                                              pieces=self._stats.pieces, out_pieces=rows.pieces if in_pieces else None)
+                self._ops.swag_sample_batched(mean, sq, ring, self.state["__dev_head"], rows[lo:hi], d,
+                                              seed=self.seed, stream_id0=self._sample_counter + lo)
         self._prefetched = [rows, 0]
         return n
-
-    _PIECES_FROM = 1 << 20
 
     def sample_parameters(self):
         self._save_original_params()
         self.state["__params_dirty"] = True
         if self._prefetched is not None:
             rows, nxt = self._prefetched
-            if isinstance(rows, RowBlock):
-                # one streaming copy of the sample's pieces into the contiguous vector the parameters view (8 D bytes)
+            n_rows = rows.shape[0]
+            if self._copy_is_cheaper:
+                # many tensors: one device copy of the row into the sample vector the parameters already view
+                # (8 D bytes of HBM traffic) beats re-pointing every tensor (~1 us of host time each)
                 with torch.no_grad():
-                    self._ops.swag_copy_row(rows.row(nxt), self._sample, self._layout.d, src_pieces=rows.pieces)
+                    self._sample.copy_(rows[nxt])
                 self._point_at_sample_vector()
-                n_rows = rows.n_rows
             else:
-                n_rows = rows.shape[0]
-                if self._copy_is_cheaper:
-                    # many tensors: one device copy of the row into the sample vector the parameters already view
-                    # (8 D bytes of HBM traffic) beats re-pointing every tensor (~1 us of host time each)
-                    with torch.no_grad():
-                        self._sample.copy_(rows[nxt])
-                    self._point_at_sample_vector()
-                else:
-                    self._layout.point_data(self._plist, rows[nxt])
-                    self._points_at = "row"
+                self._layout.point_data(self._plist, rows[nxt])
+                self._points_at = "row"
             self._sample_counter += 1
             self._prefetched = [rows, nxt + 1] if nxt + 1 < n_rows else None
             return
@@ -198,7 +178,7 @@ class SwagOptimizer(BayesianOptimizer):
         mean, sq, ring = self._stat_rows()
         with torch.no_grad():
             self._ops.swag_sample(mean, sq, ring, self.state["__dev_head"], self._sample, d, eps_w=eps_w, eps_d=eps_d,
-                                  seed=self.seed, stream_id=self._sample_counter, pieces=self._stats.pieces)
+                                  seed=self.seed, stream_id=self._sample_counter)
         self._sample_counter += 1
         # vector_to_parameters (swag.py:58): the parameters become views of the sampled vector
         self._point_at_sample_vector()
@@ -244,25 +224,24 @@ class SwagOptimizer(BayesianOptimizer):
                     updates = self.state["__updates"]
                     head = self.state["__dev_head"]
                     mean, sq, _ = self._stat_rows()
-                    self._ops.swag_update(self._theta, mean, sq, self._stats.row(head), updates, self._layout.d,
-                                          pieces=self._stats.pieces)
+                    self._ops.swag_update(self._theta, mean, sq, self._stats[head], updates, self._layout.d)
                     self.state["__dev_head"] = (head + 1) % self.deviation_samples
                     self.param_dist = None
                     self._prefetched = None
 
     # ---- reference-layout accessors ------------------------------------
     def mean_vector(self) -> torch.Tensor:
-        return self._stats.gather(self.deviation_samples)
+        return self._stats[self.deviation_samples, :self._layout.d]
 
     def sq_vector(self) -> torch.Tensor:
-        return self._stats.gather(self.deviation_samples + 1)
+        return self._stats[self.deviation_samples + 1, :self._layout.d]
 
     def deviations_dk(self) -> torch.Tensor:
         """The deviation matrix in the reference's layout: ``[D, K]``, oldest
         column first, newest last (what swag.py:103-104 maintains by rolling)."""
         k, head = self.deviation_samples, self.state["__dev_head"]
         order = [(head + c) % k for c in range(k)]
-        return self._stats.gather(order).t().contiguous()
+        return self._stats[order, :self._layout.d].t().contiguous()
 
     def sample_batch(self, n_samples: int, seed: Optional[int] = None, stream_id0: Optional[int] = None) -> torch.Tensor:
         """``n_samples`` posterior samples ``[S, D]`` in one pass over the statistics
@@ -276,8 +255,7 @@ class SwagOptimizer(BayesianOptimizer):
             for lo in range(0, n_samples, 32):
                 hi = min(n_samples, lo + 32)
                 self._ops.swag_sample_batched(mean, sq, ring, self.state["__dev_head"], out[lo:hi], d,
-                                              seed=self.seed if seed is None else seed, stream_id0=s0 + lo,
-                                              pieces=self._stats.pieces)
+                                              seed=self.seed if seed is None else seed, stream_id0=s0 + lo)
         if stream_id0 is None:
             self._sample_counter += n_samples
         return out[:, :d]
@@ -307,16 +285,15 @@ class SwagOptimizer(BayesianOptimizer):
         self._sample_counter = int(self.state.pop("__sample_counter", 0))
 
         loaded_mean, loaded_sq, devs = self.state["__mean"], self.state["__sq_weights"], self.state["__deviations"]
-        self._stats = RowBlock(k + 2, d, dev)
-        self._stats.scatter(k, loaded_mean.reshape(-1)[:d])
-        self._stats.scatter(k + 1, loaded_sq.reshape(-1)[:d])
-        if devs.dim() == 2 and devs.shape[0] == d and devs.shape[1] == k and not (d == k and "__dev_head" in self.state):
-            for c in range(k):                                   # reference layout [D, K]: column c -> ring row c, head 0
-                self._stats.scatter(c, devs[:, c])
-            self.state["__dev_head"] = 0
-        else:
-            for r in range(k):                                   # ring rows [K, >= D]
-                self._stats.scatter(r, devs[r, :d])
+        self._stats = torch.zeros((k + 2, ld), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            self._stats[k, :d] = loaded_mean.reshape(-1)[:d].to(dev).float()
+            self._stats[k + 1, :d] = loaded_sq.reshape(-1)[:d].to(dev).float()
+            if devs.dim() == 2 and devs.shape[0] == d and devs.shape[1] == k and not (d == k and "__dev_head" in self.state):
+                self._stats[:k, :d] = devs.to(dev).float().t()   # reference layout [D, K]: column c -> ring row c, head 0
+                self.state["__dev_head"] = 0
+            else:
+                self._stats[:k, :d] = devs[:, :d].to(dev).float()    # ring rows [K, >= D]
         self._publish_stats()
         # re-alias the parameters to the flat weight vector (values come from the model's own state_dict)
         with torch.no_grad():

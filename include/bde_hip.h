@@ -238,21 +238,14 @@ int bde_svgd_fused_adam(float* P, const float* G, float* exp_avg, float* exp_avg
  * Logical column c of the reference (0 = oldest ... K-1 = newest) is physical
  * row (head + c) mod K, where `head` is the row the NEXT update overwrites.
  *
- * Row storage.  Every statistics row (mean, sq, each ring row) and every output row of the batched sampler is
- * either contiguous (log2_piece = 0) or cut into PIECES of 2^log2_piece floats (log2_piece = 12, or 7 for tests: the
- * piece size is a compile-time parameter of the kernels -- as a runtime value it cost the sampler 20 %), piece c of a
- * row lying piece_stride floats behind its piece c - 1.  The optimizer keeps the K + 2 statistics rows interleaved:
- * one buffer [n_pieces][K + 2][2^log2_piece], row pointer = address of the row's first piece, ld = 2^log2_piece =
- * distance between two rows inside a piece, piece_stride = (K + 2) * 2^log2_piece.  A pass over the statistics then
- * walks one contiguous region per piece instead of K + 2 streams a row length apart (the same shape streams 15 %
- * faster on MI355X, profiles/r02_layout_probes.txt).  mean, sq and dev share one (log2_piece, piece_stride). */
+ * Rows are contiguous (round 3 kept them interleaved in 16 KB pieces; no bench.py record showed a gain and the
+ * layout is gone -- DESIGN.md section 8). */
 
 /* One moment update, n = the already incremented `__updates` counter
  * (swag.py:97-104): mean = (n*mean + theta)/(n+1); sq = (n*sq + theta^2)/(n+1);
  * dev_row[:] = theta - mean_new.  The caller passes dev_row = the ring row `head` and
  * advances head.  theta is contiguous.  Bit-exact with the reference's fp32 CPU arithmetic. */
-int bde_swag_update(const float* theta, float* mean, float* sq, float* dev_row,
-                    int64_t n, int64_t D, int log2_piece, int64_t piece_stride, void* stream);
+int bde_swag_update(const float* theta, float* mean, float* sq, float* dev_row, int64_t n, int64_t D, void* stream);
 
 /* One posterior sample (swag.py:57,112-114 + LowRankMultivariateNormal.rsample):
  *   out = mean + sum_c dev[col c] * eps_w[c] / sqrt(2 (K-1))
@@ -263,21 +256,15 @@ int bde_swag_update(const float* theta, float* mean, float* sq, float* dev_row,
  * out and eps_d are contiguous [D] (out is the vector the model's parameters view). */
 int bde_swag_sample(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
                     const float* eps_w, const float* eps_d, uint64_t seed, uint64_t stream_id,
-                    float* out, int64_t D, int log2_piece, int64_t piece_stride, void* stream);
+                    float* out, int64_t D, void* stream);
 
 /* S <= BDE_MAX_BATCH samples in ONE pass over the statistics (MFMA low-rank product; Philox
  * streams stream_id0 + s, identical to S calls of bde_swag_sample).  eps_w [S, K] / eps_d [S, ld_eps] (contiguous
- * rows) may be NULL.  out: S rows ld_out floats apart, stored in pieces (log2_piece_out, piece_stride_out) -- the
- * optimizer interleaves them like the statistics ([n_pieces][S][2^log2_piece_out]) -- or contiguous. */
+ * rows) may be NULL.  out: S contiguous rows ld_out floats apart.  K <= 20: the next tile's ring rows travel through
+ * the LDS-DMA while the current tile's noise epilogue runs. */
 int bde_swag_sample_batched(const float* mean, const float* sq, const float* dev, int K, int64_t ld, int head,
                             const float* eps_w, const float* eps_d, int64_t ld_eps, uint64_t seed, uint64_t stream_id0,
-                            float* out, int64_t ld_out, int S, int64_t D, int log2_piece, int64_t piece_stride,
-                            int log2_piece_out, int64_t piece_stride_out, void* stream);
-
-/* dst row = src row, each stored in pieces or contiguous: serving a batched sample (its pieces -> the contiguous
- * vector the parameters view, one streaming copy), and the accessors / checkpoints (swag.py:32-34's layouts). */
-int bde_swag_copy_row(const float* src, int log2_piece_src, int64_t piece_stride_src, float* dst, int log2_piece_dst,
-                      int64_t piece_stride_dst, int64_t D, void* stream);
+                            float* out, int64_t ld_out, int S, int64_t D, void* stream);
 
 /* In-kernel noise: Philox4x32 (Salmon et al., SC'11) keyed by `seed`, counter = (float4 index, stream id, domain),
  * normals by Box-Muller on the top 24 bits of each word.  `rounds`: 10 = the published default, used by every draw of
@@ -359,6 +346,21 @@ int bde_local_reparam_bwd(const float* g, const float* var, const float* eps, ui
  * Contiguous, 16-byte aligned buffers of n floats; outputs are overwritten. */
 int bde_var_operand_fwd(const float* v, int mode, float* out, int64_t n, void* stream);
 int bde_var_operand_bwd(const float* g, const float* v, int mode, float* gv, int64_t n, void* stream);
+
+/* The whole local-reparameterisation forward of a mean-field CONVOLUTION layer (BBBConv2d, bbb_layers.py:146-154) as
+ * ONE kernel: both convolutions of lines 146-147 -- conv2d(x, W_mu, b_mu) and conv2d(clamp(x^2, 1e-4), w_s2, b_var) --
+ * as one implicit GEMM with two accumulators per output tile over the same staged input windows (zero padding applied
+ * after the clamp, as F.conv2d pads the clamped tensor), then out = mean + sqrt(var) * eps (lines 148-154) in the
+ * epilogue.  x [N, C, H, W], w_mu / w_s2 [O, C, KH, KW] (w_s2 = clamp(softplus(W_rho)^2, 1e-4): bde_var_operand_fwd
+ * mode 1, once per weight version), b_mu / b_var [O] or NULL (b_var = softplus(b_rho)^2, NOT clamped: line 147),
+ * out / var_out [N, O, Ho, Wo] (var_out = the total activation variance, which the backward pass needs); all fp32,
+ * contiguous NCHW.  eps [N, O, Ho, Wo] or NULL = Philox(seed, stream_id) with the element numbering of
+ * bde_local_reparam_fwd over the flat output (so bde_local_reparam_bwd regenerates the same noise).
+ * bde_conv_lrt_supported: 1 when a tiling exists (kernel <= 7 x 7, stride / padding per axis, no dilation / groups). */
+int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w);
+int bde_conv_lrt_fwd(const float* x, const float* w_mu, const float* w_s2, const float* b_mu, const float* b_var,
+                     const float* eps, uint64_t seed, uint64_t stream_id, float* out, float* var_out, int N, int C, int H,
+                     int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, void* stream);
 
 /* The whole local-reparameterisation forward of a mean-field LINEAR layer (bbb_layers.py:61-80, sampling =
  * "activations") for small batches (B <= 128): W_mu / W_rho [O, I] row-major are streamed ONCE, sigma^2 =

@@ -203,58 +203,29 @@ class OracleOps:
             self._gram_P = P[:, :d].clone()
 
     # ------------------------------------------------------------ SWAG --
-    # rows stored in pieces (ops.RowBlock): the checker gathers them into contiguous copies and scatters results back
-    @staticmethod
-    def _pieces_view(first_piece, pieces, d):
-        lp, stride = pieces
-        piece = 1 << lp
-        n_pieces = (d + piece - 1) // piece
-        return torch.as_strided(first_piece, (n_pieces, piece), (stride, 1))
-
-    def _get_row(self, t, pieces, d):
-        if pieces is None:
-            return t[:d].clone()
-        return self._pieces_view(t, pieces, d).reshape(-1)[:d].clone()
-
-    def _set_row(self, t, pieces, d, vec):
-        if pieces is None:
-            t[:d] = vec
-            return
-        v = self._pieces_view(t, pieces, d)
-        full = torch.zeros(v.numel(), dtype=vec.dtype)
-        full[:d] = vec
-        v.copy_(full.view(v.shape))
-
-    def swag_update(self, theta, mean, sq, dev_row, n, d, pieces=None):
+    def swag_update(self, theta, mean, sq, dev_row, n, d):
         t = theta[:d]
-        m = (n * self._get_row(mean, pieces, d) + t) / (n + 1)
-        s = (n * self._get_row(sq, pieces, d) + t ** 2) / (n + 1)
-        self._set_row(mean, pieces, d, m)
-        self._set_row(sq, pieces, d, s)
-        self._set_row(dev_row, pieces, d, t - m)
+        m = (n * mean[:d] + t) / (n + 1)
+        s = (n * sq[:d] + t ** 2) / (n + 1)
+        mean[:d] = m
+        sq[:d] = s
+        dev_row[:d] = t - m
 
-    def _logical(self, dev, head, d, pieces=None):
+    def _logical(self, dev, head, d):
         k = dev.shape[0]
-        return torch.stack([self._get_row(dev[(head + c) % k], pieces, d) for c in range(k)], dim=1)   # [D, K]
+        return torch.stack([dev[(head + c) % k, :d] for c in range(k)], dim=1)   # [D, K]
 
-    def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0, pieces=None):
+    def swag_sample(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id=0):
         k = dev.shape[0]
         if eps_w is None:
-            eps_w = _philox(seed, stream_id, k, PH.DOMAIN_LOWRANK, PH.SWAG_ROUNDS)       # the samplers' 7-round streams
+            eps_w = _philox(seed, stream_id, k, PH.DOMAIN_LOWRANK, PH.SWAG_ROUNDS)       # the samplers' own round count
             eps_d = _philox(seed, stream_id, d, rounds=PH.SWAG_ROUNDS)
-        out[:d] = O.swag_sample(self._get_row(mean, pieces, d), self._get_row(sq, pieces, d),
-                                self._logical(dev, head, d, pieces), eps_w, eps_d[:d])
+        out[:d] = O.swag_sample(mean[:d].clone(), sq[:d].clone(), self._logical(dev, head, d), eps_w, eps_d[:d])
 
-    def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0, pieces=None,
-                            out_pieces=None):
+    def swag_sample_batched(self, mean, sq, dev, head, out, d, eps_w=None, eps_d=None, seed=0, stream_id0=0):
         for s in range(out.shape[0]):
-            row = torch.zeros(d)
-            self.swag_sample(mean, sq, dev, head, row, d, None if eps_w is None else eps_w[s],
-                             None if eps_d is None else eps_d[s], seed, stream_id0 + s, pieces=pieces)
-            self._set_row(out[s], out_pieces, d, row)
-
-    def swag_copy_row(self, src, dst, d, src_pieces=None, dst_pieces=None):
-        self._set_row(dst, dst_pieces, d, self._get_row(src, src_pieces, d))
+            self.swag_sample(mean, sq, dev, head, out[s], d, None if eps_w is None else eps_w[s],
+                             None if eps_d is None else eps_d[s], seed, stream_id0 + s)
 
     # ----------------------------------------------------------- Gauss --
     def reduce_ws(self, device):

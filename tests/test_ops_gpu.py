@@ -597,71 +597,34 @@ def test_svgd_segmented_gradients_equal_flat_rows(ops):
 
 
 # ------------------------------------------------------------------ SWAG --
-def test_swag_rows_in_pieces_equal_contiguous_rows(ops):
-    """The optimizer keeps the K + 2 statistics rows (and prefetched samples) interleaved in pieces
-    (include/bde_hip.h "Row storage", ops.RowBlock).  Same arithmetic per element: moment update, single sample,
-    batched samples and the row copy must give the BITS of the contiguous-row calls, for sizes below one piece, at
-    piece boundaries, with a D % 4 tail, and for small (128 floats) and the product's (4096 floats) pieces."""
-    from beyond_deep_ensembles_amd.ops import RowBlock
+def test_swag_batched_sampler_both_kernels_equal_single_samples(ops):
+    """bde_swag_sample_batched runs the LDS-DMA pipelined kernel for K <= 20 ring rows and the register kernel above;
+    either must give the BITS of S calls of bde_swag_sample (same FMA order per element, same Philox streams), for
+    sizes below one 128-parameter tile, at tile boundaries, with a D % 4 tail and a partial last tile, odd and even K,
+    K = 1, and S from 1 to the maximum of 32; with in-kernel and with supplied noise; nothing is written past D."""
     torch.manual_seed(41)
-    k, s_n = 5, 7
-    for d in (3, 128, 129, 4096, 4099, 3 * 4096, 70_001):
-        for lp in (7, 12):
-            ld = (d + 63) // 64 * 64
-            theta0 = torch.randn(d) * 0.05
-            mean, sq = padded(theta0), padded(theta0 ** 2)
-            ring = torch.zeros(k, ld, device=DEV)
-            blk = RowBlock(k + 2, d, DEV, log2_piece=lp)
-            blk.scatter(k, theta0)
-            blk.scatter(k + 1, theta0 ** 2)
-            head = 0
-            for n in range(1, 8):
-                th = padded(theta0 + torch.randn(d) * 1e-3 * n)
-                ops.swag_update(th, mean, sq, ring[head], n, d)
-                ops.swag_update(th, blk.row(k), blk.row(k + 1), blk.row(head), n, d, pieces=blk.pieces)
-                head = (head + 1) % k
-            torch.cuda.synchronize()
-            assert torch.equal(blk.gather(k), mean[:d]) and torch.equal(blk.gather(k + 1), sq[:d]), (d, lp)
-            assert torch.equal(blk.gather(list(range(k))), ring[:, :d]), (d, lp)
-            # nothing outside the rows' elements was written (the tail of the last piece stays zero)
-            tail = blk.buf.permute(1, 0, 2).reshape(k + 2, -1)[:, d:]
-            assert tail.numel() == 0 or float(tail.abs().max()) == 0.0
-            # one sample, supplied noise and Philox
-            ew, ed = torch.randn(k, device=DEV), padded(torch.randn(d))
-            a, b = torch.zeros(ld, device=DEV), torch.zeros(ld, device=DEV)
-            ops.swag_sample(mean, sq, ring, head, a, d, eps_w=ew, eps_d=ed)
-            ops.swag_sample(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, b, d, eps_w=ew, eps_d=ed, pieces=blk.pieces)
-            assert torch.equal(a[:d], b[:d]), (d, lp)
-            ops.swag_sample(mean, sq, ring, head, a, d, seed=3, stream_id=11)
-            ops.swag_sample(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, b, d, seed=3, stream_id=11, pieces=blk.pieces)
-            assert torch.equal(a[:d], b[:d]), (d, lp)
-            # batched: contiguous in / contiguous out, pieces in / contiguous out, pieces in / pieces out
-            flat_out, mixed_out = torch.zeros(s_n, ld, device=DEV), torch.zeros(s_n, ld, device=DEV)
-            out_blk = RowBlock(s_n + 2, d, DEV, log2_piece=lp)          # two spare rows: rows(1, 1 + S) is offset on purpose
-            ops.swag_sample_batched(mean, sq, ring, head, flat_out, d, seed=3, stream_id0=11)
-            ops.swag_sample_batched(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, mixed_out, d, seed=3, stream_id0=11,
-                                    pieces=blk.pieces)
-            ops.swag_sample_batched(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, out_blk.rows(1, 1 + s_n), d, seed=3,
-                                    stream_id0=11, pieces=blk.pieces, out_pieces=out_blk.pieces)
-            torch.cuda.synchronize()
-            assert torch.equal(flat_out[:, :d], mixed_out[:, :d]), (d, lp)
-            assert torch.equal(out_blk.gather(list(range(1, 1 + s_n))), flat_out[:, :d]), (d, lp)
-            assert float(out_blk.gather(0).abs().max()) == 0.0 and float(out_blk.gather(s_n + 1).abs().max()) == 0.0
-            assert torch.equal(flat_out[0, :d], a[:d])                                      # stream 11 = the single sample
-            # supplied noise rows (contiguous) with outputs in pieces
+    for d in (3, 4, 127, 128, 129, 4099, 70_001):
+        ld = (d + 63) // 64 * 64
+        for k, s_n in ((1, 2), (5, 7), (19, 30), (20, 32), (21, 3), (30, 30)):
+            stat = torch.zeros(k + 2, ld, device=DEV)
+            stat[:k, :d] = torch.randn(k, d, device=DEV) * 1e-2
+            stat[k, :d] = torch.randn(d, device=DEV) * 0.05
+            stat[k + 1, :d] = stat[k, :d] ** 2 + torch.rand(d, device=DEV) * 1e-3
+            ring, mean, sq = stat[:k], stat[k], stat[k + 1]
+            head = k // 2
+            out = torch.full((s_n, ld), 7.0, device=DEV)
+            ops.swag_sample_batched(mean, sq, ring, head, out, d, seed=3, stream_id0=11)
+            one = torch.zeros(ld, device=DEV)
+            for s in range(s_n):
+                ops.swag_sample(mean, sq, ring, head, one, d, seed=3, stream_id=11 + s)
+                assert torch.equal(out[s, :d], one[:d]), (d, k, s)
+            assert ld == d or float((out[:, d:] - 7.0).abs().max()) == 0.0, (d, k)
             ewb, edb = torch.randn(s_n, k, device=DEV), torch.zeros(s_n, ld, device=DEV)
             edb[:, :d] = torch.randn(s_n, d, device=DEV)
-            ops.swag_sample_batched(mean, sq, ring, head, flat_out, d, eps_w=ewb, eps_d=edb)
-            ops.swag_sample_batched(blk.row(k), blk.row(k + 1), blk.rows(0, k), head, out_blk.rows(1, 1 + s_n), d, eps_w=ewb,
-                                    eps_d=edb, pieces=blk.pieces, out_pieces=out_blk.pieces)
-            assert torch.equal(out_blk.gather(list(range(1, 1 + s_n))), flat_out[:, :d]), (d, lp)
-            # the row copy: pieces -> contiguous (serving a prefetched sample) and back
-            got = torch.zeros(ld, device=DEV)
-            ops.swag_copy_row(out_blk.row(3), got, d, src_pieces=out_blk.pieces)
-            assert torch.equal(got[:d], flat_out[2, :d]) and float(got[d:].abs().max() if ld > d else 0.0) == 0.0
-            back = RowBlock(2, d, DEV, log2_piece=lp)
-            ops.swag_copy_row(got, back.row(1), d, dst_pieces=back.pieces)
-            assert torch.equal(back.gather(1), flat_out[2, :d]) and float(back.gather(0).abs().max()) == 0.0
+            ops.swag_sample_batched(mean, sq, ring, head, out, d, eps_w=ewb, eps_d=edb)
+            for s in (0, s_n - 1):
+                ops.swag_sample(mean, sq, ring, head, one, d, eps_w=ewb[s], eps_d=edb[s])
+                assert torch.equal(out[s, :d], one[:d]), (d, k, s)
 
 
 def test_swag_update_bit_exact(ops):
@@ -1135,6 +1098,70 @@ def test_lrt_linear_forward(ops):
         ops.lrt_linear_fwd(wide[:, :i], dev(w_mu), dev(w_rho), dev(b_mu), dev(b_rho), True, out2, None, eps=dev(eps))
         assert (out2 - out).abs().max().item() <= tol_o
     assert not ops.lrt_linear_supported(129, 10, 10) and ops.lrt_linear_supported(128, 10, 10)
+
+
+CONV_CASES = [
+    # (N, C, H, W, O, K, stride, padding, bias)            the CIFAR ResNet-20 layer shapes of BASELINE configs[1] ...
+    (8, 3, 32, 32, 16, 3, (1, 1), (1, 1), True), (8, 16, 32, 32, 16, 3, (1, 1), (1, 1), True),
+    (8, 16, 32, 32, 32, 3, (2, 2), (1, 1), True), (8, 32, 16, 16, 32, 3, (1, 1), (1, 1), False),
+    (8, 32, 16, 16, 64, 3, (2, 2), (1, 1), True), (9, 64, 8, 8, 64, 3, (1, 1), (1, 1), True),
+    (4, 16, 32, 32, 32, 1, (2, 2), (0, 0), False),                                       # a 1x1 stride-2 shortcut
+    # ... and ragged ones: odd channel counts, rectangular images, no / wide padding, per-axis strides, 5x5 and 7x7 kernels
+    (3, 5, 9, 11, 7, 3, (1, 1), (0, 0), True), (2, 7, 13, 6, 33, 3, (2, 1), (1, 2), True), (5, 4, 12, 12, 20, 5, (1, 1), (2, 2), True),
+    (2, 3, 30, 30, 64, 7, (2, 2), (3, 3), False), (1, 130, 7, 7, 40, 3, (1, 1), (1, 1), True), (2, 64, 14, 14, 64, 1, (1, 1), (0, 0), True),
+    (3, 20, 28, 28, 16, 3, (1, 1), (1, 1), True),
+]
+
+
+def test_conv_lrt_forward(ops):
+    """bde_conv_lrt_fwd -- BBBConv2d's two convolutions (bbb_layers.py:146-147) as one dual-accumulator implicit GEMM
+    with the sampling epilogue (148-154) -- against the fp64 evaluation of those lines; the allowance is twice the
+    deviation of the reference's own fp32 op sequence (torch CPU conv2d)."""
+    import torch.nn.functional as F
+    from oracle import philox as PH
+    torch.manual_seed(33)
+    for n, c, h, w, o, k, stride, padding, bias in CONV_CASES:
+        x = torch.randn(n, c, h, w)
+        x[0, 0, :2] = 0.0                                               # exercises the clamp on x^2
+        w_mu, w_rho = torch.randn(o, c, k, k) * 0.1, torch.randn(o, c, k, k) * 1.5 - 3.0
+        w_rho[0, 0] = -8.0                                              # ... and on sigma^2
+        b_mu, b_rho = (torch.randn(o) * 0.1, torch.randn(o) - 3.0) if bias else (None, None)
+
+        def ref(dt):
+            xx = x.to(dt)
+            mean = F.conv2d(xx, w_mu.to(dt), None if b_mu is None else b_mu.to(dt), stride=stride, padding=padding)
+            var = F.conv2d((xx ** 2).clamp(min=1e-4), (F.softplus(w_rho.to(dt)) ** 2).clamp(min=1e-4),
+                           None if b_rho is None else F.softplus(b_rho.to(dt)) ** 2, stride=stride, padding=padding)
+            return mean, var
+        m64, v64 = ref(torch.float64)
+        m32, v32 = ref(torch.float32)
+        eps = torch.randn(m32.shape)
+        out64, out32 = m64 + v64.sqrt() * eps.double(), m32 + v32.sqrt() * eps
+        dev = lambda t: None if t is None else t.to(DEV).contiguous()
+        xd, wm = dev(x), dev(w_mu)
+        ws2 = torch.empty_like(wm)
+        ops.var_operand_fwd(dev(w_rho), 1, ws2)
+        bvar = None
+        if bias:
+            bvar = torch.empty(o, device=DEV)
+            ops.var_operand_fwd(dev(b_rho), 2, bvar)
+        assert ops.conv_lrt_supported(x.shape, w_mu.shape, stride, padding), (n, c, h, w, o, k)
+        out, var = torch.full(m32.shape, 9.0, device=DEV), torch.full(m32.shape, 9.0, device=DEV)
+        ops.conv_lrt_fwd(xd, wm, ws2, dev(b_mu), bvar, stride, padding, out, var, eps=dev(eps))
+        tol_v = max(2 * (v32.double() - v64).abs().max().item(), 3e-6 * v64.abs().max().item())
+        tol_o = max(2 * (out32.double() - out64).abs().max().item(), 3e-6 * out64.abs().max().item())
+        case = (n, c, h, w, o, k, stride, padding)
+        assert (var.cpu().double() - v64).abs().max().item() <= tol_v, case
+        assert (out.cpu().double() - out64).abs().max().item() <= tol_o, case
+        # deterministic, and the in-kernel noise is the Philox stream of the flat NCHW output element (the numbering of
+        # bde_local_reparam_fwd, whose backward regenerates it)
+        out2, var2 = torch.empty_like(out), torch.empty_like(var)
+        ops.conv_lrt_fwd(xd, wm, ws2, dev(b_mu), bvar, stride, padding, out2, var2, eps=dev(eps))
+        assert torch.equal(out, out2) and torch.equal(var, var2)
+        ops.conv_lrt_fwd(xd, wm, ws2, dev(b_mu), bvar, stride, padding, out2, var2, seed=9, stream_id=4)
+        z = torch.from_numpy(PH.normals(9, 4, out2.numel())).view(out2.shape)
+        assert (out2.cpu().double() - (m64 + v64.sqrt() * z)).abs().max().item() <= tol_o + 5e-6 * v64.sqrt().max().item(), case
+        assert torch.equal(var, var2)
 
 
 def test_lrt_linear_backward(ops):
