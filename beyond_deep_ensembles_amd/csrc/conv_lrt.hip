@@ -28,6 +28,7 @@ using f32x4c = __attribute__((ext_vector_type(4))) float;
 
 struct ConvGeo {
   int N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo;
+  int dh, dw;      // dilation of the INPUT image (1 in the forward; the layer's stride in the input-gradient pass)
 };
 struct ConvTile {
   int NI, TH, bands, CC, PH, PWP, WP, WK, PT, tiles_per_img, kcpad_max;
@@ -49,11 +50,21 @@ template <> struct Mfma<16> {
 };
 
 // LDS: xs [NI][CC][PH][PWP] | x2s (same) | wm [kcpad][MF] | ws [kcpad][MF] | kofs [kcpad] (int)
-template <int MF, int PT_MAX, bool RNG>
+//
+// MODE 0: the forward above.  MODE 1: the INPUT gradient of the same layer as the same implicit GEMM,
+//   dx = convT(g, W_mu) + 2 x [x^2 >= 1e-4] * convT(gvar, sigma^2)
+// (g = gradient of the layer output, gvar = g eps / (2 sqrt(var)) from bde_local_reparam_bwd): the "input" images are g
+// and gvar [N, O', Ho', Wo'] (two tensors instead of x and clamp(x^2)), dilated by the layer's stride (zeros between
+// the samples: a stride-s layer spends s^2 times the products here) and padded by K - 1 - p, the "weights" are
+// W^T flipped -- gathered from the [O', C', KH, KW] tensors while staging --, the "output" has the layer's C' input
+// channels and H' x W' pixels at stride 1, and the epilogue applies the clamp's derivative with x.  ConvGeo then
+// describes THAT convolution: C = O', (H, W) = (Ho', Wo') before dilation (dh, dw), O = C', (Ho, Wo) = (H', W').
+template <int MF, int PT_MAX, bool RNG, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ wmu, const float* __restrict__ ws2,
-    const float* __restrict__ bmu, const float* __restrict__ bvar, const float* __restrict__ eps, uint64_t seed,
-    uint64_t stream_id, float* __restrict__ out, float* __restrict__ var_out, ConvGeo g, ConvTile t) {
+    const float* __restrict__ x, const float* __restrict__ x_second, const float* __restrict__ wmu,
+    const float* __restrict__ ws2, const float* __restrict__ bmu, const float* __restrict__ bvar,
+    const float* __restrict__ eps, uint64_t seed, uint64_t stream_id, float* __restrict__ out,
+    float* __restrict__ var_out, ConvGeo g, ConvTile t) {
   using M = Mfma<MF>;
   using Acc = typename M::Acc;
   constexpr int KS = M::KS;
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < PT_MAX; ++i) accm[i] = accv[i] = Acc{};
 
-  const int hi0 = ho0 * g.sh - g.ph;                       // input row of patch row 0
+  const int hi0 = ho0 * g.sh - g.ph;                       // (dilated) input row of patch row 0
   for (int c0 = 0; c0 < g.C; c0 += t.CC) {
     const int cc = min(t.CC, g.C - c0);
     const int kc = cc * khw;
@@ -106,11 +117,18 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
       const int img = e / (cc * row_elems), rem = e % (cc * row_elems);
       const int c = rem / row_elems, rr = rem % row_elems;
       const int py = rr / t.PWP, px = rr % t.PWP;
-      const int hi = hi0 + py, wi = px - g.pw;
+      int hi = hi0 + py, wi = px - g.pw;
       float v = 0.f, v2 = 0.f;
-      if (img0 + img < g.N && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
-        v = x[((static_cast<int64_t>(img0 + img) * g.C + c0 + c) * g.H + hi) * g.W + wi];
-        v2 = fmaxf(v * v, 1e-4f);
+      bool inside = img0 + img < g.N && hi >= 0 && wi >= 0;
+      if (MODE == 1) {                                     // dilated input: only multiples of the dilation carry a sample
+        inside = inside && hi % g.dh == 0 && wi % g.dw == 0;
+        hi /= g.dh;
+        wi /= g.dw;
+      }
+      if (inside && hi < g.H && wi < g.W) {
+        const int64_t src = ((static_cast<int64_t>(img0 + img) * g.C + c0 + c) * g.H + hi) * g.W + wi;
+        v = x[src];
+        v2 = MODE == 0 ? fmaxf(v * v, 1e-4f) : x_second[src];
       }
       const int dst = img * img_floats + c * row_elems + rr;
       xs[dst] = v;
@@ -121,7 +139,13 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
       const int o = e % MF, k = e / MF;
       float a = 0.f, b = 0.f;
       if (o0 + o < g.O && k < kc) {
-        const int64_t src = static_cast<int64_t>(o0 + o) * ktot + c0 * khw + k;
+        int64_t src;
+        if (MODE == 0) {
+          src = static_cast<int64_t>(o0 + o) * ktot + c0 * khw + k;
+        } else {                                           // W^T flipped: row = the layer's input channel, k = (o', r, q)
+          const int oc = c0 + k / khw, rq = k % khw;
+          src = (static_cast<int64_t>(oc) * g.O + o0 + o) * khw + (khw - 1 - rq);
+        }
         a = wmu[src];
         b = ws2[src];
       }
@@ -195,6 +219,11 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
       const int o = o0 + M::row(r, h);
       if (o < g.O) {
         const int64_t e = base + o * howo;
+        if (MODE == 1) {                                   // bmu = the layer's input x: d clamp(x^2, 1e-4) / dx = 2 x [x^2 >= 1e-4]
+          const float xv = bmu[e];
+          out[e] = accm[i][r] + (xv * xv >= 1e-4f ? 2.0f * xv * accv[i][r] : 0.f);
+          continue;
+        }
         const float mean = accm[i][r] + (bmu ? bmu[o] : 0.f);
         const float var = accv[i][r] + (bvar ? bvar[o] : 0.f);
         float z;
@@ -285,34 +314,67 @@ static bool plan_fwd(const ConvGeo& g, FwdPlan& p) {
 
 }  // namespace
 
-extern "C" int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw) {
-  if (N < 1 || C < 1 || H < 1 || W < 1 || O < 1 || KH < 1 || KW < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0) return 0;
+static bool layer_geo(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw, ConvGeo& g) {
+  if (N < 1 || C < 1 || H < 1 || W < 1 || O < 1 || KH < 1 || KW < 1 || KH > 7 || KW > 7 || sh < 1 || sw < 1 || ph < 0 || pw < 0)
+    return false;
   const int Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
-  if (Ho < 1 || Wo < 1 || KH > 7 || KW > 7) return 0;
+  if (Ho < 1 || Wo < 1) return false;
+  g = ConvGeo{N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo, 1, 1};
+  return true;
+}
+
+// the input-gradient pass as a convolution: channels O -> C, g dilated by the stride, padding K - 1 - p, stride 1
+static bool data_grad_geo(const ConvGeo& l, ConvGeo& g) {
+  if (l.ph > l.KH - 1 || l.pw > l.KW - 1) return false;
+  g = ConvGeo{l.N, l.O, l.Ho, l.Wo, l.C, l.KH, l.KW, 1, 1, l.KH - 1 - l.ph, l.KW - 1 - l.pw, l.H, l.W, l.sh, l.sw};
+  return true;
+}
+
+extern "C" int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw) {
+  ConvGeo g, d;
   FwdPlan p;
-  return plan_fwd(ConvGeo{N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo}, p) ? 1 : 0;
+  return layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) && plan_fwd(g, p) && data_grad_geo(g, d) && plan_fwd(d, p) ? 1 : 0;
 }
 
 extern "C" int bde_conv_lrt_fwd(const float* x, const float* w_mu, const float* w_s2, const float* b_mu, const float* b_var,
                                 const float* eps, uint64_t seed, uint64_t stream_id, float* out, float* var_out, int N,
                                 int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
-  if (!x || !w_mu || !w_s2 || !out || !var_out || !bde_conv_lrt_supported(N, C, H, W, O, KH, KW, sh, sw, ph, pw))
-    return BDE_ERR_INVALID;
-  const int Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
-  const ConvGeo g{N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo};
+  ConvGeo g;
   FwdPlan p;
-  if (!plan_fwd(g, p)) return BDE_ERR_INVALID;
+  if (!x || !w_mu || !w_s2 || !out || !var_out || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) || !plan_fwd(g, p))
+    return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* none = nullptr;
 #define BDE_CONV_LAUNCH(MF_, PT_, RNG_)                                                                                  \
-  hipLaunchKernelGGL((conv_lrt_fwd_kernel<MF_, PT_, RNG_>), p.grid, dim3(256), p.lds, s, x, w_mu, w_s2, b_mu, b_var, eps, seed, \
-                     stream_id, out, var_out, g, p.t)
+  hipLaunchKernelGGL((conv_lrt_fwd_kernel<MF_, PT_, RNG_, 0>), p.grid, dim3(256), p.lds, s, x, none, w_mu, w_s2, b_mu, b_var, eps, \
+                     seed, stream_id, out, var_out, g, p.t)
   if (p.mf == 16) { if (eps) BDE_CONV_LAUNCH(16, 8, false); else BDE_CONV_LAUNCH(16, 8, true); }
   else { if (eps) BDE_CONV_LAUNCH(32, 4, false); else BDE_CONV_LAUNCH(32, 4, true); }
 #undef BDE_CONV_LAUNCH
   return to_err(hipGetLastError());
 }
 
+extern "C" int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, const float* w_mu, const float* w_s2, const float* x,
+                                     float* g_x, int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph,
+                                     int pw, void* stream) {
+  ConvGeo l, g;
+  FwdPlan p;
+  if (!g_out || !g_var || !w_mu || !w_s2 || !x || !g_x || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, l) ||
+      !data_grad_geo(l, g) || !plan_fwd(g, p))
+    return BDE_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* none = nullptr;
+  float* no_out = nullptr;
+  if (p.mf == 16)
+    hipLaunchKernelGGL((conv_lrt_fwd_kernel<16, 8, false, 1>), p.grid, dim3(256), p.lds, s, g_out, g_var, w_mu, w_s2, x, none, none,
+                       uint64_t{0}, uint64_t{0}, g_x, no_out, g, p.t);
+  else
+    hipLaunchKernelGGL((conv_lrt_fwd_kernel<32, 4, false, 1>), p.grid, dim3(256), p.lds, s, g_out, g_var, w_mu, w_s2, x, none, none,
+                       uint64_t{0}, uint64_t{0}, g_x, no_out, g, p.t);
+  return to_err(hipGetLastError());
+}
+
 extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_conv_lrt(void) {
   hipFuncAttributes attr;
-  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::conv_lrt_fwd_kernel<32, 4, true>)));
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::conv_lrt_fwd_kernel<32, 4, true, 0>)));
 }

@@ -1,0 +1,307 @@
+// Backward of the local-reparameterisation CONVOLUTION layer (BBBConv2d, bbb_layers.py:146-154), weight side:
+//
+//   dW_mu [o, c, r, q] = sum_{n, ho, wo} g   [n, o, ho, wo] * x          [n, c, ho s - p + r, wo s - p + q]
+//   dS2   [o, c, r, q] = sum_{n, ho, wo} gvar[n, o, ho, wo] * clamp(x^2) [n, c, ...]              (0 in the padding)
+//   dW_rho = dS2 * [softplus(rho)^2 >= 1e-4] * 2 softplus(rho) sigmoid(rho)
+//
+// (g = gradient of the layer output, gvar = g eps / (2 sqrt(var)) from bde_local_reparam_bwd) -- what autograd computes
+// with two weight-gradient convolutions plus the element-wise chain in the reference.  One implicit GEMM with two
+// accumulators: rows = output channels, columns = (c, r, q), reduction over the output PIXELS.  A workgroup owns a
+// [MF rows x CT * MF columns] block of both gradient matrices and a share of the (image group, row band) items; per
+// item it stages the input patch of the block's channels once as x and clamp(x^2), the block's rows of g and gvar, and
+// a pixel -> patch-offset table; its four waves take the k-steps (2 or 4 pixels each) round robin, are summed through
+// LDS in wave order, and the block goes to a partials buffer [share][2][O][C KH KW]; bde's finish pass adds the shares
+// in order (fixed order everywhere: bit-reproducible) and applies the chain rule for rho.
+#include "bde_common.hpp"
+
+namespace bde {
+
+using f32x16w = __attribute__((ext_vector_type(16))) float;
+using f32x4w = __attribute__((ext_vector_type(4))) float;
+
+struct WgGeo {
+  int N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo;
+};
+struct WgTile {
+  int NI, TH, bands, PS, CT, colgroups, PH, PWP, cmax, GP, npix;
+};
+
+template <int MF> struct MfmaW;
+template <> struct MfmaW<32> {
+  using Acc = f32x16w;
+  static constexpr int KS = 2, REGS = 16;
+  __device__ __forceinline__ static Acc run(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+  __device__ __forceinline__ static int row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+};
+template <> struct MfmaW<16> {
+  using Acc = f32x4w;
+  static constexpr int KS = 4, REGS = 4;
+  __device__ __forceinline__ static Acc run(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  __device__ __forceinline__ static int row(int r, int h) { return 4 * h + r; }
+};
+
+// LDS: xs [NI][cmax][PH][PWP] | x2s | gs [MF][GP] | gvs [MF][GP] | pixtab [npix]   (reused for the wave reduction)
+template <int MF, int CT_MAX>
+__global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                const float* __restrict__ gvar, float* __restrict__ part,
+                                                                WgGeo geo, WgTile t) {
+  using M = MfmaW<MF>;
+  using Acc = typename M::Acc;
+  constexpr int KS = M::KS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int row_elems = t.PH * t.PWP;
+  const int khw = geo.KH * geo.KW, ktot = geo.C * khw;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane / MF, idx = lane % MF;
+  const int otile = blockIdx.y / t.colgroups, cg = blockIdx.y % t.colgroups;
+  const int o0 = otile * MF, col0 = cg * t.CT * MF;
+  const int col_end = min(ktot, col0 + t.CT * MF);
+  const int c_lo = col0 / khw, c_hi = (col_end - 1) / khw, cc = c_hi - c_lo + 1;
+  const int img_floats = cc * row_elems;
+  const int patch_floats = t.NI * t.cmax * row_elems;
+  float* xs = lds;
+  float* x2s = lds + patch_floats;
+  float* gs = lds + 2 * patch_floats;
+  float* gvs = gs + MF * t.GP;
+  int* pixtab = reinterpret_cast<int*>(gvs + MF * t.GP);
+
+  int kofs[CT_MAX];
+#pragma unroll
+  for (int ct = 0; ct < CT_MAX; ++ct) {
+    const int col = col0 + ct * MF + idx;
+    kofs[ct] = 0;
+    if (ct < t.CT && col < ktot) {
+      const int c = col / khw - c_lo, rq = col % khw;
+      kofs[ct] = c * row_elems + (rq / geo.KW) * t.PWP + (rq % geo.KW);
+    }
+  }
+  Acc accm[CT_MAX], accv[CT_MAX];
+#pragma unroll
+  for (int ct = 0; ct < CT_MAX; ++ct) accm[ct] = accv[ct] = Acc{};
+
+  const int bpi = t.TH * geo.Wo;                               // band pixels per image
+  const int64_t howo = static_cast<int64_t>(geo.Ho) * geo.Wo;
+  const int items = ((geo.N + t.NI - 1) / t.NI) * t.bands;
+  for (int item = blockIdx.x; item < items; item += t.PS) {
+    const int img0 = (item / t.bands) * t.NI, band = item % t.bands;
+    const int ho0 = band * t.TH;
+    const int th = min(t.TH, geo.Ho - ho0);
+    const int hi0 = ho0 * geo.sh - geo.ph;
+    __syncthreads();
+    for (int e = threadIdx.x; e < t.NI * cc * row_elems; e += 256) {
+      const int img = e / (cc * row_elems), rem = e % (cc * row_elems);
+      const int c = rem / row_elems, rr = rem % row_elems;
+      const int hi = hi0 + rr / t.PWP, wi = rr % t.PWP - geo.pw;
+      float v = 0.f, v2 = 0.f;
+      if (img0 + img < geo.N && hi >= 0 && hi < geo.H && wi >= 0 && wi < geo.W) {
+        v = x[((static_cast<int64_t>(img0 + img) * geo.C + c_lo + c) * geo.H + hi) * geo.W + wi];
+        v2 = fmaxf(v * v, 1e-4f);
+      }
+      xs[img * img_floats + rem] = v;
+      x2s[img * img_floats + rem] = v2;
+    }
+    for (int e = threadIdx.x; e < MF * t.npix; e += 256) {
+      const int o = e / t.npix, pp = e % t.npix;
+      const int img = pp / bpi, p = pp % bpi;
+      const int hl = p / geo.Wo, wo = p % geo.Wo;
+      float a = 0.f, b = 0.f;
+      if (img < t.NI && img0 + img < geo.N && hl < th && o0 + o < geo.O) {
+        const int64_t src = (static_cast<int64_t>(img0 + img) * geo.O + o0 + o) * howo + static_cast<int64_t>(ho0 + hl) * geo.Wo + wo;
+        a = g[src];
+        b = gvar[src];
+      }
+      gs[o * t.GP + pp] = a;
+      gvs[o * t.GP + pp] = b;
+    }
+    for (int pp = threadIdx.x; pp < t.npix; pp += 256) {
+      const int img = pp / bpi, p = pp % bpi;
+      const int hl = p / geo.Wo, wo = p % geo.Wo;
+      pixtab[pp] = (img < t.NI && hl < th) ? img * img_floats + hl * geo.sh * t.PWP + wo * geo.sw : 0;
+    }
+    __syncthreads();
+    const int ksteps = t.npix / KS;
+    for (int ks = wave; ks < ksteps; ks += 4) {
+      const int pix = ks * KS + h;
+      const int po = pixtab[pix];
+      const float am = gs[idx * t.GP + pix], av = gvs[idx * t.GP + pix];
+#pragma unroll
+      for (int ct = 0; ct < CT_MAX; ++ct) {
+        if (ct < t.CT) {                                       // wave-uniform
+          const float b = xs[po + kofs[ct]], b2 = x2s[po + kofs[ct]];
+          accm[ct] = M::run(am, b, accm[ct]);
+          accv[ct] = M::run(av, b2, accv[ct]);
+        }
+      }
+    }
+  }
+
+  // ---- the four waves' blocks summed in wave order through LDS (one wave's block at a time: 18-32 KB)
+  float* red = lds;
+  for (int s = 1; s < 4; ++s) {
+    __syncthreads();
+    if (wave == s) {
+#pragma unroll
+      for (int ct = 0; ct < CT_MAX; ++ct)
+#pragma unroll
+        for (int r = 0; r < M::REGS; ++r) {
+          red[((ct * 2 + 0) * M::REGS + r) * 64 + lane] = accm[ct][r];
+          red[((ct * 2 + 1) * M::REGS + r) * 64 + lane] = accv[ct][r];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT_MAX; ++ct)
+#pragma unroll
+        for (int r = 0; r < M::REGS; ++r) {
+          accm[ct][r] += red[((ct * 2 + 0) * M::REGS + r) * 64 + lane];
+          accv[ct][r] += red[((ct * 2 + 1) * M::REGS + r) * 64 + lane];
+        }
+    }
+  }
+  if (wave != 0) return;
+  // part [share][2][O][ktot]
+  float* pm = part + static_cast<int64_t>(blockIdx.x) * 2 * geo.O * ktot;
+  float* pv = pm + static_cast<int64_t>(geo.O) * ktot;
+#pragma unroll
+  for (int ct = 0; ct < CT_MAX; ++ct) {
+    const int col = col0 + ct * MF + idx;
+    if (ct < t.CT && col < ktot) {
+#pragma unroll
+      for (int r = 0; r < M::REGS; ++r) {
+        const int o = o0 + M::row(r, h);
+        if (o < geo.O) {
+          pm[static_cast<int64_t>(o) * ktot + col] = accm[ct][r];
+          pv[static_cast<int64_t>(o) * ktot + col] = accv[ct][r];
+        }
+      }
+    }
+  }
+}
+
+// shares summed in order; chain rule of sigma^2 = clamp(softplus(rho)^2, 1e-4) for the rho gradient
+__global__ __launch_bounds__(kBlock) void conv_lrt_wgrad_finish_kernel(const float* __restrict__ part, int shares, int64_t n,
+                                                                       const float* __restrict__ w_rho,
+                                                                       float* __restrict__ g_wmu, float* __restrict__ g_wrho) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float sm = 0.f, sv = 0.f;
+    for (int s = 0; s < shares; ++s) {
+      sm += part[(static_cast<int64_t>(s) * 2 + 0) * n + i];
+      sv += part[(static_cast<int64_t>(s) * 2 + 1) * n + i];
+    }
+    g_wmu[i] = sm;
+    const SoftplusSigmoid ss = softplus_sigmoid(w_rho[i]);
+    const float s2 = ss.sp * ss.sp;
+    g_wrho[i] = s2 >= 1e-4f ? sv * (2.0f * ss.sp * ss.sg) : 0.f;
+  }
+}
+
+}  // namespace bde
+
+using namespace bde;
+
+namespace {
+
+struct WgPlan {
+  WgTile t;
+  int mf, otiles;
+  dim3 grid;
+  size_t lds;
+};
+
+static bool plan_wgrad(const WgGeo& g, WgPlan& p) {
+  const int mf = g.O <= 16 ? 16 : 32;
+  const int ct_max = mf == 16 ? 9 : 4;
+  const int ks = mf == 32 ? 2 : 4;
+  const int regs = mf == 32 ? 16 : 4;
+  const int khw = g.KH * g.KW, ktot = g.C * khw;
+  const int otiles = (g.O + mf - 1) / mf;
+  const int ct = std::min(ct_max, (ktot + mf - 1) / mf);
+  const int colgroups = (ktot + ct * mf - 1) / (ct * mf);
+  const int cmax = std::min(g.C, (ct * mf + khw - 2) / khw + 1);
+  const size_t red = sizeof(float) * static_cast<size_t>(ct_max) * 2 * regs * 64;
+  bool found = false;
+  double best_score = -1.0;
+  WgTile best{};
+  size_t best_lds = 0;
+  for (int th = g.Ho; th >= 1; th = (th > 1 ? (th + 1) / 2 : 0)) {
+    const int bands = (g.Ho + th - 1) / th;
+    for (int ni = 8; ni >= 1; ni /= 2) {
+      if (ni > 1 && th != g.Ho) continue;
+      const int ph = (th - 1) * g.sh + g.KH, pwp = (g.Wo - 1) * g.sw + g.KW;
+      int npix = ni * th * g.Wo;
+      npix = (npix + ks * 4 - 1) / (ks * 4) * (ks * 4);
+      int gp = npix;
+      if (mf == 32) gp |= 1; else gp = (gp + 31) / 32 * 32 + 2;
+      const size_t lds = sizeof(float) * (2ull * ni * cmax * ph * pwp + 2ull * mf * gp + npix);
+      if (std::max(lds, red) > 64 * 1024) continue;
+      const int items = ((g.N + ni - 1) / ni) * bands;
+      const int blocks = otiles * colgroups;
+      const int ps = std::max(1, std::min(items, (768 + blocks - 1) / blocks));
+      const double fill = std::min(1.0, static_cast<double>(ps) * blocks / 512.0);
+      const double halo = static_cast<double>(th) / ph;
+      const double big = std::min(1.0, static_cast<double>(npix) / 256.0);      // enough k-steps per staging
+      const double score = fill * (0.5 + 0.5 * halo) * (0.5 + 0.5 * big);
+      if (score > best_score) {
+        best_score = score;
+        best = WgTile{ni, th, bands, ps, ct, colgroups, ph, pwp, cmax, gp, npix};
+        best_lds = std::max(lds, red);
+        found = true;
+      }
+    }
+  }
+  if (!found) return false;
+  p.t = best;
+  p.mf = mf;
+  p.otiles = otiles;
+  p.grid = dim3(static_cast<unsigned>(best.PS), static_cast<unsigned>(otiles * colgroups));
+  p.lds = best_lds;
+  return true;
+}
+
+static bool geo_ok(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw, WgGeo& g) {
+  if (N < 1 || C < 1 || H < 1 || W < 1 || O < 1 || KH < 1 || KW < 1 || KH > 7 || KW > 7 || sh < 1 || sw < 1 || ph < 0 || pw < 0)
+    return false;
+  const int Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
+  if (Ho < 1 || Wo < 1) return false;
+  g = WgGeo{N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo};
+  return true;
+}
+
+}  // namespace
+
+// bytes of the partials buffer bde_conv_lrt_bwd_weight needs (0: unsupported geometry)
+extern "C" size_t bde_conv_lrt_bwd_weight_ws_bytes(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph,
+                                                   int pw) {
+  WgGeo g;
+  WgPlan p;
+  if (!geo_ok(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) || !plan_wgrad(g, p)) return 0;
+  return sizeof(float) * static_cast<size_t>(p.t.PS) * 2 * O * C * KH * KW;
+}
+
+extern "C" int bde_conv_lrt_bwd_weight(const float* x, const float* g, const float* gvar, const float* w_rho, void* ws,
+                                       float* g_wmu, float* g_wrho, int N, int C, int H, int W, int O, int KH, int KW, int sh,
+                                       int sw, int ph, int pw, void* stream) {
+  WgGeo geo;
+  WgPlan p;
+  if (!x || !g || !gvar || !w_rho || !ws || !g_wmu || !g_wrho || !geo_ok(N, C, H, W, O, KH, KW, sh, sw, ph, pw, geo) ||
+      !plan_wgrad(geo, p))
+    return BDE_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(ws);
+  if (p.mf == 16)
+    hipLaunchKernelGGL((conv_lrt_wgrad_kernel<16, 9>), p.grid, dim3(256), p.lds, s, x, g, gvar, part, geo, p.t);
+  else
+    hipLaunchKernelGGL((conv_lrt_wgrad_kernel<32, 4>), p.grid, dim3(256), p.lds, s, x, g, gvar, part, geo, p.t);
+  const int64_t n = static_cast<int64_t>(O) * C * KH * KW;
+  hipLaunchKernelGGL(conv_lrt_wgrad_finish_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, part, p.t.PS, n, w_rho, g_wmu,
+                     g_wrho);
+  return to_err(hipGetLastError());
+}
+
+extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_conv_lrt_bwd(void) {
+  hipFuncAttributes attr;
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::conv_lrt_wgrad_kernel<32, 4>)));
+}

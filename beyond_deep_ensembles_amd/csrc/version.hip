@@ -4,6 +4,7 @@ extern "C" const char* bde_arch(void) { return "gfx950"; }
 
 extern "C" {
 int bde_internal_load_conv_lrt(void);
+int bde_internal_load_conv_lrt_bwd(void);
 int bde_internal_load_gauss(void);
 int bde_internal_load_ivon(void);
 int bde_internal_load_lrt(void);
@@ -20,7 +21,7 @@ int bde_internal_load_swag_batched(void);
 // the device with other processes calls this first, from one thread, so that no kernel's first launch coincides with
 // them (profiles/r03_first_launch_*.txt).  Idempotent, cheap after the first call; needs a visible device.
 extern "C" int bde_init(void) {
-  int (*const loaders[])(void) = {bde_internal_load_conv_lrt,   bde_internal_load_gauss,      bde_internal_load_ivon,       bde_internal_load_lrt,
+  int (*const loaders[])(void) = {bde_internal_load_conv_lrt,   bde_internal_load_conv_lrt_bwd, bde_internal_load_gauss,      bde_internal_load_ivon,       bde_internal_load_lrt,
                                   bde_internal_load_lrt_bwd,    bde_internal_load_svgd,       bde_internal_load_svgd_fused,
                                   bde_internal_load_svgd_small, bde_internal_load_swag,       bde_internal_load_swag_batched};
   for (auto load : loaders) {

@@ -472,6 +472,30 @@ class HipOps:
                                          stream_id, _ptr(out), _ptr(var_out), n, c, h, w, o, kh, kw, stride[0], stride[1],
                                          padding[0], padding[1], _stream()), "bde_conv_lrt_fwd")
 
+    @_on_device_of
+    def conv_lrt_bwd_data(self, g_out, g_var, w_mu, w_s2, x, g_x, stride, padding):
+        """g_x of BBBConv2d: both transposed convolutions + the clamp's derivative in one launch."""
+        n, c, h, w = x.shape
+        o, _, kh, kw = w_mu.shape
+        _check(self.lib.bde_conv_lrt_bwd_data(_ptr(g_out, "g_out"), _ptr(g_var), _ptr(w_mu), _ptr(w_s2), _ptr(x), _ptr(g_x), n, c,
+                                              h, w, o, kh, kw, stride[0], stride[1], padding[0], padding[1], _stream()),
+               "bde_conv_lrt_bwd_data")
+
+    @_on_device_of
+    def conv_lrt_bwd_weight(self, x, g_out, g_var, w_rho, g_wmu, g_wrho, stride, padding, ws=None):
+        """g_wmu / g_wrho of BBBConv2d: two weight-gradient convolutions + the rho chain rule in two launches."""
+        n, c, h, w = x.shape
+        o, _, kh, kw = w_rho.shape
+        geo = (n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0], padding[1])
+        need = int(self.lib.bde_conv_lrt_bwd_weight_ws_bytes(*geo))
+        if need == 0:
+            raise BdeKernelError("bde_conv_lrt_bwd_weight: unsupported geometry")
+        if ws is None or ws.numel() * ws.element_size() < need:
+            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        _check(self.lib.bde_conv_lrt_bwd_weight(_ptr(x, "x"), _ptr(g_out), _ptr(g_var), _ptr(w_rho), _ptr(ws), _ptr(g_wmu),
+                                                _ptr(g_wrho), *geo, _stream()), "bde_conv_lrt_bwd_weight")
+        return ws
+
     def lrt_linear_supported(self, b: int, i: int, o: int) -> bool:
         return bool(self.lib.bde_lrt_linear_supported(b, i, o))
 

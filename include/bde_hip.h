@@ -362,6 +362,24 @@ int bde_conv_lrt_fwd(const float* x, const float* w_mu, const float* w_s2, const
                      const float* eps, uint64_t seed, uint64_t stream_id, float* out, float* var_out, int N, int C, int H,
                      int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, void* stream);
 
+/* Backward of that layer (the autograd graph of bbb_layers.py:146-154) given g = dL/d out and
+ * g_var = g eps / (2 sqrt(var)) (bde_local_reparam_bwd on g, var_out and the forward's noise):
+ *   bde_conv_lrt_bwd_data:   g_x = convT(g, W_mu) + 2 x [x^2 >= 1e-4] convT(g_var, w_s2) -- the same dual-accumulator
+ *                            implicit GEMM as the forward over g / g_var dilated by the stride, weights transposed and
+ *                            flipped while staging, the clamp's derivative in the epilogue;
+ *   bde_conv_lrt_bwd_weight: g_wmu = corr(x, g), g_wrho = corr(clamp(x^2), g_var) * [sigma^2 >= 1e-4] 2 sigma sigmoid(rho):
+ *                            dual-accumulator implicit GEMM reducing over the output pixels, per-share partial blocks in
+ *                            `ws` (bde_conv_lrt_bwd_weight_ws_bytes) summed in a fixed order by a finish pass.
+ * The bias gradients are plain channel sums of g and g_var (callers: torch.sum / bde_var_operand_bwd mode 2). */
+int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, const float* w_mu, const float* w_s2, const float* x,
+                          float* g_x, int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w,
+                          int pad_h, int pad_w, void* stream);
+size_t bde_conv_lrt_bwd_weight_ws_bytes(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h,
+                                        int pad_w);
+int bde_conv_lrt_bwd_weight(const float* x, const float* g_out, const float* g_var, const float* w_rho, void* ws,
+                            float* g_wmu, float* g_wrho, int N, int C, int H, int W, int O, int KH, int KW, int stride_h,
+                            int stride_w, int pad_h, int pad_w, void* stream);
+
 /* The whole local-reparameterisation forward of a mean-field LINEAR layer (bbb_layers.py:61-80, sampling =
  * "activations") for small batches (B <= 128): W_mu / W_rho [O, I] row-major are streamed ONCE, sigma^2 =
  * clamp(softplus(rho)^2, 1e-4) and clamp(x^2, 1e-4) are formed on the fly and both products run on the f32 MFMA

@@ -1164,6 +1164,58 @@ def test_conv_lrt_forward(ops):
         assert torch.equal(var, var2)
 
 
+def test_conv_lrt_backward(ops):
+    """bde_local_reparam_bwd + bde_conv_lrt_bwd_data + bde_conv_lrt_bwd_weight (the autograd graph of
+    bbb_layers.py:146-154: two transposed and two weight-gradient convolutions + the element-wise chain) against fp64
+    autograd of those lines; the allowance is twice the deviation of fp32 autograd of the same lines (torch CPU)."""
+    import torch.nn.functional as F
+    torch.manual_seed(35)
+    for n, c, h, w, o, k, stride, padding, bias in CONV_CASES:
+        x = torch.randn(n, c, h, w)
+        x[0, 0, :2] = 0.0
+        x[0, 0, 2, : min(w, 3)] = 5e-3                                  # x^2 below the clamp but not zero
+        w_mu, w_rho = torch.randn(o, c, k, k) * 0.1, torch.randn(o, c, k, k) * 1.5 - 3.0
+        w_rho[0, 0] = -8.0
+        b_mu, b_rho = (torch.randn(o) * 0.1, torch.randn(o) - 3.0) if bias else (None, None)
+        eps, gout = None, None
+
+        def run(dt):
+            leaves = [t.to(dt).clone().requires_grad_(True) for t in (x, w_mu, w_rho)]
+            xx, wm, wr = leaves
+            bm = None if b_mu is None else b_mu.to(dt)
+            br = None if b_rho is None else b_rho.to(dt)
+            mean = F.conv2d(xx, wm, bm, stride=stride, padding=padding)
+            var = F.conv2d((xx ** 2).clamp(min=1e-4), (F.softplus(wr) ** 2).clamp(min=1e-4),
+                           None if br is None else F.softplus(br) ** 2, stride=stride, padding=padding)
+            nonlocal eps, gout
+            if eps is None:
+                eps, gout = torch.randn(mean.shape, dtype=torch.float64), torch.randn(mean.shape, dtype=torch.float64)
+            outv = mean + var.sqrt() * eps.to(dt)
+            return [t.detach() for t in torch.autograd.grad(outv, leaves, gout.to(dt))] + [var.detach()]
+        g64 = run(torch.float64)
+        g32 = run(torch.float32)
+        dev = lambda t: None if t is None else t.to(DEV).float().contiguous()
+        xd, wm, wr = dev(x), dev(w_mu), dev(w_rho)
+        ws2 = torch.empty_like(wm)
+        ops.var_operand_fwd(wr, 1, ws2)
+        var = dev(g32[3])
+        gd, ed = dev(gout), dev(eps)
+        gvar = torch.empty_like(gd)
+        ops.local_reparam_bwd(gd.view(-1), var.view(-1), gvar.view(-1), gd.numel(), eps=ed.view(-1))
+        gx = torch.full_like(xd, 9.0)
+        ops.conv_lrt_bwd_data(gd, gvar, wm, ws2, xd, gx, stride, padding)
+        gwm, gwr = torch.full_like(wm, 9.0), torch.full_like(wr, 9.0)
+        ops.conv_lrt_bwd_weight(xd, gd, gvar, wr, gwm, gwr, stride, padding)
+        case = (n, c, h, w, o, k, stride, padding)
+        for name, got, i in (("g_x", gx, 0), ("g_wmu", gwm, 1), ("g_wrho", gwr, 2)):
+            tol = max(2 * (g32[i].double() - g64[i]).abs().max().item(), 3e-6 * g64[i].abs().max().item())
+            assert (got.cpu().double() - g64[i]).abs().max().item() <= tol, (name, case)
+        gwm2, gwr2, gx2 = torch.empty_like(gwm), torch.empty_like(gwr), torch.empty_like(gx)     # deterministic
+        ops.conv_lrt_bwd_weight(xd, gd, gvar, wr, gwm2, gwr2, stride, padding)
+        ops.conv_lrt_bwd_data(gd, gvar, wm, ws2, xd, gx2, stride, padding)
+        assert torch.equal(gwm, gwm2) and torch.equal(gwr, gwr2) and torch.equal(gx, gx2), case
+
+
 def test_lrt_linear_backward(ops):
     """bde_lrt_linear_bwd (the autograd graph of bbb_layers.py:61-80 in three or four launches) against fp64 autograd
     over those lines; the allowance is twice the deviation of fp32 autograd over the same lines (CPU)."""
