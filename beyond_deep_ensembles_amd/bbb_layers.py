@@ -9,9 +9,13 @@ Same constructor arguments, attributes (``weight`` / ``bias`` GaussianParameters
 with ONE noise draw shared across the batch in eval mode when ``freeze_on_eval``.
 ``BBBLinear`` runs its whole forward as ONE fused op for batches of up to 128 rows (``bde_lrt_linear_fwd``: the
 weights are streamed once, sigma^2 / x^2 are formed on the fly, both products run on the MFMA, the noise is applied
-in the finish pass) and its backward as three launches; larger batches and ``BBBConv2d`` keep the two stock GEMMs /
-convolutions, with every element-wise piece around them fused: one pass per operand of the variance product
-(``bde_var_operand_*``) and one for the epilogue (``bde_local_reparam_*``).  What BBBOptimizer needs from the layer -- mean / rho parameters paired through
+in the finish pass) and its backward as three launches.  ``BBBConv2d`` (round 4) runs both convolutions of
+``bbb_layers.py:146-147`` as ONE dual-accumulator implicit GEMM with the sampling epilogue fused
+(``bde_conv_lrt_fwd``), its backward as an input-gradient and a weight-gradient kernel of the same kind
+(``bde_conv_lrt_bwd_*``); the weights are prepared once per version (``bde_conv_lrt_prep``).  Larger linear batches,
+unsupported convolution geometries and eval-mode frozen noise keep the two stock GEMMs / convolutions, with every
+element-wise piece around them fused: one pass per operand of the variance product (``bde_var_operand_*``) and one for
+the epilogue (``bde_local_reparam_*``).  What BBBOptimizer needs from the layer -- mean / rho parameters paired through
 GaussianParameter -- feeds the fused KL kernel.
 
 Differences from the reference, on purpose:
@@ -53,6 +57,10 @@ def _native_nodes(ops):
         return None
     mod = _host.load()
     return mod if mod is not None and hasattr(mod, "lrt_linear") else None
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
 
 
 def _lrt_linear(x, w_mu, w_rho, b_mu, b_rho, clamp_bias, eps, seed, stream_id, ops, w_s2=None, w_ds2=None):
@@ -202,6 +210,80 @@ class _LrtLinear(torch.autograd.Function):
             None, None
 
 
+class _ConvWeights:
+    """The prepared weight buffer of a fused BBBConv2d (bde_conv_lrt_prep: sigma^2, its rho-derivative and both weight
+    matrices in the kernels' staging order), computed ONCE per version of (mean, rho): the weights change at
+    ``base_optimizer.step()``, a BBB step runs ``mc_samples`` forward and backward passes per version (bbb.py:63-67).
+    Same key as ``_SigmaCache`` (addresses, autograd version counters, the process-wide epoch BBBOptimizer advances); a
+    refresh fills a NEW buffer, so a forward whose backward has not run yet keeps the buffer of its own version."""
+
+    def __init__(self):
+        self.key = None
+        self.buf = None
+
+    def drop(self) -> None:
+        self.key = None
+
+    def get(self, mean: torch.Tensor, rho: torch.Tensor, ops):
+        key = (mean.data_ptr(), mean._version, rho.data_ptr(), rho._version, tuple(rho.shape), _SigmaCache.epoch)
+        if key != self.key:
+            buf = ops.conv_lrt_wbuf(rho.shape, rho.device)
+            ops.conv_lrt_prep(mean.detach().contiguous(), rho.detach().contiguous(), buf)
+            self.key, self.buf = key, buf
+        return self.buf
+
+
+class _ConvLrt(torch.autograd.Function):
+    """The whole forward of a mean-field convolution layer in local-reparameterisation form (bbb_layers.py:146-154) as
+    ONE fused op (bde_conv_lrt_fwd: both convolutions as one dual-accumulator implicit GEMM over the same staged input
+    windows, the sampling epilogue fused); the backward is bde_local_reparam_bwd (g_var) + bde_conv_lrt_bwd_data +
+    bde_conv_lrt_bwd_weight (+ two channel sums for the bias) instead of autograd's four convolutions and ~20
+    element-wise launches."""
+
+    @staticmethod
+    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, stride, padding, eps, seed, stream_id, ops, wbuf):
+        xc = x.detach().contiguous()
+        n, o = xc.shape[0], w_mu.shape[0]
+        ho = (xc.shape[2] + 2 * padding[0] - w_mu.shape[2]) // stride[0] + 1
+        wo = (xc.shape[3] + 2 * padding[1] - w_mu.shape[3]) // stride[1] + 1
+        out = torch.empty((n, o, ho, wo), dtype=torch.float32, device=x.device)
+        var = torch.empty_like(out)
+        b_var = None
+        if b_rho is not None:
+            b_var = torch.empty_like(b_rho)
+            ops.var_operand_fwd(b_rho.detach().contiguous(), 2, b_var)          # softplus(b_rho)^2, not clamped (line 147)
+        e = None if eps is None else eps.reshape(out.shape).contiguous()
+        ops.conv_lrt_fwd(xc, wbuf, tuple(w_mu.shape), None if b_mu is None else b_mu.detach().contiguous(), b_var, stride,
+                         padding, out, var, eps=e, seed=seed, stream_id=stream_id)
+        ctx.save_for_backward(xc, w_mu, w_rho, b_rho, var, e, wbuf)
+        ctx.meta = (stride, padding, seed, stream_id, ops)
+        return out
+
+    @staticmethod
+    @once_differentiable          # the kernels produce plain tensors: no double backward
+    def backward(ctx, grad_out):
+        x, w_mu, w_rho, b_rho, var, eps, wbuf = ctx.saved_tensors
+        stride, padding, seed, stream_id, ops = ctx.meta
+        g = grad_out.contiguous()
+        gvar = torch.empty_like(g)
+        # eps None: the kernel regenerates the forward's in-kernel noise (same element numbering over the flat output)
+        ops.local_reparam_bwd(g.view(-1), var.view(-1), gvar.view(-1), g.numel(), eps=None if eps is None else eps.view(-1),
+                              seed=seed, stream_id=stream_id)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty_like(x)
+            ops.conv_lrt_bwd_data(g, gvar, wbuf, tuple(w_mu.shape), x, g_x, stride, padding)
+        g_wmu, g_wrho = torch.empty_like(w_mu), torch.empty_like(w_rho)
+        ops.conv_lrt_bwd_weight(x, g, gvar, w_rho.detach().contiguous(), g_wmu, g_wrho, stride, padding)
+        g_bmu = g_brho = None
+        if b_rho is not None:
+            g_bmu = g.sum(dim=(0, 2, 3))
+            g_bvar = gvar.sum(dim=(0, 2, 3))
+            g_brho = torch.empty_like(g_bvar)
+            ops.var_operand_bwd(g_bvar, b_rho.detach().contiguous(), 2, g_brho)
+        return g_x, g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None, None, None
+
+
 class _LocalReparamLayer(nn.Module):
     """Shared machinery: Gaussian weight/bias, noise policy, lazy KL."""
 
@@ -214,8 +296,14 @@ class _LocalReparamLayer(nn.Module):
         self.fused_epilogue = kwargs.get("fused_epilogue", True)     # one HIP pass for mean + sqrt(var) * eps
         self.fused_linear = kwargs.get("fused_linear", True)         # BBBLinear: the whole forward as one fused op
         self.sigma_cache = kwargs.get("sigma_cache", True)           # wide BBBLinear: sigma^2 once per weight version
+        self.fused_conv = kwargs.get("fused_conv", True)             # BBBConv2d: both convolutions + epilogue as one fused op
         self._sigma_cache = _SigmaCache()
-        self.invalidate_sigma_cache = self._sigma_cache.drop
+        self._conv_weights = _ConvWeights()
+
+        def drop_caches():
+            self._sigma_cache.drop()
+            self._conv_weights.drop()
+        self.invalidate_sigma_cache = drop_caches
         self.weight_prior, self.bias_prior = weight_prior, bias_prior
         gp_kwargs = {k: kwargs[k] for k in ("rng", "seed", "_ops") if k in kwargs}
         self.weight = GaussianParameter(weight_shape, **gp_kwargs)
@@ -338,6 +426,21 @@ class BBBConv2d(_LocalReparamLayer):
         if self.sampling != "activations":
             raise ValueError("Invalid value of sampling")
         w, b = self.weight, (self.bias if self.use_bias else None)
+        frozen = not self.training and self.freeze_on_eval           # eval: ONE noise draw shared by the batch (stock path)
+        if self.fused_conv and not frozen and input.dim() == 4 and input.dtype == torch.float32 \
+                and input.is_cuda == w.mean.is_cuda and hasattr(w._get_ops(), "conv_lrt_fwd"):
+            ops = w._get_ops()
+            stride, padding = _pair(self.stride), _pair(self.padding)
+            if isinstance(padding[0], int) and ops.conv_lrt_supported(input.shape, w.mean.shape, stride, padding):
+                eps = None
+                if not (w.rng == "philox" and w.noise_source is None):
+                    ho = (input.shape[2] + 2 * padding[0] - self.kernel_size) // stride[0] + 1
+                    wo = (input.shape[3] + 2 * padding[1] - self.kernel_size) // stride[1] + 1
+                    eps = normal_like(input.new_empty((input.shape[0], self.out_channels, ho, wo)))
+                wbuf = self._conv_weights.get(w.mean, w.rho, ops)
+                return _ConvLrt.apply(input, w.mean, w.rho, b.mean if b is not None else None,
+                                      b.rho if b is not None else None, stride, padding, eps, w.seed, next(_philox_stream), ops,
+                                      wbuf)
         mean = F.conv2d(input, w.mean, b.mean if b is not None else None, stride=self.stride, padding=self.padding)
         x2, s2, vb = self._var_operands(input, clamp_bias=False)     # the conv layer does not clamp its bias variance
         var = F.conv2d(x2, s2, vb, stride=self.stride, padding=self.padding)

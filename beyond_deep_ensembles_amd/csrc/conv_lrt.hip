@@ -1,4 +1,5 @@
-// Local-reparameterisation forward of a mean-field CONVOLUTION layer (BBBConv2d, bbb_layers.py:146-154) as ONE kernel:
+// Local-reparameterisation CONVOLUTION layer (BBBConv2d, bbb_layers.py:146-154): forward and input gradient, each ONE
+// kernel.
 //
 //   activation_mean = conv2d(x,                 W_mu,                       b_mu)         (line 146)
 //   activation_var  = conv2d(clamp(x^2, 1e-4),  clamp(softplus(W_rho)^2),   softplus(b_rho)^2)   (line 147)
@@ -7,18 +8,30 @@
 // The reference runs two cuDNN/MIOpen convolutions over the same input windows plus ~8 element-wise launches.  Here
 // both products are one implicit GEMM with TWO accumulators per output tile: the input patch of a band of output rows
 // is staged ONCE into LDS as x and as clamp(x^2) (zero padding applied AFTER the clamp, as F.conv2d pads the clamped
-// tensor), the weight tile as W_mu and sigma^2 (sigma^2 comes from the caller: bde_var_operand_fwd mode 1, once per
-// weight version), and every k-step issues a pair of f32 MFMAs -- (W_mu, x) and (sigma^2, clamp(x^2)) -- whose B
-// operands sit at the same LDS offset of the two patch images.  The epilogue adds the bias terms, draws eps (Philox,
-// the stream of bde_local_reparam_fwd: element e of the NCHW output uses normal (e & 3) of group e >> 2) or reads
-// it, and writes the output and the total variance (the backward needs sqrt(var)).
+// tensor), the weight tile as W_mu and sigma^2, and every k-step issues a pair of f32 MFMAs -- (W_mu, x) and
+// (sigma^2, clamp(x^2)) -- whose B operands sit at the same LDS offset of the two patch images.  The epilogue
+// transposes each accumulator tile through LDS so that a lane owns 4 consecutive pixels of one channel, adds the bias
+// terms, draws eps (Philox, the stream of bde_local_reparam_fwd: float4 group e >> 2 of the flat NCHW output) or
+// reads it, and writes output and total variance (the backward needs sqrt(var)) as 16-byte stores.
 //
 // GEMM view: rows = output channels (MF = 32 per tile on v_mfma_f32_32x32x2_f32, 16 on v_mfma_f32_16x16x4_f32 for
-// layers with <= 16 channels), columns = MF consecutive output pixels of one image (flattened ho * Wo + wo: the
-// accumulator of a lane is one pixel x several channels, so a store instruction writes MF consecutive floats per
-// channel), k = (c, r, q) over a chunk of CC input channels.  A workgroup = 4 waves = WP pixel-tile groups x WK k-splits
-// (small images have too few pixel tiles to fill the chip: the waves then split the reduction and sum their
-// accumulators through LDS in wave order -- fixed order, bit-reproducible).
+// layers with <= 16 channels), columns = MF consecutive output pixels of one image (flattened ho * Wo + wo),
+// k = (c, r, q) over a chunk of CC input channels.  A workgroup = 4 waves = WP pixel-tile groups x WK k-splits (small
+// images have too few pixel tiles to fill the chip: the waves then split the reduction and sum their accumulators
+// through LDS in wave order -- fixed order, bit-reproducible).
+//
+// Weights come pre-arranged by bde_conv_lrt_prep (once per weight version; it also evaluates sigma^2): k-major
+// [C KH KW][O padded to 32] for the forward, transposed and flipped [O KH KW][C padded to 32] for the input gradient,
+// so that staging a weight tile is a run of aligned 16-byte copies.
+//
+// MODE 1: the INPUT gradient as the same implicit GEMM,
+//   dx = convT(g, W_mu) + 2 x [x^2 >= 1e-4] * convT(gvar, sigma^2)
+// (g = gradient of the layer output, gvar = g eps / (2 sqrt(var)) from bde_local_reparam_bwd): the "input" images are
+// g and gvar [N, O', Ho', Wo'] (two tensors instead of x and clamp(x^2)), dilated by the layer's stride (zeros between
+// the samples: a stride-s layer spends s^2 times the products here) and padded by K - 1 - p, the "output" has the
+// layer's C' input channels and H' x W' pixels at stride 1, and the epilogue applies the clamp's derivative with x.
+// ConvGeo then describes THAT convolution: C = O', (H, W) = (Ho', Wo') before dilation (dh, dw), O = C',
+// (Ho, Wo) = (H', W').
 #include "bde_common.hpp"
 
 namespace bde {
@@ -29,9 +42,10 @@ using f32x4c = __attribute__((ext_vector_type(4))) float;
 struct ConvGeo {
   int N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo;
   int dh, dw;      // dilation of the INPUT image (1 in the forward; the layer's stride in the input-gradient pass)
+  int rp;          // row pitch of the pre-arranged weights: output channels padded to 32
 };
 struct ConvTile {
-  int NI, TH, bands, CC, PH, PWP, WP, WK, PT, tiles_per_img, kcpad_max;
+  int NI, TH, bands, CC, PH, PWP, WP, WK, tiles_per_img, kcpad_max;
 };
 
 template <int MF> struct Mfma;
@@ -49,27 +63,21 @@ template <> struct Mfma<16> {
   __device__ __forceinline__ static int row(int r, int h) { return 4 * h + r; }
 };
 
-// LDS: xs [NI][CC][PH][PWP] | x2s (same) | wm [kcpad][MF] | ws [kcpad][MF] | kofs [kcpad] (int)
-//
-// MODE 0: the forward above.  MODE 1: the INPUT gradient of the same layer as the same implicit GEMM,
-//   dx = convT(g, W_mu) + 2 x [x^2 >= 1e-4] * convT(gvar, sigma^2)
-// (g = gradient of the layer output, gvar = g eps / (2 sqrt(var)) from bde_local_reparam_bwd): the "input" images are g
-// and gvar [N, O', Ho', Wo'] (two tensors instead of x and clamp(x^2)), dilated by the layer's stride (zeros between
-// the samples: a stride-s layer spends s^2 times the products here) and padded by K - 1 - p, the "weights" are
-// W^T flipped -- gathered from the [O', C', KH, KW] tensors while staging --, the "output" has the layer's C' input
-// channels and H' x W' pixels at stride 1, and the epilogue applies the clamp's derivative with x.  ConvGeo then
-// describes THAT convolution: C = O', (H, W) = (Ho', Wo') before dilation (dh, dw), O = C', (Ho, Wo) = (H', W').
-template <int MF, int PT_MAX, bool RNG, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ x_second, const float* __restrict__ wmu,
-    const float* __restrict__ ws2, const float* __restrict__ bmu, const float* __restrict__ bvar,
+// LDS: xs [NI][CC][PH][PWP] | x2s (same) | wm [kcpad][MF] | ws [kcpad][MF] | kofs [kcpad] (int); the epilogue reuses
+// the front of it: per wave 2 x [MF][MF + 4] floats.
+template <int MF, int PT, bool RNG, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
+    const float* __restrict__ x, const float* __restrict__ x_second, const float* __restrict__ wt_mu,
+    const float* __restrict__ wt_s2, const float* __restrict__ bmu, const float* __restrict__ bvar,
     const float* __restrict__ eps, uint64_t seed, uint64_t stream_id, float* __restrict__ out,
     float* __restrict__ var_out, ConvGeo g, ConvTile t) {
   using M = Mfma<MF>;
   using Acc = typename M::Acc;
   constexpr int KS = M::KS;
+  constexpr int RS = MF + 4;                               // row pitch of the epilogue's transposition tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int img_floats = t.CC * t.PH * t.PWP;
+  const int row_elems = t.PH * t.PWP;
+  const int img_floats = t.CC * row_elems;
   const int patch_floats = t.NI * img_floats;
   float* xs = lds;
   float* x2s = lds + patch_floats;
@@ -87,105 +95,141 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
   const int th = min(t.TH, g.Ho - ho0);
   const int band_pixels = th * g.Wo;
   const int khw = g.KH * g.KW;
-  const int ktot = g.C * khw;
 
-  int pixoff[PT_MAX], ppix[PT_MAX], pimg[PT_MAX];
-  bool pok[PT_MAX];
+  // a wave's PT tiles are consecutive: tile = wp * PT + i
+  int pixoff[PT];
 #pragma unroll
-  for (int i = 0; i < PT_MAX; ++i) {
-    const int tile = wp + t.WP * i;
+  for (int i = 0; i < PT; ++i) {
+    const int tile = wp * PT + i;
     const int img = tile / t.tiles_per_img, p = (tile % t.tiles_per_img) * MF + idx;
-    pok[i] = i < t.PT && img < t.NI && img0 + img < g.N && p < band_pixels;
-    const int hl = pok[i] ? p / g.Wo : 0, wo = pok[i] ? p % g.Wo : 0;
-    pixoff[i] = (pok[i] ? img : 0) * img_floats + hl * g.sh * t.PWP + wo * g.sw;
-    ppix[i] = p;
-    pimg[i] = img;
+    const bool ok = img < t.NI && img0 + img < g.N && p < band_pixels;
+    const int hl = ok ? p / g.Wo : 0, wo = ok ? p % g.Wo : 0;
+    pixoff[i] = (ok ? img : 0) * img_floats + hl * g.sh * t.PWP + wo * g.sw;
   }
-  Acc accm[PT_MAX], accv[PT_MAX];
+  Acc accm[PT], accv[PT];
 #pragma unroll
-  for (int i = 0; i < PT_MAX; ++i) accm[i] = accv[i] = Acc{};
+  for (int i = 0; i < PT; ++i) accm[i] = accv[i] = Acc{};
+
+  // patch offset of tap k = (c, r, q), chunk-relative: the same for every chunk
+  for (int k = threadIdx.x; k < t.kcpad_max; k += 256) {
+    const int c = k / khw, rq = k % khw;
+    kofs[k] = c < t.CC ? c * row_elems + (rq / g.KW) * t.PWP + (rq % g.KW) : 0;
+  }
 
   const int hi0 = ho0 * g.sh - g.ph;                       // (dilated) input row of patch row 0
   for (int c0 = 0; c0 < g.C; c0 += t.CC) {
     const int cc = min(t.CC, g.C - c0);
     const int kc = cc * khw;
     const int kcpad = (kc + KS * t.WK - 1) / (KS * t.WK) * (KS * t.WK);
-    __syncthreads();                                       // the previous chunk's operand reads are done
-    // ---- stage the input patch: x and clamp(x^2) (zero outside the image: padding is applied after the clamp)
-    const int row_elems = t.PH * t.PWP;
-    for (int e = threadIdx.x; e < t.NI * cc * row_elems; e += 256) {
-      const int img = e / (cc * row_elems), rem = e % (cc * row_elems);
-      const int c = rem / row_elems, rr = rem % row_elems;
-      const int py = rr / t.PWP, px = rr % t.PWP;
-      int hi = hi0 + py, wi = px - g.pw;
-      float v = 0.f, v2 = 0.f;
-      bool inside = img0 + img < g.N && hi >= 0 && wi >= 0;
-      if (MODE == 1) {                                     // dilated input: only multiples of the dilation carry a sample
-        inside = inside && hi % g.dh == 0 && wi % g.dw == 0;
-        hi /= g.dh;
-        wi /= g.dw;
-      }
-      if (inside && hi < g.H && wi < g.W) {
-        const int64_t src = ((static_cast<int64_t>(img0 + img) * g.C + c0 + c) * g.H + hi) * g.W + wi;
-        v = x[src];
-        v2 = MODE == 0 ? fmaxf(v * v, 1e-4f) : x_second[src];
-      }
-      const int dst = img * img_floats + c * row_elems + rr;
-      xs[dst] = v;
-      x2s[dst] = v2;
-    }
-    // ---- stage the weight tile k-major ([k][MF]: conflict-free A-operand reads); rows past O and k past the chunk are zero
-    for (int e = threadIdx.x; e < kcpad * MF; e += 256) {
-      const int o = e % MF, k = e / MF;
-      float a = 0.f, b = 0.f;
-      if (o0 + o < g.O && k < kc) {
-        int64_t src;
-        if (MODE == 0) {
-          src = static_cast<int64_t>(o0 + o) * ktot + c0 * khw + k;
-        } else {                                           // W^T flipped: row = the layer's input channel, k = (o', r, q)
-          const int oc = c0 + k / khw, rq = k % khw;
-          src = (static_cast<int64_t>(oc) * g.O + o0 + o) * khw + (khw - 1 - rq);
+    if (c0 > 0) __syncthreads();                           // the previous chunk's operand reads are done
+    // ---- the input patch, one (image, channel) plane per wave trip, a patch row per lane group: x and clamp(x^2)
+    //      (zero outside the image: padding is applied after the clamp); MODE 1: g and gvar, dilated
+    for (int rc = wave; rc < t.NI * cc; rc += 4) {
+      const int img = rc / cc, c = rc % cc;                // wave-uniform
+      const bool img_ok = img0 + img < g.N;
+      const int64_t plane = (static_cast<int64_t>(img_ok ? img0 + img : 0) * g.C + c0 + c) * g.H * g.W;
+      const float* src1 = x + plane;
+      const float* src2 = MODE == 1 ? x_second + plane : x;
+      float* d1 = xs + img * img_floats + c * row_elems;
+      float* d2 = x2s + img * img_floats + c * row_elems;
+      for (int px = lane; px < t.PWP; px += 64) {
+        int wi = px - g.pw;
+        bool col_ok = img_ok && wi >= 0;
+        if (MODE == 1 && g.dw != 1) {
+          col_ok = col_ok && wi % g.dw == 0;
+          wi /= g.dw;
         }
-        a = wmu[src];
-        b = ws2[src];
+        col_ok = col_ok && wi < g.W;
+        for (int py0 = 0; py0 < t.PH; py0 += 4) {
+          float v[4], v2[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            int hi = hi0 + py0 + u;
+            bool ok = col_ok && py0 + u < t.PH && hi >= 0;
+            if (MODE == 1 && g.dh != 1) {
+              ok = ok && hi % g.dh == 0;
+              hi /= g.dh;
+            }
+            ok = ok && hi < g.H;
+            v[u] = ok ? src1[hi * g.W + wi] : 0.f;
+            if (MODE == 0) v2[u] = ok ? fmaxf(v[u] * v[u], 1e-4f) : 0.f;
+            else v2[u] = ok ? src2[hi * g.W + wi] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (py0 + u < t.PH) {
+              d1[(py0 + u) * t.PWP + px] = v[u];
+              d2[(py0 + u) * t.PWP + px] = v2[u];
+            }
+          }
+        }
       }
-      wm[e] = a;
-      wsv[e] = b;
     }
-    for (int k = threadIdx.x; k < kcpad; k += 256) {
-      int off = 0;
-      if (k < kc) {
-        const int c = k / khw, rq = k % khw;
-        off = c * row_elems + (rq / g.KW) * t.PWP + (rq % g.KW);
+    // ---- the weight tile, k-major [k][MF] (conflict-free A-operand reads): aligned float4 copies of the pre-arranged
+    //      [k][rp] matrices; k past the chunk is zero
+    {
+      constexpr int Q = MF / 4;
+      const int64_t k_base = static_cast<int64_t>(c0) * khw;
+      for (int e = threadIdx.x; e < kcpad * Q; e += 256) {
+        const int k = e / Q, o4 = e % Q;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (k < kc) {
+          const int64_t src = (k_base + k) * g.rp + o0 + 4 * o4;
+          a = ld4(wt_mu + src);
+          b = ld4(wt_s2 + src);
+        }
+        st4(wm + k * MF + 4 * o4, a);
+        st4(wsv + k * MF + 4 * o4, b);
       }
-      kofs[k] = off;
     }
     __syncthreads();
     const int ksteps = kcpad / KS;
     const int ks0 = wk * (ksteps / t.WK), ks1 = ks0 + ksteps / t.WK;
-    for (int ks = ks0; ks < ks1; ++ks) {
-      const int kk = ks * KS + h;
-      const int ko = kofs[kk];
-      const float am = wm[kk * MF + idx], as = wsv[kk * MF + idx];
+    // operands of step ks + 1 are requested before the products of step ks are issued
+    int kk = ks0 * KS + h;
+    int ko = kofs[kk];
+    float am = wm[kk * MF + idx], as = wsv[kk * MF + idx];
+    float b[PT], b2[PT];
 #pragma unroll
-      for (int i = 0; i < PT_MAX; ++i) {
-        if (i < t.PT) {                                    // wave-uniform
-          const float b = xs[pixoff[i] + ko], b2 = x2s[pixoff[i] + ko];
-          accm[i] = M::run(am, b, accm[i]);
-          accv[i] = M::run(as, b2, accv[i]);
+    for (int i = 0; i < PT; ++i) {
+      b[i] = xs[pixoff[i] + ko];
+      b2[i] = x2s[pixoff[i] + ko];
+    }
+    for (int ks = ks0; ks < ks1; ++ks) {
+      const float cam = am, cas = as;
+      float cb[PT], cb2[PT];
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        cb[i] = b[i];
+        cb2[i] = b2[i];
+      }
+      if (ks + 1 < ks1) {
+        kk += KS;
+        ko = kofs[kk];
+        am = wm[kk * MF + idx];
+        as = wsv[kk * MF + idx];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+          b[i] = xs[pixoff[i] + ko];
+          b2[i] = x2s[pixoff[i] + ko];
         }
+      }
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        accm[i] = M::run(cam, cb[i], accm[i]);
+        accv[i] = M::run(cas, cb2[i], accv[i]);
       }
     }
   }
 
   // ---- k-split: waves wk > 0 hand their accumulators to wave wk = 0 of the same pixel-tile group through LDS
+  __syncthreads();
   if (t.WK > 1) {
-    __syncthreads();
-    float* red = lds;                                      // [wave][PT_MAX][2][REGS][64]
-    const int per_wave = PT_MAX * 2 * M::REGS * 64;
+    float* red = lds;                                      // [wave][PT][2][REGS][64]
+    constexpr int per_wave = PT * 2 * M::REGS * 64;
     if (wk > 0) {
 #pragma unroll
-      for (int i = 0; i < PT_MAX; ++i)
+      for (int i = 0; i < PT; ++i)
 #pragma unroll
         for (int r = 0; r < M::REGS; ++r) {
           red[wave * per_wave + ((i * 2 + 0) * M::REGS + r) * 64 + lane] = accm[i][r];
@@ -197,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
       for (int s = 1; s < t.WK; ++s) {                     // fixed order
         const int src = (wp + s * t.WP) * per_wave;
 #pragma unroll
-        for (int i = 0; i < PT_MAX; ++i)
+        for (int i = 0; i < PT; ++i)
 #pragma unroll
           for (int r = 0; r < M::REGS; ++r) {
             accm[i][r] += red[src + ((i * 2 + 0) * M::REGS + r) * 64 + lane];
@@ -205,39 +249,129 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_fwd_kernel(
           }
       }
     }
+    __syncthreads();
   }
   if (wk != 0) return;
 
-  // ---- epilogue: bias terms, noise, output + total variance
+  // ---- epilogue.  Each tile goes through a per-wave LDS tile [MF channels][MF pixels] so that a lane ends up with 4
+  // consecutive pixels of one channel: one Philox call per float4, 16-byte loads / stores.  Needs the float4 groups of
+  // the flat output aligned with the tiles (Ho Wo and the band size multiples of 4); otherwise element by element.
   const int64_t howo = static_cast<int64_t>(g.Ho) * g.Wo;
+  const bool vec = (howo & 3) == 0 && ((t.TH * g.Wo) & 3) == 0;
+  float* tm = lds + wave * 2 * MF * RS;
+  float* tv = tm + MF * RS;
+  constexpr int Q = MF / 4;                                // float4 groups per tile row
+  // a rolled loop over the wave's tiles (its body with the Philox code is too large to replicate PT times: the compiler
+  // then gives up unrolling and puts the accumulators into scratch): tile i's accumulators are picked by uniform branches
+#pragma unroll 1
+  for (int i = 0; i < PT; ++i) {
+    const int tile = wp * PT + i;
+    const int img = tile / t.tiles_per_img, p0 = (tile % t.tiles_per_img) * MF;
+    if (img >= t.NI || img0 + img >= g.N || p0 >= band_pixels) continue;          // wave-uniform
+    const int64_t base = static_cast<int64_t>(img0 + img) * g.O * howo + static_cast<int64_t>(ho0) * g.Wo + p0;
+    Acc cm = accm[0], cv = accv[0];
 #pragma unroll
-  for (int i = 0; i < PT_MAX; ++i) {
-    if (!pok[i]) continue;
-    const int64_t base = static_cast<int64_t>(img0 + pimg[i]) * g.O * howo + static_cast<int64_t>(ho0) * g.Wo + ppix[i];
-#pragma unroll
-    for (int r = 0; r < M::REGS; ++r) {
-      const int o = o0 + M::row(r, h);
-      if (o < g.O) {
-        const int64_t e = base + o * howo;
-        if (MODE == 1) {                                   // bmu = the layer's input x: d clamp(x^2, 1e-4) / dx = 2 x [x^2 >= 1e-4]
-          const float xv = bmu[e];
-          out[e] = accm[i][r] + (xv * xv >= 1e-4f ? 2.0f * xv * accv[i][r] : 0.f);
-          continue;
-        }
-        const float mean = accm[i][r] + (bmu ? bmu[o] : 0.f);
-        const float var = accv[i][r] + (bvar ? bvar[o] : 0.f);
-        float z;
-        if (RNG) {
-          const f32x4 zz = philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag);
-          const int c = static_cast<int>(e & 3);
-          z = c == 0 ? zz.x : c == 1 ? zz.y : c == 2 ? zz.z : zz.w;
-        } else {
-          z = eps[e];
-        }
-        out[e] = mean + __builtin_sqrtf(var) * z;
-        var_out[e] = var;
+    for (int j = 1; j < PT; ++j) {
+      if (j == i) {
+        cm = accm[j];
+        cv = accv[j];
       }
     }
+    if (vec) {
+#pragma unroll
+      for (int r = 0; r < M::REGS; ++r) {
+        tm[M::row(r, h) * RS + idx] = cm[r];
+        tv[M::row(r, h) * RS + idx] = cv[r];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
+#pragma unroll
+      for (int pass = 0; pass < MF * Q / 64; ++pass) {
+        const int ch = pass * (64 / Q) + lane / Q, p4 = lane % Q;
+        const int o = o0 + ch;
+        if (o < g.O && p0 + 4 * p4 < band_pixels) {
+          const f32x4 m4 = ld4(tm + ch * RS + 4 * p4), v4 = ld4(tv + ch * RS + 4 * p4);
+          const int64_t e = base + o * howo + 4 * p4;
+          if (MODE == 1) {                                 // bmu = the layer's input x: d clamp(x^2, 1e-4) / dx = 2 x [x^2 >= 1e-4]
+            const f32x4 xv = ld4(bmu + e);
+            f32x4 d;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[c] = m4[c] + (xv[c] * xv[c] >= 1e-4f ? 2.0f * xv[c] * v4[c] : 0.f);
+            st4(out + e, d);
+          } else {
+            const float bm = bmu ? bmu[o] : 0.f, bv = bvar ? bvar[o] : 0.f;
+            const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag) : ld4(eps + e);
+            f32x4 res, var;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              var[c] = v4[c] + bv;
+              res[c] = (m4[c] + bm) + __builtin_sqrtf(var[c]) * z[c];
+            }
+            st4(out + e, res);
+            st4(var_out + e, var);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next tile overwrites the LDS tile
+    } else {
+      const int p = p0 + idx;
+      if (p < band_pixels) {
+#pragma unroll
+        for (int r = 0; r < M::REGS; ++r) {
+          const int o = o0 + M::row(r, h);
+          if (o < g.O) {
+            const int64_t e = base + o * howo + idx;
+            if (MODE == 1) {
+              const float xv = bmu[e];
+              out[e] = cm[r] + (xv * xv >= 1e-4f ? 2.0f * xv * cv[r] : 0.f);
+            } else {
+              const float mean = cm[r] + (bmu ? bmu[o] : 0.f);
+              const float var = cv[r] + (bvar ? bvar[o] : 0.f);
+              float z;
+              if (RNG) {
+                const f32x4 zz = philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag);
+                const int c = static_cast<int>(e & 3);
+                z = c == 0 ? zz.x : c == 1 ? zz.y : c == 2 ? zz.z : zz.w;
+              } else {
+                z = eps[e];
+              }
+              out[e] = mean + __builtin_sqrtf(var) * z;
+              var_out[e] = var;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Once per weight version: sigma^2 = clamp(softplus(rho)^2, 1e-4), its rho-derivative, and both weight matrices in the
+// layouts the kernels stage from.  wbuf (zero-initialised by the caller once; the padding is never written):
+//   [0]  WT_mu [ktot][op]      [1]  WT_s2 [ktot][op]           k = (c, r, q), op = O padded to 32    (forward)
+//   [2]  WB_mu [O khw][cp]     [3]  WB_s2 [O khw][cp]          k' = (o, flipped tap), cp = C padded to 32 (input gradient)
+//   [4]  DS2   [O][ktot]       [sigma^2 >= 1e-4] 2 sigma sigmoid(rho)                                 (weight gradient)
+__global__ __launch_bounds__(kBlock) void conv_lrt_prep_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
+                                                               int O, int C, int khw, int op, int cp, float* __restrict__ wbuf) {
+  const int ktot = C * khw;
+  const int64_t n = static_cast<int64_t>(O) * ktot;
+  float* wt_mu = wbuf;
+  float* wt_s2 = wt_mu + static_cast<int64_t>(ktot) * op;
+  float* wb_mu = wt_s2 + static_cast<int64_t>(ktot) * op;
+  float* wb_s2 = wb_mu + static_cast<int64_t>(O) * khw * cp;
+  float* ds2 = wb_s2 + static_cast<int64_t>(O) * khw * cp;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int o = static_cast<int>(i / ktot), k = static_cast<int>(i % ktot);
+    const int c = k / khw, rq = k % khw;
+    const float mu = w_mu[i];
+    const SoftplusSigmoid ss = softplus_sigmoid(w_rho[i]);
+    const float s2 = ss.sp * ss.sp;
+    const float s2c = fmaxf(s2, 1e-4f);
+    wt_mu[static_cast<int64_t>(k) * op + o] = mu;
+    wt_s2[static_cast<int64_t>(k) * op + o] = s2c;
+    const int64_t kb = static_cast<int64_t>(o) * khw + (khw - 1 - rq);
+    wb_mu[kb * cp + c] = mu;
+    wb_s2[kb * cp + c] = s2c;
+    ds2[i] = s2 >= 1e-4f ? 2.0f * ss.sp * ss.sg : 0.f;
   }
 }
 
@@ -249,51 +383,63 @@ namespace {
 
 struct FwdPlan {
   ConvTile t;
-  int mf;
+  int mf, pt;
   dim3 grid;
   size_t lds;
 };
 
+static inline int pad32(int v) { return (v + 31) / 32 * 32; }
+
 // Tile choice: enough workgroups to fill 256 CUs (>= 2 per CU where the layer allows), LDS <= 64 KB per workgroup
-// (two resident), <= PT_MAX pixel tiles per wave.
+// (two resident), 1 / 2 / 4 / 8 pixel tiles per wave.
 static bool plan_fwd(const ConvGeo& g, FwdPlan& p) {
   const int mf = g.O <= 16 ? 16 : 32;
   const int pt_max = mf == 16 ? 8 : 4;
   const int ks = mf == 32 ? 2 : 4;
+  const int regs = mf == 32 ? 16 : 4;
   const int khw = g.KH * g.KW;
-  const int64_t howo = static_cast<int64_t>(g.Ho) * g.Wo;
   ConvTile best{};
+  int best_pt = 0;
+  size_t best_lds = 0;
   bool found = false;
   double best_score = -1.0;
   const int otiles = (g.O + mf - 1) / mf;
+  const size_t epi = sizeof(float) * 4ull * 2 * mf * (mf + 4);
   for (int wk = 1; wk <= 4; wk *= 2) {
     const int wpn = 4 / wk;
     for (int th = 1; th <= g.Ho; ++th) {
-      if (th != g.Ho && th != 1 && th != 2 && th != 4 && th != 8 && th != 16 && th != 32) continue;
+      if (th != g.Ho && (th & (th - 1)) != 0) continue;   // whole images or power-of-two bands
       const int bands = (g.Ho + th - 1) / th;
       const int tiles_per_img = static_cast<int>((static_cast<int64_t>(th) * g.Wo + mf - 1) / mf);
       for (int ni = 1; ni <= 8; ni *= 2) {
         if (ni > 1 && th != g.Ho) continue;               // several images per workgroup only for whole (small) images
         const int tiles = ni * tiles_per_img;
-        const int pt = (tiles + wpn - 1) / wpn;
+        int pt = 1;
+        while (pt * wpn < tiles) pt *= 2;
         if (pt > pt_max) continue;
         const int ph = (th - 1) * g.sh + g.KH, pwp = (g.Wo - 1) * g.sw + g.KW;
         for (int cc = g.C; cc >= 1; cc = (cc > 8 ? cc / 2 : cc - 1)) {
           const int kc = cc * khw;
           const int kcpad = (kc + ks * wk - 1) / (ks * wk) * (ks * wk);
           const size_t lds = sizeof(float) * (2ull * ni * cc * ph * pwp + 2ull * kcpad * mf + kcpad);
-          const size_t red = wk > 1 ? sizeof(float) * 4ull * pt_max * 2 * (mf == 32 ? 16 : 4) * 64 : 0;
-          if (std::max(lds, red) > 64 * 1024) continue;
+          const size_t red = wk > 1 ? sizeof(float) * 4ull * pt * 2 * regs * 64 : 0;
+          const size_t need = std::max(std::max(lds, red), epi);
+          if (need > 64 * 1024) continue;
           const int64_t wgs = static_cast<int64_t>((g.N + ni - 1) / ni) * bands * otiles;
-          // score: chip fill first (up to 4 workgroups per CU), then fewer chunks / less halo, then no k-split
+          // score: chip fill first (up to 2 workgroups per CU), then idle waves / partial tiles, halo, chunks, k-split;
+          // re-staging the weight tile per workgroup costs more the fewer products a workgroup does per chunk
           const double fill = std::min(1.0, static_cast<double>(wgs) / 512.0);
-          const double util = static_cast<double>(tiles) / (pt * wpn);               // idle waves / partial tiles
+          const double util = static_cast<double>(tiles) / (pt * wpn);
           const double halo = static_cast<double>(th) / ph;
           const double chunks = 1.0 / ((g.C + cc - 1) / cc);
-          const double score = fill * util * (0.6 + 0.4 * halo) * (0.8 + 0.2 * chunks) * (wk == 1 ? 1.0 : 0.9);
+          const double wreuse = std::min(1.0, static_cast<double>(tiles) / 8.0);
+          const double score = (0.25 + 0.75 * fill) * util * (0.6 + 0.4 * halo) * (0.8 + 0.2 * chunks) * (0.5 + 0.5 * wreuse) *
+                               (wk == 1 ? 1.0 : 0.9);
           if (score > best_score) {
             best_score = score;
-            best = ConvTile{ni, th, bands, cc, ph, pwp, wpn, wk, pt, tiles_per_img, kcpad};
+            best = ConvTile{ni, th, bands, cc, ph, pwp, wpn, wk, tiles_per_img, kcpad};
+            best_pt = pt;
+            best_lds = need;
             found = true;
           }
           break;                                            // the largest chunk that fits is the one to take
@@ -301,34 +447,61 @@ static bool plan_fwd(const ConvGeo& g, FwdPlan& p) {
       }
     }
   }
-  (void)howo;
   if (!found) return false;
   p.t = best;
   p.mf = mf;
+  p.pt = best_pt;
   p.grid = dim3(static_cast<unsigned>(((g.N + best.NI - 1) / best.NI) * best.bands), static_cast<unsigned>(otiles));
-  const size_t lds = sizeof(float) * (2ull * best.NI * best.CC * best.PH * best.PWP + 2ull * best.kcpad_max * mf + best.kcpad_max);
-  const size_t red = best.WK > 1 ? sizeof(float) * 4ull * pt_max * 2 * (mf == 32 ? 16 : 4) * 64 : 0;
-  p.lds = std::max(lds, red);
+  p.lds = best_lds;
   return true;
 }
-
-}  // namespace
 
 static bool layer_geo(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw, ConvGeo& g) {
   if (N < 1 || C < 1 || H < 1 || W < 1 || O < 1 || KH < 1 || KW < 1 || KH > 7 || KW > 7 || sh < 1 || sw < 1 || ph < 0 || pw < 0)
     return false;
   const int Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
   if (Ho < 1 || Wo < 1) return false;
-  g = ConvGeo{N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo, 1, 1};
+  g = ConvGeo{N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo, 1, 1, pad32(O)};
   return true;
 }
 
 // the input-gradient pass as a convolution: channels O -> C, g dilated by the stride, padding K - 1 - p, stride 1
 static bool data_grad_geo(const ConvGeo& l, ConvGeo& g) {
   if (l.ph > l.KH - 1 || l.pw > l.KW - 1) return false;
-  g = ConvGeo{l.N, l.O, l.Ho, l.Wo, l.C, l.KH, l.KW, 1, 1, l.KH - 1 - l.ph, l.KW - 1 - l.pw, l.H, l.W, l.sh, l.sw};
+  g = ConvGeo{l.N, l.O, l.Ho, l.Wo, l.C, l.KH, l.KW, 1, 1, l.KH - 1 - l.ph, l.KW - 1 - l.pw, l.H, l.W, l.sh, l.sw, pad32(l.C)};
   return true;
 }
+
+struct WBuf {
+  const float *wt_mu, *wt_s2, *wb_mu, *wb_s2, *ds2;
+};
+static WBuf wbuf_parts(const float* wbuf, int O, int C, int khw) {
+  const int64_t ktot = static_cast<int64_t>(C) * khw, op = pad32(O), cp = pad32(C);
+  WBuf b;
+  b.wt_mu = wbuf;
+  b.wt_s2 = b.wt_mu + ktot * op;
+  b.wb_mu = b.wt_s2 + ktot * op;
+  b.wb_s2 = b.wb_mu + static_cast<int64_t>(O) * khw * cp;
+  b.ds2 = b.wb_s2 + static_cast<int64_t>(O) * khw * cp;
+  return b;
+}
+
+template <int MODE, bool RNG>
+static void launch_conv(const FwdPlan& p, hipStream_t s, const float* a, const float* a2, const float* wm, const float* ws,
+                        const float* b1, const float* b2, const float* eps, uint64_t seed, uint64_t stream_id, float* out,
+                        float* var_out, const ConvGeo& g) {
+#define BDE_CONV_CASE(MF_, PT_)                                                                                         \
+  if (p.mf == MF_ && p.pt == PT_) {                                                                                    \
+    hipLaunchKernelGGL((conv_lrt_kernel<MF_, PT_, RNG, MODE>), p.grid, dim3(256), p.lds, s, a, a2, wm, ws, b1, b2, eps, seed, \
+                       stream_id, out, var_out, g, p.t);                                                               \
+    return;                                                                                                            \
+  }
+  BDE_CONV_CASE(16, 1) BDE_CONV_CASE(16, 2) BDE_CONV_CASE(16, 4) BDE_CONV_CASE(16, 8)
+  BDE_CONV_CASE(32, 1) BDE_CONV_CASE(32, 2) BDE_CONV_CASE(32, 4)
+#undef BDE_CONV_CASE
+}
+
+}  // namespace
 
 extern "C" int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw) {
   ConvGeo g, d;
@@ -336,45 +509,50 @@ extern "C" int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH,
   return layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) && plan_fwd(g, p) && data_grad_geo(g, d) && plan_fwd(d, p) ? 1 : 0;
 }
 
-extern "C" int bde_conv_lrt_fwd(const float* x, const float* w_mu, const float* w_s2, const float* b_mu, const float* b_var,
-                                const float* eps, uint64_t seed, uint64_t stream_id, float* out, float* var_out, int N,
-                                int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
-  ConvGeo g;
-  FwdPlan p;
-  if (!x || !w_mu || !w_s2 || !out || !var_out || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) || !plan_fwd(g, p))
-    return BDE_ERR_INVALID;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const float* none = nullptr;
-#define BDE_CONV_LAUNCH(MF_, PT_, RNG_)                                                                                  \
-  hipLaunchKernelGGL((conv_lrt_fwd_kernel<MF_, PT_, RNG_, 0>), p.grid, dim3(256), p.lds, s, x, none, w_mu, w_s2, b_mu, b_var, eps, \
-                     seed, stream_id, out, var_out, g, p.t)
-  if (p.mf == 16) { if (eps) BDE_CONV_LAUNCH(16, 8, false); else BDE_CONV_LAUNCH(16, 8, true); }
-  else { if (eps) BDE_CONV_LAUNCH(32, 4, false); else BDE_CONV_LAUNCH(32, 4, true); }
-#undef BDE_CONV_LAUNCH
+extern "C" size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW) {
+  if (O < 1 || C < 1 || KH < 1 || KW < 1) return 0;
+  const size_t khw = static_cast<size_t>(KH) * KW, ktot = khw * C;
+  return 2 * ktot * pad32(O) + 2 * static_cast<size_t>(O) * khw * pad32(C) + static_cast<size_t>(O) * ktot;
+}
+
+extern "C" int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, int O, int C, int KH, int KW, float* wbuf, void* stream) {
+  if (!w_mu || !w_rho || !wbuf || !aligned16(wbuf) || bde_conv_lrt_prep_floats(O, C, KH, KW) == 0) return BDE_ERR_INVALID;
+  const int64_t n = static_cast<int64_t>(O) * C * KH * KW;
+  hipLaunchKernelGGL(conv_lrt_prep_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w_mu, w_rho, O,
+                     C, KH * KW, pad32(O), pad32(C), wbuf);
   return to_err(hipGetLastError());
 }
 
-extern "C" int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, const float* w_mu, const float* w_s2, const float* x,
-                                     float* g_x, int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph,
-                                     int pw, void* stream) {
+extern "C" int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, const float* b_var, const float* eps,
+                                uint64_t seed, uint64_t stream_id, float* out, float* var_out, int N, int C, int H, int W,
+                                int O, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
+  ConvGeo g;
+  FwdPlan p;
+  if (!x || !wbuf || !out || !var_out || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) || !plan_fwd(g, p))
+    return BDE_ERR_INVALID;
+  if (!aligned16(wbuf) || !aligned16(out) || !aligned16(var_out) || (eps && !aligned16(eps))) return BDE_ERR_INVALID;
+  const WBuf w = wbuf_parts(wbuf, O, C, KH * KW);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (eps) launch_conv<0, false>(p, s, x, nullptr, w.wt_mu, w.wt_s2, b_mu, b_var, eps, seed, stream_id, out, var_out, g);
+  else launch_conv<0, true>(p, s, x, nullptr, w.wt_mu, w.wt_s2, b_mu, b_var, eps, seed, stream_id, out, var_out, g);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, const float* wbuf, const float* x, float* g_x,
+                                     int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw,
+                                     void* stream) {
   ConvGeo l, g;
   FwdPlan p;
-  if (!g_out || !g_var || !w_mu || !w_s2 || !x || !g_x || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, l) ||
-      !data_grad_geo(l, g) || !plan_fwd(g, p))
+  if (!g_out || !g_var || !wbuf || !x || !g_x || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, l) || !data_grad_geo(l, g) ||
+      !plan_fwd(g, p))
     return BDE_ERR_INVALID;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const float* none = nullptr;
-  float* no_out = nullptr;
-  if (p.mf == 16)
-    hipLaunchKernelGGL((conv_lrt_fwd_kernel<16, 8, false, 1>), p.grid, dim3(256), p.lds, s, g_out, g_var, w_mu, w_s2, x, none, none,
-                       uint64_t{0}, uint64_t{0}, g_x, no_out, g, p.t);
-  else
-    hipLaunchKernelGGL((conv_lrt_fwd_kernel<32, 4, false, 1>), p.grid, dim3(256), p.lds, s, g_out, g_var, w_mu, w_s2, x, none, none,
-                       uint64_t{0}, uint64_t{0}, g_x, no_out, g, p.t);
+  if (!aligned16(wbuf) || !aligned16(x) || !aligned16(g_x)) return BDE_ERR_INVALID;
+  const WBuf w = wbuf_parts(wbuf, O, C, KH * KW);
+  launch_conv<1, false>(p, static_cast<hipStream_t>(stream), g_out, g_var, w.wb_mu, w.wb_s2, x, nullptr, nullptr, 0, 0, g_x, nullptr, g);
   return to_err(hipGetLastError());
 }
 
 extern "C" __attribute__((visibility("hidden"))) int bde_internal_load_conv_lrt(void) {
   hipFuncAttributes attr;
-  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::conv_lrt_fwd_kernel<32, 4, true, 0>)));
+  return bde::to_err(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&bde::conv_lrt_kernel<32, 4, true, 0>)));
 }

@@ -89,30 +89,54 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     const int th = min(t.TH, geo.Ho - ho0);
     const int hi0 = ho0 * geo.sh - geo.ph;
     __syncthreads();
-    for (int e = threadIdx.x; e < t.NI * cc * row_elems; e += 256) {
-      const int img = e / (cc * row_elems), rem = e % (cc * row_elems);
-      const int c = rem / row_elems, rr = rem % row_elems;
-      const int hi = hi0 + rr / t.PWP, wi = rr % t.PWP - geo.pw;
-      float v = 0.f, v2 = 0.f;
-      if (img0 + img < geo.N && hi >= 0 && hi < geo.H && wi >= 0 && wi < geo.W) {
-        v = x[((static_cast<int64_t>(img0 + img) * geo.C + c_lo + c) * geo.H + hi) * geo.W + wi];
-        v2 = fmaxf(v * v, 1e-4f);
+    // the input patch of the block's channels: one (image, channel) plane per wave trip, lanes along a patch row
+    for (int rc = wave; rc < t.NI * cc; rc += 4) {
+      const int img = rc / cc, c = rc % cc;                    // wave-uniform
+      const bool img_ok = img0 + img < geo.N;
+      const float* src = x + (static_cast<int64_t>(img_ok ? img0 + img : 0) * geo.C + c_lo + c) * geo.H * geo.W;
+      float* d1 = xs + img * img_floats + c * row_elems;
+      float* d2 = x2s + img * img_floats + c * row_elems;
+      for (int px = lane; px < t.PWP; px += 64) {
+        const int wi = px - geo.pw;
+        const bool col_ok = img_ok && wi >= 0 && wi < geo.W;
+        for (int py0 = 0; py0 < t.PH; py0 += 4) {
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int hi = hi0 + py0 + u;
+            const bool ok = col_ok && py0 + u < t.PH && hi >= 0 && hi < geo.H;
+            v[u] = ok ? src[hi * geo.W + wi] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (py0 + u < t.PH) {
+              const int hi = hi0 + py0 + u;
+              const bool ok = col_ok && hi >= 0 && hi < geo.H;
+              d1[(py0 + u) * t.PWP + px] = v[u];
+              d2[(py0 + u) * t.PWP + px] = ok ? fmaxf(v[u] * v[u], 1e-4f) : 0.f;
+            }
+          }
+        }
       }
-      xs[img * img_floats + rem] = v;
-      x2s[img * img_floats + rem] = v2;
     }
-    for (int e = threadIdx.x; e < MF * t.npix; e += 256) {
-      const int o = e / t.npix, pp = e % t.npix;
-      const int img = pp / bpi, p = pp % bpi;
-      const int hl = p / geo.Wo, wo = p % geo.Wo;
-      float a = 0.f, b = 0.f;
-      if (img < t.NI && img0 + img < geo.N && hl < th && o0 + o < geo.O) {
-        const int64_t src = (static_cast<int64_t>(img0 + img) * geo.O + o0 + o) * howo + static_cast<int64_t>(ho0 + hl) * geo.Wo + wo;
-        a = g[src];
-        b = gvar[src];
+    // the block's rows of g and gvar, one (row, image) strip per wave trip (contiguous pixels of a band), and the
+    // pixel -> patch offset table
+    for (int ro = wave; ro < MF * t.NI; ro += 4) {
+      const int o = ro / t.NI, img = ro % t.NI;                // wave-uniform
+      const bool ok_row = img0 + img < geo.N && o0 + o < geo.O;
+      const int64_t src0 = (static_cast<int64_t>(ok_row ? img0 + img : 0) * geo.O + (ok_row ? o0 + o : 0)) * howo +
+                           static_cast<int64_t>(ho0) * geo.Wo;
+      for (int p = lane; p < bpi; p += 64) {
+        const bool ok = ok_row && p < th * geo.Wo;
+        gs[o * t.GP + img * bpi + p] = ok ? g[src0 + p] : 0.f;
+        gvs[o * t.GP + img * bpi + p] = ok ? gvar[src0 + p] : 0.f;
       }
-      gs[o * t.GP + pp] = a;
-      gvs[o * t.GP + pp] = b;
+    }
+    const int padn = t.npix - t.NI * bpi;                      // the padding behind the last image's strip
+    for (int e = threadIdx.x; e < MF * padn; e += 256) {
+      const int o = e / padn, pp = t.NI * bpi + e % padn;
+      gs[o * t.GP + pp] = 0.f;
+      gvs[o * t.GP + pp] = 0.f;
     }
     for (int pp = threadIdx.x; pp < t.npix; pp += 256) {
       const int img = pp / bpi, p = pp % bpi;

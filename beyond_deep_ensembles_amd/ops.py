@@ -463,22 +463,33 @@ class HipOps:
         return c == c2 and bool(self.lib.bde_conv_lrt_supported(n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0],
                                                                  padding[1]))
 
-    @_on_device_of
-    def conv_lrt_fwd(self, x, w_mu, w_s2, b_mu, b_var, stride, padding, out, var_out, eps=None, seed=0, stream_id=0):
-        """BBBConv2d forward (bbb_layers.py:146-154) in one launch; all tensors contiguous fp32 NCHW / OIHW."""
-        n, c, h, w = x.shape
-        o, _, kh, kw = w_mu.shape
-        _check(self.lib.bde_conv_lrt_fwd(_ptr(x, "x"), _ptr(w_mu), _ptr(w_s2), _ptr(b_mu), _ptr(b_var), _ptr(eps), seed,
-                                         stream_id, _ptr(out), _ptr(var_out), n, c, h, w, o, kh, kw, stride[0], stride[1],
-                                         padding[0], padding[1], _stream()), "bde_conv_lrt_fwd")
+    def conv_lrt_wbuf(self, w_shape, device) -> torch.Tensor:
+        """The zero-initialised buffer bde_conv_lrt_prep fills (sigma^2 and the weight matrices in staging order)."""
+        o, c, kh, kw = (int(v) for v in w_shape)
+        return torch.zeros(int(self.lib.bde_conv_lrt_prep_floats(o, c, kh, kw)), dtype=torch.float32, device=device)
 
     @_on_device_of
-    def conv_lrt_bwd_data(self, g_out, g_var, w_mu, w_s2, x, g_x, stride, padding):
+    def conv_lrt_prep(self, w_mu, w_rho, wbuf):
+        """Once per weight version: sigma^2, its rho-derivative and the re-arranged weight matrices into ``wbuf``."""
+        o, c, kh, kw = w_mu.shape
+        _check(self.lib.bde_conv_lrt_prep(_ptr(w_mu, "w_mu"), _ptr(w_rho), o, c, kh, kw, _ptr(wbuf), _stream()), "bde_conv_lrt_prep")
+
+    @_on_device_of
+    def conv_lrt_fwd(self, x, wbuf, w_shape, b_mu, b_var, stride, padding, out, var_out, eps=None, seed=0, stream_id=0):
+        """BBBConv2d forward (bbb_layers.py:146-154) in one launch; all tensors contiguous fp32 NCHW."""
+        n, c, h, w = x.shape
+        o, _, kh, kw = w_shape
+        _check(self.lib.bde_conv_lrt_fwd(_ptr(x, "x"), _ptr(wbuf), _ptr(b_mu), _ptr(b_var), _ptr(eps), seed, stream_id,
+                                         _ptr(out), _ptr(var_out), n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0],
+                                         padding[1], _stream()), "bde_conv_lrt_fwd")
+
+    @_on_device_of
+    def conv_lrt_bwd_data(self, g_out, g_var, wbuf, w_shape, x, g_x, stride, padding):
         """g_x of BBBConv2d: both transposed convolutions + the clamp's derivative in one launch."""
         n, c, h, w = x.shape
-        o, _, kh, kw = w_mu.shape
-        _check(self.lib.bde_conv_lrt_bwd_data(_ptr(g_out, "g_out"), _ptr(g_var), _ptr(w_mu), _ptr(w_s2), _ptr(x), _ptr(g_x), n, c,
-                                              h, w, o, kh, kw, stride[0], stride[1], padding[0], padding[1], _stream()),
+        o, _, kh, kw = w_shape
+        _check(self.lib.bde_conv_lrt_bwd_data(_ptr(g_out, "g_out"), _ptr(g_var), _ptr(wbuf), _ptr(x), _ptr(g_x), n, c, h, w, o,
+                                              kh, kw, stride[0], stride[1], padding[0], padding[1], _stream()),
                "bde_conv_lrt_bwd_data")
 
     @_on_device_of

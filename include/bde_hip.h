@@ -347,33 +347,40 @@ int bde_local_reparam_bwd(const float* g, const float* var, const float* eps, ui
 int bde_var_operand_fwd(const float* v, int mode, float* out, int64_t n, void* stream);
 int bde_var_operand_bwd(const float* g, const float* v, int mode, float* gv, int64_t n, void* stream);
 
-/* The whole local-reparameterisation forward of a mean-field CONVOLUTION layer (BBBConv2d, bbb_layers.py:146-154) as
- * ONE kernel: both convolutions of lines 146-147 -- conv2d(x, W_mu, b_mu) and conv2d(clamp(x^2, 1e-4), w_s2, b_var) --
- * as one implicit GEMM with two accumulators per output tile over the same staged input windows (zero padding applied
- * after the clamp, as F.conv2d pads the clamped tensor), then out = mean + sqrt(var) * eps (lines 148-154) in the
- * epilogue.  x [N, C, H, W], w_mu / w_s2 [O, C, KH, KW] (w_s2 = clamp(softplus(W_rho)^2, 1e-4): bde_var_operand_fwd
- * mode 1, once per weight version), b_mu / b_var [O] or NULL (b_var = softplus(b_rho)^2, NOT clamped: line 147),
+/* The local-reparameterisation CONVOLUTION layer (BBBConv2d, bbb_layers.py:146-154), forward and backward.
+ *
+ * bde_conv_lrt_prep -- once per weight VERSION (the weights change at base_optimizer.step(); a BBB step runs mc_samples
+ * forward / backward passes per version, bbb.py:63-67): sigma^2 = clamp(softplus(W_rho)^2, 1e-4), its rho-derivative,
+ * and both weight matrices re-arranged the way the kernels stage them (k-major, output channels padded to 32, for the
+ * forward; transposed and flipped for the input gradient).  wbuf: bde_conv_lrt_prep_floats() floats, 16-byte aligned,
+ * ZERO-INITIALISED by the caller once (the padding is never written).
+ *
+ * bde_conv_lrt_fwd -- both convolutions of lines 146-147, conv2d(x, W_mu, b_mu) and conv2d(clamp(x^2, 1e-4), sigma^2,
+ * b_var), as ONE implicit GEMM with two accumulators per output tile over the same staged input windows (zero padding
+ * applied after the clamp, as F.conv2d pads the clamped tensor), then out = mean + sqrt(var) * eps (lines 148-154) in
+ * the epilogue.  x [N, C, H, W], b_mu / b_var [O] or NULL (b_var = softplus(b_rho)^2, NOT clamped: line 147),
  * out / var_out [N, O, Ho, Wo] (var_out = the total activation variance, which the backward pass needs); all fp32,
- * contiguous NCHW.  eps [N, O, Ho, Wo] or NULL = Philox(seed, stream_id) with the element numbering of
- * bde_local_reparam_fwd over the flat output (so bde_local_reparam_bwd regenerates the same noise).
- * bde_conv_lrt_supported: 1 when a tiling exists (kernel <= 7 x 7, stride / padding per axis, no dilation / groups). */
-int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w);
-int bde_conv_lrt_fwd(const float* x, const float* w_mu, const float* w_s2, const float* b_mu, const float* b_var,
-                     const float* eps, uint64_t seed, uint64_t stream_id, float* out, float* var_out, int N, int C, int H,
-                     int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, void* stream);
-
-/* Backward of that layer (the autograd graph of bbb_layers.py:146-154) given g = dL/d out and
- * g_var = g eps / (2 sqrt(var)) (bde_local_reparam_bwd on g, var_out and the forward's noise):
- *   bde_conv_lrt_bwd_data:   g_x = convT(g, W_mu) + 2 x [x^2 >= 1e-4] convT(g_var, w_s2) -- the same dual-accumulator
- *                            implicit GEMM as the forward over g / g_var dilated by the stride, weights transposed and
- *                            flipped while staging, the clamp's derivative in the epilogue;
+ * contiguous NCHW, 16-byte aligned.  eps [N, O, Ho, Wo] or NULL = Philox(seed, stream_id) with the element numbering
+ * of bde_local_reparam_fwd over the flat output (so bde_local_reparam_bwd regenerates the same noise).
+ *
+ * Backward, given g = dL/d out and g_var = g eps / (2 sqrt(var)) (bde_local_reparam_bwd on g, var_out and the noise):
+ *   bde_conv_lrt_bwd_data:   g_x = convT(g, W_mu) + 2 x [x^2 >= 1e-4] convT(g_var, sigma^2) -- the same dual-accumulator
+ *                            implicit GEMM over g / g_var dilated by the stride, the clamp's derivative in the epilogue;
  *   bde_conv_lrt_bwd_weight: g_wmu = corr(x, g), g_wrho = corr(clamp(x^2), g_var) * [sigma^2 >= 1e-4] 2 sigma sigmoid(rho):
  *                            dual-accumulator implicit GEMM reducing over the output pixels, per-share partial blocks in
  *                            `ws` (bde_conv_lrt_bwd_weight_ws_bytes) summed in a fixed order by a finish pass.
- * The bias gradients are plain channel sums of g and g_var (callers: torch.sum / bde_var_operand_bwd mode 2). */
-int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, const float* w_mu, const float* w_s2, const float* x,
-                          float* g_x, int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w,
-                          int pad_h, int pad_w, void* stream);
+ * The bias gradients are plain channel sums of g and g_var (callers: torch.sum / bde_var_operand_bwd mode 2).
+ *
+ * bde_conv_lrt_supported: 1 when tilings exist for the layer and its input gradient (kernel <= 7 x 7, stride / padding
+ * per axis with padding <= kernel - 1, no dilation / groups). */
+int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w);
+size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW);
+int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, int O, int C, int KH, int KW, float* wbuf, void* stream);
+int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, const float* b_var, const float* eps, uint64_t seed,
+                     uint64_t stream_id, float* out, float* var_out, int N, int C, int H, int W, int O, int KH, int KW,
+                     int stride_h, int stride_w, int pad_h, int pad_w, void* stream);
+int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, const float* wbuf, const float* x, float* g_x, int N, int C,
+                          int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, void* stream);
 size_t bde_conv_lrt_bwd_weight_ws_bytes(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h,
                                         int pad_w);
 int bde_conv_lrt_bwd_weight(const float* x, const float* g_out, const float* g_var, const float* w_rho, void* ws,

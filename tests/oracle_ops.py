@@ -6,6 +6,7 @@ run here.  The product never constructs it."""
 import math
 
 import torch
+import torch.nn.functional as F
 
 from oracle import bde_oracle as O
 from oracle import philox as PH
@@ -226,6 +227,39 @@ class OracleOps:
         for s in range(out.shape[0]):
             self.swag_sample(mean, sq, dev, head, out[s], d, None if eps_w is None else eps_w[s],
                              None if eps_d is None else eps_d[s], seed, stream_id0 + s)
+
+    # ---------------------------------------------------- BBBConv2d (fused) --
+    def conv_lrt_supported(self, x_shape, w_shape, stride, padding):
+        return int(x_shape[1]) == int(w_shape[1]) and max(int(w_shape[2]), int(w_shape[3])) <= 7 and \
+            padding[0] <= int(w_shape[2]) - 1 and padding[1] <= int(w_shape[3]) - 1
+
+    def conv_lrt_wbuf(self, w_shape, device):
+        return torch.zeros(4)
+
+    def conv_lrt_prep(self, w_mu, w_rho, wbuf):
+        if not hasattr(self, "_conv_w"):
+            self._conv_w = {}
+        self._conv_w[wbuf.data_ptr()] = (w_mu.detach().clone(), (F.softplus(w_rho.detach()) ** 2).clamp(min=1e-4), wbuf)
+
+    def conv_lrt_fwd(self, x, wbuf, w_shape, b_mu, b_var, stride, padding, out, var_out, eps=None, seed=0, stream_id=0):
+        w_mu, s2, _ = self._conv_w[wbuf.data_ptr()]
+        mean = F.conv2d(x, w_mu, b_mu, stride=stride, padding=padding)                       # bbb_layers.py:146
+        var = F.conv2d((x ** 2).clamp(min=1e-4), s2, b_var, stride=stride, padding=padding)  # :147
+        z = eps if eps is not None else _philox(seed, stream_id, out.numel()).view(out.shape)
+        out.copy_(mean + torch.sqrt(var) * z)
+        var_out.copy_(var)
+
+    def conv_lrt_bwd_data(self, g_out, g_var, wbuf, w_shape, x, g_x, stride, padding):
+        w_mu, s2, _ = self._conv_w[wbuf.data_ptr()]
+        gm = torch.nn.grad.conv2d_input(x.shape, w_mu, g_out, stride=stride, padding=padding)
+        gv = torch.nn.grad.conv2d_input(x.shape, s2, g_var, stride=stride, padding=padding)
+        g_x.copy_(gm + torch.where(x * x >= 1e-4, 2.0 * x * gv, torch.zeros_like(x)))
+
+    def conv_lrt_bwd_weight(self, x, g_out, g_var, w_rho, g_wmu, g_wrho, stride, padding, ws=None):
+        g_wmu.copy_(torch.nn.grad.conv2d_weight(x, w_rho.shape, g_out, stride=stride, padding=padding))
+        gs2 = torch.nn.grad.conv2d_weight((x ** 2).clamp(min=1e-4), w_rho.shape, g_var, stride=stride, padding=padding)
+        sp = F.softplus(w_rho)
+        g_wrho.copy_(torch.where(sp * sp >= 1e-4, gs2 * 2.0 * sp * torch.sigmoid(w_rho), torch.zeros_like(gs2)))
 
     # ----------------------------------------------------------- Gauss --
     def reduce_ws(self, device):

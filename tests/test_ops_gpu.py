@@ -1139,15 +1139,15 @@ def test_conv_lrt_forward(ops):
         out64, out32 = m64 + v64.sqrt() * eps.double(), m32 + v32.sqrt() * eps
         dev = lambda t: None if t is None else t.to(DEV).contiguous()
         xd, wm = dev(x), dev(w_mu)
-        ws2 = torch.empty_like(wm)
-        ops.var_operand_fwd(dev(w_rho), 1, ws2)
+        wbuf = ops.conv_lrt_wbuf(w_mu.shape, DEV)
+        ops.conv_lrt_prep(wm, dev(w_rho), wbuf)
         bvar = None
         if bias:
             bvar = torch.empty(o, device=DEV)
             ops.var_operand_fwd(dev(b_rho), 2, bvar)
         assert ops.conv_lrt_supported(x.shape, w_mu.shape, stride, padding), (n, c, h, w, o, k)
         out, var = torch.full(m32.shape, 9.0, device=DEV), torch.full(m32.shape, 9.0, device=DEV)
-        ops.conv_lrt_fwd(xd, wm, ws2, dev(b_mu), bvar, stride, padding, out, var, eps=dev(eps))
+        ops.conv_lrt_fwd(xd, wbuf, w_mu.shape, dev(b_mu), bvar, stride, padding, out, var, eps=dev(eps))
         tol_v = max(2 * (v32.double() - v64).abs().max().item(), 3e-6 * v64.abs().max().item())
         tol_o = max(2 * (out32.double() - out64).abs().max().item(), 3e-6 * out64.abs().max().item())
         case = (n, c, h, w, o, k, stride, padding)
@@ -1156,9 +1156,9 @@ def test_conv_lrt_forward(ops):
         # deterministic, and the in-kernel noise is the Philox stream of the flat NCHW output element (the numbering of
         # bde_local_reparam_fwd, whose backward regenerates it)
         out2, var2 = torch.empty_like(out), torch.empty_like(var)
-        ops.conv_lrt_fwd(xd, wm, ws2, dev(b_mu), bvar, stride, padding, out2, var2, eps=dev(eps))
+        ops.conv_lrt_fwd(xd, wbuf, w_mu.shape, dev(b_mu), bvar, stride, padding, out2, var2, eps=dev(eps))
         assert torch.equal(out, out2) and torch.equal(var, var2)
-        ops.conv_lrt_fwd(xd, wm, ws2, dev(b_mu), bvar, stride, padding, out2, var2, seed=9, stream_id=4)
+        ops.conv_lrt_fwd(xd, wbuf, w_mu.shape, dev(b_mu), bvar, stride, padding, out2, var2, seed=9, stream_id=4)
         z = torch.from_numpy(PH.normals(9, 4, out2.numel())).view(out2.shape)
         assert (out2.cpu().double() - (m64 + v64.sqrt() * z)).abs().max().item() <= tol_o + 5e-6 * v64.sqrt().max().item(), case
         assert torch.equal(var, var2)
@@ -1196,14 +1196,14 @@ def test_conv_lrt_backward(ops):
         g32 = run(torch.float32)
         dev = lambda t: None if t is None else t.to(DEV).float().contiguous()
         xd, wm, wr = dev(x), dev(w_mu), dev(w_rho)
-        ws2 = torch.empty_like(wm)
-        ops.var_operand_fwd(wr, 1, ws2)
+        wbuf = ops.conv_lrt_wbuf(w_mu.shape, DEV)
+        ops.conv_lrt_prep(wm, wr, wbuf)
         var = dev(g32[3])
         gd, ed = dev(gout), dev(eps)
         gvar = torch.empty_like(gd)
         ops.local_reparam_bwd(gd.view(-1), var.view(-1), gvar.view(-1), gd.numel(), eps=ed.view(-1))
         gx = torch.full_like(xd, 9.0)
-        ops.conv_lrt_bwd_data(gd, gvar, wm, ws2, xd, gx, stride, padding)
+        ops.conv_lrt_bwd_data(gd, gvar, wbuf, w_mu.shape, xd, gx, stride, padding)
         gwm, gwr = torch.full_like(wm, 9.0), torch.full_like(wr, 9.0)
         ops.conv_lrt_bwd_weight(xd, gd, gvar, wr, gwm, gwr, stride, padding)
         case = (n, c, h, w, o, k, stride, padding)
@@ -1212,7 +1212,7 @@ def test_conv_lrt_backward(ops):
             assert (got.cpu().double() - g64[i]).abs().max().item() <= tol, (name, case)
         gwm2, gwr2, gx2 = torch.empty_like(gwm), torch.empty_like(gwr), torch.empty_like(gx)     # deterministic
         ops.conv_lrt_bwd_weight(xd, gd, gvar, wr, gwm2, gwr2, stride, padding)
-        ops.conv_lrt_bwd_data(gd, gvar, wm, ws2, xd, gx2, stride, padding)
+        ops.conv_lrt_bwd_data(gd, gvar, wbuf, w_mu.shape, xd, gx2, stride, padding)
         assert torch.equal(gwm, gwm2) and torch.equal(gwr, gwr2) and torch.equal(gx, gx2), case
 
 
