@@ -25,6 +25,7 @@ SIGNATURES = {
     "bde_svgd_ws_bytes": (c_size_t, [c_int]),
     "bde_svgd_kstat_floats": (c_size_t, [c_int]),
     "bde_svgd_gram": (c_int, [_P, c_int, c_int64, c_int64, _P, _P]),
+    "bde_svgd_set_gram_keep_bytes": (c_int, [c_int64]),
     "bde_svgd_kstats": (c_int, [_P, c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
     "bde_svgd_gram_finish": (c_int, [_P, c_int, _P, _P]),
     "bde_svgd_kstats_gmat": (c_int, [_P, c_int, c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_int, _P, _P]),
@@ -32,12 +33,11 @@ SIGNATURES = {
     "bde_svgd_step": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_float, c_float, c_float, c_float, _P, _P, _P]),
     "bde_svgd_small_supported": (c_int, [c_int, c_int64]),
     "bde_svgd_step_small": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
-                                    c_int, _P, _P, c_int, _P, _P]),
-    "bde_svgd_small_set_timeout_us": (c_int, [c_int64]),
+                                    c_int, _P, _P, _P]),
     "bde_svgd_step_small_sgd": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_float, c_float, c_float, c_double, c_double,
-                                        c_double, c_double, c_int, c_int, _P, _P, c_int, _P, _P]),
+                                        c_double, c_double, c_int, c_int, _P, _P, _P]),
     "bde_svgd_step_small_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, c_float, c_float, c_float, c_double,
-                                         c_double, c_double, c_double, c_double, c_int64, _P, _P, c_int, _P, _P]),
+                                         c_double, c_double, c_double, c_double, c_int64, _P, _P, _P]),
     "bde_svgd_apply_sgd": (c_int, [_P, _P, _P, c_int, c_int64, c_int64, c_double, c_double, c_double, c_double,
                                    c_int, c_int, _P]),
     "bde_svgd_apply_adam": (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int64, c_double, c_double, c_double, c_double,

@@ -22,6 +22,7 @@
 // fp32 ridge (~20 flop/B) -> HBM-bound; the MFMA is used for the Gram
 // contraction because it leaves the VALU free for the centring, not because
 // the kernel is matrix-bound.
+#include <atomic>
 #include "svgd_gram.hpp"
 
 namespace bde {
@@ -523,6 +524,17 @@ extern "C" size_t bde_svgd_kstat_floats(int M) {
   return static_cast<size_t>(4 * M * M + M + 4);
 }
 
+// Bytes of the Gram walk's tail that stay cacheable for the combine pass (default 240 MB of the 256 MB Infinity Cache);
+// a tuning hook (tools/gram_split_ab.py: the A/B at M = 5, 8, 16), process-wide, < 0 restores the default.
+static std::atomic<int64_t> g_gram_keep_bytes{240000000};
+extern "C" int bde_svgd_set_gram_keep_bytes(int64_t bytes) {
+  g_gram_keep_bytes.store(bytes < 0 ? 240000000 : bytes, std::memory_order_relaxed);
+  return 0;
+}
+static inline int gram_split_now(int M, int64_t D) {
+  return gram_nt_split(M, D, static_cast<double>(g_gram_keep_bytes.load(std::memory_order_relaxed)));
+}
+
 extern "C" int bde_svgd_gram(const float* P, int M, int64_t D, int64_t ld, void* ws, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || !ws || !aligned16(ws)) return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -532,14 +544,14 @@ extern "C" int bde_svgd_gram(const float* P, int M, int64_t D, int64_t ld, void*
     const int64_t tiles = (n4 + kGramU * 8 - 1) / (kGramU * 8);
     const int grid = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, kGramMaxBlocks));
     hipLaunchKernelGGL(svgd_gram_kernel<2>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, wsf,
-                       GramRows{0, 0, 0, 0, 0, gram_nt_split(M, D)});
+                       GramRows{0, 0, 0, 0, 0, gram_split_now(M, D)});
     return to_err(hipGetLastError());
   }
   const int64_t tiles = (n4 + kGramU * 4 - 1) / (kGramU * 4);
   const int grid = static_cast<int>(std::min<int64_t>((tiles + 3) / 4, kGramMaxBlocks));
   if (M <= BDE_FAST_PARTICLES) {
     hipLaunchKernelGGL(svgd_gram_kernel<1>, dim3(grid), dim3(kGramBlock), 0, s, P, M, D, ld, wsf,
-                       GramRows{0, 8, 8, M - 8, 0, gram_nt_split(M, D)});
+                       GramRows{0, 8, 8, M - 8, 0, gram_split_now(M, D)});
     return to_err(hipGetLastError());
   }
   // generic: one 16-row tile per pair of 8-particle groups, then the pairs' tiles -> d2 [M, M]
@@ -671,9 +683,8 @@ extern "C" int bde_svgd_step(const float* P, const float* G, float* out, int M, 
                              float kernel_grad_scale, float dataset_size, float sign, void* ws, float* kstat,
                              void* stream) {
   if (!G) return BDE_ERR_INVALID;
-  if (bde_svgd_small_supported(M, D))   // as two ordinary launches: nothing in them waits for another workgroup
-    return bde_svgd_step_small(P, G, out, M, D, ld, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, ws, kstat,
-                               2, nullptr, stream);
+  if (bde_svgd_small_supported(M, D))
+    return bde_svgd_step_small(P, G, out, M, D, ld, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, ws, kstat, stream);
   int rc = bde_svgd_gram(P, M, D, ld, ws, stream);
   if (rc) return rc;
   rc = bde_svgd_kstats(ws, M, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, kstat, stream);

@@ -83,9 +83,9 @@ struct GramRows {
 
 // The tail of the Gram walk that is kept cacheable for the combine pass: what fits the Infinity Cache (256 MiB,
 // minus headroom for the pass's own partials and whatever else is live).
-static inline int gram_nt_split(int M, int64_t D) {
+static inline int gram_nt_split(int M, int64_t D, double keep = 240e6) {
   const double total = 4.0 * static_cast<double>(M) * static_cast<double>(D);
-  const double keep = 240e6;
+  if (keep <= 0.0) return 1000;                      // nothing kept cacheable: the whole walk non-temporal
   if (total <= keep) return 0;
   return static_cast<int>(1000.0 * (1.0 - keep / total));
 }

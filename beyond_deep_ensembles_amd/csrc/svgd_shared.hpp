@@ -5,16 +5,8 @@
 namespace bde {
 
 // ws header (1.5 KB, so that the partial tiles behind it start on a 128-byte line): ws[0] = #partial tiles,
-// ws[1] = padded M (8 or 16).  The rest are the hand-off words of the single-launch path (svgd_small.hip), each on
-// a 128-byte line of its own: 8 sharded arrive counters (word 32 + 32 s) that only ever count up, the target
-// word (their sum once the previous launch on this workspace had fully arrived) and the 64-bit outcome word
-// (arrival target of the last single launch, COMMIT / ABORT).  The header must be ZERO-filled
-// once after allocation; nothing is ever reset (uint32 wrap-around is handled by comparing differences).
+// ws[1] = padded M (8 or 16); the rest is unused (rounds 2-3 kept the hand-off words of a single-launch path there).
 constexpr int kWsHeaderFloats = 32 * 12;
-constexpr int kWsShards = 8;
-constexpr int kWsArriveWord = 32;                         // + 32 * shard
-constexpr int kWsTargetWord = 32 + 32 * kWsShards;
-constexpr int kWsStateWord = kWsTargetWord + 32;          // 64-bit outcome word of the last single launch (svgd_small.hip)
 constexpr int kGramMaxBlocks = 1024;       // 4 workgroups per CU: best measured (tools/kexp.hip)
 
 // Per-particle Adam scalars of the SHARED step counter (advanced once per particle).

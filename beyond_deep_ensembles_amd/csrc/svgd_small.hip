@@ -1,49 +1,23 @@
-// SVGD posterior update for SMALL models in ONE launch (CIFAR ResNet-20 scale: D = 273,610).
+// SVGD posterior update for SMALL models (CIFAR ResNet-20 scale: D = 273,610) as TWO launches of one kernel.
 //
 // Reference: src/algos/svgd.py:14-32,86-89 -- the same arithmetic as svgd.hip.  At a few hundred
 // thousand parameters the three-launch path (gram -> kstats -> combine) is not bandwidth-bound
-// any more: 35 MB of traffic is ~6 us of HBM time, but two launch boundaries, a one-workgroup
-// statistics kernel and the combine's cold scalar loads made it 27 us (round-1 profile).  Here
-// the whole update is one persistent launch, one workgroup per CU:
+// any more: 35 MB of traffic is ~6 us of HBM time, but a one-workgroup statistics kernel between two
+// launch boundaries and the combine's cold scalar loads made it 27 us (round-1 profile).  Here:
 //
-//   phase 1  every workgroup owns <= 512 consecutive float4 columns of P: centred Gram partial
-//            of its slice on the f32 MFMA (same tiles as svgd_gram_kernel<2>), published with
-//            write-through (sc1) stores;
-//   hand-off one fire-and-forget agent-scope atomic add per workgroup on one of 8 SHARDED arrive
-//            counters (a single counter serialises 256 adds at ~12 ns each); one wave per workgroup
-//            polls all 8 counters with ONE 8-lane sc1 load per poll until they sum to the grid size
-//            (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + drained vmcnt + counter
-//            add on the producer, sc1 poll + workgroup barrier + sc1 loads on the consumer) -- two
-//            dependent memory round trips instead of the four of a counter tree.  While it waits,
-//            the workgroup's P and G columns for phase 2 are already in flight into registers (P
-//            from the XCD's L2, where phase 1 just put it);
-//   phase 2  EVERY workgroup reduces all partials in the same fixed order (fp64) and evaluates the
-//            kernel statistics redundantly (a few hundred scalar operations), keeps the 2 M^2
-//            coefficients in LDS, and combines its own columns.
+//   launch 1 (phase kSmallGramOnly)   every workgroup owns <= 512 consecutive float4 columns of P: centred Gram
+//            partial of its slice on the f32 MFMA (same tiles as svgd_gram_kernel<2>), written to the workspace;
+//   launch 2 (phase kSmallAfterGram)  EVERY workgroup reduces all partials in the same fixed order (fp64) and
+//            evaluates the kernel statistics redundantly (a few hundred scalar operations, one wave, shuffles), keeps
+//            the 2 M^2 coefficients in LDS, and combines its own columns -- or, OPT != 0, continues through the M
+//            shared-state base-optimizer applications and writes the updated particles.
 //
-// P is read once from HBM (4 M D), G once (4 M D), out written once (4 M D): 12 M D bytes, no
-// second pass over P.  The counters only count up (each launch waits for "previous total + grid
-// size", kept in the workspace), so nothing is reset and the caller only has to hand in a
-// workspace that was zeroed once.  Measured timeline at D = 273,610 (tools/kexp6.hip,
-// profiles/r02_small_step_timeline_v3_and_gram_ab.txt).
+// P is read from HBM once (the second launch finds its columns in L2), G once, out written once: 12 M D bytes.
 //
-// The hand-off waits for workgroups of the same launch, which only works while all of them are resident at once.
-// On an otherwise idle MI355X they are (<= 256 workgroups of 512 threads, one per CU), but this is an ordinary launch:
-// other processes or streams can hold CUs, and two such launches could each be partly resident and wait for the
-// rest.  Therefore the wait is BOUNDED and the launch decides as ONE unit whether the update happens:
-//   * the polling wave gives up after `timeout` ticks of the 100 MHz wall clock (default 2 ms);
-//   * the outcome of a launch is ONE 64-bit word of the workspace, (stamp, status), written by compare-and-swap against
-//     its value at launch start: workgroup 0 proposes (want, COMMIT) once it has seen all arrivals, whoever times out
-//     proposes (want, ABORT); exactly one proposal wins, everybody reads the outcome in the same load that polls the
-//     counters and follows it.  So either every workgroup runs phase 2 or none does -- an aborted launch leaves P, the
-//     optimizer state and `out` untouched;
-//   * ABORT is sticky: later workgroups of that launch, and later single launches on the workspace, see it when they
-//     start and return at once (they do not arrive, so the counters stay consistent); an aborting workgroup also sets
-//     the caller's `abort_flag` word (host-visible memory), which is how the caller learns that it must redo the update;
-//   * the redo is the SAME kernel as two ordinary launches (`phase` 1: Gram partials only; `phase` 2: everything
-//     after the hand-off) -- no inter-workgroup wait, hence no residency requirement, and bit-identical results
-//     (same grid, same partials, same summation order).  Phase 2 also repairs an aborted workspace (target word :=
-//     arrivals counted so far, status cleared).
+// Rounds 2 and 3 also ran both halves as ONE persistent launch with an in-kernel hand-off between the workgroups
+// (round 2: unbounded wait, 10.7 us, could hang a shared device; round 3: bounded wait + a compare-and-swap
+// COMMIT / ABORT outcome word + redo path, 14.3 us against 14.7 us for these two launches).  A protocol, a
+// shared-device hazard and a recovery path in the shell for 0.3 us: removed in round 4.
 #include "svgd_gram.hpp"
 #include <atomic>
 #include <cstdlib>
@@ -71,10 +45,7 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Outcome word of a launch (kWsStateWord, 64 bit): low half = the launch's arrival target, high half = status.
-constexpr unsigned kSmallCommit = 1u, kSmallAbort = 2u;
-constexpr unsigned kSmallDefaultTimeoutTicks = 200000u;          // 2 ms of the 100 MHz wall clock
-enum : int { kSmallSingle = 0, kSmallGramOnly = 1, kSmallAfterGram = 2 };
+enum : int { kSmallGramOnly = 1, kSmallAfterGram = 2 };
 
 // The kernel statistics of svgd_stats_core for M <= 8 (M * M <= 64 entries), evaluated by ONE wave with
 // cross-lane shuffles instead of LDS round trips and workgroup barriers (2.0 us -> well under 1 us on the
@@ -168,10 +139,8 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
                                                                         StatParams sp, float* __restrict__ ws,
                                                                         float* __restrict__ kstat, float* s0, float* s1,
                                                                         SgdParams sk, AdamParams ak, AdamSteps ast,
-                                                                        int phase, unsigned timeout_ticks,
-                                                                        int* abort_flag) {
+                                                                        int phase) {
   constexpr int MP = 8, MP2 = 64;
-  __shared__ int s_decision;
   __shared__ float tile[kSmallWaves][16][17];
   __shared__ double red[(kSmallBlock / (MP2 / 2)) * MP2];           // [16 slices][64]
   __shared__ double gmat[MP2];
@@ -180,21 +149,9 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nwg = gridDim.x;
-  unsigned* words = reinterpret_cast<unsigned*>(ws);
   float* part = ws + kWsHeaderFloats;
 
   BDE_TS(0)
-  // arrivals counted so far on this workspace (all launches before this one) and the outcome word as this workgroup
-  // finds it; requested first, needed at the poll
-  unsigned arrived_before = 0;
-  unsigned long long state_seen = 0;
-  unsigned long long* state = reinterpret_cast<unsigned long long*>(words + kWsStateWord);
-  if (phase == kSmallSingle && wave == 0) {
-    arrived_before = __hip_atomic_load(words + kWsTargetWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    state_seen = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // an earlier launch on this workspace (or this one, before this workgroup started) was abandoned: do not arrive
-  const bool poisoned = static_cast<unsigned>(state_seen >> 32) == kSmallAbort;
   // ---------------- phase 1: centred Gram partial of this workgroup's columns ----------------
   const int r16 = lane & 15, kq = lane >> 4;
   const int c4 = (r16 >> 3) * 4 + kq;
@@ -251,10 +208,6 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
     st_sc1(part + static_cast<int64_t>(blockIdx.x) * MP2 + tid, s);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the write-through stores have left this CU
     BDE_TS(2)
-    // arrive: one agent-scope add on this workgroup's shard counter, fire and forget
-    if (tid == 0 && phase == kSmallSingle && !poisoned)
-      __hip_atomic_fetch_add(words + kWsArriveWord + 32 * (blockIdx.x & (kWsShards - 1)), 1u, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
   }
   BDE_TS(3)
   if (phase == kSmallGramOnly) {                                   // first of two launches: the partials are the result
@@ -265,7 +218,7 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
     return;
   }
 
-  // ---------------- phase 2 operands: requested now, consumed after the hand-off ----------------
+  // ---------------- second launch: this workgroup's operands, requested before the partials are reduced ----------------
   const int64_t n4 = D >> 2;                                       // full float4 columns
   const int64_t cA = t0 * kSmallTile4 + tid;
   const int64_t colEnd = (t1 * kSmallTile4 < n4) ? t1 * kSmallTile4 : n4;
@@ -285,86 +238,7 @@ __global__ __launch_bounds__(kSmallBlock, 1) void svgd_step_small_kernel(const f
     if (OPT == 2) a1 = ld4(s1 + 4 * cA);
   }
 
-  // ---------------- hand-off: wave 0 polls the 8 shard counters (one 8-lane load per poll), for a bounded time ----------------
-  if (phase == kSmallSingle && wave == 0) {
-    // ONE load per poll brings the 8 shard counters (lanes 0-7) AND the outcome word (lanes 8, 9: stamp, status)
-    const unsigned* poll_ptr = lane < kWsShards ? words + kWsArriveWord + 32 * lane
-                                                : words + kWsStateWord + (lane == kWsShards + 1 ? 1 : 0);
-    const unsigned want = arrived_before + static_cast<unsigned>(nwg);
-    const unsigned long long commit_word = static_cast<unsigned long long>(want) | (static_cast<unsigned long long>(kSmallCommit) << 32);
-    const unsigned long long abort_word = static_cast<unsigned long long>(want) | (static_cast<unsigned long long>(kSmallAbort) << 32);
-    // The launch decides as ONE unit through the outcome word.  COMMIT is proposed by workgroup 0 alone, once it has
-    // seen every arrival (one uncontended compare-and-swap per launch -- 238 workgroups proposing it cost 5 us of
-    // serialised atomics); everybody else sees the decision in the poll that follows.  ABORT is proposed by whoever runs
-    // out of time.  Both are compare-and-swaps against the value the word had when the launch started, so exactly one
-    // proposal wins and the loser follows it.
-    int decision = 0;
-    if (poisoned || timeout_ticks == 0u) decision = -1;                  // nothing to wait for: propose ABORT right away
-    const unsigned long long t_start = wall_clock64();
-    unsigned polls = 0;
-    while (decision == 0) {
-      const unsigned c = (lane < kWsShards + 2) ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      unsigned total = 0;
-#pragma unroll
-      for (int sh = 0; sh < kWsShards; ++sh) total += __builtin_amdgcn_readlane(c, sh);
-      const unsigned stamp = __builtin_amdgcn_readlane(c, kWsShards), status = __builtin_amdgcn_readlane(c, kWsShards + 1);
-      if (status == kSmallAbort) {
-        decision = static_cast<int>(kSmallAbort);
-      } else if (status == kSmallCommit && stamp == want) {
-        decision = static_cast<int>(kSmallCommit);
-      } else if (static_cast<int>(total - want) >= 0 && blockIdx.x == 0) {   // difference: immune to uint32 wrap-around
-        unsigned long long cur = state_seen;
-        if (lane == 0 && __hip_atomic_compare_exchange_strong(state, &cur, commit_word, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_AGENT))
-          cur = commit_word;
-        const unsigned st = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur >> 32));
-        decision = st == kSmallCommit ? static_cast<int>(kSmallCommit) : static_cast<int>(kSmallAbort);
-      } else {
-        // the clock is read on every 8th unsuccessful poll (~1 us apart): workgroups that cannot become resident
-        // together must not wait for each other forever
-        if ((++polls & 7u) == 0u && wall_clock64() - t_start > static_cast<unsigned long long>(timeout_ticks)) decision = -1;
-        else __builtin_amdgcn_s_sleep(4);
-      }
-    }
-    if (decision < 0) {                                                  // out of time (or abandoned workspace): propose ABORT
-      decision = static_cast<int>(kSmallAbort);
-      if (!poisoned) {
-        unsigned long long cur = state_seen;
-        if (lane == 0 && __hip_atomic_compare_exchange_strong(state, &cur, abort_word, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_AGENT))
-          cur = abort_word;
-        const unsigned st = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur >> 32));
-        const unsigned sm = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(cur));
-        if (st == kSmallCommit && sm == want) decision = static_cast<int>(kSmallCommit);   // workgroup 0 was faster: all are here
-      }
-    }
-    if (lane == 0) {
-      s_decision = decision;
-      if (decision == static_cast<int>(kSmallAbort)) {
-        if (abort_flag) __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      } else if (blockIdx.x == 0) {
-        // every workgroup read the old target before it arrived, so it can move on now
-        __hip_atomic_store(words + kWsTargetWord, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  if (phase == kSmallAfterGram && blockIdx.x == 0 && tid == 0) {
-    // second of two launches (stream-ordered behind whatever ran on this workspace before): if a single launch was
-    // abandoned here, count its arrivals into the target and clear the status, so the workspace is usable again
-    const unsigned long long st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (static_cast<unsigned>(st >> 32) == kSmallAbort) {
-      unsigned total = 0;
-      for (int sh = 0; sh < kWsShards; ++sh)
-        total += __hip_atomic_load(words + kWsArriveWord + 32 * sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(words + kWsTargetWord, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(state, static_cast<unsigned long long>(total) | (static_cast<unsigned long long>(kSmallCommit) << 32),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   BDE_TS(4)
-  __syncthreads();
-  if (phase == kSmallSingle && s_decision != static_cast<int>(kSmallCommit)) return;     // uniform: nothing was written
-
   // fixed-order fp64 reduction of ALL partial tiles (every workgroup computes the same bits): 8-byte sc1 loads, all
   // of a thread's loads in flight before the first add, unconditional (a predicated load gets a basic block and an
   // s_waitcnt of its own: 8 us instead of 1) -- slots past the grid re-read the last partial and are dropped
@@ -504,29 +378,12 @@ struct SmallOpt {
   AdamSteps ast{};
 };
 
-// How long the polling wave of a single launch waits for the other workgroups, in ticks of the 100 MHz wall clock.
-// Process-wide; BDE_SMALL_TIMEOUT_US in the environment (read once) or bde_svgd_small_set_timeout_us() change it.
-// 0 = give up without polling (every single launch is abandoned: the test hook for the recovery path).
-static std::atomic<unsigned>& small_timeout_ticks() {
-  static std::atomic<unsigned> ticks{[] {
-    const char* e = std::getenv("BDE_SMALL_TIMEOUT_US");
-    if (e && *e) {
-      const long long us = std::atoll(e);
-      if (us >= 0) return static_cast<unsigned>(std::min<long long>(us, 40000000LL) * 100);
-    }
-    return kSmallDefaultTimeoutTicks;
-  }()};
-  return ticks;
-}
-
 template <int M>
 static int launch_small(const float* P, const float* G, float* out, int64_t D, int64_t ld, int grid, int tpw,
-                        const StatParams& sp, float* ws, float* kstat, const SmallOpt& o, int launches, int* abort_flag,
-                        hipStream_t s) {
-  const unsigned timeout = small_timeout_ticks().load(std::memory_order_relaxed);
+                        const StatParams& sp, float* ws, float* kstat, const SmallOpt& o, hipStream_t s) {
 #define BDE_SMALL_LAUNCH(HG, OPT, PHASE)                                                                             \
   hipLaunchKernelGGL((svgd_step_small_kernel<M, HG, OPT>), dim3(grid), dim3(kSmallBlock), 0, s, P, G, out, D, ld, tpw, \
-                     sp, ws, kstat, o.s0, o.s1, o.sk, o.ak, o.ast, PHASE, timeout, abort_flag)
+                     sp, ws, kstat, o.s0, o.s1, o.sk, o.ak, o.ast, PHASE)
 #define BDE_SMALL_VARIANT(PHASE)                   \
   do {                                             \
     if (o.kind == 1) BDE_SMALL_LAUNCH(true, 1, PHASE);      \
@@ -534,23 +391,16 @@ static int launch_small(const float* P, const float* G, float* out, int64_t D, i
     else if (G) BDE_SMALL_LAUNCH(true, 0, PHASE);           \
     else BDE_SMALL_LAUNCH(false, 0, PHASE);                 \
   } while (0)
-  if (launches == 2) {
-    // the same kernel as two ordinary launches: no inter-workgroup wait, same partials, same summation order
-    BDE_SMALL_VARIANT(kSmallGramOnly);
-    BDE_SMALL_VARIANT(kSmallAfterGram);
-  } else {
-    BDE_SMALL_VARIANT(kSmallSingle);
-  }
+  BDE_SMALL_VARIANT(kSmallGramOnly);
+  BDE_SMALL_VARIANT(kSmallAfterGram);
 #undef BDE_SMALL_VARIANT
 #undef BDE_SMALL_LAUNCH
   return to_err(hipGetLastError());
 }
 
-// The hand-off inside the kernel needs ALL workgroups of the launch resident at once.  A whole MI355X holds 256 of
-// them with room to spare; a partition of the chip (CPX mode: 32 CUs) or a smaller part does not, and the launch would
-// wait for workgroups that can never start.  The limit is what the CURRENT device can hold (CUs x workgroups per CU
-// at this kernel's register / LDS footprint), queried once per device; without a device (the build container) the
-// full-chip figure applies.
+// One workgroup per CU: the grid is what the CURRENT device holds at once (CUs x workgroups per CU at this kernel's
+// register / LDS footprint, at most 256), queried once per device -- a partition of the chip (CPX mode: 32 CUs) gets a
+// smaller grid and a smaller limit on D; without a device (the build container) the full-chip figure applies.
 static int small_resident_limit() {
   static std::atomic<int> cache[64];
   int dev = 0;
@@ -569,8 +419,7 @@ static int small_resident_limit() {
 }
 
 static int small_dispatch(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld, const StatParams& sp,
-                          float* ws, float* kstat, const SmallOpt& o, int launches, int* abort_flag, hipStream_t s) {
-  if (launches != 1 && launches != 2) return BDE_ERR_INVALID;
+                          float* ws, float* kstat, const SmallOpt& o, hipStream_t s) {
   const int64_t n_tiles = (((D + 3) >> 2) + kSmallTile4 - 1) / kSmallTile4;
   const int max_grid = small_resident_limit();
   const int tpw = static_cast<int>((n_tiles + max_grid - 1) / max_grid);
@@ -579,7 +428,7 @@ static int small_dispatch(const float* P, const float* G, float* out, int M, int
   switch (M) {
 #define BDE_CASE(m) \
   case m:           \
-    return launch_small<m>(P, G, out, D, ld, grid, tpw, sp, ws, kstat, o, launches, abort_flag, s);
+    return launch_small<m>(P, G, out, D, ld, grid, tpw, sp, ws, kstat, o, s);
     BDE_CASE(1) BDE_CASE(2) BDE_CASE(3) BDE_CASE(4) BDE_CASE(5) BDE_CASE(6) BDE_CASE(7) BDE_CASE(8)
 #undef BDE_CASE
   }
@@ -596,13 +445,6 @@ extern "C" int bde_svgd_small_supported(int M, int64_t D) {
   return n_tiles <= static_cast<int64_t>(small_resident_limit()) * kSmallMaxTilesPerWG;
 }
 
-extern "C" int bde_svgd_small_set_timeout_us(int64_t microseconds) {
-  small_timeout_ticks().store(microseconds < 0 ? kSmallDefaultTimeoutTicks
-                                               : static_cast<unsigned>(std::min<int64_t>(microseconds, 40000000) * 100),
-                              std::memory_order_relaxed);
-  return 0;
-}
-
 static StatParams small_stat_params(int M, float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
                                     float h_override, int mode) {
   return StatParams{l2_reg, kernel_grad_scale, dataset_size, sign, h_override,
@@ -611,21 +453,20 @@ static StatParams small_stat_params(int M, float l2_reg, float kernel_grad_scale
 
 extern "C" int bde_svgd_step_small(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
                                    float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
-                                   float h_override, int mode, void* ws, float* kstat, int launches, int* abort_flag,
-                                   void* stream) {
+                                   float h_override, int mode, void* ws, float* kstat, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || !out || !ws || !kstat || !aligned16(out) || !aligned16(ws) || (G && !aligned16(G)) ||
       out == P || (mode != 0 && mode != 1) || (mode == 0 && !G))
     return BDE_ERR_INVALID;
   if (!bde_svgd_small_supported(M, D)) return BDE_ERR_INVALID;
   return small_dispatch(P, mode == 0 ? G : nullptr, out, M, D, ld,
                         small_stat_params(M, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, mode),
-                        static_cast<float*>(ws), kstat, SmallOpt{}, launches, abort_flag, static_cast<hipStream_t>(stream));
+                        static_cast<float*>(ws), kstat, SmallOpt{}, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int bde_svgd_step_small_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
                                        float l2_reg, float kernel_grad_scale, float dataset_size, double lr,
                                        double momentum, double dampening, double weight_decay, int nesterov, int first,
-                                       void* ws, float* kstat, int launches, int* abort_flag, void* stream) {
+                                       void* ws, float* kstat, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || !G || !aligned16(G) || !ws || !aligned16(ws) || !kstat ||
       (momentum != 0.0 && (!momentum_buf || !aligned16(momentum_buf))) || !bde_svgd_small_supported(M, D))
     return BDE_ERR_INVALID;
@@ -635,13 +476,13 @@ extern "C" int bde_svgd_step_small_sgd(float* P, const float* G, float* momentum
   o.sk = SgdParams{static_cast<float>(lr), static_cast<float>(momentum), static_cast<float>(1.0 - dampening),
                    static_cast<float>(weight_decay), nesterov, first};
   return small_dispatch(P, G, P, M, D, ld, small_stat_params(M, l2_reg, kernel_grad_scale, dataset_size, -1.f, 0.f, 0),
-                        static_cast<float*>(ws), kstat, o, launches, abort_flag, static_cast<hipStream_t>(stream));
+                        static_cast<float*>(ws), kstat, o, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int bde_svgd_step_small_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D,
                                         int64_t ld, float l2_reg, float kernel_grad_scale, float dataset_size, double lr,
                                         double beta1, double beta2, double eps, double weight_decay, int64_t step0,
-                                        void* ws, float* kstat, int launches, int* abort_flag, void* stream) {
+                                        void* ws, float* kstat, void* stream) {
   if (!svgd_args_ok(P, M, D, ld) || !G || !aligned16(G) || !ws || !aligned16(ws) || !kstat || !exp_avg || !exp_avg_sq ||
       !aligned16(exp_avg) || !aligned16(exp_avg_sq) || step0 < 0 || !bde_svgd_small_supported(M, D))
     return BDE_ERR_INVALID;
@@ -653,7 +494,7 @@ extern "C" int bde_svgd_step_small_adam(float* P, const float* G, float* exp_avg
                     static_cast<float>(1.0 - beta2), static_cast<float>(eps), static_cast<float>(weight_decay)};
   o.ast = make_adam_steps(lr, beta1, beta2, step0);
   return small_dispatch(P, G, P, M, D, ld, small_stat_params(M, l2_reg, kernel_grad_scale, dataset_size, -1.f, 0.f, 0),
-                        static_cast<float*>(ws), kstat, o, launches, abort_flag, static_cast<hipStream_t>(stream));
+                        static_cast<float*>(ws), kstat, o, static_cast<hipStream_t>(stream));
 }
 
 // bde_init(): load this translation unit's code object on the current device now (HIP otherwise uploads it at the

@@ -181,6 +181,10 @@ class HipOps:
         m = P.shape[0]
         _check(self.lib.bde_svgd_gram(_ptr(P, "P"), m, d, _ld(P), _ptr(ws), _stream()), "bde_svgd_gram")
 
+    def svgd_set_gram_keep_bytes(self, nbytes: int) -> None:
+        """Tuning hook (process-wide): how much of the Gram pass's tail stays cacheable for the combine pass."""
+        _check(self.lib.bde_svgd_set_gram_keep_bytes(int(nbytes)), "bde_svgd_set_gram_keep_bytes")
+
     @_on_device_of
     def svgd_kstats(self, ws, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override=0.0, mode=0):
         _check(self.lib.bde_svgd_kstats(_ptr(ws), m, l2_reg, kernel_grad_scale, dataset_size, sign, h_override, mode,
@@ -227,58 +231,37 @@ class HipOps:
     def svgd_small_supported(self, m: int, d: int) -> bool:
         return bool(self.lib.bde_svgd_small_supported(m, d))
 
-    @staticmethod
-    def small_abort_flag() -> torch.Tensor:
-        """A host-visible int32 word for ``abort_flag``: pinned host memory, which the device addresses directly.  A
-        single launch that gave up sets it to 1; read it once the stream has passed the kernel."""
-        return torch.zeros(1, dtype=torch.int32).pin_memory()
-
-    @staticmethod
-    def _flag_ptr(abort_flag):
-        if abort_flag is None:
-            return None
-        if abort_flag.dtype != torch.int32 or not (abort_flag.is_cuda or abort_flag.is_pinned()):
-            raise BdeKernelError("abort_flag: expected an int32 tensor in pinned host (or device) memory")
-        return abort_flag.data_ptr()
-
-    def svgd_small_set_timeout_us(self, microseconds: int) -> None:
-        """Bound on the in-kernel wait of a single launch (process-wide; < 0: default 2000, 0: give up at once)."""
-        self.lib.bde_svgd_small_set_timeout_us(int(microseconds))
-
     @_on_device_of
     def svgd_step_small(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat, h_override=0.0,
-                        mode=0, launches=2, abort_flag=None):
-        """The whole update for small models; mode 1 = rbf's grad_kernel (G may be None).  launches = 1: one persistent
-        launch with a bounded in-kernel hand-off (may give up: abort_flag); 2: the same kernel as two ordinary launches."""
+                        mode=0):
+        """The whole update for small models (two launches of one kernel); mode 1 = rbf's grad_kernel (G may be None)."""
         m = P.shape[0]
         if (G is not None and _ld(G) != _ld(P)) or _ld(out) != _ld(P):
             raise BdeKernelError("P, G, out must share one leading dimension")
         _check(self.lib.bde_svgd_step_small(_ptr(P, "P"), _ptr(G, "G"), _ptr(out, "out"), m, d, _ld(P), l2_reg,
                                             kernel_grad_scale, dataset_size, sign, h_override, mode, _ptr(ws),
-                                            _ptr(kstat), int(launches), self._flag_ptr(abort_flag), _stream()),
+                                            _ptr(kstat), _stream()),
                "bde_svgd_step_small")
 
     @_on_device_of
     def svgd_step_small_sgd(self, P, G, buf, d, l2_reg, kernel_grad_scale, dataset_size, ws, kstat, lr, momentum,
-                            dampening, weight_decay, nesterov, first, launches=2, abort_flag=None):
+                            dampening, weight_decay, nesterov, first):
         """Whole step (statistics, -phi, M shared-state SGD applications, particles updated in place)."""
         if _ld(G) != _ld(P):
             raise BdeKernelError("P and G must share one leading dimension")
         _check(self.lib.bde_svgd_step_small_sgd(_ptr(P, "P"), _ptr(G, "G"), _ptr(buf), P.shape[0], d, _ld(P), l2_reg,
                                                 kernel_grad_scale, dataset_size, lr, momentum, dampening, weight_decay,
-                                                int(nesterov), int(first), _ptr(ws), _ptr(kstat), int(launches),
-                                                self._flag_ptr(abort_flag), _stream()),
+                                                int(nesterov), int(first), _ptr(ws), _ptr(kstat), _stream()),
                "bde_svgd_step_small_sgd")
 
     @_on_device_of
     def svgd_step_small_adam(self, P, G, exp_avg, exp_avg_sq, d, l2_reg, kernel_grad_scale, dataset_size, ws, kstat, lr,
-                             beta1, beta2, eps, weight_decay, step0, launches=2, abort_flag=None):
+                             beta1, beta2, eps, weight_decay, step0):
         if _ld(G) != _ld(P):
             raise BdeKernelError("P and G must share one leading dimension")
         _check(self.lib.bde_svgd_step_small_adam(_ptr(P, "P"), _ptr(G, "G"), _ptr(exp_avg), _ptr(exp_avg_sq), P.shape[0],
                                                  d, _ld(P), l2_reg, kernel_grad_scale, dataset_size, lr, beta1, beta2, eps,
-                                                 weight_decay, int(step0), _ptr(ws), _ptr(kstat), int(launches),
-                                                 self._flag_ptr(abort_flag), _stream()),
+                                                 weight_decay, int(step0), _ptr(ws), _ptr(kstat), _stream()),
                "bde_svgd_step_small_adam")
 
     @_on_device_of

@@ -106,14 +106,11 @@ class SVGDOptimizer(BayesianOptimizer):
           reuse_gram          with fuse_base_optimizer: the fused kernel also emits the Gram partials of the updated
                               particles, so the next step skips the Gram pass.  Only valid while nothing but this
                               optimizer modifies the particles between two steps (call invalidate_gram() otherwise).
-          single_launch       None (default) / "two": small models on one GPU run the whole update with the small-model kernel
-                              (bde_svgd_step_small*) as TWO ordinary launches (Gram partials; everything after).  True:
-                              with a fused base optimizer, as ONE persistent launch whose in-kernel hand-off waits a
-                              bounded time -- for a device this process has to itself; if that launch ever gives up
-                              (device shared with other work), the update is redone as two launches (identical results)
-                              and stays that way.  With the wait bounded and the outcome agreed between the workgroups
-                              the single launch is no faster than the two (14.3 vs 14.7 us at ResNet-20 size; the
-                              unbounded round-2 kernel took 10.7), hence the default.  False: the staged kernels
+          single_launch       None (default): small models on one GPU (bde_svgd_small_supported: M <= 8, D <= 524,288) run
+                              the whole update with the small-model kernel (bde_svgd_step_small*: two launches).  False: the
+                              streaming kernels (Gram -> statistics -> combine / fused) at every size.  (Rounds 2-3 also
+                              offered True = one persistent launch with an in-kernel hand-off; it was no faster than the two
+                              launches once its wait was bounded, and is gone.)
     '''
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
@@ -189,14 +186,12 @@ class SVGDOptimizer(BayesianOptimizer):
                 self._exchange = exchange
         if fuse_base_optimizer == "auto":
             fuse_base_optimizer = self._fusable(base_optimizer, plist, particle_count)
-        if single_launch not in (None, True, False, "two"):
-            raise ValueError("single_launch must be None, True, False or 'two'")
+        if single_launch is True:
+            raise ValueError("single_launch=True (one persistent launch with an in-kernel hand-off) was removed in round 4: it "
+                             "was no faster than the two launches of the default; pass None")
+        if single_launch not in (None, False, "two"):
+            raise ValueError("single_launch must be None, 'two' or False")
         self._single_launch = single_launch
-        # the persistent single launch (bounded in-kernel wait): its outcome is checked before anything reads or
-        # overwrites what it worked on -- see _check_single_launch
-        self._small_launches = 1 if single_launch is True else 2
-        self._small_flag = None
-        self._small_pending = None
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
         # 17 <= particle_count <= 64: -phi by the blocked update kernel, then ONE launch applies the base optimizer to all
         # particles in order with its shared state (bde_svgd_apply_sgd / adam) instead of particle_count torch steps
@@ -316,28 +311,7 @@ class SVGDOptimizer(BayesianOptimizer):
             return self._Gown[particle_idx - self._local_particles().start]
         return self._G[particle_idx]
 
-    def _check_single_launch(self) -> None:
-        """The persistent single launch of the previous step may have given up (its workgroups could not all become
-        resident within the bound: the device is shared).  Then nothing was written; the update is redone NOW from the
-        untouched gradients and optimizer state as two ordinary launches of the same kernel (bit-identical results),
-        and single launches are not used again by this optimizer.  Called on entry of everything that reads or
-        overwrites the particles / gradients; costs one event query when the kernel has long finished."""
-        pending = self._small_pending
-        if pending is None:
-            return
-        self._small_pending = None
-        event, redo = pending
-        event.synchronize()
-        if int(self._small_flag[0]) != 0:
-            self._small_flag[0] = 0
-            self._small_launches = 2
-            warnings.warn("SVGD single-launch update gave up waiting for its workgroups (device shared with other work); "
-                          "redone as two launches, which this optimizer now always uses")
-            with torch.no_grad():
-                redo()
-
     def step(self, forward_closure, backward_closure, grad_scaler=None):
-        self._check_single_launch()
         OptState = _opt_state()
         base = self.state["__base_optimizer"]
         m, d = self.state["__particle_count"], self._layout.d
@@ -461,7 +435,6 @@ class SVGDOptimizer(BayesianOptimizer):
         """Everything after the forward/backward passes (svgd.py:82-105): gradient exchange (multi-GPU), kernel
         statistics, -phi and the base-optimizer applications.  ``total_loss`` = sum of this rank's particle losses;
         returns the mean loss over all particles.  (bench.py times exactly this.)"""
-        self._check_single_launch()
         base = self.state["__base_optimizer"]
         m = self.state["__particle_count"]
         with torch.no_grad():
@@ -498,7 +471,7 @@ class SVGDOptimizer(BayesianOptimizer):
         if single_launch or m > 16:
             self._grads_to_rows(self._G, 0, m)                           # these kernels read flat rows
         if fused and single_launch:
-            # small model on one GPU: statistics, -phi and the M shared-state optimizer applications in ONE launch
+            # small model on one GPU: statistics, -phi and the M shared-state optimizer applications by the small-model kernel
             self._fused_apply(base, [(self._P, self._G, d, 0)], single_launch=True)
             self._gram_valid = False
             self._use_particle(m - 1)
@@ -817,7 +790,7 @@ class SVGDOptimizer(BayesianOptimizer):
                     l2, scale, n, _ = self._stat_args()
                     args = (P, G, st["buf"], d, l2, scale, n, self._ws, self._kstat, g0["lr"], g0["momentum"],
                             g0["dampening"], g0["weight_decay"], g0["nesterov"], st["first"])
-                    self._launch_small(self._ops.svgd_step_small_sgd, args)
+                    self._ops.svgd_step_small_sgd(*args)
                     continue
                 if seg is not None:
                     self._ops.svgd_fused_sgd_seg(P, seg, st["buf"], d, self._kstat, g0["lr"], g0["momentum"],
@@ -842,7 +815,7 @@ class SVGDOptimizer(BayesianOptimizer):
                     l2, scale, n, _ = self._stat_args()
                     args = (P, G, st["exp_avg"], st["exp_avg_sq"], d, l2, scale, n, self._ws, self._kstat, float(g0["lr"]),
                             g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"], st["step"])
-                    self._launch_small(self._ops.svgd_step_small_adam, args)
+                    self._ops.svgd_step_small_adam(*args)
                     continue
                 if seg is not None:
                     self._ops.svgd_fused_adam_seg(P, seg, st["exp_avg"], st["exp_avg_sq"], d, self._kstat, float(g0["lr"]),
@@ -856,19 +829,6 @@ class SVGDOptimizer(BayesianOptimizer):
             raise RuntimeError(f"fuse_base_optimizer supports torch.optim.SGD and torch.optim.Adam, got {type(base)}")
         if advance:
             self._fused_advance()
-
-    def _launch_small(self, op, args) -> None:
-        """The small-model kernel with the fused optimizer: ONE persistent launch while that has never given up on this
-        optimizer (its outcome is checked by _check_single_launch before the next use of P / G), two launches otherwise."""
-        if self._small_launches == 2 or not hasattr(self._ops, "small_abort_flag"):
-            op(*args, launches=2)
-            return
-        if self._small_flag is None:
-            self._small_flag = self._ops.small_abort_flag()
-        op(*args, launches=1, abort_flag=self._small_flag)
-        event = torch.cuda.Event()
-        event.record()
-        self._small_pending = (event, lambda: op(*args, launches=2))
 
     def _fused_advance(self):
         """One SVGD step = particle_count applications of the shared optimizer."""
@@ -885,7 +845,6 @@ class SVGDOptimizer(BayesianOptimizer):
     def sample_parameters(self):
         '''Point the model at the next particle, round robin (svgd.py:107-112).  With dimension-sharded
         particles only this rank's own particles are available, so the cycle runs over those.'''
-        self._check_single_launch()
         count = self.state["__particle_count"]
         current = self.state["__current_particle"]
         if self._exchange == "alltoall":
@@ -915,7 +874,6 @@ class SVGDOptimizer(BayesianOptimizer):
     def _particle_rows(self) -> torch.Tensor:
         """``[M, d]`` in the flat row layout (alignment padding included).  With exchange="alltoall" the slices are
         gathered first (a collective)."""
-        self._check_single_launch()
         d = self._layout.d
         if self._exchange != "alltoall":
             return self._P[:, :d]
@@ -936,7 +894,6 @@ class SVGDOptimizer(BayesianOptimizer):
         """Overwrite all particles with ``particles [M, D]`` (the layout ``.particles`` returns).  ``.particles`` itself is
         a copy whenever a tensor needed alignment padding, so in-place edits go through here.  Not available with
         exchange="alltoall" (load a checkpoint instead)."""
-        self._check_single_launch()
         if self._exchange == "alltoall":
             raise NotImplementedError("set_particles with exchange='alltoall': use load_state_dict")
         m = self.state["__particle_count"]
@@ -951,7 +908,6 @@ class SVGDOptimizer(BayesianOptimizer):
 
     @property
     def kernel_stats(self) -> dict:
-        self._check_single_launch()
         m = self.state["__particle_count"]
         ks = self._kstat
         return {"kernel": ks[:m * m].view(m, m), "d2": ks[m * m:2 * m * m].view(m, m),
@@ -974,7 +930,6 @@ class SVGDOptimizer(BayesianOptimizer):
         particles and the shared optimizer state are sharded by columns, so this is a COLLECTIVE there (every rank of
         the group must call it; every rank gets the complete dict): the slices are gathered, the fused optimizer's state
         is published into ``base_optimizer.state`` in torch's own layout, and ``__fused`` carries full-length buffers."""
-        self._check_single_launch()
         if self._exchange != "alltoall":
             return super().state_dict()
         m, d, ld = self.state["__particle_count"], self._layout.d, self._layout.ld
@@ -1024,7 +979,6 @@ class SVGDOptimizer(BayesianOptimizer):
         values are copied into the flat buffer and the state re-aliased to it.  With exchange="alltoall" every rank
         loads the same (complete) dict and keeps its own particles' rows and its column slice of all particles and of
         the shared optimizer state; no communication."""
-        self._check_single_launch()
         super().load_state_dict(state_dict)
         self._gram_valid = False
         # shared optimizer state of the fused path: re-adopted (and re-published into base.state) at the next step

@@ -84,6 +84,10 @@ size_t bde_svgd_kstat_floats(int M);
 /* Stage 1: per-workgroup partial Gram matrices of the mean-centred particles
  * into ws.  P [M, ld]. */
 int bde_svgd_gram(const float* P, int M, int64_t D, int64_t ld, void* ws, void* stream);
+/* Tuning hook: bytes of the Gram walk's tail loaded cacheably (so that the combine pass finds them in the 256 MB
+ * Infinity Cache); the head of the walk is loaded non-temporally.  Default 240 MB; 0 = all non-temporal; < 0 restores
+ * the default.  Process-wide.  tools/gram_split_ab.py sweeps it at M = 5, 8 and 16 (profiles/r04_gram_split_*.txt). */
+int bde_svgd_set_gram_keep_bytes(int64_t bytes);
 
 /* Stage 2: reduce the partials, bandwidth, kernel, coefficients -> kstat.
  * phi = K @ (-(G + l2_reg/2 * P)) + kernel_grad_scale * gradK / dataset_size
@@ -114,50 +118,37 @@ int bde_svgd_kstats_gmat(const double* gmats, int n_mats, int64_t mat_stride, in
 int bde_svgd_combine(const float* P, const float* G, float* out, int M, int64_t D,
                      int64_t ld, int64_t ldg, const float* kstat, void* stream);
 
-/* One SVGD posterior update (svgd.py:86-89) on `stream`: the single-launch path when
+/* One SVGD posterior update (svgd.py:86-89) on `stream`: the small-model kernel (two launches) when
  * bde_svgd_small_supported(M, D), otherwise the three stages back to back. */
 int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
                   float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
                   void* ws, float* kstat, void* stream);
 
-/* Small models (M <= 8 and D <= 524,288, e.g. the CIFAR ResNet-20 of the reference: D = 273,610): the whole
- * update in ONE persistent launch -- per-workgroup Gram partials, an in-kernel hand-off through an agent-scope
- * counter, the kernel statistics evaluated redundantly by every workgroup, and the combine of the columns each
- * workgroup already holds in registers.  12*M*D bytes of HBM traffic, no launch boundaries.  Same results as the
+/* Small models (M <= 8 and D <= 524,288, e.g. the CIFAR ResNet-20 of the reference: D = 273,610): the update as TWO
+ * launches of one kernel, one workgroup per CU -- (1) per-workgroup Gram partials of the columns a workgroup owns,
+ * (2) every workgroup reduces all partials in the same fixed order, evaluates the kernel statistics redundantly and
+ * combines its own columns (which the first launch left in L2).  12*M*D bytes of HBM traffic.  Same results as the
  * three-stage path up to the order of the partial sums.  mode / h_override as in bde_svgd_kstats (mode 1: G may
  * be NULL, out = grad_kernel).  bde_svgd_small_supported() answers for the CURRENT device (CUs x resident workgroups
  * per CU, queried once per device), so a partition of the chip (CPX mode) gets a smaller limit on D or the
- * three-stage path.
- *
- * `launches` selects how the hand-off between the two halves of the kernel happens:
- *   1  ONE launch; the workgroups wait for each other inside the kernel, for a BOUNDED time (2 ms by default,
- *      bde_svgd_small_set_timeout_us).  That needs all (<= 256) workgroups resident at once, which an otherwise idle
- *      device gives but a shared one may not.  The launch decides as one unit: if any workgroup gives up, NO workgroup
- *      writes anything (P, out and the optimizer state are untouched), `*abort_flag` (host-visible memory, e.g. pinned;
- *      may be NULL) is set to 1 and the workspace refuses further single launches until a two-launch call repaired it.
- *      The caller checks the flag once the stream has passed the kernel and then redoes the update with launches = 2.
- *   2  the SAME kernel as two ordinary launches (Gram partials; everything after the hand-off): no waiting inside the
- *      kernel, no residency requirement, bit-identical results.  abort_flag is not used.
- * bde_svgd_step() uses launches = 2. */
+ * three-stage path.  (Rounds 2-3 also offered both halves as one persistent launch with an in-kernel hand-off; it was
+ * no faster once its wait was bounded and is gone.) */
 int bde_svgd_small_supported(int M, int64_t D);
 int bde_svgd_step_small(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
                         float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
-                        float h_override, int mode, void* ws, float* kstat, int launches, int* abort_flag, void* stream);
-/* Waiting time of a single launch in microseconds (process-wide; < 0 restores the default, 0 makes every single
- * launch give up without waiting -- the hook the recovery tests use).  Also BDE_SMALL_TIMEOUT_US in the environment. */
-int bde_svgd_small_set_timeout_us(int64_t microseconds);
+                        float h_override, int mode, void* ws, float* kstat, void* stream);
 
-/* The same launch continued through the M shared-state base-optimizer applications (svgd.py:92-103, semantics of
+/* The second launch continued through the M shared-state base-optimizer applications (svgd.py:92-103, semantics of
  * bde_svgd_fused_sgd / bde_svgd_fused_adam): the updated particles are written back over P -- the whole
- * SVGDOptimizer.step minus forward/backward in ONE launch for small models, (12*M + 8)*D bytes (SGD). */
+ * SVGDOptimizer.step minus forward/backward in two launches for small models, (12*M + 8)*D bytes (SGD). */
 int bde_svgd_step_small_sgd(float* P, const float* G, float* momentum_buf, int M, int64_t D, int64_t ld,
                             float l2_reg, float kernel_grad_scale, float dataset_size, double lr, double momentum,
                             double dampening, double weight_decay, int nesterov, int first, void* ws, float* kstat,
-                            int launches, int* abort_flag, void* stream);
+                            void* stream);
 int bde_svgd_step_small_adam(float* P, const float* G, float* exp_avg, float* exp_avg_sq, int M, int64_t D, int64_t ld,
                              float l2_reg, float kernel_grad_scale, float dataset_size, double lr, double beta1,
                              double beta2, double eps, double weight_decay, int64_t step0, void* ws, float* kstat,
-                             int launches, int* abort_flag, void* stream);
+                             void* stream);
 
 /* ---- gradients handed over WITHOUT a copy (the "_store_grads" clones of svgd.py:129-133 removed) ----
  * The flat row of a particle is the concatenation of its parameter tensors, each starting on a float4 boundary.

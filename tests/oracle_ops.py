@@ -47,19 +47,19 @@ class OracleOps:
         return m <= 8 and d <= 524288
 
     def svgd_step_small(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat, h_override=0.0,
-                        mode=0, launches=2, abort_flag=None):
+                        mode=0):
         self.svgd_gram(P, d, ws)
         self.svgd_kstats(ws, P.shape[0], l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override, mode)
         self.svgd_combine(P, G, out, d, kstat)
 
     def svgd_step_small_sgd(self, P, G, buf, d, l2_reg, kernel_grad_scale, dataset_size, ws, kstat, lr, momentum,
-                            dampening, weight_decay, nesterov, first, launches=2, abort_flag=None):
+                            dampening, weight_decay, nesterov, first):
         self.svgd_gram(P, d, ws)
         self.svgd_kstats(ws, P.shape[0], l2_reg, kernel_grad_scale, dataset_size, -1.0, kstat)
         self.svgd_fused_sgd(P, G, buf, d, kstat, lr, momentum, dampening, weight_decay, nesterov, first)
 
     def svgd_step_small_adam(self, P, G, exp_avg, exp_avg_sq, d, l2_reg, kernel_grad_scale, dataset_size, ws, kstat, lr,
-                             beta1, beta2, eps, weight_decay, step0, launches=2, abort_flag=None):
+                             beta1, beta2, eps, weight_decay, step0):
         self.svgd_gram(P, d, ws)
         self.svgd_kstats(ws, P.shape[0], l2_reg, kernel_grad_scale, dataset_size, -1.0, kstat)
         self.svgd_fused_adam(P, G, exp_avg, exp_avg_sq, d, kstat, lr, beta1, beta2, eps, weight_decay, step0)

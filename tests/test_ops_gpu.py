@@ -141,11 +141,10 @@ def test_svgd_deterministic_and_ragged_sizes(ops):
         assert err <= max(2 * err_ref, 3e-6 * np.max(np.abs(phi64))), (m, d, err, err_ref)
 
 
-def test_svgd_single_launch_path(ops):
-    """bde_svgd_step_small (one persistent launch: Gram partials -> in-kernel hand-off -> redundant statistics ->
-    combine) against the three-stage path and the fp64 anchor: sizes around its tile / workgroup / eligibility
-    boundaries, the CIFAR ResNet-20 size of BASELINE configs 2-3, in place, and many launches on one workspace
-    (the hand-off counters only count up: every launch waits for "previous total + its grid size")."""
+def test_svgd_small_model_kernel(ops):
+    """bde_svgd_step_small (two launches of one kernel: Gram partials; redundant statistics + combine) against the
+    three-stage path and the fp64 anchor: sizes around its tile / workgroup / eligibility boundaries, the CIFAR
+    ResNet-20 size of BASELINE configs 2-3, in place, and many calls on one workspace."""
     torch.manual_seed(3)
     assert ops.svgd_small_supported(8, 273_610) and ops.svgd_small_supported(8, 524_288)
     assert not ops.svgd_small_supported(8, 524_289) and not ops.svgd_small_supported(9, 1000)
@@ -164,55 +163,21 @@ def test_svgd_single_launch_path(ops):
         assert np.max(np.abs(-b.numpy() - phi64)) <= tol, (m, d)
         assert torch.allclose(ka[:m * m], kb[:m * m], rtol=0, atol=2e-6), (m, d)        # K
         assert torch.allclose(a, b, rtol=0, atol=float(tol)), (m, d)
-    # in place + repeated SINGLE launches (launches=1: in-kernel hand-off) on ONE workspace
+    # in place, and repeated calls on ONE workspace beside unrelated work on another stream: same bits every time
     m, d = 8, 273_610
     P, G = torch.randn(m, d) * 0.05, torch.randn(m, d) * 0.01
     Pb, G0 = flat_rows(P), flat_rows(G)
     ws, ks = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV)
-    flag = ops.small_abort_flag()
     ref = torch.zeros_like(G0)
-    ops.svgd_step_small(Pb, G0, ref, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks, launches=2)     # two ordinary launches
-    one = torch.zeros_like(G0)
-    ops.svgd_step_small(Pb, G0, one, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks, launches=1, abort_flag=flag)
-    torch.cuda.synchronize()
-    assert int(flag[0]) == 0, "a single launch gave up on an idle device"
-    assert torch.equal(one[:, :d], ref[:, :d])                                           # same kernel, same bits
-    for _ in range(200):
-        Gb = G0.clone()
-        ops.svgd_step_small(Pb, Gb, Gb, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks, launches=1, abort_flag=flag)
-    torch.cuda.synchronize()
-    assert int(flag[0]) == 0
-    assert torch.equal(Gb[:, :d], ref[:, :d])
-    # the hand-off words only count up: after 201 single launches of a 238-workgroup grid the 8 shard counters sum to
-    # the target word, and the outcome word says COMMIT for that target
-    words = ws[:384].view(torch.int32).cpu()
-    target = int(words[32 + 32 * 8])
-    assert int(words[32:32 + 32 * 8:32].sum()) == target and target > 0
-    assert int(words[32 + 32 * 9]) == target and int(words[32 + 32 * 9 + 1]) == 1
-    # the in-kernel hand-off under UNEVEN load: another stream keeps the CUs busy with unrelated streaming work while
-    # the single-launch kernel runs 100 times; every result must equal the quiet-machine result bit for bit (a launch
-    # that gave up -- it may, the wait is bounded -- leaves its output untouched and is redone as two launches)
+    ops.svgd_step_small(Pb, G0, ref, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks)
     hog_stream, hog = torch.cuda.Stream(), torch.empty(64 << 20, device=DEV)
-    outs = [torch.full_like(G0, 7.0) for _ in range(4)]
-    torch.cuda.synchronize()
-    gave_up = 0
-    for it in range(100):
+    for it in range(50):
         with torch.cuda.stream(hog_stream):
             hog.add_(1.0)
-            if it % 3 == 0:
-                hog[: (1 << 20) * (1 + it % 7)].mul_(0.5)
-        ops.svgd_step_small(Pb, G0, outs[it % 4], d, 3e-4, 1.0, 50000.0, -1.0, ws, ks, launches=1, abort_flag=flag)
-        torch.cuda.current_stream().synchronize()
-        if int(flag[0]) != 0:
-            flag[0] = 0
-            gave_up += 1
-            assert torch.equal(outs[it % 4], torch.full_like(G0, 7.0))                   # nothing was written
-            ops.svgd_step_small(Pb, G0, outs[it % 4], d, 3e-4, 1.0, 50000.0, -1.0, ws, ks, launches=2)
-            torch.cuda.current_stream().synchronize()
-        assert torch.equal(outs[it % 4][:, :d], ref[:, :d]), it
-        outs[it % 4].fill_(7.0)
+        Gb = G0.clone()
+        ops.svgd_step_small(Pb, Gb, Gb, d, 3e-4, 1.0, 50000.0, -1.0, ws, ks)
     torch.cuda.synchronize()
-    print(f"single launches that gave up beside a busy stream: {gave_up} / 100")
+    assert torch.equal(Gb[:, :d], ref[:, :d])
     # rbf mode (grad_kernel) through the same launch
     out = torch.zeros_like(Pb)
     ops.svgd_step_small(Pb, None, out, d, 0.0, 1.0, 1.0, 1.0, ws, ks, mode=1)
@@ -342,8 +307,8 @@ def test_svgd_fused_equals_combine_plus_apply(ops):
                 np.testing.assert_allclose(s0b[:d].cpu().numpy(), s0a[:d].cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
-def test_svgd_single_launch_fused_step(ops):
-    """bde_svgd_step_small_sgd / _adam (the whole SVGDOptimizer.step minus forward/backward in ONE launch) ==
+def test_svgd_small_model_fused_step(ops):
+    """bde_svgd_step_small_sgd / _adam (the whole SVGDOptimizer.step minus forward/backward by the small-model kernel) ==
     bde_svgd_step_small followed by bde_svgd_apply_* (svgd.py:86-103), over several steps with carried state, at
     ragged sizes and the CIFAR ResNet-20 size."""
     torch.manual_seed(15)
@@ -374,119 +339,6 @@ def test_svgd_single_launch_fused_step(ops):
                 np.testing.assert_allclose(s0b[:d].cpu().numpy(), s0a[:d].cpu().numpy(), rtol=1e-5, atol=1e-7)
                 np.testing.assert_allclose(s1b[:d].cpu().numpy(), s1a[:d].cpu().numpy(), rtol=1e-5, atol=1e-9)
             assert torch.equal(Pb[:, d:], torch.zeros_like(Pb[:, d:]))                  # padding untouched
-
-
-def test_svgd_single_launch_gives_up_cleanly(ops):
-    """The bounded hand-off of the single launch: with the wait set to zero every single launch is abandoned -- as ONE
-    unit: nothing is written (particles, optimizer state, statistics untouched), the caller's flag is set, the
-    workspace refuses further single launches, and the redo as two ordinary launches of the same kernel gives the bits
-    a successful single launch gives and makes the workspace usable again."""
-    torch.manual_seed(21)
-    m, d = 8, 273_610
-    P0, G0 = torch.randn(1, d) * 0.05 + torch.randn(m, d) * 0.01, torch.randn(m, d) * 0.01
-    flag = ops.small_abort_flag()
-
-    def fresh():
-        P, G = flat_rows(P0), flat_rows(G0)
-        P[:, d:] = 0
-        return P, G, torch.zeros(P.shape[1], device=DEV), ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV)
-    sgd = (0.05, 0.9, 0.0, 3e-4, True)
-    # what a successful single launch produces (idle device), two steps
-    Pw, G, bw, ws_w, ks_w = fresh()
-    for it in range(2):
-        ops.svgd_step_small_sgd(Pw, G, bw, d, 0.01, 1.0, 500.0, ws_w, ks_w, *sgd, it == 0, launches=1, abort_flag=flag)
-    torch.cuda.synchronize()
-    assert int(flag[0]) == 0
-    P, G, b, ws, ks = fresh()
-    before = P.clone()
-    try:
-        ops.svgd_small_set_timeout_us(0)
-        ops.svgd_step_small_sgd(P, G, b, d, 0.01, 1.0, 500.0, ws, ks, *sgd, True, launches=1, abort_flag=flag)
-        torch.cuda.synchronize()
-    finally:
-        ops.svgd_small_set_timeout_us(-1)
-    assert int(flag[0]) == 1
-    assert torch.equal(P[:, :d], before[:, :d]) and float(b.abs().max()) == 0.0 and float(ks.abs().max()) == 0.0
-    # the workspace is poisoned: a single launch with the normal bound returns at once, again without writing
-    flag[0] = 0
-    ops.svgd_step_small_sgd(P, G, b, d, 0.01, 1.0, 500.0, ws, ks, *sgd, True, launches=1, abort_flag=flag)
-    torch.cuda.synchronize()
-    assert int(flag[0]) == 1 and torch.equal(P[:, :d], before[:, :d])
-    flag[0] = 0
-    # redo as two launches: the lost step, bit for bit; the workspace is repaired ...
-    ops.svgd_step_small_sgd(P, G, b, d, 0.01, 1.0, 500.0, ws, ks, *sgd, True, launches=2)
-    # ... so the next single launch goes through
-    ops.svgd_step_small_sgd(P, G, b, d, 0.01, 1.0, 500.0, ws, ks, *sgd, False, launches=1, abort_flag=flag)
-    torch.cuda.synchronize()
-    assert int(flag[0]) == 0
-    assert torch.equal(P[:, :d], Pw[:, :d]) and torch.equal(b[:d], bw[:d]) and torch.equal(ks, ks_w)
-    words = ws[:384].view(torch.int32).cpu()
-    assert int(words[32:32 + 32 * 8:32].sum()) == int(words[32 + 32 * 8])
-    # Adam and the plain (-phi) form take the same path
-    Pa, G, s0, ws, ks = fresh()
-    s1, out = torch.zeros_like(s0), torch.full_like(G, 3.0)
-    try:
-        ops.svgd_small_set_timeout_us(0)
-        ops.svgd_step_small_adam(Pa, G, s0, s1, d, 0.01, 1.0, 500.0, ws, ks, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, launches=1,
-                                 abort_flag=flag)
-        torch.cuda.synchronize()
-        assert int(flag[0]) == 1 and torch.equal(Pa[:, :d], before[:, :d])
-        flag[0] = 0
-        ws2 = ops.svgd_ws(m, DEV)
-        ops.svgd_step_small(Pa, G, out, d, 0.01, 1.0, 500.0, -1.0, ws2, ks, launches=1, abort_flag=flag)
-        torch.cuda.synchronize()
-        assert int(flag[0]) == 1 and torch.equal(out, torch.full_like(G, 3.0))
-        flag[0] = 0
-    finally:
-        ops.svgd_small_set_timeout_us(-1)
-
-
-def _shared_device_worker(rank, n_iter, out_dir):
-    import os
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    from beyond_deep_ensembles_amd.ops import HipOps
-    ops = HipOps()
-    m, d = 8, 273_610
-    g = torch.Generator().manual_seed(77)                              # the same problem in every process
-    P = flat_rows(torch.randn(1, d, generator=g) * 0.05 + torch.randn(m, d, generator=g) * 0.01)
-    G = flat_rows(torch.randn(m, d, generator=g) * 0.01)
-    P[:, d:] = 0
-    buf, ws, ks, flag = torch.zeros(P.shape[1], device=DEV), ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV), ops.small_abort_flag()
-    gave_up = 0
-    torch.cuda.synchronize()
-    for it in range(n_iter):
-        args = (P, G, buf, d, 0.01, 1.0, 500.0, ws, ks, 1e-3, 0.9, 0.0, 3e-4, True, it == 0)
-        ops.svgd_step_small_sgd(*args, launches=1, abort_flag=flag)
-        torch.cuda.current_stream().synchronize()
-        if int(flag[0]) != 0:                                          # gave up: nothing written, redo as two launches
-            flag[0] = 0
-            gave_up += 1
-            ops.svgd_step_small_sgd(*args, launches=2)
-    torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, f"shared{rank}.npz"), P=P[:, :d].cpu().numpy(), buf=buf[:d].cpu().numpy(),
-             gave_up=np.array(gave_up))
-
-
-def test_svgd_single_launch_on_a_shared_device(tmp_path):
-    """Five processes on ONE GPU each loop the single-launch SVGD step 300 times concurrently.  One workgroup of that
-    kernel fills a CU, so their launches cannot all be resident together: before the wait was bounded this could hang the
-    device.  Every process must finish, and its particles must equal the solo run bit for bit (a launch that gives up
-    writes nothing and is redone as two launches of the same kernel)."""
-    import torch.multiprocessing as mp
-    n_proc, n_iter = 5, 300
-    from tests.spawn_one_device import spawn_ranks
-    spawn_ranks(_shared_device_worker, lambda: (n_iter, str(tmp_path)), n_proc)
-    _shared_device_worker(99, n_iter, str(tmp_path))                   # solo, in this process
-    solo = np.load(tmp_path / "shared99.npz")
-    assert int(solo["gave_up"]) == 0
-    total = 0
-    for r in range(n_proc):
-        got = np.load(tmp_path / f"shared{r}.npz")
-        np.testing.assert_array_equal(got["P"], solo["P"])
-        np.testing.assert_array_equal(got["buf"], solo["buf"])
-        total += int(got["gave_up"])
-    print(f"single launches that gave up with {n_proc} processes sharing the device: {total} / {n_proc * n_iter}")
 
 
 def test_svgd_segmented_gradients_equal_flat_rows(ops):

@@ -62,3 +62,54 @@ def test_kernel_normals_equal_the_checker_transform():
         want_w = PH.normals(4242, 11, k, PH.DOMAIN_LOWRANK, rounds=rounds)
         assert np.abs(e.cpu().numpy().astype(np.float64) - want_e).max() < 4e-6
         assert np.abs(w.cpu().numpy().astype(np.float64) - want_w).max() < 4e-6
+
+
+@pytest.mark.gpu
+def test_swag_sampler_noise_statistics_over_2_to_30_normals():
+    """the SWAG samplers draw their noise with the round count bde_swag_philox_rounds() reports.  2^30
+    of exactly those normals (the stream layout of the batched sampler: 16 streams = 16 posterior samples x 2^26
+    parameters each), with 5-sigma bounds for a sample of this size: mean, variance, skewness, kurtosis, lag-1 and
+    lag-4 (next float4 group) autocorrelation inside a stream, correlation between NEIGHBOURING STREAMS at the same
+    parameter (= between consecutive posterior samples), the 64-bin chi-square of the uniformised values, and the tail
+    mass beyond 4 sigma.  The published 10-round function passes the same bounds (the control)."""
+    import math
+    from beyond_deep_ensembles_amd.ops import HipOps
+    ops = HipOps()
+    dev = "cuda:0"
+    n_streams, per = 16, 1 << 26
+    n = n_streams * per
+    for rounds in sorted({ops.swag_philox_rounds, PH.ROUNDS}):
+        s1 = s2 = s3 = s4 = lag1 = lag4 = cross = 0.0
+        tail = 0
+        hist = torch.zeros(64, dtype=torch.float64, device=dev)
+        prev = None
+        buf = torch.empty(per, device=dev)
+        for s in range(n_streams):
+            ops.philox_normal(20261003, 1000 + s, eps_d=buf, d=per, rounds=rounds)
+            z = buf.double()
+            s1 += float(z.sum())
+            s2 += float((z * z).sum())
+            s3 += float((z ** 3).sum())
+            s4 += float((z ** 4).sum())
+            lag1 += float((z[1:] * z[:-1]).sum())
+            lag4 += float((z[4:] * z[:-4]).sum())
+            tail += int((buf.abs() > 4.0).sum())
+            u = 0.5 * (1.0 + torch.erf(z / math.sqrt(2.0)))
+            hist += torch.histc(u.float(), bins=64, min=0.0, max=1.0).double()
+            if prev is not None:
+                cross += float((z * prev).sum())
+            prev = z.clone()
+            del z, u
+        mean, var = s1 / n, s2 / n - (s1 / n) ** 2
+        sd = 5.0 / math.sqrt(n)
+        assert abs(mean) < sd, (rounds, mean)
+        assert abs(var - 1.0) < 5.0 * math.sqrt(2.0 / n), (rounds, var)
+        assert abs(s3 / n) < 5.0 * math.sqrt(15.0 / n), (rounds, s3 / n)
+        assert abs(s4 / n - 3.0) < 5.0 * math.sqrt(96.0 / n), (rounds, s4 / n)
+        assert abs(lag1 / n) < sd and abs(lag4 / n) < sd, (rounds, lag1 / n, lag4 / n)
+        assert abs(cross / (n - per)) < 5.0 / math.sqrt(n - per), (rounds, cross / (n - per))
+        expect = n / 64.0
+        chi2 = float(((hist - expect) ** 2 / expect).sum())
+        assert chi2 < 63 + 5.0 * math.sqrt(2 * 63), (rounds, chi2)                 # chi^2_63: mean 63, sd 11.2
+        p_tail = 2.0 * 0.5 * math.erfc(4.0 / math.sqrt(2.0))                     # 6.33e-5
+        assert abs(tail - n * p_tail) < 5.0 * math.sqrt(n * p_tail), (rounds, tail, n * p_tail)

@@ -60,9 +60,6 @@ def flat(ts):
     ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "staged"),
     ("adam_wd", lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=1e-2), "staged_fused"),
     ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "staged_reuse_gram"),
-    # ONE persistent launch with the bounded in-kernel hand-off (single_launch=True) instead of the default two launches
-    ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "one_launch"),
-    ("adam", lambda ps: torch.optim.Adam(ps, lr=1e-3), "one_launch"),
     # the reference's OWN constructor call, no extra keyword (experiments/iwildcam/models.py:120): fuse_base_optimizer="auto"
     ("adam", lambda ps: torch.optim.Adam(ps, lr=1e-3), "default"),
     ("sgd", lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4), "default"),
@@ -85,7 +82,7 @@ def test_svgd_trajectory(golden, backend, name, make_opt, fuse):
     base = make_opt(model.parameters())
     extra = {} if fuse == "default" else dict(
         fuse_base_optimizer=fuse not in (False, "staged"), reuse_gram=fuse in ("reuse_gram", "staged_reuse_gram"),
-        single_launch=False if str(fuse).startswith("staged") else (True if fuse == "one_launch" else None))
+        single_launch=False if str(fuse).startswith("staged") else None)
     opt = bde.SVGDOptimizer(model.parameters(), reset, base, particle_count=m, dataset_size=64,
                             l2_reg=float(g["l2_reg"]), kernel_grad_scale=float(g["scale"]), _ops=ops, **extra)
     if fuse == "default":
@@ -1376,46 +1373,6 @@ def test_bbb_group_draw_is_never_stale(backend):
 
 
 @pytest.mark.gpu
-def test_svgd_shell_recovers_from_an_abandoned_single_launch():
-    """Small model, fused base optimizer, single_launch=True: the update is ONE persistent launch with a bounded in-kernel wait.  When such
-    a launch gives up (forced here by a zero bound), the optimizer notices on its next entry, redoes the update as two
-    launches of the same kernel from the untouched gradients and optimizer state, warns once and never uses single
-    launches again -- and the trajectory is bit-identical to the undisturbed run (svgd.py:65-105 semantics unchanged)."""
-    import warnings
-    from beyond_deep_ensembles_amd.ops import HipOps
-    ops, dev = HipOps(), torch.device("cuda:0")
-
-    def run(disturb):
-        torch.manual_seed(31)
-        model = nn.Sequential(nn.Linear(13, 64), nn.Tanh(), nn.Linear(64, 1)).to(dev)
-        params = list(model.parameters())
-        base = torch.optim.SGD(params, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)
-        opt = bde.SVGDOptimizer(params, lambda: bde.reset_model_params(model), base, particle_count=5, dataset_size=64,
-                                l2_reg=0.01, fuse_base_optimizer=True, single_launch=True)
-        g = torch.Generator().manual_seed(5)
-        x, y = torch.randn(64, 13, generator=g).to(dev), torch.randn(64, 1, generator=g).to(dev)
-        losses, caught = [], []
-        for t in range(5):
-            if disturb and t == 1:
-                ops.svgd_small_set_timeout_us(0)
-            try:
-                with warnings.catch_warnings(record=True) as w:
-                    warnings.simplefilter("always")
-                    losses.append(float(opt.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())))
-                    caught += [str(i.message) for i in w]
-            finally:
-                ops.svgd_small_set_timeout_us(-1)
-        return opt.particles.clone(), losses, caught, opt
-
-    clean_p, clean_l, clean_w, clean_opt = run(False)
-    assert not [m for m in clean_w if "single-launch" in m] and clean_opt._small_launches == 1
-    got_p, got_l, got_w, got_opt = run(True)
-    assert len([m for m in got_w if "single-launch" in m]) == 1
-    assert got_opt._small_launches == 2 and got_opt._small_pending is None
-    assert torch.equal(got_p, clean_p)
-    assert got_l == clean_l
-
-
 def test_bbb_linear_sigma_cache_follows_the_weights(backend):
     """A wide BBBLinear keeps sigma^2 of its weight matrix per weight VERSION: computed at the first forward, reused by
     the following forwards / backwards (bbb.py:63-67 runs mc_samples of them per step), recomputed after ANY in-place
