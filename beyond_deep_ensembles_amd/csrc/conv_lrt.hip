@@ -509,6 +509,23 @@ extern "C" int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH,
   return layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) && plan_fwd(g, p) && data_grad_geo(g, d) && plan_fwd(d, p) ? 1 : 0;
 }
 
+// The tiling the kernels would run with (tests / tools: tests/conv_emulator.py replays the kernels' index arithmetic on the
+// CPU with exactly these numbers).  which = 0: forward, 1: input gradient.  out[16]: MF, PT, NI, TH, bands, CC, PH, PWP, WP,
+// WK, tiles_per_img, kcpad_max, grid.x, grid.y, LDS bytes, 0.  Returns 0, or BDE_ERR_INVALID for an unsupported geometry.
+extern "C" int bde_conv_lrt_plan(int which, int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw,
+                                 int* out) {
+  ConvGeo l, g;
+  FwdPlan p;
+  if (!out || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, l)) return BDE_ERR_INVALID;
+  g = l;
+  if (which == 1 && !data_grad_geo(l, g)) return BDE_ERR_INVALID;
+  if (!plan_fwd(g, p)) return BDE_ERR_INVALID;
+  const int v[16] = {p.mf, p.pt, p.t.NI, p.t.TH, p.t.bands, p.t.CC, p.t.PH, p.t.PWP, p.t.WP, p.t.WK, p.t.tiles_per_img,
+                     p.t.kcpad_max, static_cast<int>(p.grid.x), static_cast<int>(p.grid.y), static_cast<int>(p.lds), 0};
+  for (int i = 0; i < 16; ++i) out[i] = v[i];
+  return 0;
+}
+
 extern "C" size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW) {
   if (O < 1 || C < 1 || KH < 1 || KW < 1) return 0;
   const size_t khw = static_cast<size_t>(KH) * KW, ktot = khw * C;

@@ -296,6 +296,19 @@ static bool geo_ok(int N, int C, int H, int W, int O, int KH, int KW, int sh, in
 
 }  // namespace
 
+// The tiling of the weight-gradient kernel (tests / tools).  out[16]: MF, CT_MAX, NI, TH, bands, PS, CT, colgroups, PH, PWP,
+// cmax, GP, npix, grid.y, LDS bytes, otiles.
+extern "C" int bde_conv_lrt_bwd_weight_plan(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw,
+                                            int* out) {
+  WgGeo g;
+  WgPlan p;
+  if (!out || !geo_ok(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) || !plan_wgrad(g, p)) return BDE_ERR_INVALID;
+  const int v[16] = {p.mf, p.mf == 16 ? 9 : 4, p.t.NI, p.t.TH, p.t.bands, p.t.PS, p.t.CT, p.t.colgroups, p.t.PH, p.t.PWP,
+                     p.t.cmax, p.t.GP, p.t.npix, static_cast<int>(p.grid.y), static_cast<int>(p.lds), p.otiles};
+  for (int i = 0; i < 16; ++i) out[i] = v[i];
+  return 0;
+}
+
 // bytes of the partials buffer bde_conv_lrt_bwd_weight needs (0: unsupported geometry)
 extern "C" size_t bde_conv_lrt_bwd_weight_ws_bytes(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph,
                                                    int pw) {

@@ -365,6 +365,14 @@ int bde_var_operand_bwd(const float* g, const float* v, int mode, float* gv, int
  * bde_conv_lrt_supported: 1 when tilings exist for the layer and its input gradient (kernel <= 7 x 7, stride / padding
  * per axis with padding <= kernel - 1, no dilation / groups). */
 int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w);
+/* The tilings the kernels run with, for tests and tools (tests/conv_emulator.py replays the kernels' index arithmetic
+ * on the CPU with exactly these numbers).  bde_conv_lrt_plan: which = 0 forward, 1 input gradient; out[16] = MF, PT, NI, TH,
+ * bands, CC, PH, PWP, WP, WK, tiles_per_img, kcpad_max, grid.x, grid.y, LDS bytes, 0.  bde_conv_lrt_bwd_weight_plan:
+ * out[16] = MF, CT_MAX, NI, TH, bands, PS, CT, colgroups, PH, PWP, cmax, GP, npix, grid.y, LDS bytes, otiles. */
+int bde_conv_lrt_plan(int which, int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h,
+                      int pad_w, int* out);
+int bde_conv_lrt_bwd_weight_plan(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h,
+                                 int pad_w, int* out);
 size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW);
 int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, int O, int C, int KH, int KW, float* wbuf, void* stream);
 int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, const float* b_var, const float* eps, uint64_t seed,

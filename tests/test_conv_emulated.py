@@ -1,0 +1,64 @@
+"""The fused BBBConv2d kernels' index arithmetic replayed on the CPU (tests/conv_emulator.py) against torch's conv2d and
+autograd: forward (bbb_layers.py:146-154), input gradient and weight gradient, with the tilings the library itself
+plans.  Runs without a GPU; the kernels themselves are tested by tests/test_ops_gpu.py::test_conv_lrt_*."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import conv_emulator as E
+
+# (N, C, H, W, O, K, stride, padding, bias): small batches of the ResNet-20 layer shapes (so that the planner picks the
+# tilings of the real layers: they depend on C, O, H, W, not on N beyond the grid) and ragged geometries
+CASES = [
+    (2, 3, 32, 32, 16, 3, (1, 1), (1, 1), True), (2, 16, 32, 32, 16, 3, (1, 1), (1, 1), True),
+    (2, 16, 32, 32, 32, 3, (2, 2), (1, 1), True), (3, 32, 16, 16, 32, 3, (1, 1), (1, 1), False),
+    (2, 32, 16, 16, 64, 3, (2, 2), (1, 1), True), (3, 64, 8, 8, 64, 3, (1, 1), (1, 1), True),
+    (2, 16, 32, 32, 32, 1, (2, 2), (0, 0), False),
+    (3, 5, 9, 11, 7, 3, (1, 1), (0, 0), True), (2, 7, 13, 6, 33, 3, (2, 1), (1, 2), True), (3, 4, 12, 12, 20, 5, (1, 1), (2, 2), True),
+    (1, 3, 30, 30, 40, 7, (2, 2), (3, 3), False), (1, 70, 7, 7, 40, 3, (1, 1), (1, 1), True),
+]
+
+
+def _layer(n, c, h, w, o, k, bias, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g)
+    x[0, 0, :2] = 0.0
+    x[0, 0, 2, : min(w, 3)] = 5e-3
+    w_mu, w_rho = torch.randn(o, c, k, k, generator=g) * 0.1, torch.randn(o, c, k, k, generator=g) * 1.5 - 3.0
+    w_rho[0, 0] = -8.0
+    b_mu, b_rho = (torch.randn(o, generator=g) * 0.1, torch.randn(o, generator=g) - 3.0) if bias else (None, None)
+    return x, w_mu, w_rho, b_mu, b_rho
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"N{c[0]}C{c[1]}_{c[2]}x{c[3]}_O{c[4]}k{c[5]}s{c[6][0]}{c[6][1]}p{c[7][0]}{c[7][1]}" for c in CASES])
+def test_emulated_kernels_equal_torch(case):
+    n, c, h, w, o, k, stride, padding, bias = case
+    geo = (n, c, h, w, o, k, k, stride[0], stride[1], padding[0], padding[1])
+    x, w_mu, w_rho, b_mu, b_rho = _layer(n, c, h, w, o, k, bias, seed=7)
+    leaves = [t.double().clone().requires_grad_(True) for t in (x, w_mu, w_rho)]
+    xx, wm, wr = leaves
+    mean = F.conv2d(xx, wm, None if b_mu is None else b_mu.double(), stride=stride, padding=padding)
+    var = F.conv2d((xx ** 2).clamp(min=1e-4), (F.softplus(wr) ** 2).clamp(min=1e-4),
+                   None if b_rho is None else F.softplus(b_rho.double()) ** 2, stride=stride, padding=padding)
+    g = torch.Generator().manual_seed(3)
+    eps, gout = torch.randn(mean.shape, generator=g), torch.randn(mean.shape, generator=g)
+    out64 = mean + var.sqrt() * eps.double()
+    gx64, gwm64, gwr64 = torch.autograd.grad(out64, leaves, gout.double())
+
+    wb = E.prep(w_mu.numpy(), w_rho.numpy())
+    bvar = None if b_rho is None else (F.softplus(b_rho) ** 2).numpy()
+    out, var_out = E.conv_kernel(0, geo, x.numpy(), None, wb["wt_mu"], wb["wt_s2"], None if b_mu is None else b_mu.numpy(), bvar,
+                                 eps.numpy())
+    assert np.isfinite(out).all() and np.isfinite(var_out).all(), "an output element was never written (or read unwritten LDS)"
+    np.testing.assert_allclose(var_out, var.detach().numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(out, out64.detach().numpy(), rtol=2e-5, atol=2e-5)
+
+    gvar = (gout * eps / (2.0 * var.detach().sqrt())).float().numpy()
+    gx = E.conv_kernel(1, geo, gout.numpy(), gvar, wb["wb_mu"], wb["wb_s2"], x.numpy(), None, None)
+    assert np.isfinite(gx).all()
+    np.testing.assert_allclose(gx, gx64.numpy(), rtol=3e-5, atol=3e-5 * float(gx64.abs().max()))
+
+    gwm, gwr = E.wgrad_kernel(geo, x.numpy(), gout.numpy(), gvar, w_rho.numpy())
+    np.testing.assert_allclose(gwm, gwm64.numpy(), rtol=3e-5, atol=3e-5 * float(gwm64.abs().max()))
+    np.testing.assert_allclose(gwr, gwr64.numpy(), rtol=3e-5, atol=3e-5 * float(gwr64.abs().max()))
