@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _lines():
     out = []
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*bench*.json")) +
-                       glob.glob(os.path.join(ROOT, "profiles", "r03_*bench*.json"))):
+                       glob.glob(os.path.join(ROOT, "profiles", "r03_*bench*.json")) +
+                       glob.glob(os.path.join(ROOT, "profiles", "r04_*bench*.json"))):
         with open(path) as fh:
             text = fh.read().strip().splitlines()[-1]
         out.append((os.path.basename(path), json.loads(text)))
