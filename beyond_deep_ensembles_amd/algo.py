@@ -205,6 +205,27 @@ def collect_grads(params: Sequence[torch.nn.Parameter], views: Sequence[torch.Te
     return keep
 
 
+def _light_step(fn):
+    """torch wraps every Optimizer subclass's ``step`` (Optimizer.profile_hook_step): a profiler range, the step pre /
+    post hooks, ``_optimizer_step_code``.  With no hook registered and no profiler running that wrapper is pure host
+    cost -- 30-60 us per call on the GPU boxes, a third of a small model's whole SVGD step -- so ``step`` takes it only
+    when it has something to do: a hook on this optimizer, a global optimizer hook, or an active autograd profiler.
+    (``hooked = True`` is the marker torch itself checks before wrapping.)"""
+    import functools
+    import torch.optim.optimizer as _o
+    full = Optimizer.profile_hook_step(fn)
+
+    @functools.wraps(fn)
+    def step(self, *args, **kwargs):
+        hooks = getattr(self, "_optimizer_step_pre_hooks", None) is not None      # LastLayerBayesianOptimizer has no Optimizer state
+        if hooks and (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _o._global_optimizer_pre_hooks or
+                      _o._global_optimizer_post_hooks or torch.autograd._profiler_enabled()):
+            return full(self, *args, **kwargs)
+        return fn(self, *args, **kwargs)
+    step.hooked = True
+    return step
+
+
 class BayesianOptimizer(Optimizer):
     """Base of the posterior-inference optimizers; the public surface is the reference's
     (``src/algos/algo.py:5-80``):
@@ -220,6 +241,11 @@ class BayesianOptimizer(Optimizer):
     ``init_grad_scaler(scaler)``                 call once before the first step when using AMP
     ==========================================  ==================================================
     """
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        if "step" in cls.__dict__ and not getattr(cls.__dict__["step"], "hooked", False):
+            cls.step = _light_step(cls.__dict__["step"])
 
     def __init__(self, params, defaults):
         super().__init__(params, defaults)

@@ -219,6 +219,14 @@ class ParticleSet {
     return static_cast<int64_t>(keep_[row].size());
   }
 
+  // end(i) immediately followed by begin(next): one call from the interpreter instead of two (the step of a small model
+  // is host-bound: 8 particles x 2 calls were a sixth of it)
+  int64_t end_begin(int64_t i, at::Tensor table, int64_t row, int64_t M, int64_t zero_addr, int64_t next) {
+    const int64_t kept = end(i, std::move(table), row, M, zero_addr);
+    begin(next);
+    return kept;
+  }
+
   // (Handing the tensors to a worker thread instead was measured: the 8 x 161 frees, 0.28 ms, leave this thread, but the
   // closures get slower by as much -- allocator lock and, for gradients with Python wrappers, the interpreter lock --
   // and the step takes the same time: profiles/r03_shell_host_profile_release_ab.txt.)
@@ -253,6 +261,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("begin", &ParticleSet::begin)
       .def("set_grads", &ParticleSet::set_grads)
       .def("end", &ParticleSet::end)
+      .def("end_begin", &ParticleSet::end_begin)
       .def("release", &ParticleSet::release);
   m.def("repoint", &repoint, "param.data / param.grad = views, for whole parameter lists", py::arg("params"),
         py::arg("datas"), py::arg("grads"));

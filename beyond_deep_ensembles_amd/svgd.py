@@ -312,11 +312,16 @@ class SVGDOptimizer(BayesianOptimizer):
         return self._G[particle_idx]
 
     def step(self, forward_closure, backward_closure, grad_scaler=None):
+        local = self._local_particles()
+        if grad_scaler is None or not grad_scaler.is_enabled():
+            pset = self._particle_set()
+            if pset is not None and self._seg is not None and not self._overlap and hasattr(pset, "end_begin"):
+                return self._step_fast(forward_closure, backward_closure, local, pset)
         OptState = _opt_state()
         base = self.state["__base_optimizer"]
-        m, d = self.state["__particle_count"], self._layout.d
         total_loss = None
-        for particle_idx in self._local_particles():
+        last = local[-1]
+        for particle_idx in local:
             self._set_grad_scaler_state(grad_scaler, OptState.READY, base)
             self._begin_particle(particle_idx)
             loss = forward_closure()
@@ -326,7 +331,7 @@ class SVGDOptimizer(BayesianOptimizer):
                 total_loss = loss.detach().to(device=self._params_device(), dtype=torch.float32, copy=True)
             else:
                 total_loss += loss.detach()
-            if self._overlap and particle_idx == self._local_particles()[-1] and not self._scaler_active(grad_scaler):
+            if self._overlap and particle_idx == last and not self._scaler_active(grad_scaler):
                 self._begin_overlap(particle_idx, total_loss)
             backward_closure(loss)
             if not self._prepare_and_check_grads(grad_scaler, base):
@@ -334,6 +339,32 @@ class SVGDOptimizer(BayesianOptimizer):
             self._end_particle(particle_idx)
 
         return self._posterior_update(total_loss, grad_scaler)
+
+    def _step_fast(self, forward_closure, backward_closure, local, pset):
+        """The same loop for the common case -- no GradScaler, no overlapped exchange, native ParticleSet: nothing but
+        the closures, the loss sum and ONE native call per particle (end of particle i + begin of particle i + 1)
+        between two forward passes.  A small model's step is host-bound (BENCH extra svgd_step_cifar_resnet20_shell_fused:
+        ~115 us per step around 15 us of kernels in round 3)."""
+        if self._seg_host is None:
+            self._seg_host = self._seg.staging()
+        table, m_tab, zero = self._seg_host, self._seg.m, self._zeros.data_ptr()
+        row_off = local.start if self._exchange == "alltoall" else 0
+        first, last = local.start, local.stop - 1
+        pset.begin(first)
+        total_loss = None
+        for particle_idx in local:
+            loss = forward_closure()
+            if total_loss is None:
+                total_loss = loss.detach().to(device=self._P.device if self._P is not None else self._Pown.device,
+                                              dtype=torch.float32, copy=True)
+            else:
+                total_loss += loss.detach()
+            backward_closure(loss)
+            if particle_idx != last:
+                pset.end_begin(particle_idx, table, particle_idx - row_off, m_tab, zero, particle_idx + 1)
+            else:
+                pset.end(particle_idx, table, particle_idx - row_off, m_tab, zero)
+        return self._posterior_update(total_loss, None)
 
     def _particle_set(self):
         """The native object that runs the per-particle loops over its own tensor lists (csrc/host.cpp ParticleSet);

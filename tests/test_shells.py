@@ -195,6 +195,38 @@ def test_svgd_streaming_path_through_the_shell(backend, variant):
         assert float(base.state_dict()["state"][0]["step"]) == 3 * m
 
 
+def test_step_hooks_and_profiler_ranges_still_work(backend):
+    """BayesianOptimizer.step skips torch's per-call wrapper (profiler range + hook dispatch: a third of a small model's
+    step in host time) only while it has nothing to do: a step pre / post hook registered on the optimizer (or globally)
+    fires exactly as on any torch optimizer, and under an active profiler the "Optimizer.step#..." range is recorded."""
+    ops, dev = backend
+    torch.manual_seed(2)
+    model = make_mlp().to(dev)
+    base = torch.optim.SGD(model.parameters(), lr=0.05)
+    opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=3, dataset_size=16,
+                            _ops=ops)
+    x, y = torch.randn(8, 13, device=dev), torch.randn(8, 1, device=dev)
+    step = lambda: opt.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward())
+    assert getattr(type(opt).step, "hooked", False)          # torch does not wrap it a second time
+    step()
+    seen = []
+    h1 = opt.register_step_pre_hook(lambda o, args, kwargs: seen.append("pre"))
+    h2 = opt.register_step_post_hook(lambda o, args, kwargs: seen.append("post"))
+    step()
+    assert seen == ["pre", "post"]
+    h1.remove()
+    h2.remove()
+    step()
+    assert seen == ["pre", "post"]
+    if dev.type == "cpu":
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+            step()
+        assert any("Optimizer.step#SVGDOptimizer.step" in e.key for e in prof.key_averages())
+    # the combinator has no Optimizer state of its own: its step takes the light path too
+    ll = bde.LastLayerBayesianOptimizer(opt, torch.optim.SGD([torch.nn.Parameter(torch.zeros(2, device=dev))], lr=0.1))
+    assert torch.isfinite(ll.step(lambda: F.mse_loss(model(x), y), lambda l: l.backward()))
+
+
 def test_svgd_many_particles(backend):
     """particle_count > 16: the blocked update kernel, then (fuse_base_optimizer) ONE launch that applies the base optimizer
     to all particles in order with its shared state -- the same trajectory as the reference's loop of base.step() calls."""
