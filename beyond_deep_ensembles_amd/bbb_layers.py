@@ -428,10 +428,11 @@ class BBBConv2d(_LocalReparamLayer):
         w, b = self.weight, (self.bias if self.use_bias else None)
         frozen = not self.training and self.freeze_on_eval           # eval: ONE noise draw shared by the batch (stock path)
         if self.fused_conv and not frozen and input.dim() == 4 and input.dtype == torch.float32 \
+                and not isinstance(self.padding, str) and not isinstance(self.stride, str) \
                 and input.is_cuda == w.mean.is_cuda and hasattr(w._get_ops(), "conv_lrt_fwd"):
             ops = w._get_ops()
             stride, padding = _pair(self.stride), _pair(self.padding)
-            if isinstance(padding[0], int) and ops.conv_lrt_supported(input.shape, w.mean.shape, stride, padding):
+            if ops.conv_lrt_supported(input.shape, w.mean.shape, stride, padding):
                 eps = None
                 if not (w.rng == "philox" and w.noise_source is None):
                     ho = (input.shape[2] + 2 * padding[0] - self.kernel_size) // stride[0] + 1
