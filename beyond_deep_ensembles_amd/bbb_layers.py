@@ -224,11 +224,13 @@ class _ConvWeights:
     def drop(self) -> None:
         self.key = None
 
-    def get(self, mean: torch.Tensor, rho: torch.Tensor, ops):
-        key = (mean.data_ptr(), mean._version, rho.data_ptr(), rho._version, tuple(rho.shape), _SigmaCache.epoch)
+    def get(self, mean: torch.Tensor, rho: torch.Tensor, b_rho, ops):
+        key = (mean.data_ptr(), mean._version, rho.data_ptr(), rho._version, tuple(rho.shape), _SigmaCache.epoch,
+               None if b_rho is None else (b_rho.data_ptr(), b_rho._version))
         if key != self.key:
             buf = ops.conv_lrt_wbuf(rho.shape, rho.device)
-            ops.conv_lrt_prep(mean.detach().contiguous(), rho.detach().contiguous(), buf)
+            ops.conv_lrt_prep(mean.detach().contiguous(), rho.detach().contiguous(), buf,
+                              None if b_rho is None else b_rho.detach().contiguous())
             self.key, self.buf = key, buf
         return self.buf
 
@@ -248,13 +250,10 @@ class _ConvLrt(torch.autograd.Function):
         wo = (xc.shape[3] + 2 * padding[1] - w_mu.shape[3]) // stride[1] + 1
         out = torch.empty((n, o, ho, wo), dtype=torch.float32, device=x.device)
         var = torch.empty_like(out)
-        b_var = None
-        if b_rho is not None:
-            b_var = torch.empty_like(b_rho)
-            ops.var_operand_fwd(b_rho.detach().contiguous(), 2, b_var)          # softplus(b_rho)^2, not clamped (line 147)
         e = None if eps is None else eps.reshape(out.shape).contiguous()
-        ops.conv_lrt_fwd(xc, wbuf, tuple(w_mu.shape), None if b_mu is None else b_mu.detach().contiguous(), b_var, stride,
-                         padding, out, var, eps=e, seed=seed, stream_id=stream_id)
+        # the bias variance softplus(b_rho)^2 (not clamped, line 147) was evaluated by the preparation pass
+        ops.conv_lrt_fwd(xc, wbuf, tuple(w_mu.shape), None if b_mu is None else b_mu.detach().contiguous(), b_rho is not None,
+                         stride, padding, out, var, eps=e, seed=seed, stream_id=stream_id)
         ctx.save_for_backward(xc, w_mu, w_rho, b_rho, var, e, wbuf)
         ctx.meta = (stride, padding, seed, stream_id, ops)
         return out
@@ -438,7 +437,7 @@ class BBBConv2d(_LocalReparamLayer):
                     ho = (input.shape[2] + 2 * padding[0] - self.kernel_size) // stride[0] + 1
                     wo = (input.shape[3] + 2 * padding[1] - self.kernel_size) // stride[1] + 1
                     eps = normal_like(input.new_empty((input.shape[0], self.out_channels, ho, wo)))
-                wbuf = self._conv_weights.get(w.mean, w.rho, ops)
+                wbuf = self._conv_weights.get(w.mean, w.rho, b.rho if b is not None else None, ops)
                 return _ConvLrt.apply(input, w.mean, w.rho, b.mean if b is not None else None,
                                       b.rho if b is not None else None, stride, padding, eps, w.seed, next(_philox_stream), ops,
                                       wbuf)

@@ -349,8 +349,10 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
 //   [0]  WT_mu [ktot][op]      [1]  WT_s2 [ktot][op]           k = (c, r, q), op = O padded to 32    (forward)
 //   [2]  WB_mu [O khw][cp]     [3]  WB_s2 [O khw][cp]          k' = (o, flipped tap), cp = C padded to 32 (input gradient)
 //   [4]  DS2   [O][ktot]       [sigma^2 >= 1e-4] 2 sigma sigmoid(rho)                                 (weight gradient)
+//   [5]  BVAR  [op]            softplus(b_rho)^2, NOT clamped (bbb_layers.py:147); zero without a bias
 __global__ __launch_bounds__(kBlock) void conv_lrt_prep_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
-                                                               int O, int C, int khw, int op, int cp, float* __restrict__ wbuf) {
+                                                               const float* __restrict__ b_rho, int O, int C, int khw, int op,
+                                                               int cp, float* __restrict__ wbuf) {
   const int ktot = C * khw;
   const int64_t n = static_cast<int64_t>(O) * ktot;
   float* wt_mu = wbuf;
@@ -358,8 +360,13 @@ __global__ __launch_bounds__(kBlock) void conv_lrt_prep_kernel(const float* __re
   float* wb_mu = wt_s2 + static_cast<int64_t>(ktot) * op;
   float* wb_s2 = wb_mu + static_cast<int64_t>(O) * khw * cp;
   float* ds2 = wb_s2 + static_cast<int64_t>(O) * khw * cp;
+  float* bvar = ds2 + n;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (i < O) {
+      const float sb = b_rho ? softplus(b_rho[i]) : 0.f;
+      bvar[i] = sb * sb;
+    }
     const int o = static_cast<int>(i / ktot), k = static_cast<int>(i % ktot);
     const int c = k / khw, rq = k % khw;
     const float mu = w_mu[i];
@@ -473,7 +480,7 @@ static bool data_grad_geo(const ConvGeo& l, ConvGeo& g) {
 }
 
 struct WBuf {
-  const float *wt_mu, *wt_s2, *wb_mu, *wb_s2, *ds2;
+  const float *wt_mu, *wt_s2, *wb_mu, *wb_s2, *ds2, *bvar;
 };
 static WBuf wbuf_parts(const float* wbuf, int O, int C, int khw) {
   const int64_t ktot = static_cast<int64_t>(C) * khw, op = pad32(O), cp = pad32(C);
@@ -483,6 +490,7 @@ static WBuf wbuf_parts(const float* wbuf, int O, int C, int khw) {
   b.wb_mu = b.wt_s2 + ktot * op;
   b.wb_s2 = b.wb_mu + static_cast<int64_t>(O) * khw * cp;
   b.ds2 = b.wb_s2 + static_cast<int64_t>(O) * khw * cp;
+  b.bvar = b.ds2 + static_cast<int64_t>(O) * ktot;
   return b;
 }
 
@@ -529,18 +537,19 @@ extern "C" int bde_conv_lrt_plan(int which, int N, int C, int H, int W, int O, i
 extern "C" size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW) {
   if (O < 1 || C < 1 || KH < 1 || KW < 1) return 0;
   const size_t khw = static_cast<size_t>(KH) * KW, ktot = khw * C;
-  return 2 * ktot * pad32(O) + 2 * static_cast<size_t>(O) * khw * pad32(C) + static_cast<size_t>(O) * ktot;
+  return 2 * ktot * pad32(O) + 2 * static_cast<size_t>(O) * khw * pad32(C) + static_cast<size_t>(O) * ktot + pad32(O);
 }
 
-extern "C" int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, int O, int C, int KH, int KW, float* wbuf, void* stream) {
+extern "C" int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, const float* b_rho, int O, int C, int KH, int KW,
+                                 float* wbuf, void* stream) {
   if (!w_mu || !w_rho || !wbuf || !aligned16(wbuf) || bde_conv_lrt_prep_floats(O, C, KH, KW) == 0) return BDE_ERR_INVALID;
-  const int64_t n = static_cast<int64_t>(O) * C * KH * KW;
-  hipLaunchKernelGGL(conv_lrt_prep_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w_mu, w_rho, O,
-                     C, KH * KW, pad32(O), pad32(C), wbuf);
+  const int64_t n = static_cast<int64_t>(O) * C * KH * KW;                    // n >= O: the bias entries ride along
+  hipLaunchKernelGGL(conv_lrt_prep_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w_mu, w_rho,
+                     b_rho, O, C, KH * KW, pad32(O), pad32(C), wbuf);
   return to_err(hipGetLastError());
 }
 
-extern "C" int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, const float* b_var, const float* eps,
+extern "C" int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, int has_bias_var, const float* eps,
                                 uint64_t seed, uint64_t stream_id, float* out, float* var_out, int N, int C, int H, int W,
                                 int O, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
   ConvGeo g;
@@ -549,6 +558,7 @@ extern "C" int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* 
     return BDE_ERR_INVALID;
   if (!aligned16(wbuf) || !aligned16(out) || !aligned16(var_out) || (eps && !aligned16(eps))) return BDE_ERR_INVALID;
   const WBuf w = wbuf_parts(wbuf, O, C, KH * KW);
+  const float* b_var = has_bias_var ? w.bvar : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (eps) launch_conv<0, false>(p, s, x, nullptr, w.wt_mu, w.wt_s2, b_mu, b_var, eps, seed, stream_id, out, var_out, g);
   else launch_conv<0, true>(p, s, x, nullptr, w.wt_mu, w.wt_s2, b_mu, b_var, eps, seed, stream_id, out, var_out, g);

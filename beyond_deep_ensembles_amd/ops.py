@@ -452,17 +452,20 @@ class HipOps:
         return torch.zeros(int(self.lib.bde_conv_lrt_prep_floats(o, c, kh, kw)), dtype=torch.float32, device=device)
 
     @_on_device_of
-    def conv_lrt_prep(self, w_mu, w_rho, wbuf):
-        """Once per weight version: sigma^2, its rho-derivative and the re-arranged weight matrices into ``wbuf``."""
+    def conv_lrt_prep(self, w_mu, w_rho, wbuf, b_rho=None):
+        """Once per weight version: sigma^2, its rho-derivative, the bias variance softplus(b_rho)^2 and the re-arranged
+        weight matrices into ``wbuf``."""
         o, c, kh, kw = w_mu.shape
-        _check(self.lib.bde_conv_lrt_prep(_ptr(w_mu, "w_mu"), _ptr(w_rho), o, c, kh, kw, _ptr(wbuf), _stream()), "bde_conv_lrt_prep")
+        _check(self.lib.bde_conv_lrt_prep(_ptr(w_mu, "w_mu"), _ptr(w_rho), _ptr(b_rho), o, c, kh, kw, _ptr(wbuf), _stream()),
+               "bde_conv_lrt_prep")
 
     @_on_device_of
-    def conv_lrt_fwd(self, x, wbuf, w_shape, b_mu, b_var, stride, padding, out, var_out, eps=None, seed=0, stream_id=0):
-        """BBBConv2d forward (bbb_layers.py:146-154) in one launch; all tensors contiguous fp32 NCHW."""
+    def conv_lrt_fwd(self, x, wbuf, w_shape, b_mu, bias_var, stride, padding, out, var_out, eps=None, seed=0, stream_id=0):
+        """BBBConv2d forward (bbb_layers.py:146-154) in one launch; all tensors contiguous fp32 NCHW.  ``bias_var``: add
+        the bias variance conv_lrt_prep evaluated from its ``b_rho``."""
         n, c, h, w = x.shape
         o, _, kh, kw = w_shape
-        _check(self.lib.bde_conv_lrt_fwd(_ptr(x, "x"), _ptr(wbuf), _ptr(b_mu), _ptr(b_var), _ptr(eps), seed, stream_id,
+        _check(self.lib.bde_conv_lrt_fwd(_ptr(x, "x"), _ptr(wbuf), _ptr(b_mu), int(bool(bias_var)), _ptr(eps), seed, stream_id,
                                          _ptr(out), _ptr(var_out), n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0],
                                          padding[1], _stream()), "bde_conv_lrt_fwd")
 

@@ -342,14 +342,15 @@ int bde_var_operand_bwd(const float* g, const float* v, int mode, float* gv, int
  *
  * bde_conv_lrt_prep -- once per weight VERSION (the weights change at base_optimizer.step(); a BBB step runs mc_samples
  * forward / backward passes per version, bbb.py:63-67): sigma^2 = clamp(softplus(W_rho)^2, 1e-4), its rho-derivative,
- * and both weight matrices re-arranged the way the kernels stage them (k-major, output channels padded to 32, for the
- * forward; transposed and flipped for the input gradient).  wbuf: bde_conv_lrt_prep_floats() floats, 16-byte aligned,
+ * the bias variance, and both weight matrices re-arranged the way the kernels stage them (k-major, output channels padded
+ * to 32, for the forward; transposed and flipped for the input gradient).  wbuf: bde_conv_lrt_prep_floats() floats, 16-byte aligned,
  * ZERO-INITIALISED by the caller once (the padding is never written).
  *
  * bde_conv_lrt_fwd -- both convolutions of lines 146-147, conv2d(x, W_mu, b_mu) and conv2d(clamp(x^2, 1e-4), sigma^2,
  * b_var), as ONE implicit GEMM with two accumulators per output tile over the same staged input windows (zero padding
  * applied after the clamp, as F.conv2d pads the clamped tensor), then out = mean + sqrt(var) * eps (lines 148-154) in
- * the epilogue.  x [N, C, H, W], b_mu / b_var [O] or NULL (b_var = softplus(b_rho)^2, NOT clamped: line 147),
+ * the epilogue.  x [N, C, H, W], b_mu [O] or NULL; has_bias_var != 0: the bias variance softplus(b_rho)^2 (NOT clamped:
+ * line 147) that bde_conv_lrt_prep evaluated from its b_rho argument (NULL there = no bias variance) is added,
  * out / var_out [N, O, Ho, Wo] (var_out = the total activation variance, which the backward pass needs); all fp32,
  * contiguous NCHW, 16-byte aligned.  eps [N, O, Ho, Wo] or NULL = Philox(seed, stream_id) with the element numbering
  * of bde_local_reparam_fwd over the flat output (so bde_local_reparam_bwd regenerates the same noise).
@@ -374,8 +375,9 @@ int bde_conv_lrt_plan(int which, int N, int C, int H, int W, int O, int KH, int 
 int bde_conv_lrt_bwd_weight_plan(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h,
                                  int pad_w, int* out);
 size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW);
-int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, int O, int C, int KH, int KW, float* wbuf, void* stream);
-int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, const float* b_var, const float* eps, uint64_t seed,
+int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, const float* b_rho, int O, int C, int KH, int KW, float* wbuf,
+                      void* stream);
+int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, int has_bias_var, const float* eps, uint64_t seed,
                      uint64_t stream_id, float* out, float* var_out, int N, int C, int H, int W, int O, int KH, int KW,
                      int stride_h, int stride_w, int pad_h, int pad_w, void* stream);
 int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, const float* wbuf, const float* x, float* g_x, int N, int C,

@@ -236,13 +236,15 @@ class OracleOps:
     def conv_lrt_wbuf(self, w_shape, device):
         return torch.zeros(4)
 
-    def conv_lrt_prep(self, w_mu, w_rho, wbuf):
+    def conv_lrt_prep(self, w_mu, w_rho, wbuf, b_rho=None):
         if not hasattr(self, "_conv_w"):
             self._conv_w = {}
-        self._conv_w[wbuf.data_ptr()] = (w_mu.detach().clone(), (F.softplus(w_rho.detach()) ** 2).clamp(min=1e-4), wbuf)
+        b_var = None if b_rho is None else F.softplus(b_rho.detach()) ** 2
+        self._conv_w[wbuf.data_ptr()] = (w_mu.detach().clone(), (F.softplus(w_rho.detach()) ** 2).clamp(min=1e-4), wbuf, b_var)
 
-    def conv_lrt_fwd(self, x, wbuf, w_shape, b_mu, b_var, stride, padding, out, var_out, eps=None, seed=0, stream_id=0):
-        w_mu, s2, _ = self._conv_w[wbuf.data_ptr()]
+    def conv_lrt_fwd(self, x, wbuf, w_shape, b_mu, bias_var, stride, padding, out, var_out, eps=None, seed=0, stream_id=0):
+        w_mu, s2, _, b_var = self._conv_w[wbuf.data_ptr()]
+        b_var = b_var if bias_var else None
         mean = F.conv2d(x, w_mu, b_mu, stride=stride, padding=padding)                       # bbb_layers.py:146
         var = F.conv2d((x ** 2).clamp(min=1e-4), s2, b_var, stride=stride, padding=padding)  # :147
         z = eps if eps is not None else _philox(seed, stream_id, out.numel()).view(out.shape)
@@ -250,7 +252,7 @@ class OracleOps:
         var_out.copy_(var)
 
     def conv_lrt_bwd_data(self, g_out, g_var, wbuf, w_shape, x, g_x, stride, padding):
-        w_mu, s2, _ = self._conv_w[wbuf.data_ptr()]
+        w_mu, s2 = self._conv_w[wbuf.data_ptr()][:2]
         gm = torch.nn.grad.conv2d_input(x.shape, w_mu, g_out, stride=stride, padding=padding)
         gv = torch.nn.grad.conv2d_input(x.shape, s2, g_var, stride=stride, padding=padding)
         g_x.copy_(gm + torch.where(x * x >= 1e-4, 2.0 * x * gv, torch.zeros_like(x)))

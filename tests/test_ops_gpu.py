@@ -992,11 +992,8 @@ def test_conv_lrt_forward(ops):
         dev = lambda t: None if t is None else t.to(DEV).contiguous()
         xd, wm = dev(x), dev(w_mu)
         wbuf = ops.conv_lrt_wbuf(w_mu.shape, DEV)
-        ops.conv_lrt_prep(wm, dev(w_rho), wbuf)
-        bvar = None
-        if bias:
-            bvar = torch.empty(o, device=DEV)
-            ops.var_operand_fwd(dev(b_rho), 2, bvar)
+        ops.conv_lrt_prep(wm, dev(w_rho), wbuf, dev(b_rho))
+        bvar = bias
         assert ops.conv_lrt_supported(x.shape, w_mu.shape, stride, padding), (n, c, h, w, o, k)
         out, var = torch.full(m32.shape, 9.0, device=DEV), torch.full(m32.shape, 9.0, device=DEV)
         ops.conv_lrt_fwd(xd, wbuf, w_mu.shape, dev(b_mu), bvar, stride, padding, out, var, eps=dev(eps))

@@ -22,7 +22,7 @@ for n, c, h, w, o, k, s, p in shapes:
     ops.var_operand_fwd(wr, 1, ws2)
     ops.var_operand_fwd(br, 2, bv)
     wbuf = ops.conv_lrt_wbuf(wm.shape, dev)
-    ops.conv_lrt_prep(wm, wr, wbuf)
+    ops.conv_lrt_prep(wm, wr, wbuf, br)
     ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
     out, var = torch.empty(n, o, ho, wo, device=dev), torch.empty(n, o, ho, wo, device=dev)
     if not ops.conv_lrt_supported(x.shape, wm.shape, (s, s), (p, p)):
@@ -30,7 +30,7 @@ for n, c, h, w, o, k, s, p in shapes:
         continue
 
     def fused():
-        ops.conv_lrt_fwd(x, wbuf, wm.shape, bm, bv, (s, s), (p, p), out, var, seed=1, stream_id=2)
+        ops.conv_lrt_fwd(x, wbuf, wm.shape, bm, True, (s, s), (p, p), out, var, seed=1, stream_id=2)
 
     def torch_seq():
         mean = F.conv2d(x, wm, bm, stride=s, padding=p)
