@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int row_elems = t.PH * t.PWP;
   const int img_floats = t.CC * row_elems;
-  const int patch_floats = t.NI * img_floats;
+  const int patch_floats = (t.NI * img_floats + 3) & ~3;    // the weight tiles behind the two patch images are written as float4
   float* xs = lds;
   float* x2s = lds + patch_floats;
   float* wm = lds + 2 * patch_floats;
@@ -257,7 +257,10 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
   // consecutive pixels of one channel: one Philox call per float4, 16-byte loads / stores.  Needs the float4 groups of
   // the flat output aligned with the tiles (Ho Wo and the band size multiples of 4); otherwise element by element.
   const int64_t howo = static_cast<int64_t>(g.Ho) * g.Wo;
-  const bool vec = (howo & 3) == 0 && ((t.TH * g.Wo) & 3) == 0;
+  const uintptr_t ptr_bits = reinterpret_cast<uintptr_t>(out) | (MODE == 1 ? reinterpret_cast<uintptr_t>(bmu)
+                                                                            : reinterpret_cast<uintptr_t>(var_out) |
+                                                                                  (RNG ? 0 : reinterpret_cast<uintptr_t>(eps)));
+  const bool vec = (howo & 3) == 0 && ((t.TH * g.Wo) & 3) == 0 && (ptr_bits & 15) == 0;
   float* tm = lds + wave * 2 * MF * RS;
   float* tv = tm + MF * RS;
   constexpr int Q = MF / 4;                                // float4 groups per tile row
@@ -428,7 +431,7 @@ static bool plan_fwd(const ConvGeo& g, FwdPlan& p) {
         for (int cc = g.C; cc >= 1; cc = (cc > 8 ? cc / 2 : cc - 1)) {
           const int kc = cc * khw;
           const int kcpad = (kc + ks * wk - 1) / (ks * wk) * (ks * wk);
-          const size_t lds = sizeof(float) * (2ull * ni * cc * ph * pwp + 2ull * kcpad * mf + kcpad);
+          const size_t lds = sizeof(float) * (2ull * ((static_cast<size_t>(ni) * cc * ph * pwp + 3) & ~size_t{3}) + 2ull * kcpad * mf + kcpad);
           const size_t red = wk > 1 ? sizeof(float) * 4ull * pt * 2 * regs * 64 : 0;
           const size_t need = std::max(std::max(lds, red), epi);
           if (need > 64 * 1024) continue;
@@ -556,7 +559,7 @@ extern "C" int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* 
   FwdPlan p;
   if (!x || !wbuf || !out || !var_out || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) || !plan_fwd(g, p))
     return BDE_ERR_INVALID;
-  if (!aligned16(wbuf) || !aligned16(out) || !aligned16(var_out) || (eps && !aligned16(eps))) return BDE_ERR_INVALID;
+  if (!aligned16(wbuf)) return BDE_ERR_INVALID;           // out / var_out / eps: 16-byte alignment only selects the float4 epilogue
   const WBuf w = wbuf_parts(wbuf, O, C, KH * KW);
   const float* b_var = has_bias_var ? w.bvar : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -573,7 +576,7 @@ extern "C" int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, con
   if (!g_out || !g_var || !wbuf || !x || !g_x || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, l) || !data_grad_geo(l, g) ||
       !plan_fwd(g, p))
     return BDE_ERR_INVALID;
-  if (!aligned16(wbuf) || !aligned16(x) || !aligned16(g_x)) return BDE_ERR_INVALID;
+  if (!aligned16(wbuf)) return BDE_ERR_INVALID;
   const WBuf w = wbuf_parts(wbuf, O, C, KH * KW);
   launch_conv<1, false>(p, static_cast<hipStream_t>(stream), g_out, g_var, w.wb_mu, w.wb_s2, x, nullptr, nullptr, 0, 0, g_x, nullptr, g);
   return to_err(hipGetLastError());

@@ -93,7 +93,8 @@ def conv_kernel(mode, layer_geo, a1, a2, wt_mu, wt_s2, b1, b2, eps):
     tpi, kcpad_max = p["tiles_per_img"], p["kcpad_max"]
     row_elems = PH * PWP
     img_floats = CC * row_elems
-    patch_floats = NI * img_floats
+    patch_floats = (NI * img_floats + 3) & ~3                  # float4 (16-byte) alignment of the weight tiles behind the patches
+    assert (2 * patch_floats) % 4 == 0 and MF % 4 == 0 and RS % 4 == 0 and (2 * MF * RS) % 4 == 0 and g["rp"] % 4 == 0
     khw = g["KH"] * g["KW"]
     howo = g["Ho"] * g["Wo"]
     out = np.full(g["N"] * g["O"] * howo, np.nan, np.float32)
@@ -170,6 +171,7 @@ def conv_kernel(mode, layer_geo, a1, a2, wt_mu, wt_s2, b1, b2, eps):
                     k, o4 = e // Q, e % Q
                     if k < kc:
                         src = (k_base + k) * g["rp"] + o0 + 4 * o4
+                        assert src % 4 == 0 and (k * MF + 4 * o4) % 4 == 0
                         wm[k * MF + 4 * o4:k * MF + 4 * o4 + 4] = wt_mu.reshape(-1)[src:src + 4]
                         wsv[k * MF + 4 * o4:k * MF + 4 * o4 + 4] = wt_s2.reshape(-1)[src:src + 4]
                     else:
