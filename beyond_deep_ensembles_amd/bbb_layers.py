@@ -438,6 +438,11 @@ class BBBConv2d(_LocalReparamLayer):
                     wo = (input.shape[3] + 2 * padding[1] - self.kernel_size) // stride[1] + 1
                     eps = normal_like(input.new_empty((input.shape[0], self.out_channels, ho, wo)))
                 wbuf = self._conv_weights.get(w.mean, w.rho, b.rho if b is not None else None, ops)
+                native = _native_nodes(ops)
+                if native is not None and hasattr(native, "conv_lrt"):
+                    return native.conv_lrt(input, w.mean, w.rho, b.mean if b is not None else None,
+                                           b.rho if b is not None else None, stride[0], stride[1], padding[0], padding[1], eps,
+                                           w.seed, next(_philox_stream), wbuf)
                 return _ConvLrt.apply(input, w.mean, w.rho, b.mean if b is not None else None,
                                       b.rho if b is not None else None, stride, padding, eps, w.seed, next(_philox_stream), ops,
                                       wbuf)

@@ -167,6 +167,88 @@ struct VarOperand : public torch::autograd::Function<VarOperand> {
   }
 };
 
+// ---- BBBConv2d, sampling="activations" (bbb_layers.py:146-154): forward bde_conv_lrt_fwd (both convolutions + the sampling
+// epilogue in one launch); backward bde_local_reparam_bwd (g_var) + bde_conv_lrt_bwd_data + bde_conv_lrt_bwd_weight + two
+// channel sums for the bias.  `wbuf` = the weight buffer bde_conv_lrt_prep filled for THIS version of (w_mu, w_rho, b_rho).
+struct ConvLrt : public torch::autograd::Function<ConvLrt> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho,
+                            const c10::optional<at::Tensor>& b_mu_, const c10::optional<at::Tensor>& b_rho_, int64_t sh,
+                            int64_t sw, int64_t ph, int64_t pw, const c10::optional<at::Tensor>& eps_, int64_t seed,
+                            int64_t stream_id, const at::Tensor& wbuf) {
+    at::Tensor b_mu = opt(b_mu_), b_rho = opt(b_rho_), eps = opt(eps_);
+    check_f32_cuda(x, "x");
+    check_f32_cuda(w_mu, "w_mu");
+    check_f32_cuda(w_rho, "w_rho");
+    check_f32_cuda(wbuf, "wbuf");
+    TORCH_CHECK(x.dim() == 4 && w_mu.dim() == 4 && x.size(1) == w_mu.size(1), "conv_lrt: x [N, C, H, W], w [O, C, KH, KW]");
+    TORCH_CHECK(b_mu.defined() == b_rho.defined(), "bias mean and rho come together");
+    c10::DeviceGuard guard(x.device());
+    const at::Tensor xc = x.detach().contiguous();
+    const int N = static_cast<int>(xc.size(0)), C = static_cast<int>(xc.size(1)), H = static_cast<int>(xc.size(2)),
+              W = static_cast<int>(xc.size(3)), O = static_cast<int>(w_mu.size(0)), KH = static_cast<int>(w_mu.size(2)),
+              KW = static_cast<int>(w_mu.size(3));
+    const int64_t Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
+    at::Tensor out = at::empty({N, O, Ho, Wo}, xc.options()), var = at::empty({N, O, Ho, Wo}, xc.options());
+    at::Tensor e;
+    if (eps.defined()) e = eps.reshape(out.sizes()).contiguous();
+    at::Tensor bm;
+    if (b_mu.defined()) bm = b_mu.detach().contiguous();
+    const int rc = bde_conv_lrt_fwd(ptr(xc), ptr(wbuf), ptr(bm), b_rho.defined() ? 1 : 0, ptr(e), static_cast<uint64_t>(seed),
+                                    static_cast<uint64_t>(stream_id), mptr(out), mptr(var), N, C, H, W, O, KH, KW,
+                                    static_cast<int>(sh), static_cast<int>(sw), static_cast<int>(ph), static_cast<int>(pw),
+                                    current_stream(xc));
+    TORCH_CHECK(rc == 0, "bde_conv_lrt_fwd failed with code ", rc);
+    ctx->save_for_backward({xc, w_mu, w_rho, b_rho, var, e, wbuf});
+    ctx->saved_data["geo"] = std::vector<int64_t>{sh, sw, ph, pw};
+    ctx->saved_data["seed"] = seed;
+    ctx->saved_data["stream_id"] = stream_id;
+    return out;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grad_outputs) {
+    check_once_differentiable(grad_outputs);
+    const variable_list saved = ctx->get_saved_variables();
+    const at::Tensor &x = saved[0], &w_mu = saved[1], &w_rho = saved[2], &b_rho = saved[3], &var = saved[4], &eps = saved[5],
+                     &wbuf = saved[6];
+    const std::vector<int64_t> geo = ctx->saved_data["geo"].toIntVector();
+    const int sh = static_cast<int>(geo[0]), sw = static_cast<int>(geo[1]), ph = static_cast<int>(geo[2]), pw = static_cast<int>(geo[3]);
+    c10::DeviceGuard guard(x.device());
+    const int N = static_cast<int>(x.size(0)), C = static_cast<int>(x.size(1)), H = static_cast<int>(x.size(2)),
+              W = static_cast<int>(x.size(3)), O = static_cast<int>(w_mu.size(0)), KH = static_cast<int>(w_mu.size(2)),
+              KW = static_cast<int>(w_mu.size(3));
+    const at::Tensor g = grad_outputs[0].contiguous();
+    at::Tensor gvar = at::empty_like(g);
+    void* stream = current_stream(x);
+    int rc = bde_local_reparam_bwd(ptr(g), ptr(var), ptr(eps), static_cast<uint64_t>(ctx->saved_data["seed"].toInt()),
+                                   static_cast<uint64_t>(ctx->saved_data["stream_id"].toInt()), mptr(gvar), g.numel(), stream);
+    TORCH_CHECK(rc == 0, "bde_local_reparam_bwd failed with code ", rc);
+    at::Tensor g_x;
+    if (ctx->needs_input_grad(0)) {
+      g_x = at::empty_like(x);
+      rc = bde_conv_lrt_bwd_data(ptr(g), ptr(gvar), ptr(wbuf), ptr(x), mptr(g_x), N, C, H, W, O, KH, KW, sh, sw, ph, pw, stream);
+      TORCH_CHECK(rc == 0, "bde_conv_lrt_bwd_data failed with code ", rc);
+    }
+    const at::Tensor wr = w_rho.detach().contiguous();
+    at::Tensor g_wmu = at::empty_like(wr), g_wrho = at::empty_like(wr);
+    const size_t ws_bytes = bde_conv_lrt_bwd_weight_ws_bytes(N, C, H, W, O, KH, KW, sh, sw, ph, pw);
+    TORCH_CHECK(ws_bytes > 0, "conv_lrt: unsupported geometry in the weight-gradient pass");
+    at::Tensor ws = at::empty({static_cast<int64_t>((ws_bytes + 3) / 4)}, x.options());
+    rc = bde_conv_lrt_bwd_weight(ptr(x), ptr(g), ptr(gvar), ptr(wr), ws.data_ptr(), mptr(g_wmu), mptr(g_wrho), N, C, H, W, O, KH,
+                                 KW, sh, sw, ph, pw, stream);
+    TORCH_CHECK(rc == 0, "bde_conv_lrt_bwd_weight failed with code ", rc);
+    at::Tensor g_bmu, g_brho;
+    if (b_rho.defined()) {
+      g_bmu = g.sum({0, 2, 3});
+      const at::Tensor g_bvar = gvar.sum({0, 2, 3}), br = b_rho.detach().contiguous();
+      g_brho = at::empty_like(g_bvar);
+      rc = bde_var_operand_bwd(ptr(g_bvar), ptr(br), 2, mptr(g_brho), br.numel(), stream);     // d softplus(rho)^2 / d rho
+      TORCH_CHECK(rc == 0, "bde_var_operand_bwd failed with code ", rc);
+    }
+    return {g_x, g_wmu, g_wrho, g_bmu, g_brho, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+            at::Tensor(), at::Tensor()};
+  }
+};
+
 }  // namespace
 
 void bind_autograd_nodes(py::module_& m) {
@@ -183,6 +265,15 @@ void bind_autograd_nodes(py::module_& m) {
         [](const at::Tensor& mean, const at::Tensor& var, const c10::optional<at::Tensor>& eps, int64_t seed,
            int64_t stream_id) { return LocalReparam::apply(mean, var, eps, seed, stream_id); },
         "mean + sqrt(var) * eps", py::arg("mean"), py::arg("var"), py::arg("eps"), py::arg("seed"), py::arg("stream_id"));
+  m.def("conv_lrt",
+        [](const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho, const c10::optional<at::Tensor>& b_mu,
+           const c10::optional<at::Tensor>& b_rho, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+           const c10::optional<at::Tensor>& eps, int64_t seed, int64_t stream_id, const at::Tensor& wbuf) {
+          return ConvLrt::apply(x, w_mu, w_rho, b_mu, b_rho, sh, sw, ph, pw, eps, seed, stream_id, wbuf);
+        },
+        "BBBConv2d forward (local reparameterisation, fused) with its fused backward", py::arg("x"), py::arg("w_mu"),
+        py::arg("w_rho"), py::arg("b_mu"), py::arg("b_rho"), py::arg("sh"), py::arg("sw"), py::arg("ph"), py::arg("pw"),
+        py::arg("eps"), py::arg("seed"), py::arg("stream_id"), py::arg("wbuf"));
   m.def("var_operand", [](const at::Tensor& v, int64_t mode) { return VarOperand::apply(v, mode); },
         "clamp(v^2) / clamp(softplus(v)^2) / softplus(v)^2", py::arg("v"), py::arg("mode"));
 }

@@ -1287,6 +1287,28 @@ def test_native_autograd_nodes_equal_python_nodes():
             out = native.var_operand(v, mode) if node == "native" else L._VarOperand.apply(v, mode, ops)
             res.append([out.detach(), torch.autograd.grad(out, v, grad_outputs=torch.full_like(out, 0.3))[0]])
         assert all(torch.equal(a, c) for a, c in zip(*res)), mode
+    # the fused convolution layer (round 4): C++ node == Python Function, with and without bias / supplied noise / input gradient
+    for n, c, h, w, o, k, s_, p_, bias in [(4, 16, 32, 32, 16, 3, 1, 1, True), (3, 5, 9, 11, 7, 3, 2, 1, False), (2, 32, 16, 16, 64, 3, 2, 1, True)]:
+        x0 = torch.randn(n, c, h, w, device=dev)
+        w_mu, w_rho = torch.randn(o, c, k, k, device=dev) * 0.1, torch.randn(o, c, k, k, device=dev) - 3
+        b_mu, b_rho = (torch.randn(o, device=dev) * 0.1, torch.randn(o, device=dev) - 3) if bias else (None, None)
+        wbuf = ops.conv_lrt_wbuf(w_mu.shape, dev)
+        ops.conv_lrt_prep(w_mu, w_rho, wbuf, b_rho)
+        ho, wo = (h + 2 * p_ - k) // s_ + 1, (w + 2 * p_ - k) // s_ + 1
+        for eps in (None, torch.randn(n, o, ho, wo, device=dev)):
+            for x_grad in (True, False):
+                res = []
+                for node in ("native", "python"):
+                    leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (x0, w_mu, w_rho, b_mu, b_rho)]
+                    leaves[0].requires_grad_(x_grad)
+                    if node == "native":
+                        out = native.conv_lrt(*leaves, s_, s_, p_, p_, eps, 5, 9, wbuf)
+                    else:
+                        out = L._ConvLrt.apply(*leaves, (s_, s_), (p_, p_), eps, 5, 9, ops, wbuf)
+                    wrt = [t for t in leaves if t is not None and t.requires_grad]
+                    grads = torch.autograd.grad(out, wrt, grad_outputs=torch.ones_like(out) * 0.5)
+                    res.append([out.detach()] + list(grads))
+                assert all(torch.equal(a, c2) for a, c2 in zip(*res)), (n, c, h, w, o, bias, eps is None, x_grad)
     # a layer without input gradient, and errors raised as exceptions
     xin = torch.randn(8, 13, device=dev)
     leaves = [t.requires_grad_(True) for t in (torch.randn(50, 13, device=dev), torch.randn(50, 13, device=dev) - 3)]
