@@ -23,6 +23,7 @@ Fixture list:
   ref_*_checkpoint.pt state_dict()s written by the reference optimizers (wire compatibility); ref_svgd_checkpoint4*:
                       four particles, nesterov SGD, two further reference steps (multi-rank resume)
   rank1.npz           BBBOptimizer over the reference's Rank1Linear, 2 components, draws recorded
+  conv_lrt.npz        the reference's BBBConv2d layer: output + all five gradients at the ResNet-20 layer shapes
 """
 import math
 import os
@@ -463,6 +464,57 @@ def gen_lrt():
     np.savez_compressed(os.path.join(OUT, "lrt.npz"), **out)
 
 
+def gen_conv():
+    """conv_lrt.npz: the REFERENCE's BBBConv2d (bbb_layers.py:105-160, sampling="activations", training mode) on seeded
+    inputs: the output and d(sum(out * g)) / d(input, weight mean / rho, bias mean / rho) from its autograd graph, at the
+    CIFAR ResNet-20 layer shapes (small batch) and two ragged geometries.  The bias gradients are stored in full; the
+    weight gradients as per-output-channel sums, per-(c, r, q) sums, one seeded projection, the absolute maximum and a
+    raw corner; the input gradient and the output as per-image-and-channel sums, per-pixel sums, a projection and a raw
+    corner (the inputs are regenerated by the tests from the seeds)."""
+    from conv_cases import CONV_CASES, conv_case_inputs, conv_probe_w   # oracle/conv_cases.py: seeded inputs shared with the tests
+    out = {"cases": np.array(CONV_CASES)}
+    prior = ref_bbb.GaussianPrior(0, 1.0)
+    for seed, n, c, h, w, o, k, stride, padding, bias in CONV_CASES:
+        x, w_mu, w_rho, b_mu, b_rho, eps, g, probe_x = conv_case_inputs(seed, n, c, h, w, o, k, stride, padding)
+        layer = ref_bbb_layers.BBBConv2d(c, o, k, prior, prior, stride=stride, padding=padding, bias=bool(bias))
+        layer.train()
+        with torch.no_grad():
+            layer.weight.mean.copy_(torch.from_numpy(w_mu))
+            layer.weight.rho.copy_(torch.from_numpy(w_rho))
+            if bias:
+                layer.bias.mean.copy_(torch.from_numpy(b_mu))
+                layer.bias.rho.copy_(torch.from_numpy(b_rho))
+        xin = torch.from_numpy(x).requires_grad_(True)
+        old = ref_bbb_layers.normal_like
+        ref_bbb_layers.normal_like = lambda t: torch.from_numpy(eps)
+        try:
+            y = layer(xin)
+        finally:
+            ref_bbb_layers.normal_like = old
+        leaves = [xin, layer.weight.mean, layer.weight.rho] + ([layer.bias.mean, layer.bias.rho] if bias else [])
+        grads = torch.autograd.grad(y, leaves, grad_outputs=torch.from_numpy(g))
+        t = f"c{seed}_"
+        pw_ = torch.from_numpy(conv_probe_w(seed, o, c, k)).double()
+        for name, gw in (("g_wmu", grads[1]), ("g_wrho", grads[2])):
+            f64 = gw.double()
+            out[t + name + "_rowsum"] = f64.sum((1, 2, 3)).numpy()         # [O]
+            out[t + name + "_colsum"] = f64.sum(0).reshape(-1).numpy()     # [C K K]
+            out[t + name + "_proj"] = np.array((f64 * pw_).sum().item())
+            out[t + name + "_absmax"] = np.array(gw.abs().max().item())
+            out[t + name + "_corner"] = npy(gw[:2, :2])                    # raw values incl. the clamped sigma^2 entries
+        if bias:
+            out[t + "g_bmu"], out[t + "g_brho"] = npy(grads[3]), npy(grads[4])
+        pe = torch.from_numpy(eps).double()           # the output's projection uses the noise tensor: same shape, seeded
+        for name, full, pr in (("out", y.detach(), pe), ("g_x", grads[0], torch.from_numpy(probe_x).double())):
+            f64 = full.double()
+            out[t + name + "_planes"] = f64.sum((2, 3)).numpy()          # [N, channels]
+            out[t + name + "_pixels"] = f64.sum((0, 1)).numpy()          # [H, W]
+            out[t + name + "_proj"] = np.array((f64 * pr).sum().item())
+            out[t + name + "_absmax"] = np.array(full.abs().max().item())
+            out[t + name + "_corner"] = npy(full[0, :, :2, :3])          # a few raw values incl. the clamped corner
+    np.savez_compressed(os.path.join(OUT, "conv_lrt.npz"), **out)
+
+
 def gen_ivon():
     out = {}
     cases = []
@@ -645,6 +697,7 @@ elif __name__ == "__main__":
     gen_bbb()
     gen_bbb2()
     gen_lrt()
+    gen_conv()
     gen_ivon()
     gen_ensemble()
     gen_checkpoints()

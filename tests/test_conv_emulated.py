@@ -62,3 +62,37 @@ def test_emulated_kernels_equal_torch(case):
     gwm, gwr = E.wgrad_kernel(geo, x.numpy(), gout.numpy(), gvar, w_rho.numpy())
     np.testing.assert_allclose(gwm, gwm64.numpy(), rtol=3e-5, atol=3e-5 * float(gwm64.abs().max()))
     np.testing.assert_allclose(gwr, gwr64.numpy(), rtol=3e-5, atol=3e-5 * float(gwr64.abs().max()))
+
+
+def test_emulated_kernels_equal_the_reference_layer():
+    """The same replay against the fixture written from the REFERENCE's BBBConv2d (tests/golden/conv_lrt.npz): what the
+    kernels' index arithmetic produces for the reference's seeded inputs matches the reference's own output and weight /
+    input gradients (sums, projections, raw corners) -- for three of the fixture's cases (a ResNet-20 16 -> 16 layer, the
+    stride-2 16 -> 32 transition, the ragged 5 x 5 case)."""
+    import os
+    from oracle.conv_cases import conv_case_inputs, conv_probe_w
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "conv_lrt.npz"), allow_pickle=False)
+    for seed, n, c, h, w, o, k, stride, padding, bias in g["cases"].tolist():
+        if seed not in (202, 203, 209):
+            continue
+        x, w_mu, w_rho, b_mu, b_rho, eps, gout, probe_x = conv_case_inputs(seed, n, c, h, w, o, k, stride, padding)
+        geo = (n, c, h, w, o, k, k, stride, stride, padding, padding)
+        wb = E.prep(w_mu, w_rho)
+        bvar = (F.softplus(torch.from_numpy(b_rho)) ** 2).numpy() if bias else None
+        out, var = E.conv_kernel(0, geo, x, None, wb["wt_mu"], wb["wt_s2"], b_mu if bias else None, bvar, eps)
+        t = f"c{seed}_"
+        amax = float(g[t + "out_absmax"])
+        np.testing.assert_allclose(out.astype(np.float64).sum((2, 3)), g[t + "out_planes"], atol=3e-5 * amax * np.sqrt(out.shape[2] * out.shape[3]))
+        np.testing.assert_allclose(out[0, :, :2, :3], g[t + "out_corner"], atol=3e-5 * amax)
+        gvar = (gout * eps / (2.0 * np.sqrt(var))).astype(np.float32)
+        gx = E.conv_kernel(1, geo, gout, gvar, wb["wb_mu"], wb["wb_s2"], x, None, None)
+        amax = float(g[t + "g_x_absmax"])
+        np.testing.assert_allclose(gx.astype(np.float64).sum((2, 3)), g[t + "g_x_planes"], atol=3e-5 * amax * np.sqrt(h * w))
+        np.testing.assert_allclose(gx[0, :, :2, :3], g[t + "g_x_corner"], atol=3e-5 * amax)
+        gwm, gwr = E.wgrad_kernel(geo, x, gout, gvar, w_rho)
+        pw = conv_probe_w(seed, o, c, k).astype(np.float64)
+        for name, gw in (("g_wmu", gwm), ("g_wrho", gwr)):
+            amax = float(g[t + name + "_absmax"])
+            np.testing.assert_allclose(gw.astype(np.float64).sum((1, 2, 3)), g[t + name + "_rowsum"], atol=3e-5 * amax * np.sqrt(c * k * k))
+            np.testing.assert_allclose((gw * pw).sum(), float(g[t + name + "_proj"]), atol=3e-5 * amax * np.sqrt(o * c * k * k))
+            np.testing.assert_allclose(gw[:2, :2], g[t + name + "_corner"], atol=3e-5 * amax)

@@ -1361,6 +1361,68 @@ def test_bbb_linear_layer_matches_reference_layer(golden, backend, monkeypatch):
             assert abs(gw.abs().max().item() - amax) <= 2e-5 * amax, name
 
 
+@pytest.mark.parametrize("path", ["fused", "stock"])
+def test_bbb_conv2d_layer_matches_reference_layer(golden, backend, monkeypatch, path):
+    """bde.BBBConv2d forward + backward against the REFERENCE's BBBConv2d on the same seeded inputs (conv_lrt.npz, written
+    by oracle/gen_golden.py from the reference's own layer and autograd graph): output and all five gradients at the CIFAR
+    ResNet-20 layer shapes (first layer, the three stages, both stride-2 transitions, a 1x1 shortcut) and two ragged
+    geometries.  "fused": bde_conv_lrt_fwd / _bwd_data / _bwd_weight (HIP; the CPU checker runs torch convolutions behind
+    the same autograd Function); "stock": fused_conv=False, round 3's composition."""
+    ops, dev = backend
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    from oracle.conv_cases import conv_case_inputs, conv_probe_w
+    g = golden("conv_lrt.npz")
+    prior = bde.GaussianPrior(0, 1.0)
+    fused_calls = []
+    if path == "fused":
+        real_fwd = ops.conv_lrt_fwd
+        monkeypatch.setattr(ops, "conv_lrt_fwd", lambda *a, **k: (fused_calls.append(1), real_fwd(*a, **k))[1])
+    for seed, n, c, h, w, o, k, stride, padding, bias in g["cases"].tolist():
+        x, w_mu, w_rho, b_mu, b_rho, eps, gout, probe_x = [T(a).to(dev) for a in conv_case_inputs(seed, n, c, h, w, o, k, stride, padding)]
+        layer = bde.BBBConv2d(c, o, k, prior, prior, stride=stride, padding=padding, bias=bool(bias), fused_conv=path == "fused",
+                              _ops=ops).to(dev).train()
+        with torch.no_grad():
+            layer.weight.mean.copy_(w_mu)
+            layer.weight.rho.copy_(w_rho)
+            if bias:
+                layer.bias.mean.copy_(b_mu)
+                layer.bias.rho.copy_(b_rho)
+        monkeypatch.setattr(L, "normal_like", lambda t: eps.to(t.device))
+        xin = x.clone().requires_grad_(True)
+        out = layer(xin)
+        leaves = [xin, layer.weight.mean, layer.weight.rho] + ([layer.bias.mean, layer.bias.rho] if bias else [])
+        grads = [t.detach().cpu().double() for t in torch.autograd.grad(out, leaves, grad_outputs=gout)]
+        t = f"c{seed}_"
+        case = (seed, n, c, h, w, o, k, stride, padding, bias)
+
+        def close(ours, want, scale, what):
+            want = torch.as_tensor(np.asarray(want), dtype=torch.float64)
+            tol = 3e-5 * max(float(scale), 1e-6)                      # fp32 convolutions in a different summation order
+            err = (torch.as_tensor(ours, dtype=torch.float64) - want).abs().max().item()
+            assert err <= tol, (what, case, err, tol)
+        kk = c * k * k
+        for name, full, pr in (("out", out.detach().cpu().double(), eps.cpu().double()), ("g_x", grads[0], probe_x.cpu().double())):
+            amax = float(g[t + name + "_absmax"])
+            close(full.sum((2, 3)), g[t + name + "_planes"], amax * np.sqrt(full.shape[2] * full.shape[3]), name + " plane sums")
+            close(full.sum((0, 1)), g[t + name + "_pixels"], amax * np.sqrt(full.shape[0] * full.shape[1]), name + " pixel sums")
+            close((full * pr).sum(), g[t + name + "_proj"], amax * np.sqrt(full.numel()), name + " projection")
+            close(full[0, :, :2, :3], g[t + name + "_corner"], amax, name + " corner")
+            assert abs(full.abs().max().item() - amax) <= 3e-5 * amax, name
+        pw = T(conv_probe_w(seed, o, c, k)).double()
+        for name, gw in (("g_wmu", grads[1]), ("g_wrho", grads[2])):
+            amax = float(g[t + name + "_absmax"])
+            close(gw.sum((1, 2, 3)), g[t + name + "_rowsum"], amax * np.sqrt(kk), name + " row sums")
+            close(gw.sum(0).reshape(-1), g[t + name + "_colsum"], amax * np.sqrt(o), name + " column sums")
+            close((gw * pw).sum(), g[t + name + "_proj"], amax * np.sqrt(o * kk), name + " projection")
+            close(gw[:2, :2], g[t + name + "_corner"], amax, name + " corner")
+            assert abs(gw.abs().max().item() - amax) <= 3e-5 * amax, name
+        if bias:
+            close(grads[3], g[t + "g_bmu"], np.abs(g[t + "g_bmu"]).max(), "g_bmu")
+            close(grads[4], g[t + "g_brho"], max(np.abs(g[t + "g_brho"]).max(), 1e-3), "g_brho")
+    if path == "fused":
+        assert len(fused_calls) == len(g["cases"])                   # every case took the fused op
+
+
 def test_svgd_fuse_auto_eligibility(backend):
     """fuse_base_optimizer="auto" fuses exactly the base optimizers whose step() the kernel reproduces."""
     ops, dev = backend
