@@ -1,0 +1,94 @@
+"""TEST INFRASTRUCTURE: compile kernel sources of beyond_deep_ensembles_amd/csrc for the CPU execution model of
+hip_emu.hpp.  The sources are used as they are, except for what a host compiler cannot parse:
+
+  * `#include <hip/hip_runtime.h>`              -> `#include "hip_emu.hpp"`
+  * `extern __shared__ [aligned] T name[];`     -> `T* name = static_cast<T*>(hip_emu::dyn_lds());`
+  * `asm volatile("s_waitcnt vmcnt(N)" ...);`   -> `hip_emu::waitcnt_vm(N); hip_emu::wave_sync();`  (this lane's LDS-DMA
+                                                   requests land here, not before; then the wave meets)
+  * `asm volatile("s_waitcnt lgkmcnt(0)" ...);` -> `hip_emu::wave_sync();`  -- the lanes of a wave are fibers that run from
+                                                   rendezvous to rendezvous, not in lockstep, so a hand-off through LDS
+                                                   between lanes of ONE wave needs a meeting point; the kernels written
+                                                   for this (conv_lrt*.hip, swag_batched.hip) carry an explicit s_waitcnt
+                                                   at exactly those places (the implicit hand-offs of the other kernels
+                                                   are covered by the lockstep-at-LDS-access scheduling, hip_emu.cpp)
+  * every other `asm volatile(...)` statement   -> dropped (register-class barriers)
+
+The result is cached under tests/hip_emu/_build/ keyed by the content of every input."""
+import hashlib
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "beyond_deep_ensembles_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+HEADERS = ["bde_common.hpp", "svgd_shared.hpp", "svgd_gram.hpp"]
+
+_EXTERN_LDS = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];")
+_ASM = re.compile(r"asm\s+volatile\s*\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\)\s*;")
+
+
+def _asm(match):
+    text = match.group(0)
+    m = re.search(r"vmcnt\((\d+)\)", text)
+    if m:
+        return f"hip_emu::waitcnt_vm({m.group(1)}); hip_emu::wave_sync();"
+    if "lgkmcnt" in text:
+        return "hip_emu::wave_sync();"
+    return ";"
+
+
+def transform(text, name):
+    text = text.replace("#include <hip/hip_runtime.h>", '#include "hip_emu.hpp"')
+    text = text.replace('#include "../../include/bde_hip.h"', f'#include "{os.path.join(ROOT, "include", "bde_hip.h")}"')
+    text = _EXTERN_LDS.sub(lambda m: f"{m.group(1)}* {m.group(2)} = static_cast<{m.group(1)}*>(hip_emu::dyn_lds());", text)
+    text = _ASM.sub(_asm, text)
+    return f'#line 1 "{os.path.join(CSRC, name)}"\n' + text
+
+
+def available():
+    return os.path.exists(CLANG) and os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h")
+
+
+def build(sources, defines=()):
+    """-> path of a shared library holding the C-ABI entry points of `sources` (names under csrc/) on the CPU model."""
+    names = list(sources) + HEADERS
+    texts = {n: transform(open(os.path.join(CSRC, n)).read(), n) for n in names}
+    emu = [open(os.path.join(HERE, f)).read() for f in ("hip_emu.hpp", "hip_emu.cpp")]
+    key = hashlib.sha256(("\0".join(texts[n] for n in names) + "\0".join(emu) + repr(tuple(defines))).encode()).hexdigest()[:16]
+    out_dir = os.path.join(HERE, "_build", key)
+    lib = os.path.join(out_dir, "libbde_emu.so")
+    if os.path.exists(lib):
+        return lib
+    os.makedirs(out_dir, exist_ok=True)
+    for n in names:
+        with open(os.path.join(out_dir, n.replace(".hip", ".cpp") if n.endswith(".hip") else n), "w") as fh:
+            fh.write(texts[n])
+    flags = ["-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-attributes",
+             "-Wno-ignored-attributes", "-I", HERE, "-I", "/opt/rocm/include", "-I", out_dir] + [f"-D{d}" for d in defines]
+    # the kernel sources (not hip_emu.cpp) get clang's thread-sanitizer INSTRUMENTATION only; hip_emu.cpp implements the
+    # callbacks (lockstep of a wave's lanes at LDS accesses), the sanitizer runtime is not linked
+    tsan = ["-fsanitize=thread", "-mllvm", "-tsan-instrument-func-entry-exit=0", "-mllvm", "-tsan-instrument-atomics=0",
+            "-mllvm", "-tsan-instrument-memintrinsics=0", "-mllvm", "-tsan-instrument-read-before-write=1"]
+    objs = []
+    procs = []
+    for n in list(sources) + ["hip_emu.cpp"]:
+        src = os.path.join(HERE, n) if n == "hip_emu.cpp" else os.path.join(out_dir, n.replace(".hip", ".cpp"))
+        obj = os.path.join(out_dir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        extra = [] if n == "hip_emu.cpp" else tsan
+        procs.append((n, subprocess.Popen([CLANG] + flags + extra + ["-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for n, p in procs:
+        log = p.communicate()[0].decode()
+        if p.returncode:
+            raise RuntimeError(f"hip_emu build of {n} failed:\n{log[-6000:]}")
+    tmp = lib + ".tmp"
+    subprocess.check_call([CLANG, "-shared", "-o", tmp] + objs + ["-lpthread"])
+    os.replace(tmp, lib)
+    return lib
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(sys.argv[1:] or ["conv_lrt.hip", "conv_lrt_bwd.hip"]))

@@ -1,0 +1,406 @@
+// TEST INFRASTRUCTURE (see hip_emu.hpp): the fiber scheduler, barriers, LDS / buffer guard pages and the handful of HIP
+// runtime entry points the host side of libbde_hip calls.  One OS thread per worker, one workgroup at a time per worker,
+// one ucontext fiber per lane; fibers switch only inside a rendezvous (block or wave barrier), round-robin.
+#include "hip_emu.hpp"
+
+#include <link.h>
+#include <sys/mman.h>
+#include <ucontext.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace hip_emu {
+
+thread_local Lane* cur = nullptr;
+
+struct Dma {
+  const void* src;
+  void* dst;
+  int bytes;
+};
+
+struct Wave {
+  int live = 0, arrived = 0;
+  unsigned gen = 0;
+  uint64_t live_mask = 0;
+  alignas(16) uint64_t slot[2][64 * 2];
+};
+
+struct Fiber {
+  ucontext_t uc;
+  Lane lane;
+  bool done = true;
+  std::vector<Dma> dma;
+};
+
+constexpr size_t kStack = 256 * 1024;
+constexpr size_t kLdsMax = 160 * 1024;
+static size_t page() { return static_cast<size_t>(sysconf(_SC_PAGESIZE)); }
+
+struct Worker {
+  std::vector<Fiber> fibers;
+  std::vector<Wave> waves;
+  char* stacks = nullptr;
+  size_t n_stacks = 0;
+  char* lds_map = nullptr;      // [kLdsMax + slack][guard page]
+  char* lds = nullptr;          // start of this launch's dynamic LDS: ends exactly at the guard page
+  size_t lds_bytes = 0;
+  ucontext_t main_uc;
+  int n = 0, index = 0, live = 0;
+  int b_arrived = 0;
+  unsigned b_gen = 0;
+  unsigned long progress = 0;
+  const std::function<void()>* body = nullptr;
+  const char* tls_lo = nullptr;   // this thread's TLS block of the emulated library: where the static __shared__ arrays live
+  const char* tls_hi = nullptr;
+  ~Worker() {
+    if (stacks) munmap(stacks, n_stacks * kStack);
+    if (lds_map) munmap(lds_map, (kLdsMax + page() - 1) / page() * page() + page());
+  }
+};
+
+static thread_local Worker* wk = nullptr;
+
+[[noreturn]] static void die(const char* what) {
+  Lane* l = cur;
+  std::fprintf(stderr, "hip_emu: %s (block %u,%u,%u thread %d)\n", what, l ? l->bid.x : 0, l ? l->bid.y : 0, l ? l->bid.z : 0,
+               l ? l->linear : -1);
+  std::abort();
+}
+
+static void switch_to_next() {
+  Worker* w = wk;
+  Fiber* me = &w->fibers[w->index];
+  if (w->live == 0) {
+    swapcontext(&me->uc, &w->main_uc);
+    return;
+  }
+  int nxt = w->index;
+  do {
+    nxt = nxt + 1 == w->n ? 0 : nxt + 1;
+  } while (w->fibers[nxt].done);
+  if (nxt == w->index) return;
+  w->index = nxt;
+  cur = &w->fibers[nxt].lane;
+  swapcontext(&me->uc, &w->fibers[nxt].uc);
+}
+
+// Wait (yielding) until *gen moves past `g`; a full idle cycle of every other fiber without any state change is a deadlock:
+// a barrier some lanes never reach.
+static void wait_gen(const unsigned* gen, unsigned g) {
+  Worker* w = wk;
+  unsigned long seen = w->progress;
+  int idle = 0;
+  while (*const_cast<const volatile unsigned*>(gen) == g) {
+    switch_to_next();
+    if (w->progress == seen) {
+      if (++idle > 4 * w->n + 8) die("deadlock: a barrier or wave-level operation is not reached by all lanes");
+    } else {
+      seen = w->progress;
+      idle = 0;
+    }
+  }
+}
+
+void block_sync() {
+  Worker* w = wk;
+  ++w->progress;
+  const unsigned g = w->b_gen;
+  if (++w->b_arrived == w->live) {
+    w->b_arrived = 0;
+    ++w->b_gen;
+  } else {
+    wait_gen(&w->b_gen, g);
+  }
+}
+
+void wave_sync() {
+  Worker* w = wk;
+  Wave* wv = cur->wave;
+  ++w->progress;
+  const unsigned g = wv->gen;
+  if (++wv->arrived == wv->live) {
+    wv->arrived = 0;
+    ++wv->gen;
+  } else {
+    wait_gen(&wv->gen, g);
+  }
+}
+
+// ---- lockstep within a wave ------------------------------------------------------------------------------------------
+// The kernel sources are compiled with clang's -fsanitize=thread instrumentation and THIS file supplies the callbacks
+// (the sanitizer's runtime is not linked): every load / store the kernel code performs arrives here first.  Before an
+// access to LDS (the launch's dynamic LDS, or a static __shared__ array = a thread_local of the emulated library) the
+// lane hands over to the next lane of its wave, so the 64 lanes of a wave take turns LDS access by LDS access: when a
+// lane performs its k-th access, every lane of the wave has performed its first k-1 -- what the lockstep execution
+// of a wavefront (plus the compiler's s_waitcnt) guarantees to code that hands data across lanes through LDS without
+// a workgroup barrier.
+static int tls_probe(struct dl_phdr_info* info, size_t, void* out) {
+  const char* me = reinterpret_cast<const char*>(&cur);
+  if (!info->dlpi_tls_data) return 0;
+  for (int i = 0; i < info->dlpi_phnum; ++i) {
+    if (info->dlpi_phdr[i].p_type != PT_TLS) continue;
+    const char* lo = static_cast<const char*>(info->dlpi_tls_data);
+    const char* hi = lo + info->dlpi_phdr[i].p_memsz;
+    if (me >= lo && me < hi) {
+      static_cast<const char**>(out)[0] = lo;
+      static_cast<const char**>(out)[1] = hi;
+      return 1;
+    }
+  }
+  return 0;
+}
+
+static inline void on_access(const void* a) {
+  if (!cur) return;                                   // host code of the library
+  Worker* w = wk;
+  const char* p = static_cast<const char*>(a);
+  const bool dyn = p >= w->lds && p < w->lds + w->lds_bytes;
+  const bool stat = p >= w->tls_lo && p < w->tls_hi && p != reinterpret_cast<const char*>(&cur);
+  if (!dyn && !stat) return;
+  const int me = w->index, base = me & ~63, end = std::min(base + 64, w->n);
+  int nxt = me;
+  do {
+    nxt = nxt + 1 == end ? base : nxt + 1;
+  } while (nxt != me && w->fibers[nxt].done);
+  if (nxt == me) return;
+  ++w->progress;
+  w->index = nxt;
+  cur = &w->fibers[nxt].lane;
+  swapcontext(&w->fibers[me].uc, &w->fibers[nxt].uc);
+}
+
+uint64_t* wave_slot(unsigned parity) { return cur->wave->slot[parity & 1u]; }
+uint64_t wave_live_mask() { return cur->wave->live_mask; }
+void* dyn_lds() { return wk->lds; }
+
+static Fiber* cur_fiber() { return &wk->fibers[wk->index]; }
+
+static void dma_land(Fiber* f, size_t keep) {
+  while (f->dma.size() > keep) {
+    const Dma d = f->dma.front();
+    std::memcpy(d.dst, d.src, static_cast<size_t>(d.bytes));
+    f->dma.erase(f->dma.begin());
+  }
+}
+void dma_request(const void* src, void* lds_dst, int bytes) {
+  Worker* w = wk;
+  if (static_cast<char*>(lds_dst) < w->lds || static_cast<char*>(lds_dst) + bytes > w->lds + w->lds_bytes) die("LDS-DMA outside the dynamic LDS");
+  cur_fiber()->dma.push_back({src, lds_dst, bytes});
+}
+void waitcnt_vm(int outstanding) { dma_land(cur_fiber(), static_cast<size_t>(outstanding < 0 ? 0 : outstanding)); }
+
+static void fiber_entry() {
+  Worker* w = wk;
+  (*w->body)();
+  // the fiber that resumes here may have been switched: re-read
+  w = wk;
+  Fiber* me = cur_fiber();
+  dma_land(me, 0);
+  me->done = true;
+  --w->live;
+  ++w->progress;
+  Wave* wv = me->lane.wave;
+  --wv->live;
+  wv->live_mask &= ~(1ull << me->lane.lane);
+  if (wv->live > 0 && wv->arrived == wv->live) {     // the lanes still waiting are now complete
+    wv->arrived = 0;
+    ++wv->gen;
+  }
+  if (w->live > 0 && w->b_arrived == w->live) {
+    w->b_arrived = 0;
+    ++w->b_gen;
+  }
+  switch_to_next();
+  die("a finished fiber was resumed");
+}
+
+static void worker_setup(Worker* w, int n, size_t lds_bytes) {
+  const size_t pg = page();
+  if (static_cast<int>(w->fibers.size()) < n) w->fibers.resize(static_cast<size_t>(n));
+  if (w->n_stacks < static_cast<size_t>(n)) {
+    if (w->stacks) munmap(w->stacks, w->n_stacks * kStack);
+    w->stacks = static_cast<char*>(mmap(nullptr, static_cast<size_t>(n) * kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (w->stacks == MAP_FAILED) die("mmap of the fiber stacks failed");
+    w->n_stacks = static_cast<size_t>(n);
+  }
+  if (!w->lds_map) {
+    const size_t body = (kLdsMax + pg - 1) / pg * pg;
+    w->lds_map = static_cast<char*>(mmap(nullptr, body + pg, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (w->lds_map == MAP_FAILED) die("mmap of the LDS failed");
+    mprotect(w->lds_map + body, pg, PROT_NONE);
+  }
+  if (!w->tls_lo) {
+    const char* range[2] = {nullptr, nullptr};
+    dl_iterate_phdr(tls_probe, range);
+    w->tls_lo = range[0];
+    w->tls_hi = range[1];
+  }
+  if (lds_bytes > kLdsMax) die("more than 160 KB of dynamic LDS requested");
+  const size_t body = (kLdsMax + pg - 1) / pg * pg;
+  const size_t rounded = (lds_bytes + 15) / 16 * 16;
+  w->lds = w->lds_map + body - rounded;
+  w->lds_bytes = rounded;
+  w->n = n;
+  w->waves.resize(static_cast<size_t>((n + 63) / 64));
+}
+
+static void run_block(Worker* w, dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned bz) {
+  const int n = w->n;
+  // uninitialised LDS reads must not look like zeros
+  uint32_t* l32 = reinterpret_cast<uint32_t*>(w->lds);
+  for (size_t i = 0; i < w->lds_bytes / 4; ++i) l32[i] = std::getenv("HIP_EMU_LDS_ZERO") ? 0u : 0x7fc00badu;
+  for (auto& wv : w->waves) {
+    wv.live = wv.arrived = 0;
+    wv.gen = 0;
+    wv.live_mask = 0;
+  }
+  w->live = n;
+  w->b_arrived = 0;
+  w->b_gen = 0;
+  for (int t = 0; t < n; ++t) {
+    Fiber& f = w->fibers[t];
+    f.done = false;
+    f.dma.clear();
+    Lane& l = f.lane;
+    l.tid = {static_cast<unsigned>(t % block.x), static_cast<unsigned>((t / block.x) % block.y), static_cast<unsigned>(t / (block.x * block.y))};
+    l.bid = {bx, by, bz};
+    l.bdim = block;
+    l.gdim = grid;
+    l.linear = t;
+    l.lane = t & 63;
+    l.parity = 0;
+    l.wave = &w->waves[t >> 6];
+    ++l.wave->live;
+    l.wave->live_mask |= 1ull << l.lane;
+    getcontext(&f.uc);
+    f.uc.uc_stack.ss_sp = w->stacks + static_cast<size_t>(t) * kStack;
+    f.uc.uc_stack.ss_size = kStack;
+    f.uc.uc_link = nullptr;
+    makecontext(&f.uc, fiber_entry, 0);
+  }
+  w->index = 0;
+  cur = &w->fibers[0].lane;
+  swapcontext(&w->main_uc, &w->fibers[0].uc);
+  cur = nullptr;
+}
+
+static int n_workers() {
+  const char* e = std::getenv("HIP_EMU_WORKERS");
+  int n = e ? std::atoi(e) : static_cast<int>(std::thread::hardware_concurrency());
+  if (n < 1) n = 1;
+  if (n > 16) n = 16;
+  return n;
+}
+
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
+  const int n = static_cast<int>(block.x * block.y * block.z);
+  const long total = static_cast<long>(grid.x) * grid.y * grid.z;
+  if (n <= 0 || n > 1024 || total <= 0) return;
+  std::atomic<long> next{0};
+  auto work = [&]() {
+    static thread_local Worker worker;
+    wk = &worker;
+    worker.body = &body;
+    worker_setup(&worker, n, lds_bytes);
+    for (;;) {
+      const long b = next.fetch_add(1);
+      if (b >= total) break;
+      run_block(&worker, grid, block, static_cast<unsigned>(b % grid.x), static_cast<unsigned>((b / grid.x) % grid.y),
+                static_cast<unsigned>(b / (static_cast<long>(grid.x) * grid.y)));
+    }
+  };
+  const int nw = static_cast<int>(std::min<long>(n_workers(), total));
+  if (nw <= 1) {
+    std::thread t(work);      // never on the caller's (Python's) stack and TLS
+    t.join();
+    return;
+  }
+  std::vector<std::thread> ts;
+  for (int i = 0; i < nw; ++i) ts.emplace_back(work);
+  for (auto& t : ts) t.join();
+}
+
+}  // namespace hip_emu
+
+// ---- -fsanitize=thread callbacks (see on_access) -----------------------------------------------------------------------
+extern "C" {
+void __tsan_init() {}
+#define HIP_EMU_HOOK(n)                                                   \
+  void __tsan_read##n(void* a) { hip_emu::on_access(a); }                 \
+  void __tsan_write##n(void* a) { hip_emu::on_access(a); }                \
+  void __tsan_unaligned_read##n(void* a) { hip_emu::on_access(a); }       \
+  void __tsan_unaligned_write##n(void* a) { hip_emu::on_access(a); }
+HIP_EMU_HOOK(1)
+HIP_EMU_HOOK(2)
+HIP_EMU_HOOK(4)
+HIP_EMU_HOOK(8)
+HIP_EMU_HOOK(16)
+void __tsan_read_range(void* a, unsigned long) { hip_emu::on_access(a); }
+void __tsan_write_range(void* a, unsigned long) { hip_emu::on_access(a); }
+void __tsan_vptr_update(void**, void*) {}
+void __tsan_vptr_read(void**) {}
+void __tsan_func_entry(void*) {}
+void __tsan_func_exit() {}
+}
+
+// ---- the HIP runtime entry points the host side of the library uses ------------------------------------------------
+extern "C" {
+
+hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipFuncGetAttributes(hipFuncAttributes* attr, const void*) {
+  std::memset(attr, 0, sizeof(*attr));
+  attr->maxThreadsPerBlock = 1024;
+  return hipSuccess;
+}
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) {
+  *d = 0;
+  return hipSuccess;
+}
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
+  *v = a == hipDeviceAttributeMultiprocessorCount ? 256 : 0;
+  return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+  std::memset(p, v, n);
+  return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+  std::memmove(d, s, n);
+  return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) {
+  *n = 2;
+  return hipSuccess;
+}
+
+// Buffers with a guard page before and after: a read or write past either end faults at once.  The payload is placed so
+// that it ENDS at the trailing guard page (rounded to 16 bytes, the alignment every kernel may assume).
+void* hip_emu_alloc(size_t bytes) {
+  const size_t pg = hip_emu::page();
+  const size_t rounded = (bytes + 15) / 16 * 16;
+  const size_t body = (rounded + pg - 1) / pg * pg;
+  char* m = static_cast<char*>(mmap(nullptr, body + 2 * pg, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+  if (m == MAP_FAILED) return nullptr;
+  mprotect(m, pg, PROT_NONE);
+  mprotect(m + pg + body, pg, PROT_NONE);
+  char* p = m + pg + body - rounded;
+  std::memset(m + pg, 0xCB, body);
+  return p;
+}
+void hip_emu_free(void* p, size_t bytes) {
+  const size_t pg = hip_emu::page();
+  const size_t rounded = (bytes + 15) / 16 * 16;
+  const size_t body = (rounded + pg - 1) / pg * pg;
+  char* m = static_cast<char*>(p) + rounded - body - pg;
+  munmap(m, body + 2 * pg);
+}
+}

@@ -1,0 +1,101 @@
+"""The kernel SOURCES of beyond_deep_ensembles_amd/csrc/*.hip, executed in this GPU-less container.
+
+tests/hip_emu/ compiles the unchanged .hip files (kernels, host-side planners and the C-ABI entry points) against a CPU
+model of a workgroup -- one fiber per lane, real workgroup / wave rendezvous, the CDNA4 MFMA / DPP / shuffle register
+layouts, NaN-poisoned guard-paged LDS, guard-paged buffers, LDS-DMA that lands only at its s_waitcnt, lockstep of a
+wave's lanes at LDS accesses -- and the test bodies of tests/test_ops_gpu.py (the `-m gpu` parity tests against the
+oracle and the golden fixtures) run on it through the product's own `HipOps`.  This is test infrastructure: it says
+nothing about speed, registers or occupancy, and it is no substitute for the MI355X run of the same tests; it is what
+checks index arithmetic, barriers and tile edges of a kernel before (or without) a GPU.
+
+The model is pinned by the kernels that HAVE run on the MI355X: the bit-exact golden tests (iVON, SWAG moments, Philox,
+Gaussian draws, SVGD golden steps) give the same bits here as on the device (profiles/r03_pytest_gpu*.log)."""
+import inspect
+import os
+
+import pytest
+
+from tests.hip_emu import build as emu_build
+
+pytestmark = pytest.mark.skipif(not emu_build.available(), reason="no host clang / HIP headers to build the CPU model with")
+
+ALL = ["version.hip", "swag.hip", "swag_batched.hip", "svgd.hip", "svgd_small.hip", "svgd_fused.hip", "gauss.hip", "ivon.hip",
+       "lrt.hip", "lrt_bwd.hip", "conv_lrt.hip", "conv_lrt_bwd.hip"]
+
+# test bodies of tests/test_ops_gpu.py that run by default (seconds each on 8 cores) ...
+DEFAULT = [
+    "test_conv_lrt_forward", "test_conv_lrt_backward",                      # 12 s, 29 s: every geometry of CONV_CASES
+    "test_swag_batched_sampler_both_kernels_equal_single_samples",          # 8 s: register kernel and LDS-DMA kernel
+    "test_svgd_small_model_kernel",                                         # 16 s
+    "test_svgd_step_golden", "test_svgd_inplace_and_rbf_mode", "test_svgd_deterministic_and_ragged_sizes",
+    "test_svgd_fused_optimizers_match_torch_shared_state", "test_svgd_fused_equals_combine_plus_apply",
+    "test_svgd_segmented_gradients_equal_flat_rows", "test_swag_update_bit_exact", "test_swag_sample_golden_and_oracle",
+    "test_swag_sample_large_vs_fp64", "test_philox_streams", "test_gauss_draw_kl_golden", "test_gauss_kl_large_and_l2",
+    "test_mixture_prior_kernel", "test_gauss_draw_philox", "test_ivon_golden_bit_exact", "test_swag_edge_sizes",
+    "test_invalid_arguments_are_rejected", "test_randomized_shapes_against_oracle", "test_var_operand_kernels",
+]
+# ... and with BDE_EMU_FULL=1 (another ~3 minutes)
+SLOW = ["test_svgd_blocked_path_for_more_than_16_particles", "test_svgd_small_model_fused_step", "test_lrt_linear_forward",
+        "test_lrt_linear_backward", "test_lrt_sigma_cache_is_bit_identical", "test_lrt_linear_random_shapes"]
+# Not meaningful on the model: streams / graph capture, the "CPU tensors are rejected" check (the model feeds CPU tensors),
+# and one comparison against torch's element-wise ops at 1e-7 absolute (v_sqrt_f32 is not the host's sqrtf).
+NOT_APPLICABLE = ["test_svgd_small_model_kernel_repeated_calls_and_rbf", "test_svgd_step_is_graph_capturable",
+                  "test_svgd_rejects_bad_arguments", "test_local_reparam_epilogue"]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from tests.hip_emu.emu_ops import emulated
+    with emulated(ALL) as ops:
+        yield ops
+
+
+def _gpu_tests():
+    import tests.test_ops_gpu as G
+    return G
+
+
+def test_every_gpu_op_test_is_classified():
+    G = _gpu_tests()
+    names = [n for n, f in vars(G).items() if n.startswith("test_") and inspect.isfunction(f)]
+    assert sorted(names) == sorted(DEFAULT + SLOW + NOT_APPLICABLE)
+
+
+@pytest.mark.parametrize("name", DEFAULT + SLOW)
+def test_gpu_test_body_on_the_cpu_model(emu, golden, monkeypatch, name):
+    if name in SLOW and not os.environ.get("BDE_EMU_FULL"):
+        pytest.skip("slow on the CPU model: set BDE_EMU_FULL=1")
+    G = _gpu_tests()
+    monkeypatch.setattr(G, "DEV", "cpu")
+    fn = getattr(G, name)
+    args = {"ops": emu, "golden": golden}
+    fn(**{p: args[p] for p in inspect.signature(fn).parameters})
+
+
+def test_bbb_conv2d_layer_on_the_cpu_model_matches_the_reference_layer(emu, golden, monkeypatch):
+    """bde.BBBConv2d -> the `_ConvLrt` autograd Function -> bde_conv_lrt_prep / _fwd / _bwd_data / _bwd_weight (kernel
+    sources on the CPU model) against the fixture written from the REFERENCE's BBBConv2d (conv_lrt.npz): output and all
+    five gradients at the ResNet-20 layer shapes and the ragged geometries."""
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    import tests.test_shells as S
+    monkeypatch.setattr(L, "_native_nodes", lambda ops: None)          # the C++ nodes bind the device library
+    S.test_bbb_conv2d_layer_matches_reference_layer(golden, (emu, "cpu"), monkeypatch, "fused")
+
+
+def test_the_model_notices_a_missing_dma_wait():
+    """Sensitivity of the model: the batched SWAG sampler with its `s_waitcnt vmcnt(0)` removed (the wave still meets,
+    but the LDS-DMA requests have not landed) reads poisoned LDS and fails its parity test."""
+    from tests.hip_emu import emu_ops
+    G = _gpu_tests()
+    real = emu_build._asm
+    emu_build._asm = lambda m: "hip_emu::wave_sync();" if "vmcnt" in m.group(0) else real(m)
+    try:
+        with emu_ops.emulated(["swag.hip", "swag_batched.hip"]) as ops:
+            dev, G.DEV = G.DEV, "cpu"
+            try:
+                with pytest.raises(AssertionError):
+                    G.test_swag_batched_sampler_both_kernels_equal_single_samples(ops)
+            finally:
+                G.DEV = dev
+    finally:
+        emu_build._asm = real

@@ -163,7 +163,12 @@ def test_svgd_small_model_kernel(ops):
         assert np.max(np.abs(-b.numpy() - phi64)) <= tol, (m, d)
         assert torch.allclose(ka[:m * m], kb[:m * m], rtol=0, atol=2e-6), (m, d)        # K
         assert torch.allclose(a, b, rtol=0, atol=float(tol)), (m, d)
-    # in place, and repeated calls on ONE workspace beside unrelated work on another stream: same bits every time
+
+
+def test_svgd_small_model_kernel_repeated_calls_and_rbf(ops):
+    """... in place, and repeated calls on ONE workspace beside unrelated work on another stream: same bits every time;
+    the rbf mode through the same launch."""
+    torch.manual_seed(4)
     m, d = 8, 273_610
     P, G = torch.randn(m, d) * 0.05, torch.randn(m, d) * 0.01
     Pb, G0 = flat_rows(P), flat_rows(G)
