@@ -56,7 +56,7 @@ def build(sources, defines=()):
     names = list(sources) + HEADERS
     texts = {n: transform(open(os.path.join(CSRC, n)).read(), n) for n in names}
     emu = [open(os.path.join(HERE, f)).read() for f in ("hip_emu.hpp", "hip_emu.cpp")]
-    key = hashlib.sha256(("\0".join(texts[n] for n in names) + "\0".join(emu) + repr(tuple(defines))).encode()).hexdigest()[:16]
+    key = hashlib.sha256(("\0".join(texts[n] for n in names) + "\0".join(emu) + repr(tuple(defines)) + open(__file__).read()).encode()).hexdigest()[:16]
     out_dir = os.path.join(HERE, "_build", key)
     lib = os.path.join(out_dir, "libbde_emu.so")
     if os.path.exists(lib):
@@ -84,7 +84,9 @@ def build(sources, defines=()):
         if p.returncode:
             raise RuntimeError(f"hip_emu build of {n} failed:\n{log[-6000:]}")
     tmp = lib + ".tmp"
-    subprocess.check_call([CLANG, "-shared", "-o", tmp] + objs + ["-lpthread"])
+    # -Bsymbolic: the process may already hold libbde_hip.so / libamdhip64.so (RTLD_GLOBAL) with the same symbol names;
+    # every reference inside this library must bind to its own definitions
+    subprocess.check_call([CLANG, "-shared", "-Wl,-Bsymbolic", "-o", tmp] + objs + ["-lpthread"])
     os.replace(tmp, lib)
     return lib
 

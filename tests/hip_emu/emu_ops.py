@@ -16,6 +16,10 @@ from beyond_deep_ensembles_amd import ops as ops_mod
 from . import build as B
 
 
+ALL = ["version.hip", "swag.hip", "swag_batched.hip", "svgd.hip", "svgd_small.hip", "svgd_fused.hip", "gauss.hip", "ivon.hip",
+       "lrt.hip", "lrt_bwd.hip", "conv_lrt.hip", "conv_lrt_bwd.hip"]
+
+
 class _Shadows:
     def __init__(self, lib):
         self.lib = lib
@@ -58,6 +62,8 @@ def emulated(sources, defines=()):
     lib = load(sources, defines)
     ops = ops_mod.HipOps.__new__(ops_mod.HipOps)
     ops.lib = lib
+    ops.name = "hip_emu"                                  # the shells' "HIP kernels need CUDA parameters" guard is for the device library
+    ops.load_code_objects = lambda device: None            # bde_init() uploads code objects: nothing to upload here
     shadows = _Shadows(lib)
     real_ptr, real_check, real_stream = ops_mod._ptr, ops_mod._check, ops_mod._stream
 

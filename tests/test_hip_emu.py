@@ -19,8 +19,7 @@ from tests.hip_emu import build as emu_build
 
 pytestmark = pytest.mark.skipif(not emu_build.available(), reason="no host clang / HIP headers to build the CPU model with")
 
-ALL = ["version.hip", "swag.hip", "swag_batched.hip", "svgd.hip", "svgd_small.hip", "svgd_fused.hip", "gauss.hip", "ivon.hip",
-       "lrt.hip", "lrt_bwd.hip", "conv_lrt.hip", "conv_lrt_bwd.hip"]
+from tests.hip_emu.emu_ops import ALL
 
 # test bodies of tests/test_ops_gpu.py that run by default (seconds each on 8 cores) ...
 DEFAULT = [

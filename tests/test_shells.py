@@ -17,12 +17,25 @@ import beyond_deep_ensembles_amd as bde
 from tests.oracle_ops import OracleOps
 
 
-@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
-def backend(request):
+@pytest.fixture(params=["oracle", "emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    """"oracle": the CPU checker behind the shells; "hip": libbde_hip.so on the MI355X; "emu": the product's HipOps over the
+    kernel SOURCES compiled for the CPU execution model of tests/hip_emu (the shells then drive the real planners, C-ABI
+    entry points and kernels, lane by lane, on CPU tensors)."""
     if request.param == "oracle":
-        return OracleOps(), torch.device("cpu")
+        yield OracleOps(), torch.device("cpu")
+        return
+    if request.param == "emu":
+        from tests.hip_emu import build, emu_ops
+        if not build.available():
+            pytest.skip("no host clang / HIP headers to build the CPU model with")
+        import beyond_deep_ensembles_amd.bbb_layers as L
+        monkeypatch.setattr(L, "_native_nodes", lambda ops: None)      # the C++ autograd nodes bind the device library
+        with emu_ops.emulated(emu_ops.ALL) as ops:
+            yield ops, torch.device("cpu")
+        return
     from beyond_deep_ensembles_amd.ops import HipOps
-    return HipOps(), torch.device("cuda:0")
+    yield HipOps(), torch.device("cuda:0")
 
 
 def T(a):
@@ -482,6 +495,7 @@ def test_bbb_layers_reproduce_reference_bbblinear_trajectory(golden, backend, mo
     import beyond_deep_ensembles_amd.bbb_layers as L
     g = golden("bbb.npz")
     tape = [T(g[f"b_eps_{i}"]) for i in range(int(g["b_n_eps"]))]
+    real_normal_like = L.normal_like
     monkeypatch.setattr(L, "normal_like", lambda t: tape.pop(0).to(t.device))
     prior = bde.GaussianPrior(0, 1.0)
     model = nn.Sequential(bde.BBBLinear(13, 50, prior, prior, _ops=ops), nn.ReLU(),
@@ -509,7 +523,7 @@ def test_bbb_layers_reproduce_reference_bbblinear_trajectory(golden, backend, mo
     assert abs(float(model[0].kl) - want) <= 1e-5 * abs(want)
     model.eval()
     assert model[0].kl == 0
-    monkeypatch.undo()
+    monkeypatch.setattr(L, "normal_like", real_normal_like)
     conv = bde.BBBConv2d(3, 4, 3, prior, prior, padding=1, _ops=ops).to(dev).eval()
     out = conv(torch.ones(2, 3, 5, 5, device=dev))
     assert out.shape == (2, 4, 5, 5) and torch.equal(out[0], out[1])       # frozen noise: same sample for the batch
