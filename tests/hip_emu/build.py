@@ -91,6 +91,55 @@ def build(sources, defines=()):
     return lib
 
 
+def build_host_nodes(sources):
+    """-> path of `_bde_host_emu.so`: the C++ autograd nodes of csrc/host_autograd.cpp (what lib/_bde_host.so binds for the
+    Bayesian layers) over the CPU model.  The source is used as it is except for its two device-specific helpers: the
+    current-stream getter returns NULL and the "is a CUDA tensor" check asks for a CPU tensor.  The kernel objects of
+    build(sources) are linked INTO the module (-Bsymbolic), so its C-ABI calls cannot bind to a libbde_hip.so the process
+    may also hold."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    lib = build(sources)
+    out_dir = os.path.dirname(lib)
+    text = open(os.path.join(CSRC, "host_autograd.cpp")).read()
+    old_stream = "void* current_stream(const at::Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }"
+    assert old_stream in text and "t.is_cuda() &&" in text and "#include <c10/hip/HIPStream.h>\n" in text
+    text = text.replace(old_stream, "void* current_stream(const at::Tensor&) { return nullptr; }")
+    text = text.replace("t.is_cuda() &&", "!t.is_cuda() &&").replace("#include <c10/hip/HIPStream.h>\n", "")
+    text = text.replace('#include "../../include/bde_hip.h"', f'#include "{os.path.join(ROOT, "include", "bde_hip.h")}"')
+    text += "\nPYBIND11_MODULE(_bde_host_emu, m) { bind_autograd_nodes(m); }\n"
+    key = hashlib.sha256((text + torch.__version__).encode()).hexdigest()[:16]
+    out = os.path.join(out_dir, f"_bde_host_emu_{key}.so")
+    if os.path.exists(out):
+        return out
+    src = os.path.join(out_dir, "host_autograd_emu.cpp")
+    with open(src, "w") as fh:
+        fh.write(text)
+    objs = [os.path.join(out_dir, n.replace(".hip", ".cpp") + ".o") for n in sources] + [os.path.join(out_dir, "hip_emu.cpp.o")]
+    libs = ce.library_paths()
+    cmd = ["g++", "-O1", "-std=c++17", "-shared", "-fPIC", src] + objs + ["-o", out + ".tmp", "-I" + sysconfig.get_paths()["include"],
+           "-DTORCH_EXTENSION_NAME=_bde_host_emu", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-Wl,-Bsymbolic"]
+    cmd += ["-I" + i for i in ce.include_paths()] + ["-L" + l for l in libs]
+    cmd += ["-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10", "-lpthread", "-Wl,-rpath," + libs[0]]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if p.returncode:
+        raise RuntimeError("hip_emu build of the host autograd nodes failed:\n" + p.stdout.decode()[-6000:])
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def load_host_nodes(sources):
+    import importlib.util
+    import torch  # noqa: F401
+    path = build_host_nodes(sources)
+    spec = importlib.util.spec_from_file_location("_bde_host_emu", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 if __name__ == "__main__":
     import sys
     print(build(sys.argv[1:] or ["conv_lrt.hip", "conv_lrt_bwd.hip"]))

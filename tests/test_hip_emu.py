@@ -14,6 +14,7 @@ import inspect
 import os
 
 import pytest
+import torch
 
 from tests.hip_emu import build as emu_build
 
@@ -79,6 +80,28 @@ def test_bbb_conv2d_layer_on_the_cpu_model_matches_the_reference_layer(emu, gold
     import tests.test_shells as S
     monkeypatch.setattr(L, "_native_nodes", lambda ops: None)          # the C++ nodes bind the device library
     S.test_bbb_conv2d_layer_matches_reference_layer(golden, (emu, "cpu"), monkeypatch, "fused")
+
+
+@pytest.fixture(scope="module")
+def emu_native():
+    return emu_build.load_host_nodes(ALL)
+
+
+def test_cpp_autograd_nodes_on_the_cpu_model(emu, emu_native, golden, monkeypatch):
+    """csrc/host_autograd.cpp (the C++ autograd nodes lib/_bde_host.so gives the Bayesian layers on the device: LrtLinear,
+    LocalReparam, VarOperand, ConvLrt) compiled over the CPU model: bit-identical to the Python Functions of
+    bbb_layers.py (the body of the `-m gpu` test of the same name), and bde.BBBConv2d THROUGH the C++ ConvLrt node against
+    the fixture written from the reference's BBBConv2d."""
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    import tests.test_shells as S
+    S.check_native_nodes_equal_python_nodes(emu, torch.device("cpu"), emu_native)
+    calls = []
+    real = emu.conv_lrt_fwd
+    monkeypatch.setattr(L, "_native_nodes", lambda ops: emu_native)
+    S.test_bbb_conv2d_layer_matches_reference_layer(golden, (emu, "cpu"), monkeypatch, "fused")
+    monkeypatch.setattr(emu, "conv_lrt_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    S.test_bbb_conv_layers_reproduce_reference_cnn_trajectory(golden, (emu, "cpu"), monkeypatch, "fused_passes")
+    assert not calls                                                   # the CNN trajectory went through the C++ node
 
 
 def test_the_model_notices_a_missing_dma_wait():

@@ -21,7 +21,7 @@ from tests.oracle_ops import OracleOps
 def backend(request, monkeypatch):
     """"oracle": the CPU checker behind the shells; "hip": libbde_hip.so on the MI355X; "emu": the product's HipOps over the
     kernel SOURCES compiled for the CPU execution model of tests/hip_emu (the shells then drive the real planners, C-ABI
-    entry points and kernels, lane by lane, on CPU tensors)."""
+    entry points, C++ autograd nodes and kernels, lane by lane, on CPU tensors)."""
     if request.param == "oracle":
         yield OracleOps(), torch.device("cpu")
         return
@@ -30,7 +30,11 @@ def backend(request, monkeypatch):
         if not build.available():
             pytest.skip("no host clang / HIP headers to build the CPU model with")
         import beyond_deep_ensembles_amd.bbb_layers as L
-        monkeypatch.setattr(L, "_native_nodes", lambda ops: None)      # the C++ autograd nodes bind the device library
+        # as on the device, the Bayesian layers go through the C++ autograd nodes (csrc/host_autograd.cpp, here compiled
+        # over the CPU model; lib/_bde_host.so binds the device library)
+        native = build.load_host_nodes(emu_ops.ALL)
+        from beyond_deep_ensembles_amd.ops import HipOps
+        monkeypatch.setattr(L, "_native_nodes", lambda ops: native if isinstance(ops, HipOps) else None)
         with emu_ops.emulated(emu_ops.ALL) as ops:
             yield ops, torch.device("cpu")
         return
@@ -1097,6 +1101,10 @@ def test_bbb_conv2d_fused_path_selection_and_weight_cache(backend, monkeypatch):
     real_prep, real_fwd = ops.conv_lrt_prep, ops.conv_lrt_fwd
     ops.conv_lrt_prep = lambda *a, **k: (preps.append(1), real_prep(*a, **k))[1]
     ops.conv_lrt_fwd = lambda *a, **k: (fwds.append(1), real_fwd(*a, **k))[1]
+    native = BL._native_nodes(ops)                    # on the device the forward goes through the C++ node instead
+    if native is not None and hasattr(native, "conv_lrt"):
+        real_node = native.conv_lrt
+        monkeypatch.setattr(native, "conv_lrt", lambda *a, **k: (fwds.append(1), real_node(*a, **k))[1])
     try:
         noise = torch.randn(3, 7, 5, 6)
         real_normal_like = BL.normal_like
@@ -1269,6 +1277,12 @@ def test_native_autograd_nodes_equal_python_nodes():
     ops, dev = HipOps(), torch.device("cuda:0")
     native = L._native_nodes(ops)
     assert native is not None, "lib/_bde_host.so is missing or does not load: run __graft_entry__.build()"
+    check_native_nodes_equal_python_nodes(ops, dev, native)
+
+
+def check_native_nodes_equal_python_nodes(ops, dev, native):
+    """(also run by tests/test_hip_emu.py with host_autograd.cpp and the kernel sources built for the CPU model)"""
+    import beyond_deep_ensembles_amd.bbb_layers as L
     torch.manual_seed(31)
     for b, i, o, bias in [(16, 2048, 182, True), (5, 13, 50, True), (70, 129, 33, False), (64, 1024, 1100, True)]:
         x = torch.randn(3, b // 3 + 1, i, device=dev)[:, : max(1, b // 3)]          # a batch with leading dimensions
@@ -1388,9 +1402,13 @@ def test_bbb_conv2d_layer_matches_reference_layer(golden, backend, monkeypatch, 
     g = golden("conv_lrt.npz")
     prior = bde.GaussianPrior(0, 1.0)
     fused_calls = []
-    if path == "fused":
+    if path == "fused":                                  # the fused op is reached through the Python Function or the C++ node
         real_fwd = ops.conv_lrt_fwd
         monkeypatch.setattr(ops, "conv_lrt_fwd", lambda *a, **k: (fused_calls.append(1), real_fwd(*a, **k))[1])
+        native = L._native_nodes(ops)
+        if native is not None and hasattr(native, "conv_lrt"):
+            real_node = native.conv_lrt
+            monkeypatch.setattr(native, "conv_lrt", lambda *a, **k: (fused_calls.append(1), real_node(*a, **k))[1])
     for seed, n, c, h, w, o, k, stride, padding, bias in g["cases"].tolist():
         x, w_mu, w_rho, b_mu, b_rho, eps, gout, probe_x = [T(a).to(dev) for a in conv_case_inputs(seed, n, c, h, w, o, k, stride, padding)]
         layer = bde.BBBConv2d(c, o, k, prior, prior, stride=stride, padding=padding, bias=bool(bias), fused_conv=path == "fused",
