@@ -517,7 +517,10 @@ static void launch_conv(const FwdPlan& p, hipStream_t s, const float* a, const f
 extern "C" int bde_conv_lrt_supported(int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw) {
   ConvGeo g, d;
   FwdPlan p;
-  return layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) && plan_fwd(g, p) && data_grad_geo(g, d) && plan_fwd(d, p) ? 1 : 0;
+  return layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) && plan_fwd(g, p) && data_grad_geo(g, d) && plan_fwd(d, p) &&
+                 bde_conv_lrt_bwd_weight_ws_bytes(N, C, H, W, O, KH, KW, sh, sw, ph, pw) != 0   // ... and for the weight gradient
+             ? 1
+             : 0;
 }
 
 // The tiling the kernels would run with (tests / tools: tests/conv_emulator.py replays the kernels' index arithmetic on the

@@ -242,14 +242,16 @@ static bool plan_wgrad(const WgGeo& g, WgPlan& p) {
   const int regs = mf == 32 ? 16 : 4;
   const int khw = g.KH * g.KW, ktot = g.C * khw;
   const int otiles = (g.O + mf - 1) / mf;
-  const int ct = std::min(ct_max, (ktot + mf - 1) / mf);
-  const int colgroups = (ktot + ct * mf - 1) / (ct * mf);
-  const int cmax = std::min(g.C, (ct * mf + khw - 2) / khw + 1);
   const size_t red = sizeof(float) * static_cast<size_t>(ct_max) * 2 * regs * 64;
   bool found = false;
   double best_score = -1.0;
   WgTile best{};
   size_t best_lds = 0;
+  // ct column tiles of the [O, C*KH*KW] gradient per workgroup: as many as the accumulators hold, fewer only when the input
+  // patches of the channels they span do not fit the LDS even for one output row (wide 1x1 layers on large images)
+  for (int ct = std::min(ct_max, (ktot + mf - 1) / mf); ct >= 1 && !found; --ct) {
+  const int colgroups = (ktot + ct * mf - 1) / (ct * mf);
+  const int cmax = std::min(g.C, (ct * mf + khw - 2) / khw + 1);
   for (int th = g.Ho; th >= 1; th = (th > 1 ? (th + 1) / 2 : 0)) {
     const int bands = (g.Ho + th - 1) / th;
     for (int ni = 8; ni >= 1; ni /= 2) {
@@ -276,11 +278,12 @@ static bool plan_wgrad(const WgGeo& g, WgPlan& p) {
       }
     }
   }
+  }
   if (!found) return false;
   p.t = best;
   p.mf = mf;
   p.otiles = otiles;
-  p.grid = dim3(static_cast<unsigned>(best.PS), static_cast<unsigned>(otiles * colgroups));
+  p.grid = dim3(static_cast<unsigned>(best.PS), static_cast<unsigned>(otiles * best.colgroups));
   p.lds = best_lds;
   return true;
 }

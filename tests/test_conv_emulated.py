@@ -96,3 +96,36 @@ def test_emulated_kernels_equal_the_reference_layer():
             np.testing.assert_allclose(gw.astype(np.float64).sum((1, 2, 3)), g[t + name + "_rowsum"], atol=3e-5 * amax * np.sqrt(c * k * k))
             np.testing.assert_allclose((gw * pw).sum(), float(g[t + name + "_proj"]), atol=3e-5 * amax * np.sqrt(o * c * k * k))
             np.testing.assert_allclose(gw[:2, :2], g[t + name + "_corner"], atol=3e-5 * amax)
+
+
+def test_planner_supported_means_every_pass_has_a_tiling():
+    """bde_conv_lrt_supported (what sends a BBBConv2d layer down the fused path) holds only where ALL three passes have a
+    tiling within 64 KB of LDS: forward, input gradient and weight gradient -- over 3000 random geometries and the layer
+    shapes of ResNet-20 / -18 / -50 (a wide 1x1 layer on a 56-wide image once had a forward but no weight-gradient plan)."""
+    import ctypes
+    import random
+    from beyond_deep_ensembles_amd import _lib
+    lib = _lib.load()
+    rng = random.Random(7)
+    geos = [(1, 256, 56, 56, 64, 1, 1, 1, 1, 0, 0), (1, 64, 56, 56, 256, 1, 1, 1, 1, 0, 0), (128, 16, 32, 32, 16, 3, 3, 1, 1, 1, 1),
+            (1, 3, 224, 224, 64, 7, 7, 2, 2, 3, 3), (2, 512, 7, 7, 512, 3, 3, 1, 1, 1, 1), (1, 1024, 14, 14, 256, 1, 1, 1, 1, 0, 0),
+            (1, 2048, 7, 7, 512, 1, 1, 1, 1, 0, 0), (4, 64, 112, 112, 64, 3, 3, 1, 1, 1, 1)]
+    for _ in range(3000):
+        kh, kw = rng.randint(1, 7), rng.randint(1, 7)
+        geos.append((rng.randint(1, 130), rng.choice([1, 3, 16, 33, 64, 256, 700]), rng.randint(kh, 70), rng.randint(kw, 70),
+                     rng.choice([1, 10, 16, 64, 100, 512]), kh, kw, rng.randint(1, 3), rng.randint(1, 3), rng.randint(0, kh - 1),
+                     rng.randint(0, kw - 1)))
+    out = (ctypes.c_int * 16)()
+    n_supported = 0
+    for geo in geos:
+        if not lib.bde_conv_lrt_supported(*geo):
+            continue
+        n_supported += 1
+        for which in (0, 1):
+            assert lib.bde_conv_lrt_plan(which, *geo, out) == 0, (which, geo)
+            assert 0 < out[14] <= 64 * 1024, (which, geo, out[14])
+        assert lib.bde_conv_lrt_bwd_weight_plan(*geo, out) == 0, geo
+        assert 0 < out[14] <= 64 * 1024 and 1 <= out[6] <= out[1], (geo, list(out))
+        assert lib.bde_conv_lrt_bwd_weight_ws_bytes(*geo) > 0, geo
+    assert n_supported > 2500, n_supported                                 # the fused path is the rule, not the exception
+    assert all(lib.bde_conv_lrt_supported(*g) for g in geos[:8])

@@ -967,6 +967,7 @@ CONV_CASES = [
     (3, 5, 9, 11, 7, 3, (1, 1), (0, 0), True), (2, 7, 13, 6, 33, 3, (2, 1), (1, 2), True), (5, 4, 12, 12, 20, 5, (1, 1), (2, 2), True),
     (2, 3, 30, 30, 64, 7, (2, 2), (3, 3), False), (1, 130, 7, 7, 40, 3, (1, 1), (1, 1), True), (2, 64, 14, 14, 64, 1, (1, 1), (0, 0), True),
     (3, 20, 28, 28, 16, 3, (1, 1), (1, 1), True),
+    (1, 256, 6, 56, 64, 1, (1, 1), (0, 0), False),          # wide 1x1 on a wide image: the weight gradient runs with fewer column tiles
 ]
 
 
@@ -1002,8 +1003,11 @@ def test_conv_lrt_forward(ops):
         assert ops.conv_lrt_supported(x.shape, w_mu.shape, stride, padding), (n, c, h, w, o, k)
         out, var = torch.full(m32.shape, 9.0, device=DEV), torch.full(m32.shape, 9.0, device=DEV)
         ops.conv_lrt_fwd(xd, wbuf, w_mu.shape, dev(b_mu), bvar, stride, padding, out, var, eps=dev(eps))
-        tol_v = max(2 * (v32.double() - v64).abs().max().item(), 3e-6 * v64.abs().max().item())
-        tol_o = max(2 * (out32.double() - out64).abs().max().item(), 3e-6 * out64.abs().max().item())
+        # fp32 accumulation over c*k*k products in one chain: the relative allowance grows with the square root of its length
+        # beyond 1024 (all of CONV_CASES are below; tests/hip_emu/sweep_conv.py also runs 512-channel layers)
+        rel = 3e-6 * max(1.0, (c * k * k / 1024.0) ** 0.5)
+        tol_v = max(2 * (v32.double() - v64).abs().max().item(), rel * v64.abs().max().item())
+        tol_o = max(2 * (out32.double() - out64).abs().max().item(), rel * out64.abs().max().item())
         case = (n, c, h, w, o, k, stride, padding)
         assert (var.cpu().double() - v64).abs().max().item() <= tol_v, case
         assert (out.cpu().double() - out64).abs().max().item() <= tol_o, case
@@ -1061,8 +1065,11 @@ def test_conv_lrt_backward(ops):
         gwm, gwr = torch.full_like(wm, 9.0), torch.full_like(wr, 9.0)
         ops.conv_lrt_bwd_weight(xd, gd, gvar, wr, gwm, gwr, stride, padding)
         case = (n, c, h, w, o, k, stride, padding)
+        ho, wo = g32[3].shape[2:]
+        chain = {"g_x": o * k * k, "g_wmu": n * ho * wo, "g_wrho": n * ho * wo}         # products summed per output element
         for name, got, i in (("g_x", gx, 0), ("g_wmu", gwm, 1), ("g_wrho", gwr, 2)):
-            tol = max(2 * (g32[i].double() - g64[i]).abs().max().item(), 3e-6 * g64[i].abs().max().item())
+            rel = 3e-6 * max(1.0, (chain[name] / 1024.0) ** 0.5)
+            tol = max(2 * (g32[i].double() - g64[i]).abs().max().item(), rel * g64[i].abs().max().item())
             assert (got.cpu().double() - g64[i]).abs().max().item() <= tol, (name, case)
         gwm2, gwr2, gx2 = torch.empty_like(gwm), torch.empty_like(gwr), torch.empty_like(gx)     # deterministic
         ops.conv_lrt_bwd_weight(xd, gd, gvar, wr, gwm2, gwr2, stride, padding)
