@@ -8,6 +8,7 @@
 #include <ucontext.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,8 @@ struct Worker {
   unsigned b_gen = 0;
   unsigned long progress = 0;
   const std::function<void()>* body = nullptr;
+  std::vector<int> ring_next;     // block ring: the fiber that runs after fiber i (waves in the order HIP_EMU_WAVE_ORDER asks for)
+  int first = 0;
   const char* tls_lo = nullptr;   // this thread's TLS block of the emulated library: where the static __shared__ arrays live
   const char* tls_hi = nullptr;
   ~Worker() {
@@ -83,7 +86,7 @@ static void switch_to_next() {
   }
   int nxt = w->index;
   do {
-    nxt = nxt + 1 == w->n ? 0 : nxt + 1;
+    nxt = w->ring_next[nxt];
   } while (w->fibers[nxt].done);
   if (nxt == w->index) return;
   w->index = nxt;
@@ -285,9 +288,34 @@ static void run_block(Worker* w, dim3 grid, dim3 block, unsigned bx, unsigned by
     f.uc.uc_link = nullptr;
     makecontext(&f.uc, fiber_entry, 0);
   }
-  w->index = 0;
-  cur = &w->fibers[0].lane;
-  swapcontext(&w->main_uc, &w->fibers[0].uc);
+  // The order in which the waves of the workgroup get their turns.  Waves only interleave at rendezvous, so a missing
+  // __syncthreads() between a producer and a consumer wave stays invisible while the producer happens to run first:
+  // HIP_EMU_WAVE_ORDER=reverse runs the last wave first, =random shuffles the waves per workgroup (seeded by the block).
+  const int nwaves = (n + 63) / 64;
+  std::vector<int> order(static_cast<size_t>(nwaves));
+  for (int i = 0; i < nwaves; ++i) order[i] = i;
+  const char* mode = std::getenv("HIP_EMU_WAVE_ORDER");
+  if (mode && mode[0] == 'r' && mode[1] == 'e') {
+    for (int i = 0; i < nwaves; ++i) order[i] = nwaves - 1 - i;
+  } else if (mode && mode[0] == 'r' && mode[1] == 'a') {
+    uint64_t st = 0x9E3779B97F4A7C15ull * (1 + bx + 131ull * by + 17161ull * bz) + static_cast<uint64_t>(std::atoll(mode + 6));
+    for (int i = nwaves - 1; i > 0; --i) {
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      std::swap(order[i], order[static_cast<int>((st >> 33) % static_cast<uint64_t>(i + 1))]);
+    }
+  }
+  w->ring_next.assign(static_cast<size_t>(n), 0);
+  int prev = -1;
+  w->first = -1;
+  for (int q = 0; q < nwaves; ++q)
+    for (int t = order[q] * 64; t < std::min(n, order[q] * 64 + 64); ++t) {
+      if (prev >= 0) w->ring_next[prev] = t; else w->first = t;
+      prev = t;
+    }
+  w->ring_next[prev] = w->first;
+  w->index = w->first;
+  cur = &w->fibers[w->first].lane;
+  swapcontext(&w->main_uc, &w->fibers[w->first].uc);
   cur = nullptr;
 }
 

@@ -82,6 +82,12 @@ def test_bbb_conv2d_layer_on_the_cpu_model_matches_the_reference_layer(emu, gold
     S.test_bbb_conv2d_layer_matches_reference_layer(golden, (emu, "cpu"), monkeypatch, "fused")
 
 
+def test_smoke_body_on_the_cpu_model(emu):
+    """What __graft_entry__.smoke() runs on cuda:0 (one SVGD update, SWAG moments and a sample, against the oracle)."""
+    import __graft_entry__ as entry
+    entry.smoke_body(emu, "cpu")
+
+
 @pytest.fixture(scope="module")
 def emu_native():
     return emu_build.load_host_nodes(ALL)
