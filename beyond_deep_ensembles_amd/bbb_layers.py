@@ -272,8 +272,9 @@ class _ConvLrt(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_x = torch.empty_like(x)
             ops.conv_lrt_bwd_data(g, gvar, wbuf, tuple(w_mu.shape), x, g_x, stride, padding)
-        g_wmu, g_wrho = torch.empty_like(w_mu), torch.empty_like(w_rho)
-        ops.conv_lrt_bwd_weight(x, g, gvar, w_rho.detach().contiguous(), g_wmu, g_wrho, stride, padding)
+        wr = w_rho.detach().contiguous()
+        g_wmu, g_wrho = torch.empty_like(wr), torch.empty_like(wr)
+        ops.conv_lrt_bwd_weight(x, g, gvar, wr, g_wmu, g_wrho, stride, padding)
         g_bmu = g_brho = None
         if b_rho is not None:
             g_bmu = g.sum(dim=(0, 2, 3))
@@ -428,7 +429,8 @@ class BBBConv2d(_LocalReparamLayer):
         frozen = not self.training and self.freeze_on_eval           # eval: ONE noise draw shared by the batch (stock path)
         if self.fused_conv and not frozen and input.dim() == 4 and input.dtype == torch.float32 \
                 and not isinstance(self.padding, str) and not isinstance(self.stride, str) \
-                and input.is_cuda == w.mean.is_cuda and hasattr(w._get_ops(), "conv_lrt_fwd"):
+                and input.is_cuda == w.mean.is_cuda and w.mean.is_contiguous() and w.rho.is_contiguous() \
+                and hasattr(w._get_ops(), "conv_lrt_fwd"):
             ops = w._get_ops()
             stride, padding = _pair(self.stride), _pair(self.padding)
             if ops.conv_lrt_supported(input.shape, w.mean.shape, stride, padding):

@@ -187,7 +187,11 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
     const int N = static_cast<int>(xc.size(0)), C = static_cast<int>(xc.size(1)), H = static_cast<int>(xc.size(2)),
               W = static_cast<int>(xc.size(3)), O = static_cast<int>(w_mu.size(0)), KH = static_cast<int>(w_mu.size(2)),
               KW = static_cast<int>(w_mu.size(3));
+    TORCH_CHECK(w_rho.sizes() == w_mu.sizes() && wbuf.is_contiguous() &&
+                    static_cast<size_t>(wbuf.numel()) >= bde_conv_lrt_prep_floats(O, C, KH, KW),
+                "conv_lrt: wbuf does not belong to a layer of this shape");
     const int64_t Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
+    TORCH_CHECK(Ho >= 1 && Wo >= 1, "conv_lrt: empty output");
     at::Tensor out = at::empty({N, O, Ho, Wo}, xc.options()), var = at::empty({N, O, Ho, Wo}, xc.options());
     at::Tensor e;
     if (eps.defined()) e = eps.reshape(out.sizes()).contiguous();

@@ -440,6 +440,23 @@ class HipOps:
         _check(self.lib.bde_var_operand_bwd(_ptr(g, "g"), _ptr(v), mode, _ptr(gv), v.numel(), _stream()),
                "bde_var_operand_bwd")
 
+    @staticmethod
+    def _conv_geo(x, w_shape, stride, padding):
+        """(N, C, H, W, O, KH, KW, sh, sw, ph, pw), output shape; x must be a dense NCHW tensor of the layer's channels."""
+        if x.dim() != 4 or len(w_shape) != 4 or not x.is_contiguous() or int(x.shape[1]) != int(w_shape[1]):
+            raise BdeKernelError(f"conv_lrt: x must be a contiguous [N, C, H, W] tensor with C = {int(w_shape[1])}, got "
+                                 f"{tuple(x.shape)} with strides {tuple(x.stride())}")
+        n, c, h, w = (int(v) for v in x.shape)
+        o, _, kh, kw = (int(v) for v in w_shape)
+        sh, sw, ph, pw = int(stride[0]), int(stride[1]), int(padding[0]), int(padding[1])
+        return (n, c, h, w, o, kh, kw, sh, sw, ph, pw), (n, o, (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1)
+
+    @staticmethod
+    def _dense(t, shape, name):
+        if t is not None and (tuple(t.shape) != tuple(shape) or not t.is_contiguous()):
+            raise BdeKernelError(f"conv_lrt: {name} must be a contiguous tensor of shape {tuple(shape)}, got {tuple(t.shape)} "
+                                 f"with strides {tuple(t.stride())}")
+
     def conv_lrt_supported(self, x_shape, w_shape, stride, padding) -> bool:
         n, c, h, w = (int(v) for v in x_shape)
         o, c2, kh, kw = (int(v) for v in w_shape)
@@ -455,35 +472,51 @@ class HipOps:
     def conv_lrt_prep(self, w_mu, w_rho, wbuf, b_rho=None):
         """Once per weight version: sigma^2, its rho-derivative, the bias variance softplus(b_rho)^2 and the re-arranged
         weight matrices into ``wbuf``."""
-        o, c, kh, kw = w_mu.shape
+        o, c, kh, kw = (int(v) for v in w_mu.shape)
+        self._dense(w_mu, (o, c, kh, kw), "w_mu")
+        self._dense(w_rho, (o, c, kh, kw), "w_rho")
+        self._dense(b_rho, (o,), "b_rho")
+        if wbuf.numel() < int(self.lib.bde_conv_lrt_prep_floats(o, c, kh, kw)) or not wbuf.is_contiguous():
+            raise BdeKernelError("conv_lrt_prep: wbuf is smaller than bde_conv_lrt_prep_floats() (use conv_lrt_wbuf)")
         _check(self.lib.bde_conv_lrt_prep(_ptr(w_mu, "w_mu"), _ptr(w_rho), _ptr(b_rho), o, c, kh, kw, _ptr(wbuf), _stream()),
                "bde_conv_lrt_prep")
+
+    def _conv_wbuf_ok(self, wbuf, geo):
+        if wbuf.numel() < int(self.lib.bde_conv_lrt_prep_floats(geo[4], geo[1], geo[5], geo[6])) or not wbuf.is_contiguous():
+            raise BdeKernelError("conv_lrt: wbuf does not belong to a layer of this shape")
 
     @_on_device_of
     def conv_lrt_fwd(self, x, wbuf, w_shape, b_mu, bias_var, stride, padding, out, var_out, eps=None, seed=0, stream_id=0):
         """BBBConv2d forward (bbb_layers.py:146-154) in one launch; all tensors contiguous fp32 NCHW.  ``bias_var``: add
         the bias variance conv_lrt_prep evaluated from its ``b_rho``."""
-        n, c, h, w = x.shape
-        o, _, kh, kw = w_shape
+        geo, oshape = self._conv_geo(x, w_shape, stride, padding)
+        self._conv_wbuf_ok(wbuf, geo)
+        self._dense(out, oshape, "out")
+        self._dense(var_out, oshape, "var_out")
+        self._dense(eps, oshape, "eps")
+        self._dense(b_mu, (geo[4],), "b_mu")
         _check(self.lib.bde_conv_lrt_fwd(_ptr(x, "x"), _ptr(wbuf), _ptr(b_mu), int(bool(bias_var)), _ptr(eps), seed, stream_id,
-                                         _ptr(out), _ptr(var_out), n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0],
-                                         padding[1], _stream()), "bde_conv_lrt_fwd")
+                                         _ptr(out), _ptr(var_out), *geo, _stream()), "bde_conv_lrt_fwd")
 
     @_on_device_of
     def conv_lrt_bwd_data(self, g_out, g_var, wbuf, w_shape, x, g_x, stride, padding):
         """g_x of BBBConv2d: both transposed convolutions + the clamp's derivative in one launch."""
-        n, c, h, w = x.shape
-        o, _, kh, kw = w_shape
-        _check(self.lib.bde_conv_lrt_bwd_data(_ptr(g_out, "g_out"), _ptr(g_var), _ptr(wbuf), _ptr(x), _ptr(g_x), n, c, h, w, o,
-                                              kh, kw, stride[0], stride[1], padding[0], padding[1], _stream()),
+        geo, oshape = self._conv_geo(x, w_shape, stride, padding)
+        self._conv_wbuf_ok(wbuf, geo)
+        self._dense(g_out, oshape, "g_out")
+        self._dense(g_var, oshape, "g_var")
+        self._dense(g_x, tuple(x.shape), "g_x")
+        _check(self.lib.bde_conv_lrt_bwd_data(_ptr(g_out, "g_out"), _ptr(g_var), _ptr(wbuf), _ptr(x), _ptr(g_x), *geo, _stream()),
                "bde_conv_lrt_bwd_data")
 
     @_on_device_of
     def conv_lrt_bwd_weight(self, x, g_out, g_var, w_rho, g_wmu, g_wrho, stride, padding, ws=None):
         """g_wmu / g_wrho of BBBConv2d: two weight-gradient convolutions + the rho chain rule in two launches."""
-        n, c, h, w = x.shape
-        o, _, kh, kw = w_rho.shape
-        geo = (n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0], padding[1])
+        geo, oshape = self._conv_geo(x, tuple(w_rho.shape), stride, padding)
+        self._dense(g_out, oshape, "g_out")
+        self._dense(g_var, oshape, "g_var")
+        for t, name in ((w_rho, "w_rho"), (g_wmu, "g_wmu"), (g_wrho, "g_wrho")):
+            self._dense(t, tuple(w_rho.shape), name)
         need = int(self.lib.bde_conv_lrt_bwd_weight_ws_bytes(*geo))
         if need == 0:
             raise BdeKernelError("bde_conv_lrt_bwd_weight: unsupported geometry")

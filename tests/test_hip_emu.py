@@ -82,6 +82,67 @@ def test_bbb_conv2d_layer_on_the_cpu_model_matches_the_reference_layer(emu, gold
     S.test_bbb_conv2d_layer_matches_reference_layer(golden, (emu, "cpu"), monkeypatch, "fused")
 
 
+def test_conv_wrappers_reject_tensors_the_kernels_would_misread(emu):
+    """HipOps.conv_lrt_*: the C ABI takes raw pointers and a geometry, so the wrappers check what the kernels assume -- dense
+    NCHW tensors of exactly the shapes the geometry implies, a weight buffer of the layer's size."""
+    from beyond_deep_ensembles_amd.ops import BdeKernelError
+    ops = emu
+    x = torch.randn(2, 6, 9, 9)
+    w_mu, w_rho = torch.randn(8, 6, 3, 3) * 0.1, torch.randn(8, 6, 3, 3) - 3
+    wbuf = ops.conv_lrt_wbuf(w_mu.shape, "cpu")
+    ops.conv_lrt_prep(w_mu, w_rho, wbuf)
+    out, var = torch.empty(2, 8, 9, 9), torch.empty(2, 8, 9, 9)
+    eps = torch.randn(2, 8, 9, 9)
+    good = dict(x=x, wbuf=wbuf, w_shape=w_mu.shape, b_mu=None, bias_var=False, stride=(1, 1), padding=(1, 1), out=out, var_out=var, eps=eps)
+    ops.conv_lrt_fwd(**good)
+    bad = [dict(x=torch.randn(2, 12, 9, 9)[:, ::2]),                     # a channel slice: last stride 1, not dense
+           dict(x=x.to(memory_format=torch.channels_last)), dict(x=torch.randn(2, 5, 9, 9)), dict(out=torch.empty(2, 8, 9, 8)),
+           dict(eps=eps[:, :, :, :8]), dict(var_out=torch.empty(2, 8, 81)), dict(wbuf=wbuf[:-4]), dict(b_mu=torch.zeros(7))]
+    for change in bad:
+        with pytest.raises(BdeKernelError):
+            ops.conv_lrt_fwd(**{**good, **change})
+    g = torch.randn(2, 8, 9, 9)
+    gx, gwm, gwr = torch.empty_like(x), torch.empty_like(w_mu), torch.empty_like(w_rho)
+    ops.conv_lrt_bwd_data(g, g.clone(), wbuf, w_mu.shape, x, gx, (1, 1), (1, 1))
+    ops.conv_lrt_bwd_weight(x, g, g.clone(), w_rho, gwm, gwr, (1, 1), (1, 1))
+    with pytest.raises(BdeKernelError):
+        ops.conv_lrt_bwd_data(g[:, :, :8], g.clone(), wbuf, w_mu.shape, x, gx, (1, 1), (1, 1))
+    with pytest.raises(BdeKernelError):
+        ops.conv_lrt_bwd_data(g, g.clone(), wbuf, w_mu.shape, x, torch.empty(2, 6, 9, 10), (1, 1), (1, 1))
+    with pytest.raises(BdeKernelError):
+        ops.conv_lrt_bwd_weight(x, g, g.clone(), w_rho, gwm.permute(0, 1, 3, 2), gwr, (1, 1), (1, 1))
+    with pytest.raises(BdeKernelError):
+        ops.conv_lrt_prep(w_mu.to(memory_format=torch.channels_last), w_rho, wbuf)
+
+
+def test_bbb_conv2d_channels_last_inputs_and_weights(emu, monkeypatch):
+    """A channels_last input is copied to NCHW by the fused node; channels_last WEIGHTS (model.to(memory_format=...)) send
+    the layer down the stock path instead of handing the kernels strides they do not read.  Same results either way."""
+    import beyond_deep_ensembles_amd as bde
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    monkeypatch.setattr(L, "_native_nodes", lambda ops: None)
+    torch.manual_seed(2)
+    prior = bde.GaussianPrior(0, 1.0)
+    conv = bde.BBBConv2d(6, 8, 3, prior, prior, padding=1, _ops=emu).train()
+    x = torch.randn(2, 6, 9, 9)
+    noise = torch.randn(2, 8, 9, 9)
+    monkeypatch.setattr(L, "normal_like", lambda t: noise)
+    calls = []
+    real = emu.conv_lrt_fwd
+    monkeypatch.setattr(emu, "conv_lrt_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    ref = conv(x)
+    assert len(calls) == 1
+    out = conv(x.to(memory_format=torch.channels_last))
+    assert len(calls) == 2 and torch.equal(out, ref)
+    conv.to(memory_format=torch.channels_last)
+    assert not conv.weight.mean.is_contiguous()
+    out = conv(x)
+    assert len(calls) == 2                                                # stock convolutions
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
+    g = torch.autograd.grad(out.sum(), [conv.weight.mean, conv.weight.rho])
+    assert all(t.shape == conv.weight.mean.shape for t in g)
+
+
 def test_smoke_body_on_the_cpu_model(emu):
     """What __graft_entry__.smoke() runs on cuda:0 (one SVGD update, SWAG moments and a sample, against the oracle)."""
     import __graft_entry__ as entry
