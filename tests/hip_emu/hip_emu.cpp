@@ -3,6 +3,7 @@
 // one ucontext fiber per lane; fibers switch only inside a rendezvous (block or wave barrier), round-robin.
 #include "hip_emu.hpp"
 
+#include <dlfcn.h>
 #include <link.h>
 #include <sys/mman.h>
 #include <ucontext.h>
@@ -12,7 +13,9 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <vector>
 
@@ -26,17 +29,38 @@ struct Dma {
   int bytes;
 };
 
+// ---- LDS bank-conflict accounting (HIP_EMU_LDS_STATS=1) -----------------------------------------------------------------
+// The k-th LDS access of every lane of a wave is one wave-instruction (the lanes take turns access by access, see
+// on_access): its 64 addresses, the access size and direction give the LDS-array cycles by the CDNA4 banking rules of
+// /opt/skills/guides/MI355X_MICROARCH.md "LDS" -- lane groups per instruction, bank = (a/4) mod 32 or 64, identical
+// addresses broadcast, every further distinct address on a busy bank of a group adds a cycle.  Accumulated per code address.
+struct LdsSite {
+  uint64_t insts = 0, ideal = 0, cycles = 0;
+  int size = 0;
+  bool write = false;
+};
+struct LdsPending {
+  unsigned tag = ~0u;
+  uintptr_t pc = 0;
+  int size = 0;
+  bool write = false;
+  uint64_t mask = 0;
+  uintptr_t addr[64];
+};
+
 struct Wave {
   int live = 0, arrived = 0;
   unsigned gen = 0;
   uint64_t live_mask = 0;
   alignas(16) uint64_t slot[2][64 * 2];
+  LdsPending pend[4];
 };
 
 struct Fiber {
   ucontext_t uc;
   Lane lane;
   bool done = true;
+  unsigned lds_k = 0;             // LDS accesses of this lane so far in this workgroup
   std::vector<Dma> dma;
 };
 
@@ -58,6 +82,7 @@ struct Worker {
   unsigned b_gen = 0;
   unsigned long progress = 0;
   const std::function<void()>* body = nullptr;
+  std::unordered_map<uintptr_t, LdsSite> lds_sites;
   std::vector<int> ring_next;     // block ring: the fiber that runs after fiber i (waves in the order HIP_EMU_WAVE_ORDER asks for)
   int first = 0;
   const char* tls_lo = nullptr;   // this thread's TLS block of the emulated library: where the static __shared__ arrays live
@@ -160,7 +185,72 @@ static int tls_probe(struct dl_phdr_info* info, size_t, void* out) {
   return 0;
 }
 
-static inline void on_access(const void* a) {
+static const bool g_lds_stats = std::getenv("HIP_EMU_LDS_STATS") != nullptr;
+static std::mutex g_lds_mu;
+static std::map<uintptr_t, LdsSite> g_lds_sites;
+
+static void lds_flush(Worker* w, LdsPending& p) {
+  if (p.tag == ~0u || !p.mask) {
+    p.tag = ~0u;
+    p.mask = 0;
+    return;
+  }
+  // lane groups of the instruction (MI355X_MICROARCH.md, LDS table)
+  static const int g128[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                  {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                  {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                  {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+  int ngroups, gsize, banks;
+  const int dwords = p.size >= 4 ? p.size / 4 : 1;
+  bool table128 = false;
+  if (!p.write) {
+    if (p.size <= 4) { ngroups = 2; gsize = 32; banks = 32; }
+    else if (p.size == 8) { ngroups = 2; gsize = 32; banks = 64; }
+    else { ngroups = 4; gsize = 16; banks = 64; table128 = true; }
+  } else {
+    banks = 32;
+    if (p.size <= 4) { ngroups = 2; gsize = 32; }
+    else if (p.size == 8) { ngroups = 4; gsize = 16; }
+    else { ngroups = 8; gsize = 8; }
+  }
+  uint64_t ideal = 0, cycles = 0;
+  for (int g = 0; g < ngroups; ++g) {
+    uintptr_t seen[64][16];
+    int nseen[64] = {0};
+    bool any = false;
+    for (int q = 0; q < gsize; ++q) {
+      const int lane = table128 ? g128[g][q] : g * gsize + q;
+      if (!((p.mask >> lane) & 1u)) continue;
+      any = true;
+      for (int d = 0; d < dwords; ++d) {
+        const uintptr_t dw = p.addr[lane] / 4 + static_cast<uintptr_t>(d);
+        const int b = static_cast<int>(dw % static_cast<uintptr_t>(banks));
+        bool dup = false;
+        for (int i = 0; i < nseen[b]; ++i) dup |= seen[b][i] == dw;
+        if (!dup && nseen[b] < 16) seen[b][nseen[b]++] = dw;
+      }
+    }
+    if (!any) continue;
+    int worst = 1;
+    for (int b = 0; b < banks; ++b) worst = std::max(worst, nseen[b]);
+    ideal += 1;
+    cycles += static_cast<uint64_t>(worst);
+  }
+  LdsSite& site = w->lds_sites[p.pc];
+  site.insts += 1;
+  site.ideal += ideal;
+  site.cycles += cycles;
+  site.size = p.size;
+  site.write = p.write;
+  p.tag = ~0u;
+  p.mask = 0;
+}
+
+static void lds_flush_wave(Worker* w, Wave* wv) {
+  for (auto& p : wv->pend) lds_flush(w, p);
+}
+
+static inline void on_access(const void* a, int size, bool write, uintptr_t pc) {
   if (!cur) return;                                   // host code of the library
   Worker* w = wk;
   const char* p = static_cast<const char*>(a);
@@ -168,6 +258,22 @@ static inline void on_access(const void* a) {
   const bool stat = p >= w->tls_lo && p < w->tls_hi && p != reinterpret_cast<const char*>(&cur);
   if (!dyn && !stat) return;
   const int me = w->index, base = me & ~63, end = std::min(base + 64, w->n);
+  if (g_lds_stats) {
+    Fiber& f = w->fibers[me];
+    Wave* wv = f.lane.wave;
+    const unsigned k = f.lds_k++;
+    LdsPending& pd = wv->pend[k & 3u];
+    if (pd.tag != k || pd.pc != pc) {
+      lds_flush(w, pd);
+      pd.tag = k;
+      pd.pc = pc;
+      pd.size = size;
+      pd.write = write;
+    }
+    pd.addr[f.lane.lane] = reinterpret_cast<uintptr_t>(a);
+    pd.mask |= 1ull << f.lane.lane;
+    if (pd.mask == wv->live_mask) lds_flush(w, pd);
+  }
   int nxt = me;
   do {
     nxt = nxt + 1 == end ? base : nxt + 1;
@@ -210,6 +316,7 @@ static void fiber_entry() {
   --w->live;
   ++w->progress;
   Wave* wv = me->lane.wave;
+  if (g_lds_stats) lds_flush_wave(w, wv);
   --wv->live;
   wv->live_mask &= ~(1ull << me->lane.lane);
   if (wv->live > 0 && wv->arrived == wv->live) {     // the lanes still waiting are now complete
@@ -263,6 +370,10 @@ static void run_block(Worker* w, dim3 grid, dim3 block, unsigned bx, unsigned by
     wv.live = wv.arrived = 0;
     wv.gen = 0;
     wv.live_mask = 0;
+    for (auto& p : wv.pend) {
+      p.tag = ~0u;
+      p.mask = 0;
+    }
   }
   w->live = n;
   w->b_arrived = 0;
@@ -270,6 +381,7 @@ static void run_block(Worker* w, dim3 grid, dim3 block, unsigned bx, unsigned by
   for (int t = 0; t < n; ++t) {
     Fiber& f = w->fibers[t];
     f.done = false;
+    f.lds_k = 0;
     f.dma.clear();
     Lane& l = f.lane;
     l.tid = {static_cast<unsigned>(t % block.x), static_cast<unsigned>((t / block.x) % block.y), static_cast<unsigned>(t / (block.x * block.y))};
@@ -343,6 +455,18 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
       run_block(&worker, grid, block, static_cast<unsigned>(b % grid.x), static_cast<unsigned>((b / grid.x) % grid.y),
                 static_cast<unsigned>(b / (static_cast<long>(grid.x) * grid.y)));
     }
+    if (g_lds_stats && !worker.lds_sites.empty()) {
+      std::lock_guard<std::mutex> lock(g_lds_mu);
+      for (const auto& kv : worker.lds_sites) {
+        LdsSite& t = g_lds_sites[kv.first];
+        t.insts += kv.second.insts;
+        t.ideal += kv.second.ideal;
+        t.cycles += kv.second.cycles;
+        t.size = kv.second.size;
+        t.write = kv.second.write;
+      }
+      worker.lds_sites.clear();
+    }
   };
   const int nw = static_cast<int>(std::min<long>(n_workers(), total));
   if (nw <= 1) {
@@ -360,18 +484,19 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
 // ---- -fsanitize=thread callbacks (see on_access) -----------------------------------------------------------------------
 extern "C" {
 void __tsan_init() {}
-#define HIP_EMU_HOOK(n)                                                   \
-  void __tsan_read##n(void* a) { hip_emu::on_access(a); }                 \
-  void __tsan_write##n(void* a) { hip_emu::on_access(a); }                \
-  void __tsan_unaligned_read##n(void* a) { hip_emu::on_access(a); }       \
-  void __tsan_unaligned_write##n(void* a) { hip_emu::on_access(a); }
+#define HIP_EMU_PC reinterpret_cast<uintptr_t>(__builtin_return_address(0))
+#define HIP_EMU_HOOK(n)                                                                              \
+  void __tsan_read##n(void* a) { hip_emu::on_access(a, n, false, HIP_EMU_PC); }                      \
+  void __tsan_write##n(void* a) { hip_emu::on_access(a, n, true, HIP_EMU_PC); }                      \
+  void __tsan_unaligned_read##n(void* a) { hip_emu::on_access(a, n, false, HIP_EMU_PC); }            \
+  void __tsan_unaligned_write##n(void* a) { hip_emu::on_access(a, n, true, HIP_EMU_PC); }
 HIP_EMU_HOOK(1)
 HIP_EMU_HOOK(2)
 HIP_EMU_HOOK(4)
 HIP_EMU_HOOK(8)
 HIP_EMU_HOOK(16)
-void __tsan_read_range(void* a, unsigned long) { hip_emu::on_access(a); }
-void __tsan_write_range(void* a, unsigned long) { hip_emu::on_access(a); }
+void __tsan_read_range(void* a, unsigned long n) { hip_emu::on_access(a, static_cast<int>(n), false, HIP_EMU_PC); }
+void __tsan_write_range(void* a, unsigned long n) { hip_emu::on_access(a, static_cast<int>(n), true, HIP_EMU_PC); }
 void __tsan_vptr_update(void**, void*) {}
 void __tsan_vptr_read(void**) {}
 void __tsan_func_entry(void*) {}
@@ -412,6 +537,24 @@ hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int
 
 // Buffers with a guard page before and after: a read or write past either end faults at once.  The payload is placed so
 // that it ENDS at the trailing guard page (rounded to 16 bytes, the alignment every kernel may assume).
+// LDS statistics gathered so far (HIP_EMU_LDS_STATS=1): one line per code address,
+// "<offset in this library> <bytes> <r|w> <wave-instructions> <conflict-free cycles> <cycles>"; clears the table.
+int hip_emu_lds_report(const char* path) {
+  std::lock_guard<std::mutex> lock(hip_emu::g_lds_mu);
+  FILE* f = std::fopen(path, "w");
+  if (!f) return -1;
+  Dl_info info;
+  uintptr_t base = 0;
+  if (dladdr(reinterpret_cast<void*>(&hip_emu_lds_report), &info)) base = reinterpret_cast<uintptr_t>(info.dli_fbase);
+  for (const auto& kv : hip_emu::g_lds_sites)
+    std::fprintf(f, "0x%lx %d %c %lu %lu %lu\n", static_cast<unsigned long>(kv.first - base - 1), kv.second.size,
+                 kv.second.write ? 'w' : 'r', static_cast<unsigned long>(kv.second.insts), static_cast<unsigned long>(kv.second.ideal),
+                 static_cast<unsigned long>(kv.second.cycles));
+  std::fclose(f);
+  hip_emu::g_lds_sites.clear();
+  return 0;
+}
+
 void* hip_emu_alloc(size_t bytes) {
   const size_t pg = hip_emu::page();
   const size_t rounded = (bytes + 15) / 16 * 16;
