@@ -24,6 +24,7 @@ class _Shadows:
     def __init__(self, lib):
         self.lib = lib
         self.live = {}                                    # storage data_ptr -> (shadow ptr, nbytes, tensor kept alive)
+        self.per_storage = None                           # Traffic: storage data_ptr -> (bytes read, bytes written) by the kernels
 
     def ptr(self, t):
         st = t.untyped_storage()
@@ -40,8 +41,13 @@ class _Shadows:
         return hit[0] + (t.data_ptr() - base)
 
     def land(self):
+        out = (ctypes.c_uint64 * 2)()
         for base, (sh, nbytes, _keep) in self.live.items():
             ctypes.memmove(base, sh, nbytes)
+            if self.per_storage is not None:
+                self.lib.hip_emu_buffer_traffic(sh, out)
+                r, w = self.per_storage.get(base, (0, 0))
+                self.per_storage[base] = (r + int(out[0]), w + int(out[1]))
             self.lib.hip_emu_free(sh, nbytes)
         self.live.clear()
 
@@ -52,9 +58,39 @@ def load(sources, defines=()):
         fn = getattr(lib, name, None)
         if fn is not None:
             fn.restype, fn.argtypes = res, args
+    lib.hip_emu_count_traffic.restype, lib.hip_emu_count_traffic.argtypes = None, [ctypes.c_int]
+    lib.hip_emu_traffic.restype, lib.hip_emu_traffic.argtypes = None, [ctypes.POINTER(ctypes.c_uint64)]
+    lib.hip_emu_buffer_traffic.restype, lib.hip_emu_buffer_traffic.argtypes = None, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
     lib.hip_emu_alloc.restype, lib.hip_emu_alloc.argtypes = ctypes.c_void_p, [ctypes.c_size_t]
     lib.hip_emu_free.restype, lib.hip_emu_free.argtypes = None, [ctypes.c_void_p, ctypes.c_size_t]
     return lib
+
+
+class Traffic:
+    """``with Traffic(ops) as t: ops.kernel(...)`` -> t.read / t.written (bytes the kernels requested from / sent to the tensors
+    handed through HipOps), t.lds_read / t.lds_written, t.mfma32 / t.mfma16 (v_mfma_f32_32x32x2 / 16x16x4 wave-instructions)."""
+
+    def __init__(self, ops):
+        self.lib, self.shadows = ops.lib, ops._emu_shadows
+
+    def __enter__(self):
+        self.lib.hip_emu_count_traffic(1)
+        self.lib.hip_emu_traffic((ctypes.c_uint64 * 6)())
+        self.shadows.per_storage = {}
+        return self
+
+    def __exit__(self, *exc):
+        out = (ctypes.c_uint64 * 6)()
+        self.lib.hip_emu_traffic(out)
+        self.lib.hip_emu_count_traffic(0)
+        self.read, self.written, self.lds_read, self.lds_written, self.mfma32, self.mfma16 = (int(v) for v in out)
+        self.per_storage, self.shadows.per_storage = self.shadows.per_storage, None
+        return False
+
+    def of(self, tensor):
+        """(bytes read, bytes written) by the kernels in the storage of ``tensor`` (its coefficient tables and other
+        wave-uniform operands live in other tensors: on the device those are scalar loads, not streams)."""
+        return self.per_storage.get(tensor.untyped_storage().data_ptr(), (0, 0))
 
 
 @contextlib.contextmanager
@@ -65,6 +101,7 @@ def emulated(sources, defines=()):
     ops.name = "hip_emu"                                  # the shells' "HIP kernels need CUDA parameters" guard is for the device library
     ops.load_code_objects = lambda device: None            # bde_init() uploads code objects: nothing to upload here
     shadows = _Shadows(lib)
+    ops._emu_shadows = shadows
     real_ptr, real_check, real_stream = ops_mod._ptr, ops_mod._check, ops_mod._stream
 
     def ptr(t, name="tensor"):

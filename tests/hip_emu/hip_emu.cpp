@@ -83,6 +83,8 @@ struct Worker {
   unsigned long progress = 0;
   const std::function<void()>* body = nullptr;
   std::unordered_map<uintptr_t, LdsSite> lds_sites;
+  uint64_t traffic[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<uint64_t> buf_traffic;
   std::vector<int> ring_next;     // block ring: the fiber that runs after fiber i (waves in the order HIP_EMU_WAVE_ORDER asks for)
   int first = 0;
   const char* tls_lo = nullptr;   // this thread's TLS block of the emulated library: where the static __shared__ arrays live
@@ -185,6 +187,31 @@ static int tls_probe(struct dl_phdr_info* info, size_t, void* out) {
   return 0;
 }
 
+// ---- traffic accounting (HIP_EMU_TRAFFIC=1): bytes the kernels request from / send to the guard-paged buffers (what
+// hip_emu_alloc handed out: every tensor that went through HipOps), LDS bytes, matrix instructions.  Requests, before any
+// cache: requested / algorithmic bytes > 1 is re-reading that only L2 / the Infinity Cache can absorb on the device.
+static std::atomic<bool> g_traffic_on{std::getenv("HIP_EMU_TRAFFIC") != nullptr};      // or hip_emu_count_traffic(1)
+static std::mutex g_buf_mu;
+static std::map<uintptr_t, uintptr_t> g_buffers;                   // start -> end of every live guarded buffer
+static std::atomic<uint64_t> g_traffic[6];                         // global read, global write, LDS read, LDS write, mfma 32x32x2, mfma 16x16x4
+struct BufferSnapshot {
+  std::vector<std::pair<uintptr_t, uintptr_t>> v;
+};
+static BufferSnapshot g_snapshot;                                  // taken at launch (buffers do not change during one)
+
+static std::map<uintptr_t, std::pair<uint64_t, uint64_t>> g_buf_traffic;   // buffer start -> bytes read, written (per buffer:
+                                                                            // a kernel's coefficient tables are wave-uniform scalar
+                                                                            // loads on the device; the streams are what counts)
+static inline int buffer_index(uintptr_t a) {
+  const auto& v = g_snapshot.v;
+  size_t lo = 0, hi = v.size();
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    if (v[mid].second <= a) lo = mid + 1; else hi = mid;
+  }
+  return lo < v.size() && v[lo].first <= a ? static_cast<int>(lo) : -1;
+}
+
 static const bool g_lds_stats = std::getenv("HIP_EMU_LDS_STATS") != nullptr;
 static std::mutex g_lds_mu;
 static std::map<uintptr_t, LdsSite> g_lds_sites;
@@ -256,7 +283,18 @@ static inline void on_access(const void* a, int size, bool write, uintptr_t pc) 
   const char* p = static_cast<const char*>(a);
   const bool dyn = p >= w->lds && p < w->lds + w->lds_bytes;
   const bool stat = p >= w->tls_lo && p < w->tls_hi && p != reinterpret_cast<const char*>(&cur);
-  if (!dyn && !stat) return;
+  if (!dyn && !stat) {
+    if (g_traffic_on) {
+      const int bi = buffer_index(reinterpret_cast<uintptr_t>(a));
+      if (bi >= 0) {
+        w->traffic[write ? 1 : 0] += static_cast<uint64_t>(size);
+        if (w->buf_traffic.size() < 2 * g_snapshot.v.size()) w->buf_traffic.resize(2 * g_snapshot.v.size(), 0);
+        w->buf_traffic[2 * static_cast<size_t>(bi) + (write ? 1 : 0)] += static_cast<uint64_t>(size);
+      }
+    }
+    return;
+  }
+  if (g_traffic_on) w->traffic[write ? 3 : 2] += static_cast<uint64_t>(size);
   const int me = w->index, base = me & ~63, end = std::min(base + 64, w->n);
   if (g_lds_stats) {
     Fiber& f = w->fibers[me];
@@ -286,6 +324,9 @@ static inline void on_access(const void* a, int size, bool write, uintptr_t pc) 
 }
 
 uint64_t* wave_slot(unsigned parity) { return cur->wave->slot[parity & 1u]; }
+void count_mfma(int which) {
+  if (g_traffic_on && cur->lane == __builtin_ctzll(cur->wave->live_mask)) ++wk->traffic[4 + which];
+}
 uint64_t wave_live_mask() { return cur->wave->live_mask; }
 void* dyn_lds() { return wk->lds; }
 
@@ -301,6 +342,15 @@ static void dma_land(Fiber* f, size_t keep) {
 void dma_request(const void* src, void* lds_dst, int bytes) {
   Worker* w = wk;
   if (static_cast<char*>(lds_dst) < w->lds || static_cast<char*>(lds_dst) + bytes > w->lds + w->lds_bytes) die("LDS-DMA outside the dynamic LDS");
+  if (g_traffic_on) {                                  // a global read and an LDS write that no load / store instruction shows
+    const int bi = buffer_index(reinterpret_cast<uintptr_t>(src));
+    if (bi >= 0) {
+      w->traffic[0] += static_cast<uint64_t>(bytes);
+      if (w->buf_traffic.size() < 2 * g_snapshot.v.size()) w->buf_traffic.resize(2 * g_snapshot.v.size(), 0);
+      w->buf_traffic[2 * static_cast<size_t>(bi)] += static_cast<uint64_t>(bytes);
+    }
+    w->traffic[3] += static_cast<uint64_t>(bytes);
+  }
   cur_fiber()->dma.push_back({src, lds_dst, bytes});
 }
 void waitcnt_vm(int outstanding) { dma_land(cur_fiber(), static_cast<size_t>(outstanding < 0 ? 0 : outstanding)); }
@@ -443,6 +493,10 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
   const int n = static_cast<int>(block.x * block.y * block.z);
   const long total = static_cast<long>(grid.x) * grid.y * grid.z;
   if (n <= 0 || n > 1024 || total <= 0) return;
+  if (g_traffic_on) {
+    std::lock_guard<std::mutex> lock(g_buf_mu);
+    g_snapshot.v.assign(g_buffers.begin(), g_buffers.end());
+  }
   std::atomic<long> next{0};
   auto work = [&]() {
     static thread_local Worker worker;
@@ -454,6 +508,19 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
       if (b >= total) break;
       run_block(&worker, grid, block, static_cast<unsigned>(b % grid.x), static_cast<unsigned>((b / grid.x) % grid.y),
                 static_cast<unsigned>(b / (static_cast<long>(grid.x) * grid.y)));
+    }
+    if (g_traffic_on) {
+      for (int i = 0; i < 6; ++i) {
+        g_traffic[i] += worker.traffic[i];
+        worker.traffic[i] = 0;
+      }
+      std::lock_guard<std::mutex> lock(g_buf_mu);
+      for (size_t i = 0; 2 * i + 1 < worker.buf_traffic.size() && i < g_snapshot.v.size(); ++i) {
+        auto& t = g_buf_traffic[g_snapshot.v[i].first];
+        t.first += worker.buf_traffic[2 * i];
+        t.second += worker.buf_traffic[2 * i + 1];
+      }
+      worker.buf_traffic.assign(worker.buf_traffic.size(), 0);
     }
     if (g_lds_stats && !worker.lds_sites.empty()) {
       std::lock_guard<std::mutex> lock(g_lds_mu);
@@ -565,9 +632,31 @@ void* hip_emu_alloc(size_t bytes) {
   mprotect(m + pg + body, pg, PROT_NONE);
   char* p = m + pg + body - rounded;
   std::memset(m + pg, 0xCB, body);
+  {
+    std::lock_guard<std::mutex> lock(hip_emu::g_buf_mu);
+    hip_emu::g_buffers[reinterpret_cast<uintptr_t>(p)] = reinterpret_cast<uintptr_t>(p) + bytes;
+  }
   return p;
 }
+// out[6] = bytes read from / written to guarded buffers, LDS bytes read / written, 32x32x2 and 16x16x4 matrix instructions
+// since the last call (counted while HIP_EMU_TRAFFIC is set or after hip_emu_count_traffic(1))
+void hip_emu_count_traffic(int on) { hip_emu::g_traffic_on = on != 0; }
+// out[2] = bytes the kernels read from / wrote to the guarded buffer that starts at p, since it was allocated
+void hip_emu_buffer_traffic(void* p, uint64_t* out) {
+  std::lock_guard<std::mutex> lock(hip_emu::g_buf_mu);
+  const auto it = hip_emu::g_buf_traffic.find(reinterpret_cast<uintptr_t>(p));
+  out[0] = it == hip_emu::g_buf_traffic.end() ? 0 : it->second.first;
+  out[1] = it == hip_emu::g_buf_traffic.end() ? 0 : it->second.second;
+}
+void hip_emu_traffic(uint64_t* out) {
+  for (int i = 0; i < 6; ++i) out[i] = hip_emu::g_traffic[i].exchange(0);
+}
 void hip_emu_free(void* p, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lock(hip_emu::g_buf_mu);
+    hip_emu::g_buffers.erase(reinterpret_cast<uintptr_t>(p));
+    hip_emu::g_buf_traffic.erase(reinterpret_cast<uintptr_t>(p));
+  }
   const size_t pg = hip_emu::page();
   const size_t rounded = (bytes + 15) / 16 * 16;
   const size_t body = (rounded + pg - 1) / pg * pg;

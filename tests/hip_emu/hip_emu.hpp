@@ -49,6 +49,7 @@ void waitcnt_vm(int outstanding);
 void dma_request(const void* src, void* lds_dst, int bytes);
 uint64_t* wave_slot(unsigned parity);     // [64][2] 64-bit words of the current wave
 uint64_t wave_live_mask();
+void count_mfma(int which);
 
 template <typename T>
 inline T exchange(T mine, int from_lane) {   // every live lane of the wave calls this; returns lane `from_lane`'s value
@@ -129,6 +130,7 @@ inline floatx16 mfma_32x32x2f32(float a, float b, floatx16 c, int, int, int) {
   s[me->lane * 4] = a;
   s[me->lane * 4 + 1] = b;
   wave_sync();
+  count_mfma(0);
   const int l = me->lane, j = l & 31, hi = l >> 5;
   for (int v = 0; v < 16; ++v) {
     const int i = 8 * (v / 4) + 4 * hi + (v % 4);
@@ -147,6 +149,7 @@ inline floatx4 mfma_16x16x4f32(float a, float b, floatx4 c, int, int, int) {
   s[me->lane * 4] = a;
   s[me->lane * 4 + 1] = b;
   wave_sync();
+  count_mfma(1);
   const int l = me->lane, j = l & 15, g = l >> 4;
   for (int v = 0; v < 4; ++v) {
     const int i = 4 * g + v;

@@ -7,6 +7,7 @@ host compiler's access widths stand in for hipcc's (a float4 access is a b128, a
 
     python -m tests.hip_emu.lds_report conv            # the fused BBBConv2d kernels at the ResNet-20 layer shapes
     python -m tests.hip_emu.lds_report lrt | swag | svgd
+    python -m tests.hip_emu.lds_report traffic         # the conv kernels: bytes requested per tensor, matrix work / useful work
 """
 import collections
 import os
@@ -104,8 +105,41 @@ def svgd(ops):
     report(ops, "SVGD streaming kernels (ragged sizes test)")
 
 
+def traffic(ops):
+    """Requested bytes per tensor relative to its size and matrix-instruction work relative to the layer's useful flops."""
+    from tests.hip_emu.emu_ops import Traffic
+    layers = [("3->16 32x32", 8, 3, 32, 32, 16, 3, 1, 1), ("16->16 32x32", 8, 16, 32, 32, 16, 3, 1, 1),
+              ("16->32 s2", 8, 16, 32, 32, 32, 3, 2, 1), ("32->32 16x16", 8, 32, 16, 16, 32, 3, 1, 1),
+              ("32->64 s2", 8, 32, 16, 16, 64, 3, 2, 1), ("64->64 8x8", 16, 64, 8, 8, 64, 3, 1, 1)]
+    mfma_flop = lambda t: t.mfma32 * 2 * 32 * 32 * 2 + t.mfma16 * 2 * 16 * 16 * 4
+    for name, n, c, h, w, o, k, s, p in layers:
+        x = torch.randn(n, c, h, w)
+        w_mu, w_rho = torch.randn(o, c, k, k) * 0.1, torch.randn(o, c, k, k) - 3
+        wbuf = ops.conv_lrt_wbuf(w_mu.shape, "cpu")
+        ops.conv_lrt_prep(w_mu, w_rho, wbuf)
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        out, var = torch.empty(n, o, ho, wo), torch.empty(n, o, ho, wo)
+        flop = 2 * 2 * n * o * ho * wo * c * k * k
+        with Traffic(ops) as t:
+            ops.conv_lrt_fwd(x, wbuf, w_mu.shape, None, False, (s, s), (p, p), out, var, seed=1, stream_id=2)
+        print(f"forward         {name:14s} batch {n:2d}: x read x{t.of(x)[0] / (4 * x.numel()):5.2f}, weight buffer read {t.of(wbuf)[0] / 1e3:7.1f} KB, "
+              f"out + var written x{(t.of(out)[1] + t.of(var)[1]) / (8 * out.numel()):4.2f}, matrix flop / useful flop {mfma_flop(t) / flop:5.2f}")
+        g = torch.randn_like(out)
+        gv, gx = g.clone(), torch.empty_like(x)
+        with Traffic(ops) as t:
+            ops.conv_lrt_bwd_data(g, gv, wbuf, w_mu.shape, x, gx, (s, s), (p, p))
+        print(f"input gradient  {name:14s} batch {n:2d}: g read x{t.of(g)[0] / (4 * g.numel()):5.2f}, weight buffer read {t.of(wbuf)[0] / 1e3:7.1f} KB, "
+              f"g_x written x{t.of(gx)[1] / (4 * gx.numel()):4.2f}, matrix flop / useful flop {mfma_flop(t) / flop:5.2f}")
+        gwm, gwr = torch.empty_like(w_mu), torch.empty_like(w_mu)
+        with Traffic(ops) as t:
+            ops.conv_lrt_bwd_weight(x, g, gv, w_rho, gwm, gwr, (s, s), (p, p))
+        print(f"weight gradient {name:14s} batch {n:2d}: x read x{t.of(x)[0] / (4 * x.numel()):5.2f}, g read x{t.of(g)[0] / (4 * g.numel()):5.2f}, "
+              f"all reads {t.read / 1e3:8.1f} KB, all writes {t.written / 1e3:8.1f} KB (partials + result), matrix flop / useful flop "
+              f"{mfma_flop(t) / flop:5.2f}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "conv"
     with emulated(ALL) as ops_:
         ops_.lib.hip_emu_lds_report.argtypes = [__import__("ctypes").c_char_p]
-        {"conv": conv, "lrt": lrt, "swag": swag, "svgd": svgd}[what](ops_)
+        {"conv": conv, "lrt": lrt, "swag": swag, "svgd": svgd, "traffic": traffic}[what](ops_)

@@ -143,6 +143,56 @@ def test_bbb_conv2d_channels_last_inputs_and_weights(emu, monkeypatch):
     assert all(t.shape == conv.weight.mean.shape for t in g)
 
 
+def test_stream_traffic_equals_the_algorithmic_bytes(emu):
+    """SURVEY 8(d) / DESIGN 4 price every kernel at its ALGORITHMIC bytes (SVGD step 16 M D, batched SWAG sampling
+    4 D (K + 2 + S), ...).  The CPU model counts the bytes the kernels actually request per tensor (wave-uniform
+    coefficient tables aside: scalar loads on the device): every stream is read / written exactly once per pass -- no
+    re-reads for a cache to absorb.  (The device-side counterpart is roofline.traffic from the PMC counters.)"""
+    from tests.hip_emu.emu_ops import Traffic
+    ops = emu
+    torch.manual_seed(0)
+    m, d = 8, 70_004
+    ld = (d + 63) // 64 * 64
+    row = 4 * d                                                                  # bytes of one row's d valid floats
+    P, G = torch.randn(m, ld) * 0.05, torch.randn(m, ld) * 0.01
+    ws, ks, out = ops.svgd_ws(m, "cpu"), ops.svgd_kstat(m, "cpu"), torch.zeros(m, ld)
+    with Traffic(ops) as t:                                                      # the headline: three launches, 16 M D bytes
+        ops.svgd_gram(P, d, ws)
+        ops.svgd_kstats(ws, m, 0.0, 1.0, 50000.0, -1.0, ks)
+        ops.svgd_combine(P, G, out, d, ks)
+    assert t.of(P) == (2 * m * row, 0) and t.of(G) == (m * row, 0) and t.of(out) == (0, m * row)
+    assert t.mfma16 > 0 and sum(t.of(ws)) < 200_000                              # Gram partials: a fixed count of tiles, whatever D is
+    # fused step with Adam: particles and gradients read once, particles written once, both moments read and written once
+    ea, eas = torch.zeros(ld), torch.zeros(ld)
+    with Traffic(ops) as t:
+        ops.svgd_fused_adam(P, G, ea, eas, d, ks, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0)
+    assert t.of(P) == (m * row, m * row) and t.of(G) == (m * row, 0) and t.of(ea) == (row, row) and t.of(eas) == (row, row)
+    # SWAG: moments update 12 D in, 12 D out; S samples from K + 2 rows read ONCE
+    k, s_ = 20, 30
+    theta, mean, sq, ring = torch.randn(ld), torch.randn(ld), torch.rand(ld) + 1.0, torch.randn(k, ld) * 0.01
+    with Traffic(ops) as t:
+        ops.swag_update(theta, mean, sq, ring[3], 5, d)
+    assert t.of(theta) == (row, 0) and t.of(mean) == (row, row) and t.of(sq) == (row, row) and t.of(ring) == (0, row)
+    samples = torch.zeros(s_, ld)
+    with Traffic(ops) as t:
+        ops.swag_sample_batched(mean, sq, ring, 0, samples, d, seed=3, stream_id0=1)
+    covered = (d + 127) // 128 * 128 * 4                                         # the LDS-DMA kernel works in 128-float tiles
+    assert t.of(mean)[0] in (row, covered) and t.of(ring)[0] in (k * row, k * covered) and t.of(samples) == (0, s_ * row)
+    assert t.mfma32 > 0
+    # BBB draw + KL gradient and the iVON update: each operand once
+    rho, w = torch.randn(ld) - 3, torch.zeros(ld)
+    with Traffic(ops) as t:
+        ops.gauss_draw_fwd(mean, rho, w, d, seed=1, stream_id=2)
+    assert t.of(mean) == (row, 0) and t.of(rho) == (row, 0) and t.of(w) == (0, row)
+    # BBBLinear: the weights are streamed once per pass (8 O I forward)
+    b, i_, o = 32, 1024, 1024
+    x, w_mu, w_rho = torch.randn(b, i_), torch.randn(o, i_) * 0.1, torch.randn(o, i_) - 3
+    y, var = torch.empty(b, o), torch.empty(b, o)
+    with Traffic(ops) as t:
+        ops.lrt_linear_fwd(x, w_mu, w_rho, None, None, True, y, var, seed=1, stream_id=2)
+    assert t.of(w_mu) == (4 * o * i_, 0) and t.of(w_rho) == (4 * o * i_, 0) and t.of(y) == (0, 4 * b * o)
+
+
 def test_smoke_body_on_the_cpu_model(emu):
     """What __graft_entry__.smoke() runs on cuda:0 (one SVGD update, SWAG moments and a sample, against the oracle)."""
     import __graft_entry__ as entry
