@@ -47,6 +47,17 @@ def transform(text, name):
     return f'#line 1 "{os.path.join(CSRC, name)}"\n' + text
 
 
+def _prune(root, keep):
+    """Builds of older source states: keep the most recently used few (a full build is ~90 MB of objects)."""
+    import shutil
+    try:
+        dirs = sorted((os.path.join(root, d) for d in os.listdir(root)), key=os.path.getmtime, reverse=True)
+    except OSError:
+        return
+    for d in dirs[keep:]:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def available():
     return os.path.exists(CLANG) and os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h")
 
@@ -61,6 +72,7 @@ def build(sources, defines=()):
     lib = os.path.join(out_dir, "libbde_emu.so")
     if os.path.exists(lib):
         return lib
+    _prune(os.path.join(HERE, "_build"), keep=4)
     os.makedirs(out_dir, exist_ok=True)
     for n in names:
         with open(os.path.join(out_dir, n.replace(".hip", ".cpp") if n.endswith(".hip") else n), "w") as fh:
