@@ -62,3 +62,34 @@ def test_bench_lines_follow_the_contract():
                 assert abs(ex["allgather"]["step_ms"] - d["ms_per_step"]) <= 1e-3 * d["ms_per_step"]
             else:
                 assert {"exchange_ms", "update_ms", "step_ms", "overlap"} <= set(d["exchange"])
+
+
+def test_bench_and_tools_call_hipops_with_existing_signatures():
+    """bench.py, __graft_entry__.py and tools/*.py only run on the GPU box; every `ops.<method>(...)` call in them must at least
+    name an existing HipOps method and bind to its signature (an API change in ops.py that forgets a caller shows up here, not
+    as a missing bench entry at the end of a round)."""
+    import ast
+    import glob
+    import inspect
+    from beyond_deep_ensembles_amd.ops import HipOps
+    checked, problems = 0, []
+    for path in [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))):
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and isinstance(node.func.value, ast.Name)
+                    and node.func.value.id == "ops"):
+                continue
+            fn = getattr(HipOps, node.func.attr, None)
+            where = f"{os.path.relpath(path, ROOT)}:{node.lineno} ops.{node.func.attr}"
+            if fn is None:
+                problems.append(where + ": no such method")
+                continue
+            if isinstance(fn, property) or any(isinstance(a, ast.Starred) for a in node.args) or any(k.arg is None for k in node.keywords):
+                continue
+            try:
+                inspect.signature(fn).bind(None, *[None] * len(node.args), **{k.arg: None for k in node.keywords})
+                checked += 1
+            except TypeError as e:
+                problems.append(f"{where}: {e}")
+    assert not problems, problems
+    assert checked > 60
