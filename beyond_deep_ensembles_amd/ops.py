@@ -34,6 +34,13 @@ def _ptr(t: Optional[torch.Tensor], name: str = "tensor"):
     return t.data_ptr()
 
 
+def _ptr64(t: torch.Tensor, name: str):
+    """Device pointer of a float64 tensor (the fp64 Gram blocks of the dimension-sharded exchange)."""
+    if not t.is_cuda or t.dtype != torch.float64:
+        raise BdeKernelError(f"{name}: expected a CUDA (HIP) float64 tensor, got {t.dtype} on {t.device}")
+    return t.data_ptr()
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -195,16 +202,16 @@ class HipOps:
     @_on_device_of
     def svgd_gram_finish(self, ws, m, gmat_out):
         """Partials of ``ws`` -> fp64 Gram block ``gmat_out [257]`` (dimension-sharded exchange)."""
-        if gmat_out.dtype != torch.float64 or not gmat_out.is_cuda or gmat_out.numel() < self.GMAT_DOUBLES:
+        if gmat_out.numel() < self.GMAT_DOUBLES:
             raise BdeKernelError("gmat_out: expected a CUDA float64 tensor with >= 257 elements")
-        _check(self.lib.bde_svgd_gram_finish(_ptr(ws), m, gmat_out.data_ptr(), _stream()), "bde_svgd_gram_finish")
+        _check(self.lib.bde_svgd_gram_finish(_ptr(ws), m, _ptr64(gmat_out, "gmat_out"), _stream()), "bde_svgd_gram_finish")
 
     @_on_device_of
     def svgd_kstats_gmat(self, gmats, m, l2_reg, kernel_grad_scale, dataset_size, sign, kstat, h_override=0.0, mode=0):
         """Statistics from the ranks' Gram blocks ``gmats [n, >= 257]`` (float64), summed in row order."""
-        if gmats.dtype != torch.float64 or not gmats.is_cuda or gmats.dim() != 2 or gmats.stride(1) != 1:
+        if gmats.dim() != 2 or gmats.stride(1) != 1:
             raise BdeKernelError("gmats: expected a CUDA float64 [n, >= 257] tensor")
-        _check(self.lib.bde_svgd_kstats_gmat(gmats.data_ptr(), gmats.shape[0], gmats.stride(0), m, l2_reg,
+        _check(self.lib.bde_svgd_kstats_gmat(_ptr64(gmats, "gmats"), gmats.shape[0], gmats.stride(0), m, l2_reg,
                                              kernel_grad_scale, dataset_size, sign, h_override, mode, _ptr(kstat),
                                              _stream()), "bde_svgd_kstats_gmat")
 

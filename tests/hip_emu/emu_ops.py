@@ -102,7 +102,7 @@ def emulated(sources, defines=()):
     ops.load_code_objects = lambda device: None            # bde_init() uploads code objects: nothing to upload here
     shadows = _Shadows(lib)
     ops._emu_shadows = shadows
-    real_ptr, real_check, real_stream = ops_mod._ptr, ops_mod._check, ops_mod._stream
+    real_ptr, real_check, real_stream, real_ptr64 = ops_mod._ptr, ops_mod._check, ops_mod._stream, ops_mod._ptr64
 
     def ptr(t, name="tensor"):
         if t is None:
@@ -119,7 +119,12 @@ def emulated(sources, defines=()):
         shadows.land()
         real_check(rc, what)
 
-    ops_mod._ptr, ops_mod._check, ops_mod._stream = ptr, check, lambda: None
+    def ptr64(t, name):
+        if t.is_cuda or t.dtype != torch.float64:
+            raise ops_mod.BdeKernelError(f"{name}: expected a float64 CPU tensor on the model, got {t.dtype} on {t.device}")
+        return shadows.ptr(t)
+
+    ops_mod._ptr, ops_mod._check, ops_mod._stream, ops_mod._ptr64 = ptr, check, lambda: None, ptr64
     real_device, real_sync = torch.cuda.device, torch.cuda.synchronize
     torch.cuda.device = lambda dev: contextlib.nullcontext()          # "the output's device is current": nothing to do
     torch.cuda.synchronize = lambda *a, **k: None                     # every emulated launch has finished when it returns
@@ -128,4 +133,4 @@ def emulated(sources, defines=()):
     finally:
         shadows.land()
         torch.cuda.device, torch.cuda.synchronize = real_device, real_sync
-        ops_mod._ptr, ops_mod._check, ops_mod._stream = real_ptr, real_check, real_stream
+        ops_mod._ptr, ops_mod._check, ops_mod._stream, ops_mod._ptr64 = real_ptr, real_check, real_stream, real_ptr64

@@ -46,15 +46,39 @@ def _run_steps(model, opt, steps=3):
     return losses
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _backend(name):
+    """"oracle": the CPU checker; "emu": the product's HipOps over the kernel sources on the CPU model (tests/hip_emu)."""
+    if name == "emu":
+        from tests.hip_emu.emu_ops import ALL, emulated
+        with emulated(ALL) as ops:
+            yield ops
+    else:
+        from tests.oracle_ops import OracleOps
+        yield OracleOps()
+
+
 def _svgd_worker(rank, world, port, m, fuse, kw, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HIP_EMU_WORKERS", "2")                  # two ranks share the container's cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    kw = dict(kw)
     try:
-        from tests.oracle_ops import OracleOps
+        with _backend(kw.pop("backend", "oracle")) as ops:
+            _svgd_rank(rank, m, fuse, kw, out_dir, ops)
+    finally:
+        dist.destroy_process_group()
+
+
+def _svgd_rank(rank, m, fuse, kw, out_dir, ops):
+    if True:
         torch.set_num_threads(1)
         # different local RNG state per rank: the constructor must still agree on the particles (broadcast)
-        model, opt = _make(100 + rank, m, OracleOps(), pg=dist.group.WORLD, fuse=fuse, **dict(kw))
+        model, opt = _make(100 + rank, m, ops, pg=dist.group.WORLD, fuse=fuse, **dict(kw))
         fwd_calls = [0]
         orig = model.forward
 
@@ -74,8 +98,6 @@ def _svgd_worker(rank, world, port, m, fuse, kw, out_dir):
         losses = _run_steps(model, opt)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=opt.particles.numpy(), losses=np.array(losses),
                  fwd=np.array(fwd_calls[0]), early=np.array(early))
-    finally:
-        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("m,fuse,kw", [
@@ -136,6 +158,35 @@ def test_svgd_group_of_one_rank_with_forced_exchange(tmp_path, m, fuse, kw):
     model, opt = _make(100, m, OracleOps(), fuse=fuse, base=kw.get("base", "sgd"))
     losses = _run_steps(model, opt)
     np.testing.assert_allclose(r0["particles"], opt.particles.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=1e-6)
+
+
+@pytest.mark.parametrize("m,fuse,kw", [
+    (4, True, {}), (2, True, {"exchange_chunks": 3, "overlap_backward": True}),
+    (4, True, {"exchange": "alltoall"}), (4, True, {"exchange": "alltoall", "base": "adam"}),
+], ids=["allgather_fused", "overlap_fused", "alltoall", "alltoall_adam"])
+def test_svgd_two_ranks_on_the_cpu_model(tmp_path, m, fuse, kw):
+    """The same two-rank runs with the REAL kernels in both ranks -- HipOps over the kernel sources on the CPU model of
+    tests/hip_emu (column-slice Gram + fp64 Gram blocks + statistics from the ranks' blocks for the dimension-sharded
+    exchange, the fused update on a slice, the packer of the pipelined all-gather): replicas bit-identical, and equal to the
+    single-process run of the same kernels (what tests/test_dist_gpu.py checks with several ranks on one MI355X)."""
+    from tests.hip_emu import build
+    if not build.available():
+        pytest.skip("no host clang / HIP headers to build the CPU model with")
+    build.build(__import__("tests.hip_emu.emu_ops", fromlist=["ALL"]).ALL)          # once, before two ranks race for it
+    world = 2
+    mp.spawn(_svgd_worker, args=(world, _free_port(), m, fuse, tuple(dict(kw, backend="emu").items()), str(tmp_path)),
+             nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["particles"], r1["particles"])
+    np.testing.assert_array_equal(r0["losses"], r1["losses"])
+    torch.set_num_threads(1)
+    with _backend("emu") as ops:
+        model, opt = _make(100, m, ops, fuse=fuse, base=kw.get("base", "sgd"), single_launch=False)
+        losses = _run_steps(model, opt)
+        particles = opt.particles.numpy()
+    # the sharded Gram sums per-rank fp64 blocks, the single process one fp32-partial reduction: 1e-5 as on the device
+    np.testing.assert_allclose(r0["particles"], particles, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=1e-6)
 
 

@@ -67,6 +67,9 @@ def test_gpu_test_body_on_the_cpu_model(emu, golden, monkeypatch, name):
         pytest.skip("slow on the CPU model: set BDE_EMU_FULL=1")
     G = _gpu_tests()
     monkeypatch.setattr(G, "DEV", "cpu")
+    if name.startswith("test_conv_lrt") and not os.environ.get("BDE_EMU_FULL"):
+        # 11 of the 15 geometries by default (every ResNet-20 stage and transition, the ragged ones, the wide 1x1)
+        monkeypatch.setattr(G, "CONV_CASES", [c for i, c in enumerate(G.CONV_CASES) if i not in (3, 10, 12, 13)])
     fn = getattr(G, name)
     args = {"ops": emu, "golden": golden}
     fn(**{p: args[p] for p in inspect.signature(fn).parameters})
@@ -207,18 +210,10 @@ def emu_native():
 def test_cpp_autograd_nodes_on_the_cpu_model(emu, emu_native, golden, monkeypatch):
     """csrc/host_autograd.cpp (the C++ autograd nodes lib/_bde_host.so gives the Bayesian layers on the device: LrtLinear,
     LocalReparam, VarOperand, ConvLrt) compiled over the CPU model: bit-identical to the Python Functions of
-    bbb_layers.py (the body of the `-m gpu` test of the same name), and bde.BBBConv2d THROUGH the C++ ConvLrt node against
-    the fixture written from the reference's BBBConv2d."""
-    import beyond_deep_ensembles_amd.bbb_layers as L
+    bbb_layers.py (the body of the `-m gpu` test of the same name)."""
     import tests.test_shells as S
     S.check_native_nodes_equal_python_nodes(emu, torch.device("cpu"), emu_native)
-    calls = []
-    real = emu.conv_lrt_fwd
-    monkeypatch.setattr(L, "_native_nodes", lambda ops: emu_native)
-    S.test_bbb_conv2d_layer_matches_reference_layer(golden, (emu, "cpu"), monkeypatch, "fused")
-    monkeypatch.setattr(emu, "conv_lrt_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
-    S.test_bbb_conv_layers_reproduce_reference_cnn_trajectory(golden, (emu, "cpu"), monkeypatch, "fused_passes")
-    assert not calls                                                   # the CNN trajectory went through the C++ node
+    # (tests/test_shells.py's "emu" backend runs the layers THROUGH these nodes: the reference fixture and CNN trajectory)
 
 
 def test_the_model_notices_a_missing_dma_wait():

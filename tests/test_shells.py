@@ -153,6 +153,8 @@ def test_svgd_streaming_path_through_the_shell(backend, variant):
     oracle from the SAME particles and gradients: -phi by oracle.svgd_phi, then particle_count shared-state applications
     of a CPU torch optimizer (oracle.svgd_apply_shared_optimizer, svgd.py:92-103), in fp32 (= the reference's
     arithmetic) and in fp64 (the anchor): |ours - fp64| <= max(2 |ref32 - fp64|, 3e-6 max|step|)."""
+    if getattr(backend[0], "name", "") == "hip_emu" and variant in ("unfused_adam", "default_sgd"):
+        pytest.skip("on the CPU model two of the four variants (10 s each): the same kernels as the other two")
     import oracle.bde_oracle as O
     ops, dev = backend
     torch.manual_seed(21)

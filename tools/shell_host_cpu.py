@@ -53,6 +53,7 @@ def stub_ops():
     ops.name = "hip_stub"
     ops.load_code_objects = lambda device: None
     ops_mod._ptr = lambda t, name="tensor": None if t is None else t.data_ptr()
+    ops_mod._ptr64 = lambda t, name: t.data_ptr()
     ops_mod._stream = lambda: None
     return ops
 
