@@ -127,9 +127,9 @@ def main():
     reset = lambda: None
     measure("SVGD 8 particles, Adam, default ctor (fused)", lambda p: bde.SVGDOptimizer(
         p, reset, torch.optim.Adam(p, lr=3e-5), particle_count=8, dataset_size=50000, _ops=ops), profile=a.profile)
-    measure("SVGD 8 particles, nesterov SGD, reuse_gram", lambda p: bde.SVGDOptimizer(
+    measure("SVGD 8 particles, nesterov SGD, fused + reuse_gram", lambda p: bde.SVGDOptimizer(
         p, reset, torch.optim.SGD(p, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=3e-4), particle_count=8,
-        dataset_size=50000, reuse_gram=True, _ops=ops), profile=False)
+        dataset_size=50000, fuse_base_optimizer=True, reuse_gram=True, _ops=ops), profile=False)
     measure("SVGD 8 particles, Adam, fuse_base_optimizer=False", lambda p: bde.SVGDOptimizer(
         p, reset, torch.optim.Adam(p, lr=3e-5), particle_count=8, dataset_size=50000, fuse_base_optimizer=False, _ops=ops))
     measure("SWAG", lambda p: bde.SwagOptimizer(p, torch.optim.SGD(p, lr=1e-3, momentum=0.9), update_interval=1, start_epoch=0,
