@@ -75,6 +75,8 @@ SIGNATURES = {
     "bde_conv_lrt_bwd_weight_plan": (c_int, [c_int] * 11 + [_P]),
     "bde_conv_lrt_prep_floats": (c_size_t, [c_int] * 4),
     "bde_conv_lrt_prep": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "bde_conv_lrt_prep_strided": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P]),
+    "bde_conv_lrt_bwd_data_phases": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 11 + [_P]),
     "bde_conv_lrt_fwd": (c_int, [_P, _P, _P, c_int, _P, c_uint64, c_uint64, _P, _P] + [c_int] * 11 + [_P]),
     "bde_conv_lrt_bwd_data": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 11 + [_P]),
     "bde_conv_lrt_bwd_weight_ws_bytes": (c_size_t, [c_int] * 11),

@@ -224,13 +224,15 @@ class _ConvWeights:
     def drop(self) -> None:
         self.key = None
 
-    def get(self, mean: torch.Tensor, rho: torch.Tensor, b_rho, ops):
+    def get(self, mean: torch.Tensor, rho: torch.Tensor, b_rho, ops, stride=(1, 1), padding=(0, 0)):
+        """``stride`` / ``padding``: the layer's; a strided layer's buffer also carries the per-phase matrices of its input
+        gradient (bde_conv_lrt_prep_strided)."""
         key = (mean.data_ptr(), mean._version, rho.data_ptr(), rho._version, tuple(rho.shape), _SigmaCache.epoch,
-               None if b_rho is None else (b_rho.data_ptr(), b_rho._version))
+               None if b_rho is None else (b_rho.data_ptr(), b_rho._version), tuple(stride), tuple(padding))
         if key != self.key:
             buf = ops.conv_lrt_wbuf(rho.shape, rho.device)
             ops.conv_lrt_prep(mean.detach().contiguous(), rho.detach().contiguous(), buf,
-                              None if b_rho is None else b_rho.detach().contiguous())
+                              None if b_rho is None else b_rho.detach().contiguous(), stride=stride, padding=padding)
             self.key, self.buf = key, buf
         return self.buf
 
@@ -243,7 +245,7 @@ class _ConvLrt(torch.autograd.Function):
     element-wise launches."""
 
     @staticmethod
-    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, stride, padding, eps, seed, stream_id, ops, wbuf):
+    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, stride, padding, eps, seed, stream_id, ops, wbuf, phases=False):
         xc = x.detach().contiguous()
         n, o = xc.shape[0], w_mu.shape[0]
         ho = (xc.shape[2] + 2 * padding[0] - w_mu.shape[2]) // stride[0] + 1
@@ -255,14 +257,14 @@ class _ConvLrt(torch.autograd.Function):
         ops.conv_lrt_fwd(xc, wbuf, tuple(w_mu.shape), None if b_mu is None else b_mu.detach().contiguous(), b_rho is not None,
                          stride, padding, out, var, eps=e, seed=seed, stream_id=stream_id)
         ctx.save_for_backward(xc, w_mu, w_rho, b_rho, var, e, wbuf)
-        ctx.meta = (stride, padding, seed, stream_id, ops)
+        ctx.meta = (stride, padding, seed, stream_id, ops, bool(phases))     # phases: wbuf was prepared with this stride / padding
         return out
 
     @staticmethod
     @once_differentiable          # the kernels produce plain tensors: no double backward
     def backward(ctx, grad_out):
         x, w_mu, w_rho, b_rho, var, eps, wbuf = ctx.saved_tensors
-        stride, padding, seed, stream_id, ops = ctx.meta
+        stride, padding, seed, stream_id, ops, phases = ctx.meta
         g = grad_out.contiguous()
         gvar = torch.empty_like(g)
         # eps None: the kernel regenerates the forward's in-kernel noise (same element numbering over the flat output)
@@ -271,7 +273,7 @@ class _ConvLrt(torch.autograd.Function):
         g_x = None
         if ctx.needs_input_grad[0]:
             g_x = torch.empty_like(x)
-            ops.conv_lrt_bwd_data(g, gvar, wbuf, tuple(w_mu.shape), x, g_x, stride, padding)
+            ops.conv_lrt_bwd_data(g, gvar, wbuf, tuple(w_mu.shape), x, g_x, stride, padding, phases=phases)
         wr = w_rho.detach().contiguous()
         g_wmu, g_wrho = torch.empty_like(wr), torch.empty_like(wr)
         ops.conv_lrt_bwd_weight(x, g, gvar, wr, g_wmu, g_wrho, stride, padding)
@@ -281,7 +283,7 @@ class _ConvLrt(torch.autograd.Function):
             g_bvar = gvar.sum(dim=(0, 2, 3))
             g_brho = torch.empty_like(g_bvar)
             ops.var_operand_bwd(g_bvar, b_rho.detach().contiguous(), 2, g_brho)
-        return g_x, g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None, None, None
+        return g_x, g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None, None, None, None
 
 
 class _LocalReparamLayer(nn.Module):
@@ -439,15 +441,15 @@ class BBBConv2d(_LocalReparamLayer):
                     ho = (input.shape[2] + 2 * padding[0] - self.kernel_size) // stride[0] + 1
                     wo = (input.shape[3] + 2 * padding[1] - self.kernel_size) // stride[1] + 1
                     eps = normal_like(input.new_empty((input.shape[0], self.out_channels, ho, wo)))
-                wbuf = self._conv_weights.get(w.mean, w.rho, b.rho if b is not None else None, ops)
+                wbuf = self._conv_weights.get(w.mean, w.rho, b.rho if b is not None else None, ops, stride, padding)
                 native = _native_nodes(ops)
                 if native is not None and hasattr(native, "conv_lrt"):
                     return native.conv_lrt(input, w.mean, w.rho, b.mean if b is not None else None,
                                            b.rho if b is not None else None, stride[0], stride[1], padding[0], padding[1], eps,
-                                           w.seed, next(_philox_stream), wbuf)
+                                           w.seed, next(_philox_stream), wbuf, True)
                 return _ConvLrt.apply(input, w.mean, w.rho, b.mean if b is not None else None,
                                       b.rho if b is not None else None, stride, padding, eps, w.seed, next(_philox_stream), ops,
-                                      wbuf)
+                                      wbuf, True)
         mean = F.conv2d(input, w.mean, b.mean if b is not None else None, stride=self.stride, padding=self.padding)
         x2, s2, vb = self._var_operands(input, clamp_bias=False)     # the conv layer does not clamp its bias variance
         var = F.conv2d(x2, s2, vb, stride=self.stride, padding=self.padding)

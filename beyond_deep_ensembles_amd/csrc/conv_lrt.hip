@@ -41,8 +41,12 @@ using f32x4c = __attribute__((ext_vector_type(4))) float;
 
 struct ConvGeo {
   int N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo;
-  int dh, dw;      // dilation of the INPUT image (1 in the forward; the layer's stride in the input-gradient pass)
+  int dh, dw;      // dilation of the INPUT image (1 in the forward; the layer's stride in the dilated input-gradient pass)
   int rp;          // row pitch of the pre-arranged weights: output channels padded to 32
+  // where output pixel (i, j) of this launch lives in the output planes [OH][OW]: (oh0 + osh i, ow0 + osw j).  Ho x Wo planes
+  // written densely (osh = osw = 1, oh0 = ow0 = 0, OH = Ho, OW = Wo) everywhere except the per-phase launches of the
+  // input gradient of a strided layer, which write every sh-th row / sw-th column of g_x.
+  int osh = 1, osw = 1, oh0 = 0, ow0 = 0, OH = 0, OW = 0;
 };
 struct ConvTile {
   int NI, TH, bands, CC, PH, PWP, WP, WK, tiles_per_img, kcpad_max;
@@ -260,7 +264,9 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
   const uintptr_t ptr_bits = reinterpret_cast<uintptr_t>(out) | (MODE == 1 ? reinterpret_cast<uintptr_t>(bmu)
                                                                             : reinterpret_cast<uintptr_t>(var_out) |
                                                                                   (RNG ? 0 : reinterpret_cast<uintptr_t>(eps)));
-  const bool vec = (howo & 3) == 0 && ((t.TH * g.Wo) & 3) == 0 && (ptr_bits & 15) == 0;
+  const bool dense = g.osh == 1 && g.osw == 1 && g.OH == g.Ho && g.OW == g.Wo;
+  const bool vec = dense && (howo & 3) == 0 && ((t.TH * g.Wo) & 3) == 0 && (ptr_bits & 15) == 0;
+  const int64_t plane = static_cast<int64_t>(g.OH) * g.OW;
   float* tm = lds + wave * 2 * MF * RS;
   float* tv = tm + MF * RS;
   constexpr int Q = MF / 4;                                // float4 groups per tile row
@@ -318,11 +324,15 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     } else {
       const int p = p0 + idx;
       if (p < band_pixels) {
+        // element (image, channel o, pixel p of the band) in the output planes: dense, or the phase's rows / columns of g_x
+        const int prow = ho0 + p / g.Wo, pcol = p % g.Wo;
+        const int64_t pix = static_cast<int64_t>(g.oh0 + g.osh * prow) * g.OW + g.ow0 + g.osw * pcol;
+        const int64_t img_base = static_cast<int64_t>(img0 + img) * g.O * plane;
 #pragma unroll
         for (int r = 0; r < M::REGS; ++r) {
           const int o = o0 + M::row(r, h);
           if (o < g.O) {
-            const int64_t e = base + o * howo + idx;
+            const int64_t e = img_base + o * plane + pix;
             if (MODE == 1) {
               const float xv = bmu[e];
               out[e] = cm[r] + (xv * xv >= 1e-4f ? 2.0f * xv * cv[r] : 0.f);
@@ -352,10 +362,27 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
 //   [0]  WT_mu [ktot][op]      [1]  WT_s2 [ktot][op]           k = (c, r, q), op = O padded to 32    (forward)
 //   [2]  WB_mu [O khw][cp]     [3]  WB_s2 [O khw][cp]          k' = (o, flipped tap), cp = C padded to 32 (input gradient)
 //   [4]  DS2   [O][ktot]       [sigma^2 >= 1e-4] 2 sigma sigmoid(rho)                                 (weight gradient)
-//   [5]  BVAR  [op]            softplus(b_rho)^2, NOT clamped (bbb_layers.py:147); zero without a bias
+//   [5]  BVAR  [op]            softplus(b_rho)^2, NOT clamped (bbb_layers.py:147); zero without a bias  ([4] rounded up to 4 floats)
+//   [6]  WP_mu, [7] WP_s2      the input-gradient matrices of a STRIDED layer, one block per phase (a, b) of the output pixel
+//        grid, a-major: [O][R_a][Q_b][cp] with the taps r = rho_a + sh r' (rho_a = (a + ph) mod sh) flipped within the phase
+//        (PhaseGeo below) -- written by bde_conv_lrt_prep_strided only
+struct PhaseAxis {
+  int rho, taps, delta, count;     // first tap, number of taps, (a + p - rho) / s, number of output rows / columns of the phase
+};
+__host__ __device__ static inline PhaseAxis phase_axis(int a, int K, int s, int p, int extent) {
+  PhaseAxis x;
+  x.rho = (a + p) % s;
+  x.taps = x.rho < K ? (K - x.rho + s - 1) / s : 0;
+  x.delta = (a + p - x.rho) / s;
+  x.count = a < extent ? (extent - a + s - 1) / s : 0;
+  return x;
+}
+
 __global__ __launch_bounds__(kBlock) void conv_lrt_prep_kernel(const float* __restrict__ w_mu, const float* __restrict__ w_rho,
-                                                               const float* __restrict__ b_rho, int O, int C, int khw, int op,
-                                                               int cp, float* __restrict__ wbuf) {
+                                                               const float* __restrict__ b_rho, int O, int C, int KH, int KW,
+                                                               int op, int cp, int sh, int sw, int ph, int pw,
+                                                               float* __restrict__ wbuf) {
+  const int khw = KH * KW;
   const int ktot = C * khw;
   const int64_t n = static_cast<int64_t>(O) * ktot;
   float* wt_mu = wbuf;
@@ -363,7 +390,9 @@ __global__ __launch_bounds__(kBlock) void conv_lrt_prep_kernel(const float* __re
   float* wb_mu = wt_s2 + static_cast<int64_t>(ktot) * op;
   float* wb_s2 = wb_mu + static_cast<int64_t>(O) * khw * cp;
   float* ds2 = wb_s2 + static_cast<int64_t>(O) * khw * cp;
-  float* bvar = ds2 + n;
+  float* bvar = ds2 + ((n + 3) & ~int64_t{3});                // (rounded: the phase matrices behind it are read as float4)
+  float* wp_mu = bvar + op;
+  float* wp_s2 = wp_mu + static_cast<int64_t>(O) * khw * cp;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (i < O) {
@@ -382,6 +411,23 @@ __global__ __launch_bounds__(kBlock) void conv_lrt_prep_kernel(const float* __re
     wb_mu[kb * cp + c] = mu;
     wb_s2[kb * cp + c] = s2c;
     ds2[i] = s2 >= 1e-4f ? 2.0f * ss.sp * ss.sg : 0.f;
+    if (sh > 1 || sw > 1) {
+      // tap (r, q) belongs to the phase (a, b) with rho_a = r mod sh, rho_b = q mod sw; the blocks of the earlier phases hold
+      // O cp (taps of those phases) floats
+      const int r = rq / KW, q = rq % KW;
+      const int a = ((r % sh) - (ph % sh) + sh) % sh, b = ((q % sw) - (pw % sw) + sw) % sw;
+      int64_t before = 0;
+      for (int aa = 0; aa < sh; ++aa)
+        for (int bb = 0; bb < sw; ++bb) {
+          if (aa * sw + bb >= a * sw + b) continue;
+          before += static_cast<int64_t>(phase_axis(aa, KH, sh, ph, 1 << 20).taps) * phase_axis(bb, KW, sw, pw, 1 << 20).taps;
+        }
+      const PhaseAxis pa = phase_axis(a, KH, sh, ph, 1 << 20), pb = phase_axis(b, KW, sw, pw, 1 << 20);
+      const int rf = pa.taps - 1 - r / sh, qf = pb.taps - 1 - q / sw;                    // flipped within the phase
+      const int64_t dst = (before * O + (static_cast<int64_t>(o) * pa.taps + rf) * pb.taps + qf) * cp + c;
+      wp_mu[dst] = mu;
+      wp_s2[dst] = s2c;
+    }
   }
 }
 
@@ -472,6 +518,8 @@ static bool layer_geo(int N, int C, int H, int W, int O, int KH, int KW, int sh,
   const int Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
   if (Ho < 1 || Wo < 1) return false;
   g = ConvGeo{N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo, 1, 1, pad32(O)};
+  g.OH = Ho;
+  g.OW = Wo;
   return true;
 }
 
@@ -479,11 +527,38 @@ static bool layer_geo(int N, int C, int H, int W, int O, int KH, int KW, int sh,
 static bool data_grad_geo(const ConvGeo& l, ConvGeo& g) {
   if (l.ph > l.KH - 1 || l.pw > l.KW - 1) return false;
   g = ConvGeo{l.N, l.O, l.Ho, l.Wo, l.C, l.KH, l.KW, 1, 1, l.KH - 1 - l.ph, l.KW - 1 - l.pw, l.H, l.W, l.sh, l.sw, pad32(l.C)};
+  g.OH = l.H;
+  g.OW = l.W;
+  return true;
+}
+
+// Phase (a, b) of the input gradient of a strided layer: the output pixels (a + sh i, b + sw j) of g_x only see the taps
+// r = rho_a + sh r', q = rho_b + sw q', and for them the pass is a stride-1 convolution of the UNDILATED g with that
+// sub-kernel (flipped), g row i + delta_a - r'  ->  top padding taps_a - 1 - delta_a (rows past the image read as zero).
+// The dilated formulation (data_grad_geo) multiplies sh sw times as many products, all but one in sh sw of them by zero.
+// false: the phase has no output pixels or no taps (its pixels of g_x are zero).
+static bool phase_geo(const ConvGeo& l, int a, int b, ConvGeo& g, int64_t& wp_offset) {
+  const PhaseAxis pa = phase_axis(a, l.KH, l.sh, l.ph, l.H), pb = phase_axis(b, l.KW, l.sw, l.pw, l.W);
+  int64_t before = 0;
+  for (int aa = 0; aa < l.sh; ++aa)
+    for (int bb = 0; bb < l.sw; ++bb)
+      if (aa * l.sw + bb < a * l.sw + b)
+        before += static_cast<int64_t>(phase_axis(aa, l.KH, l.sh, l.ph, l.H).taps) * phase_axis(bb, l.KW, l.sw, l.pw, l.W).taps;
+  wp_offset = before * l.O * pad32(l.C);
+  if (pa.taps == 0 || pb.taps == 0 || pa.count == 0 || pb.count == 0) return false;
+  g = ConvGeo{l.N, l.O, l.Ho, l.Wo, l.C, pa.taps, pb.taps, 1, 1, pa.taps - 1 - pa.delta, pb.taps - 1 - pb.delta, pa.count, pb.count,
+              1, 1, pad32(l.C)};
+  g.osh = l.sh;
+  g.osw = l.sw;
+  g.oh0 = a;
+  g.ow0 = b;
+  g.OH = l.H;
+  g.OW = l.W;
   return true;
 }
 
 struct WBuf {
-  const float *wt_mu, *wt_s2, *wb_mu, *wb_s2, *ds2, *bvar;
+  const float *wt_mu, *wt_s2, *wb_mu, *wb_s2, *ds2, *bvar, *wp_mu, *wp_s2;
 };
 static WBuf wbuf_parts(const float* wbuf, int O, int C, int khw) {
   const int64_t ktot = static_cast<int64_t>(C) * khw, op = pad32(O), cp = pad32(C);
@@ -493,7 +568,9 @@ static WBuf wbuf_parts(const float* wbuf, int O, int C, int khw) {
   b.wb_mu = b.wt_s2 + ktot * op;
   b.wb_s2 = b.wb_mu + static_cast<int64_t>(O) * khw * cp;
   b.ds2 = b.wb_s2 + static_cast<int64_t>(O) * khw * cp;
-  b.bvar = b.ds2 + static_cast<int64_t>(O) * ktot;
+  b.bvar = b.ds2 + ((static_cast<int64_t>(O) * ktot + 3) & ~int64_t{3});
+  b.wp_mu = b.bvar + op;
+  b.wp_s2 = b.wp_mu + static_cast<int64_t>(O) * khw * cp;
   return b;
 }
 
@@ -543,16 +620,23 @@ extern "C" int bde_conv_lrt_plan(int which, int N, int C, int H, int W, int O, i
 extern "C" size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW) {
   if (O < 1 || C < 1 || KH < 1 || KW < 1) return 0;
   const size_t khw = static_cast<size_t>(KH) * KW, ktot = khw * C;
-  return 2 * ktot * pad32(O) + 2 * static_cast<size_t>(O) * khw * pad32(C) + static_cast<size_t>(O) * ktot + pad32(O);
+  return 2 * ktot * pad32(O) + 4 * static_cast<size_t>(O) * khw * pad32(C) + ((static_cast<size_t>(O) * ktot + 3) & ~size_t{3}) + pad32(O);
+}
+
+extern "C" int bde_conv_lrt_prep_strided(const float* w_mu, const float* w_rho, const float* b_rho, int O, int C, int KH, int KW,
+                                         int sh, int sw, int ph, int pw, float* wbuf, void* stream) {
+  if (!w_mu || !w_rho || !wbuf || !aligned16(wbuf) || bde_conv_lrt_prep_floats(O, C, KH, KW) == 0 || sh < 1 || sw < 1 || ph < 0 ||
+      pw < 0)
+    return BDE_ERR_INVALID;
+  const int64_t n = static_cast<int64_t>(O) * C * KH * KW;                    // n >= O: the bias entries ride along
+  hipLaunchKernelGGL(conv_lrt_prep_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w_mu, w_rho,
+                     b_rho, O, C, KH, KW, pad32(O), pad32(C), sh, sw, ph, pw, wbuf);
+  return to_err(hipGetLastError());
 }
 
 extern "C" int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, const float* b_rho, int O, int C, int KH, int KW,
                                  float* wbuf, void* stream) {
-  if (!w_mu || !w_rho || !wbuf || !aligned16(wbuf) || bde_conv_lrt_prep_floats(O, C, KH, KW) == 0) return BDE_ERR_INVALID;
-  const int64_t n = static_cast<int64_t>(O) * C * KH * KW;                    // n >= O: the bias entries ride along
-  hipLaunchKernelGGL(conv_lrt_prep_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), w_mu, w_rho,
-                     b_rho, O, C, KH * KW, pad32(O), pad32(C), wbuf);
-  return to_err(hipGetLastError());
+  return bde_conv_lrt_prep_strided(w_mu, w_rho, b_rho, O, C, KH, KW, 1, 1, 0, 0, wbuf, stream);
 }
 
 extern "C" int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, int has_bias_var, const float* eps,
@@ -582,6 +666,44 @@ extern "C" int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, con
   if (!aligned16(wbuf)) return BDE_ERR_INVALID;
   const WBuf w = wbuf_parts(wbuf, O, C, KH * KW);
   launch_conv<1, false>(p, static_cast<hipStream_t>(stream), g_out, g_var, w.wb_mu, w.wb_s2, x, nullptr, nullptr, 0, 0, g_x, nullptr, g);
+  return to_err(hipGetLastError());
+}
+
+extern "C" int bde_conv_lrt_bwd_data_phases(const float* g_out, const float* g_var, const float* wbuf, const float* x, float* g_x,
+                                            int N, int C, int H, int W, int O, int KH, int KW, int sh, int sw, int ph, int pw,
+                                            void* stream) {
+  ConvGeo l, g;
+  if (!g_out || !g_var || !wbuf || !x || !g_x || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, l) || !aligned16(wbuf))
+    return BDE_ERR_INVALID;
+  if (sh == 1 && sw == 1) return bde_conv_lrt_bwd_data(g_out, g_var, wbuf, x, g_x, N, C, H, W, O, KH, KW, sh, sw, ph, pw, stream);
+  // every phase needs a tiling; otherwise the dilated pass does the whole job
+  FwdPlan plans[49];
+  ConvGeo geos[49];
+  int64_t offs[49];
+  bool live[49];
+  bool zero_fill = false;
+  for (int a = 0; a < sh; ++a)
+    for (int b = 0; b < sw; ++b) {
+      const int q = a * sw + b;
+      if (q >= 49) return bde_conv_lrt_bwd_data(g_out, g_var, wbuf, x, g_x, N, C, H, W, O, KH, KW, sh, sw, ph, pw, stream);
+      live[q] = phase_geo(l, a, b, geos[q], offs[q]);
+      if (!live[q]) {
+        const PhaseAxis pa = phase_axis(a, KH, sh, ph, H), pb = phase_axis(b, KW, sw, pw, W);
+        zero_fill = zero_fill || (pa.count > 0 && pb.count > 0);        // pixels without a tap: exactly zero
+      } else if (!plan_fwd(geos[q], plans[q])) {
+        return bde_conv_lrt_bwd_data(g_out, g_var, wbuf, x, g_x, N, C, H, W, O, KH, KW, sh, sw, ph, pw, stream);
+      }
+    }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (zero_fill) {
+    const hipError_t e = hipMemsetAsync(g_x, 0, sizeof(float) * static_cast<size_t>(N) * C * H * W, s);
+    if (e != hipSuccess) return to_err(e);
+  }
+  const WBuf w = wbuf_parts(wbuf, O, C, KH * KW);
+  for (int q = 0; q < sh * sw; ++q)
+    if (live[q])
+      launch_conv<1, false>(plans[q], s, g_out, g_var, w.wp_mu + offs[q], w.wp_s2 + offs[q], x, nullptr, nullptr, 0, 0, g_x, nullptr,
+                            geos[q]);
   return to_err(hipGetLastError());
 }
 

@@ -174,7 +174,7 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho,
                             const c10::optional<at::Tensor>& b_mu_, const c10::optional<at::Tensor>& b_rho_, int64_t sh,
                             int64_t sw, int64_t ph, int64_t pw, const c10::optional<at::Tensor>& eps_, int64_t seed,
-                            int64_t stream_id, const at::Tensor& wbuf) {
+                            int64_t stream_id, const at::Tensor& wbuf, bool phases) {
     at::Tensor b_mu = opt(b_mu_), b_rho = opt(b_rho_), eps = opt(eps_);
     check_f32_cuda(x, "x");
     check_f32_cuda(w_mu, "w_mu");
@@ -206,6 +206,7 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
     ctx->saved_data["geo"] = std::vector<int64_t>{sh, sw, ph, pw};
     ctx->saved_data["seed"] = seed;
     ctx->saved_data["stream_id"] = stream_id;
+    ctx->saved_data["phases"] = phases;          // wbuf carries the per-phase input-gradient matrices of this stride / padding
     return out;
   }
 
@@ -229,7 +230,8 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
     at::Tensor g_x;
     if (ctx->needs_input_grad(0)) {
       g_x = at::empty_like(x);
-      rc = bde_conv_lrt_bwd_data(ptr(g), ptr(gvar), ptr(wbuf), ptr(x), mptr(g_x), N, C, H, W, O, KH, KW, sh, sw, ph, pw, stream);
+      rc = (ctx->saved_data["phases"].toBool() ? bde_conv_lrt_bwd_data_phases : bde_conv_lrt_bwd_data)(
+          ptr(g), ptr(gvar), ptr(wbuf), ptr(x), mptr(g_x), N, C, H, W, O, KH, KW, sh, sw, ph, pw, stream);
       TORCH_CHECK(rc == 0, "bde_conv_lrt_bwd_data failed with code ", rc);
     }
     const at::Tensor wr = w_rho.detach().contiguous();
@@ -249,7 +251,7 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
       TORCH_CHECK(rc == 0, "bde_var_operand_bwd failed with code ", rc);
     }
     return {g_x, g_wmu, g_wrho, g_bmu, g_brho, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-            at::Tensor(), at::Tensor()};
+            at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
@@ -272,12 +274,12 @@ void bind_autograd_nodes(py::module_& m) {
   m.def("conv_lrt",
         [](const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho, const c10::optional<at::Tensor>& b_mu,
            const c10::optional<at::Tensor>& b_rho, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
-           const c10::optional<at::Tensor>& eps, int64_t seed, int64_t stream_id, const at::Tensor& wbuf) {
-          return ConvLrt::apply(x, w_mu, w_rho, b_mu, b_rho, sh, sw, ph, pw, eps, seed, stream_id, wbuf);
+           const c10::optional<at::Tensor>& eps, int64_t seed, int64_t stream_id, const at::Tensor& wbuf, bool phases) {
+          return ConvLrt::apply(x, w_mu, w_rho, b_mu, b_rho, sh, sw, ph, pw, eps, seed, stream_id, wbuf, phases);
         },
         "BBBConv2d forward (local reparameterisation, fused) with its fused backward", py::arg("x"), py::arg("w_mu"),
         py::arg("w_rho"), py::arg("b_mu"), py::arg("b_rho"), py::arg("sh"), py::arg("sw"), py::arg("ph"), py::arg("pw"),
-        py::arg("eps"), py::arg("seed"), py::arg("stream_id"), py::arg("wbuf"));
+        py::arg("eps"), py::arg("seed"), py::arg("stream_id"), py::arg("wbuf"), py::arg("phases") = false);
   m.def("var_operand", [](const at::Tensor& v, int64_t mode) { return VarOperand::apply(v, mode); },
         "clamp(v^2) / clamp(softplus(v)^2) / softplus(v)^2", py::arg("v"), py::arg("mode"));
 }

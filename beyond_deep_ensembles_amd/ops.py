@@ -476,15 +476,22 @@ class HipOps:
         return torch.zeros(int(self.lib.bde_conv_lrt_prep_floats(o, c, kh, kw)), dtype=torch.float32, device=device)
 
     @_on_device_of
-    def conv_lrt_prep(self, w_mu, w_rho, wbuf, b_rho=None):
+    def conv_lrt_prep(self, w_mu, w_rho, wbuf, b_rho=None, stride=None, padding=None):
         """Once per weight version: sigma^2, its rho-derivative, the bias variance softplus(b_rho)^2 and the re-arranged
-        weight matrices into ``wbuf``."""
+        weight matrices into ``wbuf``.  With the layer's ``stride`` / ``padding`` (bde_conv_lrt_prep_strided) also the
+        per-phase input-gradient matrices of a strided layer, which ``conv_lrt_bwd_data(..., phases=True)`` needs."""
         o, c, kh, kw = (int(v) for v in w_mu.shape)
         self._dense(w_mu, (o, c, kh, kw), "w_mu")
         self._dense(w_rho, (o, c, kh, kw), "w_rho")
         self._dense(b_rho, (o,), "b_rho")
         if wbuf.numel() < int(self.lib.bde_conv_lrt_prep_floats(o, c, kh, kw)) or not wbuf.is_contiguous():
             raise BdeKernelError("conv_lrt_prep: wbuf is smaller than bde_conv_lrt_prep_floats() (use conv_lrt_wbuf)")
+        if stride is not None:
+            padding = (0, 0) if padding is None else padding
+            _check(self.lib.bde_conv_lrt_prep_strided(_ptr(w_mu, "w_mu"), _ptr(w_rho), _ptr(b_rho), o, c, kh, kw, int(stride[0]),
+                                                      int(stride[1]), int(padding[0]), int(padding[1]), _ptr(wbuf), _stream()),
+                   "bde_conv_lrt_prep_strided")
+            return
         _check(self.lib.bde_conv_lrt_prep(_ptr(w_mu, "w_mu"), _ptr(w_rho), _ptr(b_rho), o, c, kh, kw, _ptr(wbuf), _stream()),
                "bde_conv_lrt_prep")
 
@@ -506,15 +513,18 @@ class HipOps:
                                          _ptr(out), _ptr(var_out), *geo, _stream()), "bde_conv_lrt_fwd")
 
     @_on_device_of
-    def conv_lrt_bwd_data(self, g_out, g_var, wbuf, w_shape, x, g_x, stride, padding):
-        """g_x of BBBConv2d: both transposed convolutions + the clamp's derivative in one launch."""
+    def conv_lrt_bwd_data(self, g_out, g_var, wbuf, w_shape, x, g_x, stride, padding, phases=False):
+        """g_x of BBBConv2d: both transposed convolutions + the clamp's derivative in one launch -- or, for a strided layer
+        whose ``wbuf`` was prepared with this stride / padding (``phases=True``), one launch per phase of the output pixel
+        grid: sh * sw times less matrix work than convolving the zero-dilated gradient."""
         geo, oshape = self._conv_geo(x, w_shape, stride, padding)
         self._conv_wbuf_ok(wbuf, geo)
         self._dense(g_out, oshape, "g_out")
         self._dense(g_var, oshape, "g_var")
         self._dense(g_x, tuple(x.shape), "g_x")
-        _check(self.lib.bde_conv_lrt_bwd_data(_ptr(g_out, "g_out"), _ptr(g_var), _ptr(wbuf), _ptr(x), _ptr(g_x), *geo, _stream()),
-               "bde_conv_lrt_bwd_data")
+        fn = self.lib.bde_conv_lrt_bwd_data_phases if phases else self.lib.bde_conv_lrt_bwd_data
+        _check(fn(_ptr(g_out, "g_out"), _ptr(g_var), _ptr(wbuf), _ptr(x), _ptr(g_x), *geo, _stream()),
+               "bde_conv_lrt_bwd_data_phases" if phases else "bde_conv_lrt_bwd_data")
 
     @_on_device_of
     def conv_lrt_bwd_weight(self, x, g_out, g_var, w_rho, g_wmu, g_wrho, stride, padding, ws=None):

@@ -377,6 +377,17 @@ int bde_conv_lrt_bwd_weight_plan(int N, int C, int H, int W, int O, int KH, int 
 size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW);
 int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, const float* b_rho, int O, int C, int KH, int KW, float* wbuf,
                       void* stream);
+/* bde_conv_lrt_prep for a layer whose stride is known (the caller's layer object): additionally writes the input-gradient
+ * matrices of a strided layer split by PHASE of the output pixel grid -- pixel (a + sh i, b + sw j) of g_x only sees the taps
+ * r = (a + ph) mod sh + sh r', q likewise, and for those the pass is a stride-1 convolution of the undilated g with that
+ * sub-kernel.  bde_conv_lrt_bwd_data_phases (wbuf prepared by THIS function with the same stride / padding) runs one launch per
+ * phase: the matrix work of the layer's useful flops instead of sh * sw times that (bde_conv_lrt_bwd_data convolves the
+ * zero-dilated g; it stays the fallback for geometries without a per-phase tiling and for wbufs prepared without a stride). */
+int bde_conv_lrt_prep_strided(const float* w_mu, const float* w_rho, const float* b_rho, int O, int C, int KH, int KW, int stride_h,
+                              int stride_w, int pad_h, int pad_w, float* wbuf, void* stream);
+int bde_conv_lrt_bwd_data_phases(const float* g_out, const float* g_var, const float* wbuf, const float* x, float* g_x, int N,
+                                 int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w,
+                                 void* stream);
 int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, int has_bias_var, const float* eps, uint64_t seed,
                      uint64_t stream_id, float* out, float* var_out, int N, int C, int H, int W, int O, int KH, int KW,
                      int stride_h, int stride_w, int pad_h, int pad_w, void* stream);

@@ -110,13 +110,14 @@ def traffic(ops):
     from tests.hip_emu.emu_ops import Traffic
     layers = [("3->16 32x32", 8, 3, 32, 32, 16, 3, 1, 1), ("16->16 32x32", 8, 16, 32, 32, 16, 3, 1, 1),
               ("16->32 s2", 8, 16, 32, 32, 32, 3, 2, 1), ("32->32 16x16", 8, 32, 16, 16, 32, 3, 1, 1),
-              ("32->64 s2", 8, 32, 16, 16, 64, 3, 2, 1), ("64->64 8x8", 16, 64, 8, 8, 64, 3, 1, 1)]
+              ("32->64 s2", 8, 32, 16, 16, 64, 3, 2, 1), ("64->64 8x8", 16, 64, 8, 8, 64, 3, 1, 1),
+              ("16->32 1x1 s2", 8, 16, 32, 32, 32, 1, 2, 0)]
     mfma_flop = lambda t: t.mfma32 * 2 * 32 * 32 * 2 + t.mfma16 * 2 * 16 * 16 * 4
     for name, n, c, h, w, o, k, s, p in layers:
         x = torch.randn(n, c, h, w)
         w_mu, w_rho = torch.randn(o, c, k, k) * 0.1, torch.randn(o, c, k, k) - 3
         wbuf = ops.conv_lrt_wbuf(w_mu.shape, "cpu")
-        ops.conv_lrt_prep(w_mu, w_rho, wbuf)
+        ops.conv_lrt_prep(w_mu, w_rho, wbuf, stride=(s, s), padding=(p, p))
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         out, var = torch.empty(n, o, ho, wo), torch.empty(n, o, ho, wo)
         flop = 2 * 2 * n * o * ho * wo * c * k * k
@@ -126,10 +127,11 @@ def traffic(ops):
               f"out + var written x{(t.of(out)[1] + t.of(var)[1]) / (8 * out.numel()):4.2f}, matrix flop / useful flop {mfma_flop(t) / flop:5.2f}")
         g = torch.randn_like(out)
         gv, gx = g.clone(), torch.empty_like(x)
-        with Traffic(ops) as t:
-            ops.conv_lrt_bwd_data(g, gv, wbuf, w_mu.shape, x, gx, (s, s), (p, p))
-        print(f"input gradient  {name:14s} batch {n:2d}: g read x{t.of(g)[0] / (4 * g.numel()):5.2f}, weight buffer read {t.of(wbuf)[0] / 1e3:7.1f} KB, "
-              f"g_x written x{t.of(gx)[1] / (4 * gx.numel()):4.2f}, matrix flop / useful flop {mfma_flop(t) / flop:5.2f}")
+        for how, phases in (("", False), (" (per phase)", True)) if s > 1 else (("", False),):
+            with Traffic(ops) as t:
+                ops.conv_lrt_bwd_data(g, gv, wbuf, w_mu.shape, x, gx, (s, s), (p, p), phases=phases)
+            print(f"input gradient  {name:14s} batch {n:2d}: g read x{t.of(g)[0] / (4 * g.numel()):5.2f}, weight buffer read {t.of(wbuf)[0] / 1e3:7.1f} KB, "
+                  f"g_x written x{t.of(gx)[1] / (4 * gx.numel()):4.2f}, matrix flop / useful flop {mfma_flop(t) / flop:5.2f}{how}")
         gwm, gwr = torch.empty_like(w_mu), torch.empty_like(w_mu)
         with Traffic(ops) as t:
             ops.conv_lrt_bwd_weight(x, g, gv, w_rho, gwm, gwr, (s, s), (p, p))

@@ -236,7 +236,7 @@ class OracleOps:
     def conv_lrt_wbuf(self, w_shape, device):
         return torch.zeros(4)
 
-    def conv_lrt_prep(self, w_mu, w_rho, wbuf, b_rho=None):
+    def conv_lrt_prep(self, w_mu, w_rho, wbuf, b_rho=None, stride=None, padding=None):
         if not hasattr(self, "_conv_w"):
             self._conv_w = {}
         b_var = None if b_rho is None else F.softplus(b_rho.detach()) ** 2
@@ -251,7 +251,7 @@ class OracleOps:
         out.copy_(mean + torch.sqrt(var) * z)
         var_out.copy_(var)
 
-    def conv_lrt_bwd_data(self, g_out, g_var, wbuf, w_shape, x, g_x, stride, padding):
+    def conv_lrt_bwd_data(self, g_out, g_var, wbuf, w_shape, x, g_x, stride, padding, phases=False):
         w_mu, s2 = self._conv_w[wbuf.data_ptr()][:2]
         gm = torch.nn.grad.conv2d_input(x.shape, w_mu, g_out, stride=stride, padding=padding)
         gv = torch.nn.grad.conv2d_input(x.shape, s2, g_var, stride=stride, padding=padding)

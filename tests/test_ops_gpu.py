@@ -1055,25 +1055,27 @@ def test_conv_lrt_backward(ops):
         dev = lambda t: None if t is None else t.to(DEV).float().contiguous()
         xd, wm, wr = dev(x), dev(w_mu), dev(w_rho)
         wbuf = ops.conv_lrt_wbuf(w_mu.shape, DEV)
-        ops.conv_lrt_prep(wm, wr, wbuf)
+        ops.conv_lrt_prep(wm, wr, wbuf, stride=stride, padding=padding)   # with the stride: + the per-phase input-gradient matrices
         var = dev(g32[3])
         gd, ed = dev(gout), dev(eps)
         gvar = torch.empty_like(gd)
         ops.local_reparam_bwd(gd.view(-1), var.view(-1), gvar.view(-1), gd.numel(), eps=ed.view(-1))
         gx = torch.full_like(xd, 9.0)
-        ops.conv_lrt_bwd_data(gd, gvar, wbuf, w_mu.shape, xd, gx, stride, padding)
+        ops.conv_lrt_bwd_data(gd, gvar, wbuf, w_mu.shape, xd, gx, stride, padding, phases=True)   # one launch per phase if strided
+        gx_dilated = torch.full_like(xd, 9.0)                              # ... and the single launch over the zero-dilated gradient
+        ops.conv_lrt_bwd_data(gd, gvar, wbuf, w_mu.shape, xd, gx_dilated, stride, padding)
         gwm, gwr = torch.full_like(wm, 9.0), torch.full_like(wr, 9.0)
         ops.conv_lrt_bwd_weight(xd, gd, gvar, wr, gwm, gwr, stride, padding)
         case = (n, c, h, w, o, k, stride, padding)
         ho, wo = g32[3].shape[2:]
         chain = {"g_x": o * k * k, "g_wmu": n * ho * wo, "g_wrho": n * ho * wo}         # products summed per output element
-        for name, got, i in (("g_x", gx, 0), ("g_wmu", gwm, 1), ("g_wrho", gwr, 2)):
+        for name, got, i in (("g_x", gx, 0), ("g_x", gx_dilated, 0), ("g_wmu", gwm, 1), ("g_wrho", gwr, 2)):
             rel = 3e-6 * max(1.0, (chain[name] / 1024.0) ** 0.5)
             tol = max(2 * (g32[i].double() - g64[i]).abs().max().item(), rel * g64[i].abs().max().item())
             assert (got.cpu().double() - g64[i]).abs().max().item() <= tol, (name, case)
         gwm2, gwr2, gx2 = torch.empty_like(gwm), torch.empty_like(gwr), torch.empty_like(gx)     # deterministic
         ops.conv_lrt_bwd_weight(xd, gd, gvar, wr, gwm2, gwr2, stride, padding)
-        ops.conv_lrt_bwd_data(gd, gvar, wbuf, w_mu.shape, xd, gx2, stride, padding)
+        ops.conv_lrt_bwd_data(gd, gvar, wbuf, w_mu.shape, xd, gx2, stride, padding, phases=True)
         assert torch.equal(gwm, gwm2) and torch.equal(gwr, gwr2) and torch.equal(gx, gx2), case
 
 

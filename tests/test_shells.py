@@ -1323,7 +1323,7 @@ def check_native_nodes_equal_python_nodes(ops, dev, native):
         w_mu, w_rho = torch.randn(o, c, k, k, device=dev) * 0.1, torch.randn(o, c, k, k, device=dev) - 3
         b_mu, b_rho = (torch.randn(o, device=dev) * 0.1, torch.randn(o, device=dev) - 3) if bias else (None, None)
         wbuf = ops.conv_lrt_wbuf(w_mu.shape, dev)
-        ops.conv_lrt_prep(w_mu, w_rho, wbuf, b_rho)
+        ops.conv_lrt_prep(w_mu, w_rho, wbuf, b_rho, stride=(s_, s_), padding=(p_, p_))      # as the layer prepares it
         ho, wo = (h + 2 * p_ - k) // s_ + 1, (w + 2 * p_ - k) // s_ + 1
         for eps in (None, torch.randn(n, o, ho, wo, device=dev)):
             for x_grad in (True, False):
@@ -1332,9 +1332,9 @@ def check_native_nodes_equal_python_nodes(ops, dev, native):
                     leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (x0, w_mu, w_rho, b_mu, b_rho)]
                     leaves[0].requires_grad_(x_grad)
                     if node == "native":
-                        out = native.conv_lrt(*leaves, s_, s_, p_, p_, eps, 5, 9, wbuf)
+                        out = native.conv_lrt(*leaves, s_, s_, p_, p_, eps, 5, 9, wbuf, True)
                     else:
-                        out = L._ConvLrt.apply(*leaves, (s_, s_), (p_, p_), eps, 5, 9, ops, wbuf)
+                        out = L._ConvLrt.apply(*leaves, (s_, s_), (p_, p_), eps, 5, 9, ops, wbuf, True)
                     wrt = [t for t in leaves if t is not None and t.requires_grad]
                     grads = torch.autograd.grad(out, wrt, grad_outputs=torch.ones_like(out) * 0.5)
                     res.append([out.detach()] + list(grads))
