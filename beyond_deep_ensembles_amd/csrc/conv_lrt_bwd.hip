@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
   const int otile = blockIdx.y / t.colgroups, cg = blockIdx.y % t.colgroups;
   const int o0 = otile * MF, col0 = cg * t.CT * MF;
   const int col_end = min(ktot, col0 + t.CT * MF);
+  const int nct = (col_end - col0 + MF - 1) / MF;              // column tiles of this group with a column inside the matrix
   const int c_lo = col0 / khw, c_hi = (col_end - 1) / khw, cc = c_hi - c_lo + 1;
   const int img_floats = cc * row_elems;
   const int patch_floats = t.NI * t.cmax * row_elems;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
       const float am = gs[idx * t.GP + pix], av = gvs[idx * t.GP + pix];
 #pragma unroll
       for (int ct = 0; ct < CT_MAX; ++ct) {
-        if (ct < t.CT) {                                       // wave-uniform
+        if (ct < nct) {                                        // wave-uniform
           const float b = xs[po + kofs[ct]], b2 = x2s[po + kofs[ct]];
           accm[ct] = M::run(am, b, accm[ct]);
           accv[ct] = M::run(av, b2, accv[ct]);
@@ -249,8 +250,11 @@ static bool plan_wgrad(const WgGeo& g, WgPlan& p) {
   size_t best_lds = 0;
   // ct column tiles of the [O, C*KH*KW] gradient per workgroup: as many as the accumulators hold, fewer only when the input
   // patches of the channels they span do not fit the LDS even for one output row (wide 1x1 layers on large images)
-  for (int ct = std::min(ct_max, (ktot + mf - 1) / mf); ct >= 1 && !found; --ct) {
-  const int colgroups = (ktot + ct * mf - 1) / (ct * mf);
+  const int coltiles = (ktot + mf - 1) / mf;
+  for (int ct_cap = std::min(ct_max, coltiles); ct_cap >= 1 && !found; --ct_cap) {
+  // the column tiles spread evenly over the groups (9 tiles with at most 4 per group: 3 + 3 + 3, not 4 + 4 + 1)
+  const int colgroups = (coltiles + ct_cap - 1) / ct_cap;
+  const int ct = (coltiles + colgroups - 1) / colgroups;
   const int cmax = std::min(g.C, (ct * mf + khw - 2) / khw + 1);
   for (int th = g.Ho; th >= 1; th = (th > 1 ? (th + 1) / 2 : 0)) {
     const int bands = (g.Ho + th - 1) / th;
