@@ -43,11 +43,13 @@ def algorithmic(kernel, grid):
              "svgd_combine_seg_kernel<8>": 12 * M * D50,
              "svgd_fused_kernel<8, 0, true, false>": (12 * M + 8) * D50, "svgd_fused_kernel<8, 0, false, false>": (12 * M + 8) * D50,
              "svgd_fused_kernel<8, 0, true, true>": (12 * M + 8) * D50, "svgd_fused_kernel<8, 0, false, true>": (12 * M + 8) * D50,
-             "svgd_gather_seg_kernel": 8 * M * D50, "swag_copy_row_kernel<12, 0>": 8 * D50,
+             "svgd_gather_seg_kernel": 8 * M * D50,
              "svgd_apply_sgd_kernel": (12 * M + 8) * D50,
-             "swag_update_kernel<0>": 24 * D50, "swag_update_kernel<12>": 24 * D50,
-             "swag_sample_kernel<true, 0>": 4 * D50 * (K + 3), "swag_sample_kernel<true, 12>": 4 * D50 * (K + 3),
+             "swag_update_kernel": 24 * D50, "swag_update_kernel<0>": 24 * D50, "swag_update_kernel<12>": 24 * D50,   # <..>: round 3's names
+             "swag_sample_kernel<true>": 4 * D50 * (K + 3), "swag_sample_kernel<true, 0>": 4 * D50 * (K + 3),
+             "swag_sample_kernel<true, 12>": 4 * D50 * (K + 3),
              "swag_sample_batched_kernel<true>": 4 * D50 * (K + 2 + S),
+             "swag_sample_batched_dma_kernel<true, 7>": 4 * D50 * (K + 2 + S),
              "gauss_draw_fwd_kernel<true>": 12 * D50, "gauss_draw_bwd_kernel<true, true>": 24 * D50,
              "gauss_kl_kernel<true, true>": 24 * D50, "gauss_kl_kernel<true, false>": 16 * D50,
              "local_reparam_fwd_kernel<true>": 12 * D50, "ivon_sample_kernel<true>": 20 * D50, "ivon_update_kernel": 32 * D50}
