@@ -489,9 +489,17 @@ static int n_workers() {
   return n;
 }
 
-void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
+// launches per kernel (address of the __global__ function's instantiation): which template variants the tests reach
+static std::mutex g_launch_mu;
+static std::map<const void*, uint64_t> g_launches;
+
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body, const void* kernel) {
   const int n = static_cast<int>(block.x * block.y * block.z);
   const long total = static_cast<long>(grid.x) * grid.y * grid.z;
+  if (kernel) {
+    std::lock_guard<std::mutex> lock(g_launch_mu);
+    ++g_launches[kernel];
+  }
   if (n <= 0 || n > 1024 || total <= 0) return;
   if (g_traffic_on) {
     std::lock_guard<std::mutex> lock(g_buf_mu);
@@ -619,6 +627,20 @@ int hip_emu_lds_report(const char* path) {
                  static_cast<unsigned long>(kv.second.cycles));
   std::fclose(f);
   hip_emu::g_lds_sites.clear();
+  return 0;
+}
+
+// One line per kernel launched so far: "<symbol> <launches>" (the mangled name of the instantiation).
+int hip_emu_launch_report(const char* path) {
+  std::lock_guard<std::mutex> lock(hip_emu::g_launch_mu);
+  FILE* f = std::fopen(path, "w");
+  if (!f) return -1;
+  for (const auto& kv : hip_emu::g_launches) {
+    Dl_info info;
+    const char* name = dladdr(kv.first, &info) && info.dli_sname ? info.dli_sname : "?";
+    std::fprintf(f, "%s %lu\n", name, static_cast<unsigned long>(kv.second));
+  }
+  std::fclose(f);
   return 0;
 }
 

@@ -41,7 +41,7 @@ struct Lane {
 
 extern thread_local Lane* cur;
 
-void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body, const void* kernel = nullptr);
 void block_sync();
 void wave_sync();
 void* dyn_lds();
@@ -184,7 +184,7 @@ inline uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c, uint32_t table) {
 #define gridDim (hip_emu::cur->gdim)
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-  hip_emu::launch(dim3(grid), dim3(block), static_cast<size_t>(lds), [=]() { kernel(__VA_ARGS__); })
+  hip_emu::launch(dim3(grid), dim3(block), static_cast<size_t>(lds), [=]() { kernel(__VA_ARGS__); }, reinterpret_cast<const void*>(kernel))
 
 inline void __syncthreads() { hip_emu::block_sync(); }
 

@@ -968,6 +968,9 @@ CONV_CASES = [
     (2, 3, 30, 30, 64, 7, (2, 2), (3, 3), False), (1, 130, 7, 7, 40, 3, (1, 1), (1, 1), True), (2, 64, 14, 14, 64, 1, (1, 1), (0, 0), True),
     (3, 20, 28, 28, 16, 3, (1, 1), (1, 1), True),
     (1, 256, 6, 56, 64, 1, (1, 1), (0, 0), False),          # wide 1x1 on a wide image: the weight gradient runs with fewer column tiles
+    # few output channels / single images: the remaining (channel tile, pixel tiles per wave) instantiations of the kernel
+    (1, 3, 48, 48, 4, 1, (2, 2), (0, 0), True), (1, 3, 32, 32, 4, 3, (1, 1), (1, 1), False), (1, 3, 48, 48, 40, 1, (1, 1), (0, 0), True),
+    (8, 3, 32, 32, 4, 1, (1, 1), (0, 0), False), (1, 3, 16, 16, 4, 3, (1, 1), (1, 1), True),
 ]
 
 
