@@ -14,6 +14,7 @@ hip_emu.hpp.  The sources are used as they are, except for what a host compiler 
   * every other `asm volatile(...)` statement   -> dropped (register-class barriers)
 
 The result is cached under tests/hip_emu/_build/ keyed by the content of every input."""
+import contextlib
 import hashlib
 import os
 import re
@@ -51,7 +52,7 @@ def _prune(root, keep):
     """Builds of older source states: keep the most recently used few (a full build is ~90 MB of objects)."""
     import shutil
     try:
-        dirs = sorted((os.path.join(root, d) for d in os.listdir(root)), key=os.path.getmtime, reverse=True)
+        dirs = sorted((os.path.join(root, d) for d in os.listdir(root) if not d.startswith(".")), key=os.path.getmtime, reverse=True)
     except OSError:
         return
     for d in dirs[keep:]:
@@ -70,6 +71,25 @@ def build(sources, defines=()):
     key = hashlib.sha256(("\0".join(texts[n] for n in names) + "\0".join(emu) + repr(tuple(defines)) + open(__file__).read()).encode()).hexdigest()[:16]
     out_dir = os.path.join(HERE, "_build", key)
     lib = os.path.join(out_dir, "libbde_emu.so")
+    if os.path.exists(lib):
+        return lib
+    with _locked():                                   # several test processes (two-rank runs, xdist) may want it at once
+        return _build_locked(sources, defines, names, texts, out_dir, lib)
+
+
+@contextlib.contextmanager
+def _locked():
+    import fcntl
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    with open(os.path.join(HERE, "_build", ".lock"), "w") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
+def _build_locked(sources, defines, names, texts, out_dir, lib):
     if os.path.exists(lib):
         return lib
     _prune(os.path.join(HERE, "_build"), keep=4)
@@ -125,6 +145,16 @@ def build_host_nodes(sources):
     out = os.path.join(out_dir, f"_bde_host_emu_{key}.so")
     if os.path.exists(out):
         return out
+    with _locked():
+        if os.path.exists(out):
+            return out
+        return _build_host_nodes_locked(sources, text, out_dir, out)
+
+
+def _build_host_nodes_locked(sources, text, out_dir, out):
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
     src = os.path.join(out_dir, "host_autograd_emu.cpp")
     with open(src, "w") as fh:
         fh.write(text)

@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -543,15 +545,35 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
       worker.lds_sites.clear();
     }
   };
+  // watchdog: a launch that does not finish within HIP_EMU_LAUNCH_TIMEOUT seconds (default 900) is a hang the rendezvous
+  // bookkeeping did not recognise as a deadlock -- say where the workers are and abort instead of stalling the test run
+  std::mutex done_mu;
+  std::condition_variable done_cv;
+  bool done = false;
+  const char* lim = std::getenv("HIP_EMU_LAUNCH_TIMEOUT");
+  const long limit_s = lim ? std::atol(lim) : 900;
+  std::thread watchdog([&]() {
+    std::unique_lock<std::mutex> lock(done_mu);
+    if (!done_cv.wait_for(lock, std::chrono::seconds(limit_s), [&] { return done; })) {
+      Dl_info info;
+      const char* name = kernel && dladdr(kernel, &info) && info.dli_sname ? info.dli_sname : "?";
+      std::fprintf(stderr, "hip_emu: launch of %s (grid %u x %u x %u, block %d, %zu B LDS) still running after %ld s: block %ld of %ld "
+                   "handed out\n", name, grid.x, grid.y, grid.z, n, lds_bytes, limit_s, next.load(), total);
+      std::abort();
+    }
+  });
   const int nw = static_cast<int>(std::min<long>(n_workers(), total));
-  if (nw <= 1) {
-    std::thread t(work);      // never on the caller's (Python's) stack and TLS
-    t.join();
-    return;
+  {
+    std::vector<std::thread> ts;                                     // never on the caller's (Python's) stack and TLS
+    for (int i = 0; i < std::max(nw, 1); ++i) ts.emplace_back(work);
+    for (auto& t : ts) t.join();
   }
-  std::vector<std::thread> ts;
-  for (int i = 0; i < nw; ++i) ts.emplace_back(work);
-  for (auto& t : ts) t.join();
+  {
+    std::lock_guard<std::mutex> lock(done_mu);
+    done = true;
+  }
+  done_cv.notify_one();
+  watchdog.join();
 }
 
 }  // namespace hip_emu
