@@ -1093,7 +1093,9 @@ def test_lrt_linear_backward(ops):
                                       (128, 300, 70, False, True), (33, 64, 32, True, False), (1, 7, 3, True, True),
                                       (96, 1000, 200, True, True), (64, 2100, 520, True, True), (70, 129, 33, True, True),
                                       # tile-aligned wide layers: the mask-free variants of the two gradient kernels
-                                      (64, 1056, 1024, True, True), (32, 2048, 544, False, True)]:
+                                      (64, 1056, 1024, True, True), (32, 2048, 544, False, True),
+                                      # wide layers whose sizes are no multiples of 4, batch <= 64: lrt_bwd_x_kernel<1 / 2>
+                                      (32, 1030, 1027, True, True), (64, 1027, 1030, False, True)]:
         x = torch.randn(b, i)
         x[0, : min(i, 3)] = 0.0                                       # x^2 below the clamp: no gradient through it
         w_mu, w_rho = torch.randn(o, i) * 0.1, torch.randn(o, i) * 1.5 - 3.0
