@@ -699,6 +699,63 @@ def test_gauss_draw_philox(ops):
 
 
 # ------------------------------------------------------------------ iVON --
+def test_accumulating_unaligned_and_value_only_variants(ops):
+    """The instantiations the other tests do not reach (tests/hip_emu/coverage.py): gradients ACCUMULATED into existing
+    buffers (draw backward with in-kernel noise, KL, L2), the element-wise fallbacks of the draw kernels for tensors that are
+    not 16-byte aligned (views at an odd offset of a parameter buffer), and the value-only forms (no gradient requested)."""
+    torch.manual_seed(41)
+    n = 10_003
+    mean, rho = torch.randn(n, device=DEV) * 0.3, torch.randn(n, device=DEV) - 2.0
+    g = torch.randn(n, device=DEV)
+    ws = ops.reduce_ws(DEV)
+    # draw backward, Philox noise regenerated, overwrite vs accumulate
+    gm, gr = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    ops.gauss_draw_bwd(g, rho, gm, gr, n, seed=5, stream_id=6)
+    am, ar = torch.full((n,), 0.25, device=DEV), torch.full((n,), -0.5, device=DEV)
+    ops.gauss_draw_bwd(g, rho, am, ar, n, seed=5, stream_id=6, accumulate=True)
+    assert torch.allclose(am, gm + 0.25, rtol=1e-6, atol=1e-7) and torch.allclose(ar, gr - 0.5, rtol=1e-6, atol=1e-7)
+    # the same through views at an odd element offset (4-byte aligned only): forward and backward, supplied and in-kernel noise
+    big = lambda: torch.zeros(n + 1, device=DEV)
+    bm, br, bw, bg, bgm, bgr = big(), big(), big(), big(), big(), big()
+    bm[1:], br[1:], bg[1:] = mean, rho, g
+    w_al = torch.empty(n, device=DEV)
+    ops.gauss_draw_fwd(mean, rho, w_al, n, seed=5, stream_id=6)
+    ops.gauss_draw_fwd(bm[1:], br[1:], bw[1:], n, seed=5, stream_id=6)
+    assert torch.allclose(bw[1:], w_al, rtol=1e-6, atol=1e-7)
+    eps = torch.randn(n + 1, device=DEV)
+    ops.gauss_draw_fwd(bm[1:], br[1:], bw[1:], n, eps=eps[1:])
+    assert torch.allclose(bw[1:], mean + torch.nn.functional.softplus(rho) * eps[1:], rtol=2e-6, atol=1e-6)
+    ops.gauss_draw_bwd(bg[1:], br[1:], bgm[1:], bgr[1:], n, seed=5, stream_id=6)
+    assert torch.allclose(bgm[1:], gm, rtol=1e-6, atol=1e-7) and torch.allclose(bgr[1:], gr, rtol=1e-6, atol=1e-7)
+    bgm[1:], bgr[1:] = 0.25, -0.5
+    ops.gauss_draw_bwd(bg[1:], br[1:], bgm[1:], bgr[1:], n, seed=5, stream_id=6, accumulate=True)
+    assert torch.allclose(bgm[1:], gm + 0.25, rtol=1e-6, atol=1e-7) and torch.allclose(bgr[1:], gr - 0.5, rtol=1e-6, atol=1e-7)
+    ops.gauss_draw_bwd(bg[1:], br[1:], bgm[1:], bgr[1:], n, eps=eps[1:], accumulate=True)      # supplied noise, accumulating
+    assert torch.isfinite(bgm).all() and torch.isfinite(bgr).all()
+    # KL: gradients accumulated; value only
+    kl, kg_m, kg_r = torch.zeros(1, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    ops.gauss_kl(mean, rho, 0.1, 0.7, n, ws, kl_out=kl, gmean=kg_m, grho=kg_r)
+    am, ar = torch.full((n,), 0.25, device=DEV), torch.full((n,), -0.5, device=DEV)
+    kl2 = torch.zeros(1, device=DEV)
+    ops.gauss_kl(mean, rho, 0.1, 0.7, n, ws, kl_out=kl2, gmean=am, grho=ar, accumulate=True)
+    assert torch.equal(kl, kl2) and torch.allclose(am, kg_m + 0.25, rtol=1e-6, atol=1e-7) and torch.allclose(ar, kg_r - 0.5, rtol=1e-6, atol=1e-7)
+    kl3 = torch.zeros(1, device=DEV)
+    ops.gauss_kl(mean, rho, 0.1, 0.7, n, ws, kl_out=kl3)
+    assert torch.equal(kl, kl3)
+    # L2 of plain parameters (bbb.py:75-76): value only; gradient accumulated
+    v1, v2, lg = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV), torch.full((n,), 0.25, device=DEV)
+    ops.l2(mean, 0.3, n, ws, val_out=v1)
+    ops.l2(mean, 0.3, n, ws, val_out=v2, g=lg, accumulate=True)
+    want = 0.5 * 0.3 * (mean.double() ** 2).sum().item()
+    assert torch.equal(v1, v2) and abs(v1.item() - want) <= 2e-6 * abs(want)
+    assert torch.allclose(lg, 0.25 + 0.3 * mean, rtol=1e-6, atol=1e-7)
+    # mixture prior: value only == value of the value + gradient form
+    m1, m2, mg = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV), torch.empty(n, device=DEV)
+    ops.mixture_nll(mean, 0.5, 1.0, 0.05, n, ws, val_out=m1)
+    ops.mixture_nll(mean, 0.5, 1.0, 0.05, n, ws, val_out=m2, gmean=mg)
+    assert torch.equal(m1, m2)
+
+
 def test_ivon_golden_bit_exact(ops, golden):
     g = golden("ivon.npz")
     for ci, (aug, mc, damping, temp) in enumerate(g["cases"]):
