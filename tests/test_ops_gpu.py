@@ -1152,7 +1152,12 @@ def test_lrt_linear_backward(ops):
                                       # tile-aligned wide layers: the mask-free variants of the two gradient kernels
                                       (64, 1056, 1024, True, True), (32, 2048, 544, False, True),
                                       # wide layers whose sizes are no multiples of 4, batch <= 64: lrt_bwd_x_kernel<1 / 2>
-                                      (32, 1030, 1027, True, True), (64, 1027, 1030, False, True)]:
+                                      (32, 1030, 1027, True, True), (64, 1027, 1030, False, True),
+                                      # few outputs x very many inputs: ONE slice over O, the input gradient written directly
+                                      # (DIRECT) -- float4 kernel mask-free / masked at 1 and 2 batch tiles, the row kernel at 1, 2, 4
+                                      (32, 16384, 96, True, True), (64, 16384, 96, False, True), (32, 16388, 68, True, True),
+                                      (64, 16388, 68, True, True), (16, 12004, 90, True, True), (40, 12004, 90, False, True),
+                                      (96, 12004, 90, True, True)]:
         x = torch.randn(b, i)
         x[0, : min(i, 3)] = 0.0                                       # x^2 below the clamp: no gradient through it
         w_mu, w_rho = torch.randn(o, i) * 0.1, torch.randn(o, i) * 1.5 - 3.0
@@ -1254,9 +1259,12 @@ def test_lrt_sigma_cache_is_bit_identical(ops):
     pass.  Same expressions, so outputs and all five gradients equal the on-the-fly kernels bit for bit; narrow layers
     ignore the cache."""
     torch.manual_seed(29)
-    for b, i, o in [(64, 1024, 1100), (128, 2048, 700), (20, 640, 2000), (33, 4096, 512), (16, 256, 64)]:
+    for b, i, o in [(64, 1024, 1100), (128, 2048, 700), (20, 640, 2000), (33, 4096, 512), (16, 256, 64),
+                    # every remaining (batch tiles, DIRECT, FULL) form of the two input-gradient kernels, cached vs on the fly
+                    (32, 2048, 544), (64, 1056, 1024), (32, 1030, 1027), (64, 1027, 1030), (32, 16384, 96), (64, 16384, 96),
+                    (32, 16388, 68), (64, 16388, 68), (16, 12004, 90), (40, 12004, 90), (96, 12004, 90)]:
         wide = ops.lrt_sigma_cache_wanted(i, o)
-        assert wide == (i * o >= (1 << 20))
+        assert wide == (i * o >= (1 << 20) and i % 4 == 0 and i >= 512)   # (the backward reads a cache it is handed for any wide layer)
         x = torch.randn(b, i, device=DEV)
         x[0, :3] = 0.0
         w_mu, w_rho = torch.randn(o, i, device=DEV) * 0.1, torch.randn(o, i, device=DEV) * 1.5 - 3.0
