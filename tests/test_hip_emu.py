@@ -197,6 +197,14 @@ def test_stream_traffic_equals_the_algorithmic_bytes(emu):
     assert t.of(w_mu) == (4 * o * i_, 0) and t.of(w_rho) == (4 * o * i_, 0) and t.of(y) == (0, 4 * b * o)
 
 
+def test_philox_known_answers_on_the_cpu_model(emu):
+    """The in-kernel generator: the three Random123 known-answer vectors, the checker's words at both round counts, and the
+    normals against the exact Box-Muller transform of those words (the bodies of tests/test_philox.py's `-m gpu` tests)."""
+    import tests.test_philox as P
+    P.check_kernel_words(emu, "cpu")
+    P.check_kernel_normals(emu, "cpu")
+
+
 def test_smoke_body_on_the_cpu_model(emu):
     """What __graft_entry__.smoke() runs on cuda:0 (one SVGD update, SWAG moments and a sample, against the oracle)."""
     import __graft_entry__ as entry

@@ -30,8 +30,11 @@ def test_checker_normals_are_standard():
 @pytest.mark.gpu
 def test_kernel_words_equal_the_known_answers_and_the_checker():
     from beyond_deep_ensembles_amd.ops import HipOps
-    ops = HipOps()
-    dev = "cuda:0"
+    check_kernel_words(HipOps(), "cuda:0")
+
+
+def check_kernel_words(ops, dev):
+    """(tests/test_hip_emu.py runs the same body over the kernel sources on the CPU model)"""
     for counter, key, want in PH.KAT:
         seed = key[0] | (key[1] << 32)
         stream = counter[2] | (counter[3] << 32)
@@ -52,8 +55,10 @@ def test_kernel_normals_equal_the_checker_transform():
     """Box-Muller with the bare hardware log / sqrt / sin / cos stays within 4e-6 absolute of the exact transform
     of the same words (|z| <= 5.8), and the low-rank weights use their own domain."""
     from beyond_deep_ensembles_amd.ops import HipOps
-    ops = HipOps()
-    dev = "cuda:0"
+    check_kernel_normals(HipOps(), "cuda:0")
+
+
+def check_kernel_normals(ops, dev):
     d, k = 100003, 37
     e, w = torch.zeros(d, device=dev), torch.zeros(k, device=dev)
     for rounds in (PH.ROUNDS, PH.SWAG_ROUNDS):
