@@ -216,6 +216,15 @@ def test_svgd_blocked_path_for_more_than_16_particles(ops):
         Pb, Gb = flat_rows(P), flat_rows(G)
         with pytest.raises(BdeKernelError):           # in-place is a single-tile-path feature
             ops.svgd_combine(Pb, Gb, Gb, d, ks.to(DEV))
+        if m in (17, 40):                             # rbf(): K and grad_kernel (svgd.py:14-32) on the blocked path (no gradients)
+            ws, kst, out = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV), torch.zeros_like(Pb)
+            ops.svgd_gram(Pb, d, ws)
+            ops.svgd_kstats(ws, m, 0.0, 1.0, 1.0, 1.0, kst, mode=1)
+            ops.svgd_combine(Pb, None, out, d, kst)
+            _, gk64 = O.svgd_rbf(P.double())
+            _, gk32 = O.svgd_rbf(P)
+            err_ref = (gk32.double() - gk64).abs().max().item()
+            assert (out[:, :d].cpu().double() - gk64).abs().max().item() <= max(2 * err_ref, 3e-6 * gk64.abs().max().item()), (m, d)
 
 
 def test_svgd_rejects_bad_arguments(ops):
