@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""bde_conv_lrt_fwd per ResNet-20 layer shape (batch 128) against the reference's op sequence in PyTorch on the same GPU
-(two MIOpen convolutions + element-wise ops, bbb_layers.py:146-154) and against this package's round-3 composition
-(stock convolutions + fused element-wise passes)."""
+"""The fused BBBConv2d kernels per ResNet-20 layer shape (batch 128) and a few ImageNet-sized ones, each against the reference's
+op sequence in PyTorch on the same GPU: forward (bde_conv_lrt_fwd vs two MIOpen convolutions + element-wise ops,
+bbb_layers.py:146-154), input gradient (one launch over the zero-dilated gradient vs one launch per phase for strided
+layers), weight gradient, and the backward of the reference's sequence through autograd."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +23,7 @@ for n, c, h, w, o, k, s, p in shapes:
     ops.var_operand_fwd(wr, 1, ws2)
     ops.var_operand_fwd(br, 2, bv)
     wbuf = ops.conv_lrt_wbuf(wm.shape, dev)
-    ops.conv_lrt_prep(wm, wr, wbuf, br)
+    ops.conv_lrt_prep(wm, wr, wbuf, br, stride=(s, s), padding=(p, p))
     ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
     out, var = torch.empty(n, o, ho, wo, device=dev), torch.empty(n, o, ho, wo, device=dev)
     if not ops.conv_lrt_supported(x.shape, wm.shape, (s, s), (p, p)):
@@ -45,3 +46,35 @@ for n, c, h, w, o, k, s, p in shapes:
     flops = 2 * 2.0 * n * o * ho * wo * c * k * k
     print(f"N{n} C{c} {h}x{w} O{o} k{k} s{s}: fused {tf*1e6:8.1f} us ({flops/tf/1e12:5.1f} TFLOP/s)   torch sequence {tt*1e6:8.1f} us   "
           f"two MIOpen convs alone {tc*1e6:8.1f} us   speedup {tt/tf:5.2f}x", flush=True)
+    # ---- backward: g_var + input gradient (dilated / per phase) + weight gradient vs autograd of the reference's sequence
+    g = torch.randn_like(out)
+    gvar, gx = torch.empty_like(g), torch.empty_like(x)
+    gwm, gwr = torch.empty_like(wm), torch.empty_like(wr)
+    wws = [None]
+
+    def bwd_data_dilated():
+        ops.conv_lrt_bwd_data(g, gvar, wbuf, wm.shape, x, gx, (s, s), (p, p))
+
+    def bwd_data_phases():
+        ops.conv_lrt_bwd_data(g, gvar, wbuf, wm.shape, x, gx, (s, s), (p, p), phases=True)
+
+    def bwd_weight():
+        wws[0] = ops.conv_lrt_bwd_weight(x, g, gvar, wr, gwm, gwr, (s, s), (p, p), ws=wws[0])
+
+    def gvar_pass():
+        ops.local_reparam_bwd(g.view(-1), var.view(-1), gvar.view(-1), g.numel(), seed=1, stream_id=2)
+    leaves = [t.clone().requires_grad_(True) for t in (x, wm, wr, bm, br)]
+    noise = torch.randn_like(out)
+
+    def torch_fwd_bwd():
+        xx, m_, r_, bm_, br_ = leaves
+        mean = F.conv2d(xx, m_, bm_, stride=s, padding=p)
+        v = F.conv2d((xx ** 2).clamp(min=1e-4), (F.softplus(r_) ** 2).clamp(min=1e-4), F.softplus(br_) ** 2, stride=s, padding=p)
+        torch.autograd.grad(mean + torch.sqrt(v) * noise, leaves, g)
+    tg, td, tw = bench.time_loop(gvar_pass, 30), bench.time_loop(bwd_data_dilated, 30), bench.time_loop(bwd_weight, 30)
+    tp = bench.time_loop(bwd_data_phases, 30) if s > 1 else td
+    tref = bench.time_loop(torch_fwd_bwd, 20)
+    ours = tf + tg + min(td, tp) + tw
+    print(f"    backward: g_var {tg*1e6:7.1f}  input gradient {td*1e6:8.1f}" + (f" (per phase {tp*1e6:8.1f})" if s > 1 else "") +
+          f"  weight gradient {tw*1e6:8.1f} us;  forward + backward kernels {ours*1e6:8.1f} us vs the reference's sequence through autograd "
+          f"{tref*1e6:8.1f} us = {tref/ours:5.2f}x", flush=True)
