@@ -3,6 +3,7 @@ over random layer geometries -- the bodies of test_conv_lrt_forward / test_conv_
 
     python -m tests.hip_emu.sweep_conv SEED COUNT          # random geometries (kernel 1..7, stride 1..3, padding 0..k-1)
     python -m tests.hip_emu.sweep_conv imagenet            # ResNet-18/50 layer shapes at batch 1-2
+    python -m tests.hip_emu.sweep_conv batch128            # the CIFAR ResNet-20 layers at the benchmark's batch (the tilings depend on it)
 """
 import random
 import sys
@@ -15,6 +16,12 @@ IMAGENET = [(1, 3, 64, 64, 64, 7, (2, 2), (3, 3), False), (2, 64, 56, 56, 64, 3,
             (1, 64, 56, 56, 128, 3, (2, 2), (1, 1), False), (1, 128, 28, 28, 128, 3, (1, 1), (1, 1), True),
             (1, 256, 14, 14, 256, 3, (1, 1), (1, 1), False), (1, 512, 7, 7, 512, 3, (1, 1), (1, 1), True),
             (1, 256, 56, 56, 64, 1, (1, 1), (0, 0), False), (1, 64, 56, 56, 256, 1, (1, 1), (0, 0), True)]
+
+
+BATCH128 = [(128, 3, 32, 32, 16, 3, (1, 1), (1, 1), True), (128, 16, 32, 32, 16, 3, (1, 1), (1, 1), True),
+            (128, 16, 32, 32, 32, 3, (2, 2), (1, 1), True), (128, 32, 16, 16, 32, 3, (1, 1), (1, 1), False),
+            (128, 32, 16, 16, 64, 3, (2, 2), (1, 1), True), (128, 64, 8, 8, 64, 3, (1, 1), (1, 1), True),
+            (128, 16, 32, 32, 32, 1, (2, 2), (0, 0), False)]
 
 
 def random_cases(seed, count):
@@ -31,7 +38,7 @@ def random_cases(seed, count):
 
 
 def main(argv):
-    cases = IMAGENET if argv[0] == "imagenet" else random_cases(int(argv[0]), int(argv[1]))
+    cases = IMAGENET if argv[0] == "imagenet" else BATCH128 if argv[0] == "batch128" else random_cases(int(argv[0]), int(argv[1]))
     G.DEV = "cpu"
     bad = 0
     with emulated(ALL) as ops:
