@@ -193,6 +193,31 @@ def test_svgd_small_model_kernel_repeated_calls_and_rbf(ops):
     # (hipGraph capture of this launch: test_svgd_step_is_graph_capturable, whose size takes this path)
 
 
+def test_svgd_gram_load_flavour_split_does_not_change_results(ops):
+    """The Gram pass loads the head of its walk non-temporally and keeps the last `keep` bytes cacheable for the combine pass
+    (svgd.hip; 240 MB by default, so the split is only ever taken at ResNet-50 size).  Forced here at small sizes through the
+    tuning hook: all non-temporal, split at several points, all cacheable -- the load flavour must not change a single bit
+    of the partial sums, the statistics or -phi (M = 5: the reference's particle_count, 8, 16)."""
+    torch.manual_seed(17)
+    try:
+        for m, d in [(5, 70_001), (8, 273_610), (16, 40_000)]:
+            P, G = torch.randn(1, d) * 0.05 + torch.randn(m, d) * 0.01, torch.randn(m, d) * 0.01
+            total = 4 * m * d
+            results = []
+            for keep in (0, total // 7, total // 2, total - 4096, 2 * total, -1):
+                ops.svgd_set_gram_keep_bytes(keep)
+                a, ks = run_svgd_staged(ops, P, G, 3e-4, 1.0, 50000.0)
+                results.append((a, ks))
+            for a, ks in results[1:]:
+                assert torch.equal(a, results[0][0]) and torch.equal(ks, results[0][1]), (m, d)
+            phi64 = O.svgd_phi(P.double(), G.double(), 3e-4, 1.0, 50000.0).numpy()
+            ref32 = O.svgd_phi(P, G, 3e-4, 1.0, 50000.0).numpy().astype(np.float64)
+            tol = max(2 * np.max(np.abs(ref32 - phi64)), 3e-6 * np.max(np.abs(phi64)))
+            assert np.max(np.abs(-results[0][0].numpy() - phi64)) <= tol, (m, d)
+    finally:
+        ops.svgd_set_gram_keep_bytes(-1)
+
+
 def test_svgd_blocked_path_for_more_than_16_particles(ops):
     """17..64 particles: pair-of-groups Gram tiles -> d2 -> statistics -> chunked combine."""
     torch.manual_seed(9)
