@@ -494,9 +494,11 @@ def test_swag_batched_sampler_both_kernels_equal_single_samples(ops):
     sizes below one 128-parameter tile, at tile boundaries, with a D % 4 tail and a partial last tile, odd and even K,
     K = 1, and S from 1 to the maximum of 32; with in-kernel and with supplied noise; nothing is written past D."""
     torch.manual_seed(41)
-    for d in (3, 4, 127, 128, 129, 4099, 70_001):
+    # (the last size: more 128-parameter tiles than the grid has waves -- 3072 workgroups x 4 -- so that waves walk SEVERAL
+    # tiles: the software pipeline of the LDS-DMA kernel and the grid-stride loop of the register kernel)
+    for d in (3, 4, 127, 128, 129, 4099, 70_001, 3_300_003):
         ld = (d + 63) // 64 * 64
-        for k, s_n in ((1, 2), (5, 7), (19, 30), (20, 32), (21, 3), (30, 30)):
+        for k, s_n in ((1, 2), (5, 7), (19, 30), (20, 32), (21, 3), (30, 30)) if d < 1_000_000 else ((20, 3), (21, 2)):
             stat = torch.zeros(k + 2, ld, device=DEV)
             stat[:k, :d] = torch.randn(k, d, device=DEV) * 1e-2
             stat[k, :d] = torch.randn(d, device=DEV) * 0.05
