@@ -541,6 +541,52 @@ def test_swag_update_bit_exact(ops):
             assert torch.equal(logical, st.deviations)
 
 
+def test_streaming_kernels_walk_several_grid_passes(ops):
+    """Sizes beyond one pass of the capped grids (2048 workgroups x 256 threads x float4 = 2,097,152 elements): every
+    thread takes several trips of its grid-stride loop.  The other tests stay below that; bench.py runs 23.9 M elements
+    but only times.  SWAG moments bit-exact against the oracle, the samplers / draws against their formulas."""
+    torch.manual_seed(6)
+    d, k = 2_300_003, 3
+    theta0 = torch.randn(d) * 0.05
+    st = O.swag_init(theta0, k)
+    mean, sq = padded(st.mean), padded(st.sq_weights)
+    ring = torch.zeros(k, mean.numel(), device=DEV)
+    head = 0
+    for n in range(1, 5):
+        theta = theta0 + torch.randn(d) * 1e-3 * n
+        st.updates = n
+        O.swag_moment_update(st, theta)
+        ops.swag_update(padded(theta), mean, sq, ring[head], n, d)
+        head = (head + 1) % k
+    assert torch.equal(mean[:d].cpu(), st.mean) and torch.equal(sq[:d].cpu(), st.sq_weights)
+    logical = torch.stack([ring[(head + c) % k, :d].cpu() for c in range(k)], dim=1)
+    assert torch.equal(logical, st.deviations)
+    eps_w, eps_d = O.swag_draw_noise(k, d)
+    want64 = (st.mean.double() + (st.deviations.double() / math.sqrt(2 * (k - 1))) @ eps_w.double()
+              + (0.5 * (torch.relu(st.sq_weights.double() - st.mean.double() ** 2) + 1e-6)).sqrt() * eps_d.double())
+    ref32 = O.swag_sample(st.mean, st.sq_weights, st.deviations, eps_w, eps_d)
+    out = torch.zeros_like(mean)
+    ops.swag_sample(mean, sq, ring, head, out, d, eps_w=eps_w.to(DEV), eps_d=padded(eps_d))
+    err, err_ref = (out[:d].cpu().double() - want64).abs().max().item(), (ref32.double() - want64).abs().max().item()
+    assert err <= max(2 * err_ref, 1e-7), (err, err_ref)
+    # in-kernel noise: the sample is the supplied-noise sample of the Philox stream's normals, element for element
+    ew, ed = torch.zeros(k, device=DEV), torch.zeros_like(mean)
+    ops.philox_normal(9, 4, eps_w=ew, eps_d=ed, d=d, rounds=ops.swag_philox_rounds)
+    a, b = torch.zeros_like(mean), torch.zeros_like(mean)
+    ops.swag_sample(mean, sq, ring, head, a, d, seed=9, stream_id=4)
+    ops.swag_sample(mean, sq, ring, head, b, d, eps_w=ew, eps_d=ed)
+    assert torch.allclose(a[:d], b[:d], rtol=1e-6, atol=1e-7)
+    # Gaussian draw and the local-reparameterisation epilogue
+    rho, eps = torch.randn(mean.numel(), device=DEV) - 2.0, torch.randn(mean.numel(), device=DEV)
+    w = torch.zeros_like(mean)
+    ops.gauss_draw_fwd(mean, rho, w, d, eps=eps)
+    assert torch.allclose(w[:d], (mean + torch.nn.functional.softplus(rho) * eps)[:d], rtol=2e-6, atol=1e-6)
+    var = torch.rand(mean.numel(), device=DEV) + 1e-3
+    ops.local_reparam_fwd(mean, var, w, d, eps=eps)
+    assert torch.allclose(w[:d], (mean + var.sqrt() * eps)[:d], rtol=2e-6, atol=1e-6)
+    assert float(w[d:].abs().max()) == 0.0 if w.numel() > d else True          # nothing written past d
+
+
 def test_swag_sample_golden_and_oracle(ops, golden):
     g = golden("swag_stats.npz")
     for ci in range(len(g["cases"])):
