@@ -34,7 +34,7 @@ DEFAULT = [
     "test_mixture_prior_kernel", "test_gauss_draw_philox", "test_ivon_golden_bit_exact", "test_swag_edge_sizes",
     "test_invalid_arguments_are_rejected", "test_randomized_shapes_against_oracle", "test_var_operand_kernels",
     "test_accumulating_unaligned_and_value_only_variants", "test_svgd_gram_load_flavour_split_does_not_change_results",
-    "test_streaming_kernels_walk_several_grid_passes",
+    "test_streaming_kernels_walk_several_grid_passes", "test_svgd_every_particle_count",
 ]
 # ... and with BDE_EMU_FULL=1 (another ~3 minutes)
 SLOW = ["test_svgd_blocked_path_for_more_than_16_particles", "test_svgd_small_model_fused_step", "test_lrt_linear_forward",

@@ -193,6 +193,74 @@ def test_svgd_small_model_kernel_repeated_calls_and_rbf(ops):
     # (hipGraph capture of this launch: test_svgd_step_is_graph_capturable, whose size takes this path)
 
 
+def test_svgd_every_particle_count(ops):
+    """The SVGD kernels are templates over the particle count (1 .. 16 on the single-tile path): every M once through
+    -phi (against the fp64 anchor), rbf()'s grad_kernel, the fused SGD / Adam steps (== combine + apply), and for M <= 8 the
+    small-model kernel in all its forms.  The reference's configs use 5 particles, BASELINE 8."""
+    torch.manual_seed(23)
+    d = 1003
+    for m in range(1, 17):
+        P = torch.randn(1, d) * 0.05 + torch.randn(m, d) * 0.02
+        G = torch.randn(m, d) * 0.01
+        a, ks = run_svgd_staged(ops, P, G, 3e-4, 1.0, 5000.0)
+        phi64 = O.svgd_phi(P.double(), G.double(), 3e-4, 1.0, 5000.0).numpy()
+        ref32 = O.svgd_phi(P, G, 3e-4, 1.0, 5000.0).numpy().astype(np.float64)
+        tol = max(2 * np.max(np.abs(ref32 - phi64)), 3e-6 * np.max(np.abs(phi64)))
+        assert np.max(np.abs(-a.numpy() - phi64)) <= tol, m
+        Pb, Gb = flat_rows(P), flat_rows(G)
+        ws, kst, out = ops.svgd_ws(m, DEV), ops.svgd_kstat(m, DEV), torch.zeros_like(Pb)
+        ops.svgd_gram(Pb, d, ws)
+        ops.svgd_kstats(ws, m, 0.0, 1.0, 1.0, 1.0, kst, mode=1)                       # rbf(): grad_kernel, no gradients
+        ops.svgd_combine(Pb, None, out, d, kst)
+        _, gk64 = O.svgd_rbf(P.double())
+        _, gk32 = O.svgd_rbf(P)
+        err_ref = (gk32.double() - gk64).abs().max().item()
+        assert (out[:, :d].cpu().double() - gk64).abs().max().item() <= max(2 * err_ref, 3e-6 * gk64.abs().max().item() + 1e-12), m
+        # fused steps == statistics + combine + apply, with carried optimizer state
+        for kind in ("sgd", "adam"):
+            Pa, Pf = flat_rows(P), flat_rows(P)
+            Pa[:, d:] = 0
+            Pf[:, d:] = 0
+            tmp = torch.zeros_like(Gb)
+            ksa, ksf = ops.svgd_kstat(m, DEV), ops.svgd_kstat(m, DEV)
+            s0a, s1a, s0f, s1f = (torch.zeros(Pa.shape[1], device=DEV) for _ in range(4))
+            for it in range(2):
+                ops.svgd_gram(Pa, d, ws)
+                ops.svgd_kstats(ws, m, 3e-4, 1.0, 5000.0, -1.0, ksa)
+                ops.svgd_combine(Pa, Gb, tmp, d, ksa)
+                ops.svgd_gram(Pf, d, ws)
+                ops.svgd_kstats(ws, m, 3e-4, 1.0, 5000.0, -1.0, ksf)
+                if kind == "sgd":
+                    ops.svgd_apply_sgd(Pa, tmp, s0a, d, 0.05, 0.9, 0.0, 3e-4, True, it == 0)
+                    ops.svgd_fused_sgd(Pf, Gb, s0f, d, ksf, 0.05, 0.9, 0.0, 3e-4, True, it == 0)
+                else:
+                    ops.svgd_apply_adam(Pa, tmp, s0a, s1a, d, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m)
+                    ops.svgd_fused_adam(Pf, Gb, s0f, s1f, d, ksf, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m)
+                np.testing.assert_allclose(Pf[:, :d].cpu().numpy(), Pa[:, :d].cpu().numpy(), rtol=3e-6, atol=3e-7, err_msg=str((m, kind, it)))
+        if m > 8:
+            continue
+        # the small-model kernel: -phi, rbf mode, fused SGD / Adam
+        b = torch.zeros_like(Gb)
+        ops.svgd_step_small(Pb, Gb, b, d, 3e-4, 1.0, 5000.0, -1.0, ws, kst)
+        assert np.max(np.abs(-b[:, :d].cpu().numpy() - phi64)) <= tol, m
+        ops.svgd_step_small(Pb, None, b, d, 0.0, 1.0, 1.0, 1.0, ws, kst, mode=1)
+        assert (b[:, :d].cpu().double() - gk64).abs().max().item() <= max(2 * err_ref, 3e-6 * gk64.abs().max().item() + 1e-12), m
+        for kind in ("sgd", "adam"):
+            Pa, Pf = flat_rows(P), flat_rows(P)
+            Pa[:, d:] = 0
+            Pf[:, d:] = 0
+            tmp = torch.zeros_like(Gb)
+            s0a, s1a, s0f, s1f = (torch.zeros(Pa.shape[1], device=DEV) for _ in range(4))
+            ops.svgd_step_small(Pa, Gb, tmp, d, 3e-4, 1.0, 5000.0, -1.0, ws, kst)
+            if kind == "sgd":
+                ops.svgd_apply_sgd(Pa, tmp, s0a, d, 0.05, 0.9, 0.0, 3e-4, True, True)
+                ops.svgd_step_small_sgd(Pf, Gb, s0f, d, 3e-4, 1.0, 5000.0, ws, kst, 0.05, 0.9, 0.0, 3e-4, True, True)
+            else:
+                ops.svgd_apply_adam(Pa, tmp, s0a, s1a, d, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0)
+                ops.svgd_step_small_adam(Pf, Gb, s0f, s1f, d, 3e-4, 1.0, 5000.0, ws, kst, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0)
+            np.testing.assert_allclose(Pf[:, :d].cpu().numpy(), Pa[:, :d].cpu().numpy(), rtol=3e-6, atol=3e-7, err_msg=str((m, kind)))
+
+
 def test_svgd_gram_load_flavour_split_does_not_change_results(ops):
     """The Gram pass loads the head of its walk non-temporally and keeps the last `keep` bytes cacheable for the combine pass
     (svgd.hip; 240 MB by default, so the split is only ever taken at ResNet-50 size).  Forced here at small sizes through the
