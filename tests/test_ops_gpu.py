@@ -541,6 +541,13 @@ def test_svgd_segmented_gradients_equal_flat_rows(ops):
                 else:
                     ops.svgd_fused_adam(Pa, Gflat, s0a, s1a, d, ks, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m, ws_next=wa)
                     ops.svgd_fused_adam_seg(Pb, seg, s0b, s1b, d, ks, 1e-3, 0.9, 0.999, 1e-8, 1e-2, it * m, ws_next=wb)
+            if next_gram:                                       # ... and a step without the riding Gram partials
+                if kind == "sgd":
+                    ops.svgd_fused_sgd(Pa, Gflat, s0a, d, ks, 0.05, 0.9, 0.0, 3e-4, True, False)
+                    ops.svgd_fused_sgd_seg(Pb, seg, s0b, d, ks, 0.05, 0.9, 0.0, 3e-4, True, False)
+                else:
+                    ops.svgd_fused_adam(Pa, Gflat, s0a, s1a, d, ks, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 2 * m)
+                    ops.svgd_fused_adam_seg(Pb, seg, s0b, s1b, d, ks, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 2 * m)
             torch.cuda.synchronize()
             assert torch.equal(Pa, Pb) and torch.equal(s0a, s0b) and torch.equal(s1a, s1b), (m, kind)
             # the padding columns of the particles and of the state stay zero
