@@ -251,6 +251,23 @@ class BayesianOptimizer(Optimizer):
         super().__init__(params, defaults)
         self._step_supports_amp_scaling = True     # lets torch.amp.GradScaler.step() pass its kwargs through
 
+    def _keep_live_base_optimizer(self, live) -> None:
+        """After ``load_state_dict``: the reference keeps the whole base optimizer OBJECT in ``self.state`` (``svgd.py:51``,
+        ``swag.py:28``, ``bbb.py:53``), so a loaded state carries the checkpoint's copy of it -- bound to the checkpoint's
+        copies of the parameters, not to this model's (stepping it would train tensors nobody looks at; in the reference a
+        resumed run does exactly that).  Here the optimizer this shell was CONSTRUCTED with stays in charge and takes over
+        the loaded one's state (momentum / Adam moments, step counts) and hyper-parameters, matched by parameter position as
+        ``torch.optim.Optimizer.state_dict`` does.  Checkpoints written for evaluation are unaffected."""
+        loaded = self.state.get("__base_optimizer")
+        if live is None or loaded is None or loaded is live or not hasattr(loaded, "state_dict"):
+            return
+        try:
+            import copy
+            live.load_state_dict(copy.deepcopy(loaded.state_dict()))     # (a state handed over in-process must not stay shared)
+        except (ValueError, KeyError, RuntimeError):       # another optimizer class / parameter structure: keep what was loaded
+            return
+        self.state["__base_optimizer"] = live
+
     # -- the reference's abstract surface -----------------------------------
     def step(self, forward_closure, backward_closure):
         raise NotImplementedError()

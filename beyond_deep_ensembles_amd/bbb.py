@@ -186,6 +186,7 @@ class BBBOptimizer(BayesianOptimizer):
         super().__init__(params, defaults)
         self._ops = _ops or _default_ops()
         self.state["__base_optimizer"] = base_optimizer
+        self._live_base = base_optimizer
         self.mc_samples = mc_samples
         self.kl_rescaling = kl_rescaling
         self.components = components
@@ -300,6 +301,7 @@ class BBBOptimizer(BayesianOptimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._keep_live_base_optimizer(self._live_base)
         for fg in self._groups:
             fg.invalidate_draw()
         _invalidate_sigma_caches()

@@ -120,6 +120,7 @@ class SVGDOptimizer(BayesianOptimizer):
         # one param group per tensor, like the reference (svgd.py:50): groups distinguish tensors, not particles
         super().__init__([{"params": p} for p in params], {})
         self._ops = _ops or _default_ops()
+        self._live_base = base_optimizer
         for key, value in (("__base_optimizer", base_optimizer), ("__l2_reg", l2_reg), ("__dataset_size", dataset_size),
                            ("__current_particle", 0), ("__particle_count", particle_count),
                            ("__kernel_grad_scale", kernel_grad_scale)):
@@ -1011,6 +1012,7 @@ class SVGDOptimizer(BayesianOptimizer):
         loads the same (complete) dict and keeps its own particles' rows and its column slice of all particles and of
         the shared optimizer state; no communication."""
         super().load_state_dict(state_dict)
+        self._keep_live_base_optimizer(self._live_base)
         self._gram_valid = False
         # shared optimizer state of the fused path: re-adopted (and re-published into base.state) at the next step
         self._fused_loaded = self.state.pop("__fused", None)

@@ -82,6 +82,7 @@ class SwagOptimizer(BayesianOptimizer):
             self.state[param]["original_param"] = view          # swag.py:26 (a clone there)
 
         self.state["__base_optimizer"] = base_optimizer
+        self._live_base = base_optimizer
         self.state["__epoch"] = 0
         self.state["__steps_since_swag_start"] = 0
         self.state["__updates"] = 0
@@ -280,6 +281,7 @@ class SwagOptimizer(BayesianOptimizer):
 
     def load_state_dict(self, state_dict: dict):
         super().load_state_dict(state_dict)
+        self._keep_live_base_optimizer(self._live_base)
         dev, d, ld, k = self._params_device(), self._layout.d, self._layout.ld, self.deviation_samples
         self._prefetched = None                          # rows drawn from the old posterior must not be served
         self._sample_counter = int(self.state.pop("__sample_counter", 0))

@@ -234,3 +234,52 @@ def test_bbb_matches_imported_reference(ref, seed, prior_kind, mc, l2_scale, bas
         loss = float(o_o.step(lambda: F.mse_loss(m_o(xb), yb) + e_o.sum() * 0.01, lambda l: l.backward()).detach())
         assert abs(loss - losses_r[t]) <= 2e-5 * abs(losses_r[t]), (t, loss, losses_r[t])
         np.testing.assert_allclose(flat(p_o).numpy(), traj_r[t].numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("bias,mc", [(True, 3), (False, 1)])
+def test_bbb_linear_parameter_sampling_matches_imported_reference(ref, bias, mc):
+    """BBBLinear(sampling="parameters") (bbb_layers.py:43-60): mc_sample weight (and bias) draws per forward, averaged --
+    our layer and the reference's on the same weights and the same noise tape; plus GaussianParameter.sign_init and
+    collect_kl, which the drivers of the reference call."""
+    sys.path.insert(0, REF)
+    try:
+        import src.algos.bbb_layers as rl
+    finally:
+        sys.path.remove(REF)
+    import beyond_deep_ensembles_amd as bde
+    import beyond_deep_ensembles_amd.util as bu
+    from tests.oracle_ops import OracleOps
+    torch.manual_seed(5)
+    rprior, prior = ref["bbb"].GaussianPrior(0, 1.0), bde.GaussianPrior(0, 1.0)
+    theirs = rl.BBBLinear(6, 4, rprior, rprior, sampling="parameters", mc_sample=mc, bias=bias)
+    ours = bde.BBBLinear(6, 4, prior, prior, sampling="parameters", mc_sample=mc, bias=bias, rng="torch", _ops=OracleOps())
+    with torch.no_grad():
+        ours.weight.mean.copy_(theirs.weight.mean)
+        ours.weight.rho.copy_(theirs.weight.rho)
+        if bias:
+            ours.bias.mean.copy_(theirs.bias.mean)
+            ours.bias.rho.copy_(theirs.bias.rho)
+    x = torch.randn(5, 6)
+    tape = [torch.randn(4, 6) if i % (2 if bias else 1) == 0 else torch.randn(4) for i in range(mc * (2 if bias else 1))]
+    outs = []
+    for mod, layer in ((ref["util"], theirs), (bu, ours)):
+        t = list(tape)
+        old = mod.normal_like
+        mod.normal_like = lambda like: t.pop(0)
+        try:
+            outs.append(layer(x))
+        finally:
+            mod.normal_like = old
+        assert not t
+    torch.testing.assert_close(outs[1], outs[0], rtol=1e-6, atol=1e-7)
+    torch.manual_seed(9)
+    theirs.weight.sign_init()
+    torch.manual_seed(9)
+    ours.weight.sign_init()
+    assert torch.equal(ours.weight.mean, theirs.weight.mean) and torch.equal(ours.weight.rho, theirs.weight.rho)
+    net = nn.Sequential(ours, nn.Sequential(bde.BBBLinear(4, 2, prior, prior, _ops=OracleOps())))
+    net.train()
+    net(x)
+    want = float(ours.kl) + float(net[1][0].kl)
+    from beyond_deep_ensembles_amd.bbb import collect_kl                       # (bbb.py:39-43)
+    assert abs(float(collect_kl(net)) - want) <= 1e-6 * abs(want)

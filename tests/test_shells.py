@@ -297,6 +297,56 @@ def test_svgd_state_dict_roundtrip(backend):
     assert b.state[list(model.parameters())[0]]["particle_1"].data_ptr() == b._pviews[1][0].data_ptr()
 
 
+@pytest.mark.parametrize("algo,base_kind", [("svgd", "sgd"), ("svgd", "adam"), ("svgd_unfused", "sgd"), ("swag", "sgd"), ("swag", "adam")])
+def test_resuming_from_a_pickled_checkpoint_continues_the_run(backend, algo, base_kind, tmp_path):
+    """torch.save(model / optimizer state_dict) -> a NEW model + base optimizer + shell -> torch.load -> load_state_dict, as
+    the reference's drivers resume (iwildcam.py:84-88, ensemble.py:23-26): the resumed run takes the same steps as the
+    uninterrupted one.  The state carries the checkpoint's pickled base optimizer (svgd.py:51, swag.py:28), bound to ITS copies
+    of the parameters; the shell keeps the live base optimizer and hands it the loaded state (momentum / Adam moments, step
+    counts) -- without that a resumed run would step tensors nobody looks at."""
+    ops, dev = backend
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(64, 13, generator=g).to(dev), torch.randn(64, 1, generator=g).to(dev)
+
+    def make(seed):
+        torch.manual_seed(seed)
+        model = make_mlp().to(dev)
+        base = (torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4) if base_kind == "sgd"
+                else torch.optim.Adam(model.parameters(), lr=1e-2))
+        if algo.startswith("svgd"):
+            opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, particle_count=3,
+                                    dataset_size=64, l2_reg=0.01, fuse_base_optimizer="auto" if algo == "svgd" else False, _ops=ops)
+        else:
+            opt = bde.SwagOptimizer(model.parameters(), base, update_interval=1, start_epoch=0, deviation_samples=4, _ops=ops)
+        return model, opt
+
+    def run(model, opt, steps):
+        out = []
+        for t in steps:
+            xb, yb = x[(t % 4) * 16:(t % 4 + 1) * 16], y[(t % 4) * 16:(t % 4 + 1) * 16]
+            out.append(float(opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward()).detach()))
+        return out
+    m1, o1 = make(1)
+    run(m1, o1, range(3))
+    path = str(tmp_path / "ckpt.pt")
+    torch.save({"model": m1.state_dict(), "optimizer": o1.state_dict()}, path)
+    want = run(m1, o1, range(3, 6))                                   # the uninterrupted run goes on
+    m2, o2 = make(2)                                                  # a new process would build these from scratch
+    live_base = o2.get_base_optimizer()
+    ck = torch.load(path, weights_only=False)
+    m2.load_state_dict(ck["model"])
+    o2.load_state_dict(ck["optimizer"])
+    assert o2.get_base_optimizer() is live_base                       # still the optimizer over THIS model's parameters
+    got = run(m2, o2, range(3, 6))
+    np.testing.assert_allclose(got, want, rtol=2e-5)
+    if algo.startswith("svgd"):
+        np.testing.assert_allclose(o2.particles.cpu().numpy(), o1.particles.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    else:
+        for a, b in zip(m1.parameters(), m2.parameters()):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(o2.state["__mean"].cpu().numpy(), o1.state["__mean"].cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
 # ------------------------------------------------------------------ SWAG --
 def test_swag_schedule_bit_exact(golden, backend):
     ops, dev = backend
@@ -616,6 +666,47 @@ def test_ivon_state_dict_roundtrip(backend):
     assert torch.equal(l1, l2)
     for a, b in zip(p1, p2):
         assert torch.equal(o1.state[a]["mean"], o2.state[b]["mean"])
+
+
+def test_bbb_state_dict_roundtrip(backend, monkeypatch):
+    """BBBOptimizer.state_dict() / load_state_dict() (stock Optimizer pickling, as the reference's checkpoints, cifar.py:175-176):
+    a second model + optimizer restored from the first continues with the same losses and weights; loading also drops the
+    layers' cached sigma^2 / prepared convolution weights (they belong to the weights that were just replaced)."""
+    ops, dev = backend
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    torch.manual_seed(0)
+    x, y = torch.randn(16, 1, 8, 8, device=dev), torch.randn(16, 3, device=dev)
+    prior = bde.GaussianPrior(0, 1.0)
+
+    def make():
+        model = nn.Sequential(bde.BBBConv2d(1, 4, 3, prior, prior, padding=1, _ops=ops), nn.ReLU(), nn.Flatten(),
+                              bde.BBBLinear(256, 3, prior, prior, _ops=ops)).to(dev)
+        base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+        return model, bde.BBBOptimizer(model.parameters(), base, prior, dataset_size=16, mc_samples=2, _ops=ops)
+    tape = [torch.randn(16, 4, 8, 8), torch.randn(16, 3)] * 64
+    pos = [0]
+
+    def replay(t):
+        pos[0] += 1
+        return tape[pos[0] - 1][: t.shape[0]].to(t.device).reshape(t.shape)
+    monkeypatch.setattr(L, "normal_like", replay)
+    m1, o1 = make()
+    for _ in range(2):
+        o1.step(lambda: F.mse_loss(m1(x), y), lambda l: l.backward())
+    sd_model, sd_opt = m1.state_dict(), o1.state_dict()
+    m2, o2 = make()
+    m2(x)                                                             # fills the new layers' caches with ITS initial weights
+    m2.load_state_dict(sd_model)
+    epoch = L._SigmaCache.epoch
+    o2.load_state_dict(sd_opt)
+    assert L._SigmaCache.epoch > epoch                                # load_state_dict invalidates the per-version caches
+    start = pos[0]
+    l1 = o1.step(lambda: F.mse_loss(m1(x), y), lambda l: l.backward())
+    pos[0] = start
+    l2 = o2.step(lambda: F.mse_loss(m2(x), y), lambda l: l.backward())
+    torch.testing.assert_close(l2, l1, rtol=1e-6, atol=1e-7)
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
 
 
 # -------------------------------------------------------------- ensemble --
