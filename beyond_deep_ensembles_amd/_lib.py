@@ -95,6 +95,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 401        # csrc/version.hip, include/bde_hip.h
 
 
 class BdeLibraryError(RuntimeError):
@@ -125,6 +126,12 @@ def load() -> ctypes.CDLL:
             raise BdeLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    # the C signatures of existing exports have changed between ABI versions (symbol NAMES alone do not show a stale
+    # build): the table above describes exactly one version
+    have = int(lib.bde_version())
+    if have != ABI_VERSION:
+        raise BdeLibraryError(f"{LIB_PATH} reports ABI version {have}, these bindings are written for {ABI_VERSION}: "
+                              "rebuild it (make -C beyond_deep_ensembles_amd/csrc)")
     _lib = lib
     return lib
 

@@ -264,7 +264,15 @@ class BayesianOptimizer(Optimizer):
         try:
             import copy
             live.load_state_dict(copy.deepcopy(loaded.state_dict()))     # (a state handed over in-process must not stay shared)
-        except (ValueError, KeyError, RuntimeError):       # another optimizer class / parameter structure: keep what was loaded
+        except (ValueError, KeyError, RuntimeError) as e:  # another optimizer class / parameter structure: keep what was loaded
+            import warnings
+            warnings.warn(
+                f"{type(self).__name__}.load_state_dict: the checkpoint's base optimizer ({type(loaded).__name__}) does not fit "
+                f"the one this optimizer was constructed with ({type(live).__name__}): {type(e).__name__}: {e}.  The loaded "
+                "object stays in charge; it is bound to the checkpoint's copies of the parameters, so continuing to TRAIN "
+                "with it will not move this model (evaluation is unaffected).  Construct the optimizer with a base "
+                "optimizer of the checkpoint's class and parameter structure to resume training.", RuntimeWarning,
+                stacklevel=3)
             return
         self.state["__base_optimizer"] = live
 

@@ -237,6 +237,20 @@ class _ConvWeights:
         return self.buf
 
 
+def _conv_profitable(x_shape, w_shape, stride, padding, ops, needs_grad) -> bool:
+    """fused_conv="auto": fused only where conv_profit.json records a device measurement of THIS kernel version that beats
+    the stock sequence for the pass at hand (forward, or forward + backward)."""
+    from . import conv_profit
+    abi = getattr(ops, "_abi_version", None)
+    if abi is None:
+        abi = int(ops.lib.bde_version()) if hasattr(getattr(ops, "lib", None), "bde_version") else -1
+        try:
+            ops._abi_version = abi
+        except AttributeError:
+            pass
+    return conv_profit.profitable(tuple(x_shape), tuple(w_shape), stride, padding, needs_grad, abi)
+
+
 class _ConvLrt(torch.autograd.Function):
     """The whole forward of a mean-field convolution layer in local-reparameterisation form (bbb_layers.py:146-154) as
     ONE fused op (bde_conv_lrt_fwd: both convolutions as one dual-accumulator implicit GEMM over the same staged input
@@ -298,14 +312,12 @@ class _LocalReparamLayer(nn.Module):
         self.fused_epilogue = kwargs.get("fused_epilogue", True)     # one HIP pass for mean + sqrt(var) * eps
         self.fused_linear = kwargs.get("fused_linear", True)         # BBBLinear: the whole forward as one fused op
         self.sigma_cache = kwargs.get("sigma_cache", True)           # wide BBBLinear: sigma^2 once per weight version
-        self.fused_conv = kwargs.get("fused_conv", True)             # BBBConv2d: both convolutions + epilogue as one fused op
+        # BBBConv2d: both convolutions + epilogue as one fused op.  "auto" (default): only at geometries where a DEVICE
+        # measurement shows the fused kernels ahead of the stock sequence (conv_profit.py); True: wherever the kernels
+        # have a tiling; False: never (stock convolutions + fused element-wise passes)
+        self.fused_conv = kwargs.get("fused_conv", "auto")
         self._sigma_cache = _SigmaCache()
         self._conv_weights = _ConvWeights()
-
-        def drop_caches():
-            self._sigma_cache.drop()
-            self._conv_weights.drop()
-        self.invalidate_sigma_cache = drop_caches
         self.weight_prior, self.bias_prior = weight_prior, bias_prior
         gp_kwargs = {k: kwargs[k] for k in ("rng", "seed", "_ops") if k in kwargs}
         self.weight = GaussianParameter(weight_shape, **gp_kwargs)
@@ -317,6 +329,19 @@ class _LocalReparamLayer(nn.Module):
         self.weight.blundell_init()
         if self.use_bias:
             self.bias.blundell_init()
+
+    def invalidate_sigma_cache(self) -> None:
+        """Drop this layer's cached sigma^2 / prepared convolution weights (after an edit of ``rho.data`` that the
+        version counter cannot see).  A method, not a closure: layers stay picklable and a deep copy drops ITS caches."""
+        self._sigma_cache.drop()
+        self._conv_weights.drop()
+
+    def __getstate__(self):
+        # the caches hold device buffers keyed on tensor addresses of THIS process: a copy / an unpickled layer starts cold
+        state = dict(self.__dict__)
+        state["_sigma_cache"] = _SigmaCache()
+        state["_conv_weights"] = _ConvWeights()
+        return state
 
     @property
     def kl(self):
@@ -435,7 +460,10 @@ class BBBConv2d(_LocalReparamLayer):
                 and hasattr(w._get_ops(), "conv_lrt_fwd"):
             ops = w._get_ops()
             stride, padding = _pair(self.stride), _pair(self.padding)
-            if ops.conv_lrt_supported(input.shape, w.mean.shape, stride, padding):
+            if ops.conv_lrt_supported(input.shape, w.mean.shape, stride, padding) and (
+                    self.fused_conv is True or _conv_profitable(
+                        input.shape, w.mean.shape, stride, padding, ops,
+                        torch.is_grad_enabled() and (input.requires_grad or w.mean.requires_grad or w.rho.requires_grad))):
                 eps = None
                 if not (w.rng == "philox" and w.noise_source is None):
                     ho = (input.shape[2] + 2 * padding[0] - self.kernel_size) // stride[0] + 1

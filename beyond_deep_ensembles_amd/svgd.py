@@ -97,7 +97,9 @@ class SVGDOptimizer(BayesianOptimizer):
                               exactly when that is indistinguishable from particle_count calls of base.step() -- a
                               plain torch.optim.SGD / Adam (not a subclass) over exactly this optimizer's parameters,
                               one set of hyper-parameters, no amsgrad / maximize / capturable / differentiable /
-                              decoupled_weight_decay, no step hooks, particle_count <= 64 (and, for 17..64 particles,
+                              decoupled_weight_decay, no step hooks AT CONSTRUCTION (a hook registered on the base
+                              optimizer later makes the next step raise: the fused update never calls base.step(), so it
+                              could not run the hook), particle_count <= 64 (and, for 17..64 particles,
                               no chunked or dimension-sharded exchange) -- and the torch loop (False) otherwise; an
                               enabled GradScaler keeps the torch loop as well.  Up to 16 particles:
                               one pass; 17 to 64 (single GPU or exchange="allgather" without chunks): the blocked
@@ -725,7 +727,15 @@ class SVGDOptimizer(BayesianOptimizer):
         keys = [k for k in g0 if k != "params"]
         for g in groups[1:]:
             if any(g[k] != g0[k] for k in keys):
-                raise RuntimeError("fuse_base_optimizer needs identical hyper-parameters in all param groups")
+                raise RuntimeError("fuse_base_optimizer needs identical hyper-parameters in all param groups (they were "
+                                   "equal when this SVGDOptimizer was constructed): give the groups one set of "
+                                   "hyper-parameters or construct with fuse_base_optimizer=False")
+        # fusability was decided at construction; the fused kernels never call base.step(), so a step hook registered on
+        # the base optimizer SINCE would silently never run -- refuse instead
+        if getattr(base, "_optimizer_step_pre_hooks", None) or getattr(base, "_optimizer_step_post_hooks", None):
+            raise RuntimeError("the base optimizer has step hooks, which the fused SVGD update (fuse_base_optimizer) cannot "
+                               "call: register hooks before constructing the SVGDOptimizer (then 'auto' keeps the torch "
+                               "loop) or pass fuse_base_optimizer=False")
         return g0
 
     def _fused_buffers(self, base, kind):

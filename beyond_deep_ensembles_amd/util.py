@@ -132,6 +132,15 @@ class GaussianParameter(nn.Module):
             self._ops = _default_ops()
         return self._ops
 
+    def __getstate__(self):
+        # the kernel backend wraps this process's handle of libbde_hip.so (ctypes): a pickled / deep-copied module takes
+        # none along and binds the library again at its first use (torch.save(model) works as it does for the reference)
+        state = dict(self.__dict__)
+        from .ops import HipOps
+        if isinstance(state.get("_ops"), HipOps):
+            state["_ops"] = None
+        return state
+
     def sample(self) -> torch.Tensor:
         # util.py:170-171: mean + normal_like(std) * std
         group = getattr(self, "_flat_group", None)

@@ -27,12 +27,47 @@ def pytest_collection_modifyitems(config, items):
                 item.add_marker(pytest.mark.timeout(1500, method="thread"))
     except ImportError:
         pass
+    _hardware_verified_first(items)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# Test functions that were part of the last full `-m gpu` suite that ran green on an MI355X under the driver (round 3,
+# GPUTEST_r03.json: 117 passed).  Everything else -- written while the GPU pool was closed, or re-run there only in part --
+# is collected BEHIND them, and the multi-rank files last: the driver runs `pytest -x`, and a failure in the least
+# verified tests must not leave the kernel parity tests "unreached" (the first GPU call of round 4
+# stopped at test 17 of the old order).  An ordering only -- nothing is skipped.
+_NEW_SINCE_LAST_GREEN_SUITE = {
+    "test_accumulating_unaligned_and_value_only_variants", "test_bbb_components_and_sample_callers_reproduce_reference_trajectory",
+    "test_bbb_conv2d_fused_path_selection_and_weight_cache", "test_bbb_conv2d_layer_matches_reference_layer",
+    "test_bbb_state_dict_roundtrip", "test_conv_lrt_backward", "test_conv_lrt_forward", "test_predict_distributed_rccl_one_rank",
+    "test_resuming_from_a_pickled_checkpoint_continues_the_run", "test_step_hooks_and_profiler_ranges_still_work",
+    "test_streaming_kernels_walk_several_grid_passes", "test_svgd_every_particle_count",
+    "test_svgd_gram_load_flavour_split_does_not_change_results", "test_svgd_rccl_one_rank_forced_exchange",
+    "test_svgd_small_model_fused_step", "test_svgd_small_model_kernel", "test_svgd_small_model_kernel_repeated_calls_and_rbf",
+    "test_svgd_streaming_path_through_the_shell", "test_swag_batched_sampler_both_kernels_equal_single_samples",
+    "test_swag_sampler_noise_statistics_over_2_to_30_normals",
+}
+_FILE_ORDER = ["test_abi", "test_oracle_golden", "test_philox", "test_ops_gpu", "test_fullsize_gpu", "test_shells"]
+_LAST_FILES = ["test_dist_gpu", "test_dist_fullsize_gpu"]
+
+
+def _order_key(nodeid: str, name: str):
+    fname = os.path.splitext(os.path.basename(nodeid.split("::")[0]))[0]
+    base = name.split("[")[0]
+    if fname in _LAST_FILES:
+        return (3, _LAST_FILES.index(fname), base in _NEW_SINCE_LAST_GREEN_SUITE)
+    new = base in _NEW_SINCE_LAST_GREEN_SUITE or base.startswith("test_r5_")
+    rank = _FILE_ORDER.index(fname) if fname in _FILE_ORDER else len(_FILE_ORDER)
+    return (1 if new else 0, rank, False)
+
+
+def _hardware_verified_first(items) -> None:
+    items.sort(key=lambda it: _order_key(it.nodeid, it.name))      # stable: the order inside a group is the files' own
 
 
 @pytest.fixture(scope="session")
