@@ -2,8 +2,12 @@
 """The fused BBBConv2d kernels per ResNet-20 layer shape (batch 128) and a few ImageNet-sized ones, each against the reference's
 op sequence in PyTorch on the same GPU: forward (bde_conv_lrt_fwd vs two MIOpen convolutions + element-wise ops,
 bbb_layers.py:146-154), input gradient (one launch over the zero-dilated gradient vs one launch per phase for strided
-layers), weight gradient, and the backward of the reference's sequence through autograd."""
-import os, sys
+layers), weight gradient, and the backward of the reference's sequence through autograd.
+
+--table [PATH]: also write the profitability table BBBConv2d(fused_conv="auto") reads (beyond_deep_ensembles_amd/conv_profit.py;
+default PATH gpurun_out/conv_profit.json -- copy it to beyond_deep_ensembles_amd/conv_profit.json and file this tool's output under
+profiles/): per layer geometry the forward-only and forward + backward speed-ups over the reference's sequence."""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
@@ -12,6 +16,11 @@ import bench
 
 dev = torch.device("cuda", 0)
 ops = HipOps()
+table_path = None
+if "--table" in sys.argv:
+    i = sys.argv.index("--table")
+    table_path = sys.argv[i + 1] if i + 1 < len(sys.argv) and not sys.argv[i + 1].startswith("-") else "gpurun_out/conv_profit.json"
+table = {"abi": int(ops.lib.bde_version()), "source": "tools/conv_lrt_bench.py on " + torch.cuda.get_device_name(0), "layers": {}}
 shapes = [(128, 3, 32, 32, 16, 3, 1, 1), (128, 16, 32, 32, 16, 3, 1, 1), (128, 16, 32, 32, 32, 3, 2, 1), (128, 32, 16, 16, 32, 3, 1, 1),
           (128, 32, 16, 16, 64, 3, 2, 1), (128, 64, 8, 8, 64, 3, 1, 1), (128, 16, 32, 32, 32, 1, 2, 0),
           (32, 64, 56, 56, 64, 3, 1, 1), (32, 256, 14, 14, 256, 3, 1, 1), (32, 256, 56, 56, 64, 1, 1, 0)]
@@ -78,3 +87,11 @@ for n, c, h, w, o, k, s, p in shapes:
     print(f"    backward: g_var {tg*1e6:7.1f}  input gradient {td*1e6:8.1f}" + (f" (per phase {tp*1e6:8.1f})" if s > 1 else "") +
           f"  weight gradient {tw*1e6:8.1f} us;  forward + backward kernels {ours*1e6:8.1f} us vs the reference's sequence through autograd "
           f"{tref*1e6:8.1f} us = {tref/ours:5.2f}x", flush=True)
+    from beyond_deep_ensembles_amd import conv_profit
+    table["layers"][conv_profit._key(c, o, k, s, p, h, w)] = {"batch": n, "fwd": round(tt / tf, 3), "fwd_bwd": round(tref / ours, 3),
+                                                               "fused_us": round(ours * 1e6, 1), "reference_us": round(tref * 1e6, 1)}
+if table_path:
+    os.makedirs(os.path.dirname(os.path.abspath(table_path)), exist_ok=True)
+    with open(table_path, "w") as f:
+        json.dump(table, f, indent=1)
+    print("wrote", table_path)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5, second GPU call (after tools/gpu_r5a.sh is green): the round's rocprofv3 evidence on the final tree, the
+# profitability table of the fused convolution, and the A/Bs queued since round 4.
+O=gpurun_out/r5b; mkdir -p $O
+export PYTHONDONTWRITEBYTECODE=1 HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 900 python tools/conv_lrt_bench.py --table $O/conv_profit.json > $O/conv_lrt_bench.txt 2>&1; grep -v amdgpu $O/conv_lrt_bench.txt | tail -40
+timeout 2400 bash tools/gpu_profile.sh r05 > $O/gpu_profile.log 2>&1; tail -30 $O/gpu_profile.log | cut -c1-200
+timeout 600 python tools/gram_split_ab.py > $O/gram_split_ab.txt 2>&1; grep -v amdgpu $O/gram_split_ab.txt | tail -30
+for i in 1 2; do
+timeout 300 python tools/swag_batched_ab.py >> $O/swag_batched_rounds_ab.txt 2>&1
+timeout 300 python tools/swag_batched_ab.py tools/bin/libbde_philox10.so >> $O/swag_batched_rounds_ab.txt 2>&1
+done
+grep -v amdgpu.ids $O/swag_batched_rounds_ab.txt | tail -30
