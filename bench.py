@@ -701,7 +701,7 @@ def config_extras(dev):
                    "resnet20_16to32_s2_b128": (128, 16, 32, 32, 32, 3, 2, 1), "resnet20_32ch_b128": (128, 32, 16, 16, 32, 3, 1, 1),
                    "resnet20_32to64_s2_b128": (128, 32, 16, 16, 64, 3, 2, 1), "resnet20_64ch_b128": (128, 64, 8, 8, 64, 3, 1, 1)}
     for cname, (cn, cc_, chh, cww, co, ck, cs, cp) in conv_shapes.items():
-        conv = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox").to(dev)
+        conv = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=True).to(dev)
         conv3 = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=False).to(dev)
         conv3.load_state_dict(conv.state_dict())
         xc = torch.randn(cn, cc_, chh, cww, device=dev, requires_grad=True)
@@ -734,7 +734,11 @@ def config_extras(dev):
                     "kernels (1 forward launch; g_var + input-gradient + weight-gradient + finish launches backward) vs the "
                     "reference's op sequence under autograd (two MIOpen convolutions forward, four backward, ~25 element-wise "
                     "launches) and vs round 3's composition (stock convolutions + fused element-wise passes)",
-            "native_autograd_nodes": _bl._native_nodes(conv.weight._get_ops()) is not None}
+            "native_autograd_nodes": _bl._native_nodes(conv.weight._get_ops()) is not None,
+            # what BBBConv2d() without a keyword does at this geometry: the fused kernels only where conv_profit.json records
+            # a device measurement of this kernel version that beats the stock sequence (forward + backward)
+            "default_path": "fused" if _bl._conv_profitable((cn, cc_, chh, cww), (co, cc_, ck, ck), (cs, cs), (cp, cp),
+                                                             conv.weight._get_ops(), True) else "stock (round-3 composition)"}
         del conv, conv3, xc
 
     # ---- configs[0]: BBBOptimizer.step on the UCI-housing MLP (13 -> 50 -> 1 BBBLinear, 5 MC samples, Adam), whole

@@ -53,6 +53,7 @@ SIGNATURES = {
     "bde_svgd_fused_adam_seg": (c_int, [_P, _P, _P, c_int64, _P, _P, c_int, c_int64, c_int64, _P, c_double, c_double,
                                         c_double, c_double, c_double, c_int64, _P, _P]),
     "bde_svgd_gather_seg": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, _P]),
+    "bde_sum_scalars": (c_int, [_P, c_int, _P, _P]),
     "bde_swag_update": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P]),
     "bde_swag_sample": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_swag_sample_batched": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_int64, c_uint64, c_uint64, _P, c_int64,
@@ -95,7 +96,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 401        # csrc/version.hip, include/bde_hip.h
+ABI_VERSION = 402        # csrc/version.hip, include/bde_hip.h
 
 
 class BdeLibraryError(RuntimeError):

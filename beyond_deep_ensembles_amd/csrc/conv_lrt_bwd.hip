@@ -41,7 +41,7 @@ template <> struct MfmaW<16> {
 };
 
 // LDS: xs [NI][cmax][PH][PWP] | x2s | gs [MF][GP] | gvs [MF][GP] | pixtab [npix]   (reused for the wave reduction)
-template <int MF, int CT_MAX>
+template <int MF, int CT>
 __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                 const float* __restrict__ gvar, float* __restrict__ part,
                                                                 WgGeo geo, WgTile t) {
@@ -55,9 +55,8 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane / MF, idx = lane % MF;
   const int otile = blockIdx.y / t.colgroups, cg = blockIdx.y % t.colgroups;
-  const int o0 = otile * MF, col0 = cg * t.CT * MF;
-  const int col_end = min(ktot, col0 + t.CT * MF);
-  const int nct = (col_end - col0 + MF - 1) / MF;              // column tiles of this group with a column inside the matrix
+  const int o0 = otile * MF, col0 = cg * CT * MF;                // (t.CT == CT: the host instantiates the planner's choice)
+  const int col_end = min(ktot, col0 + CT * MF);
   const int c_lo = col0 / khw, c_hi = (col_end - 1) / khw, cc = c_hi - c_lo + 1;
   const int img_floats = cc * row_elems;
   const int patch_floats = t.NI * t.cmax * row_elems;
@@ -67,19 +66,19 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
   float* gvs = gs + MF * t.GP;
   int* pixtab = reinterpret_cast<int*>(gvs + MF * t.GP);
 
-  int kofs[CT_MAX];
+  int kofs[CT];
 #pragma unroll
-  for (int ct = 0; ct < CT_MAX; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     const int col = col0 + ct * MF + idx;
     kofs[ct] = 0;
-    if (ct < t.CT && col < ktot) {
+    if (col < ktot) {                                            // a column past the matrix multiplies patch element 0: never stored
       const int c = col / khw - c_lo, rq = col % khw;
       kofs[ct] = c * row_elems + (rq / geo.KW) * t.PWP + (rq % geo.KW);
     }
   }
-  Acc accm[CT_MAX], accv[CT_MAX];
+  Acc accm[CT], accv[CT];
 #pragma unroll
-  for (int ct = 0; ct < CT_MAX; ++ct) accm[ct] = accv[ct] = Acc{};
+  for (int ct = 0; ct < CT; ++ct) accm[ct] = accv[ct] = Acc{};
 
   const int bpi = t.TH * geo.Wo;                               // band pixels per image
   const int64_t howo = static_cast<int64_t>(geo.Ho) * geo.Wo;
@@ -146,43 +145,82 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     }
     __syncthreads();
     const int ksteps = t.npix / KS;
-    for (int ks = wave; ks < ksteps; ks += 4) {
-      const int pix = ks * KS + h;
-      const int po = pixtab[pix];
-      const float am = gs[idx * t.GP + pix], av = gvs[idx * t.GP + pix];
+    // the operands of this wave's NEXT k-step are requested before the products of the current one are issued (as in the
+    // forward kernel): the LDS round trip hides behind 2 CT MFMAs instead of stalling in front of them
+    int ks = wave;
+    int po = 0;
+    float am = 0.f, av = 0.f, b[CT], b2[CT];
 #pragma unroll
-      for (int ct = 0; ct < CT_MAX; ++ct) {
-        if (ct < nct) {                                        // wave-uniform
-          const float b = xs[po + kofs[ct]], b2 = x2s[po + kofs[ct]];
-          accm[ct] = M::run(am, b, accm[ct]);
-          accv[ct] = M::run(av, b2, accv[ct]);
+    for (int ct = 0; ct < CT; ++ct) b[ct] = b2[ct] = 0.f;
+    if (ks < ksteps) {
+      const int pix = ks * KS + h;
+      po = pixtab[pix];
+      am = gs[idx * t.GP + pix];
+      av = gvs[idx * t.GP + pix];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        b[ct] = xs[po + kofs[ct]];
+        b2[ct] = x2s[po + kofs[ct]];
+      }
+    }
+    for (; ks < ksteps; ks += 4) {
+      const float cam = am, cav = av;
+      float cb[CT], cb2[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        cb[ct] = b[ct];
+        cb2[ct] = b2[ct];
+      }
+      if (ks + 4 < ksteps) {
+        const int pix = (ks + 4) * KS + h;
+        po = pixtab[pix];
+        am = gs[idx * t.GP + pix];
+        av = gvs[idx * t.GP + pix];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          b[ct] = xs[po + kofs[ct]];
+          b2[ct] = x2s[po + kofs[ct]];
         }
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        accm[ct] = M::run(cam, cb[ct], accm[ct]);
+        accv[ct] = M::run(cav, cb2[ct], accv[ct]);
       }
     }
   }
 
-  // ---- the four waves' blocks summed in wave order through LDS (one wave's block at a time: 18-32 KB)
+  // ---- the four waves' blocks summed through LDS as a fixed two-round tree, (w0 + w1) + (w2 + w3): round 1 waves 1 and 3
+  //      hand their blocks to waves 0 and 2, round 2 wave 2 hands its sum to wave 0 (two blocks of CT tiles in LDS at a time:
+  //      the planner reserves them).  Fixed order: bit-reproducible.
   float* red = lds;
-  for (int s = 1; s < 4; ++s) {
-    __syncthreads();
-    if (wave == s) {
+  constexpr int per_wave = CT * 2 * M::REGS * 64;
+#pragma unroll 1
+  for (int round = 0; round < 2; ++round) {
+    const bool writer = round == 0 ? (wave & 1) == 1 : wave == 2;
+    const bool reader = round == 0 ? (wave & 1) == 0 : wave == 0;
+    float* slot = red + (round == 0 ? (wave >> 1) : 0) * per_wave;     // round 1: pair (0, 1) -> slot 0, pair (2, 3) -> slot 1
+    __syncthreads();                                             // the operand reads (round 2: the readers of round 1) are done
+    if (writer) {
 #pragma unroll
-      for (int ct = 0; ct < CT_MAX; ++ct)
+      for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
         for (int r = 0; r < M::REGS; ++r) {
-          red[((ct * 2 + 0) * M::REGS + r) * 64 + lane] = accm[ct][r];
-          red[((ct * 2 + 1) * M::REGS + r) * 64 + lane] = accv[ct][r];
+          slot[((ct * 2 + 0) * M::REGS + r) * 64 + lane] = accm[ct][r];
+          slot[((ct * 2 + 1) * M::REGS + r) * 64 + lane] = accv[ct][r];
         }
+      }
     }
     __syncthreads();
-    if (wave == 0) {
+    if (reader) {
 #pragma unroll
-      for (int ct = 0; ct < CT_MAX; ++ct)
+      for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
         for (int r = 0; r < M::REGS; ++r) {
-          accm[ct][r] += red[((ct * 2 + 0) * M::REGS + r) * 64 + lane];
-          accv[ct][r] += red[((ct * 2 + 1) * M::REGS + r) * 64 + lane];
+          accm[ct][r] += slot[((ct * 2 + 0) * M::REGS + r) * 64 + lane];
+          accv[ct][r] += slot[((ct * 2 + 1) * M::REGS + r) * 64 + lane];
         }
+      }
     }
   }
   if (wave != 0) return;
@@ -190,9 +228,9 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
   float* pm = part + static_cast<int64_t>(blockIdx.x) * 2 * geo.O * ktot;
   float* pv = pm + static_cast<int64_t>(geo.O) * ktot;
 #pragma unroll
-  for (int ct = 0; ct < CT_MAX; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     const int col = col0 + ct * MF + idx;
-    if (ct < t.CT && col < ktot) {
+    if (col < ktot) {
 #pragma unroll
       for (int r = 0; r < M::REGS; ++r) {
         const int o = o0 + M::row(r, h);
@@ -243,7 +281,7 @@ static bool plan_wgrad(const WgGeo& g, WgPlan& p) {
   const int regs = mf == 32 ? 16 : 4;
   const int khw = g.KH * g.KW, ktot = g.C * khw;
   const int otiles = (g.O + mf - 1) / mf;
-  const size_t red = sizeof(float) * static_cast<size_t>(ct_max) * 2 * regs * 64;
+  // (the wave reduction keeps two waves' blocks of ct tiles in LDS at a time: checked per candidate below)
   bool found = false;
   double best_score = -1.0;
   WgTile best{};
@@ -266,10 +304,16 @@ static bool plan_wgrad(const WgGeo& g, WgPlan& p) {
       int gp = npix;
       if (mf == 32) gp |= 1; else gp = (gp + 31) / 32 * 32 + 2;
       const size_t lds = sizeof(float) * (2ull * ni * cmax * ph * pwp + 2ull * mf * gp + npix);
+      const size_t red = sizeof(float) * 2ull * ct * 2 * regs * 64;
       if (std::max(lds, red) > 64 * 1024) continue;
       const int items = ((g.N + ni - 1) / ni) * bands;
       const int blocks = otiles * colgroups;
-      const int ps = std::max(1, std::min(items, (768 + blocks - 1) / blocks));
+      // Shares: ONE resident set of workgroups (256 CUs x 2 per CU = 512 slots; round 4 asked for 768, i.e. a second, half
+      // empty wave of workgroups and half as many more partial blocks to write and re-read), every share the same number
+      // of items (+- 1): ps = ceil(items / items_per_share)
+      const int ps_cap = std::max(1, std::min(items, 512 / blocks));
+      const int per_share = (items + ps_cap - 1) / ps_cap;
+      const int ps = (items + per_share - 1) / per_share;
       const double fill = std::min(1.0, static_cast<double>(ps) * blocks / 512.0);
       const double halo = static_cast<double>(th) / ph;
       const double big = std::min(1.0, static_cast<double>(npix) / 256.0);      // enough k-steps per staging
@@ -335,10 +379,18 @@ extern "C" int bde_conv_lrt_bwd_weight(const float* x, const float* g, const flo
     return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(ws);
-  if (p.mf == 16)
-    hipLaunchKernelGGL((conv_lrt_wgrad_kernel<16, 9>), p.grid, dim3(256), p.lds, s, x, g, gvar, part, geo, p.t);
-  else
-    hipLaunchKernelGGL((conv_lrt_wgrad_kernel<32, 4>), p.grid, dim3(256), p.lds, s, x, g, gvar, part, geo, p.t);
+  // one instantiation per (tile size, column tiles per workgroup): the product loop carries no per-tile branch
+  bool launched = false;
+#define BDE_WGRAD_CASE(MF_, CT_)                                                                                      \
+  if (!launched && p.mf == MF_ && p.t.CT == CT_) {                                                                    \
+    hipLaunchKernelGGL((conv_lrt_wgrad_kernel<MF_, CT_>), p.grid, dim3(256), p.lds, s, x, g, gvar, part, geo, p.t);    \
+    launched = true;                                                                                                  \
+  }
+  BDE_WGRAD_CASE(16, 1) BDE_WGRAD_CASE(16, 2) BDE_WGRAD_CASE(16, 3) BDE_WGRAD_CASE(16, 4) BDE_WGRAD_CASE(16, 5)
+  BDE_WGRAD_CASE(16, 6) BDE_WGRAD_CASE(16, 7) BDE_WGRAD_CASE(16, 8) BDE_WGRAD_CASE(16, 9)
+  BDE_WGRAD_CASE(32, 1) BDE_WGRAD_CASE(32, 2) BDE_WGRAD_CASE(32, 3) BDE_WGRAD_CASE(32, 4)
+#undef BDE_WGRAD_CASE
+  if (!launched) return BDE_ERR_INVALID;
   const int64_t n = static_cast<int64_t>(O) * C * KH * KW;
   hipLaunchKernelGGL(conv_lrt_wgrad_finish_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, part, p.t.PS, n, w_rho, g_wmu,
                      g_wrho);

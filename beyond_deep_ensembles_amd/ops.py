@@ -344,6 +344,26 @@ class HipOps:
         _check(self.lib.bde_svgd_gather_seg(seg.ptrs.data_ptr(), seg.chunks.data_ptr() + 32 * q0, q1 - q0, _ptr(G, "G"),
                                             seg.m, row0, n_rows, _ld(G), _stream()), "bde_svgd_gather_seg")
 
+    def sum_scalars(self, scalars, out) -> None:
+        """out[()] = ((s0 + s1) + s2) + ... in fp32, this order, ONE launch (bde_sum_scalars): the returned loss of a
+        step (svgd.py:66,72: ``total_loss += loss`` per particle).  ``scalars``: 1..64 fp32 one-element device tensors."""
+        import ctypes
+        n = len(scalars)
+        if not 1 <= n <= 64:
+            raise BdeKernelError("sum_scalars: 1..64 scalars expected")
+        ptrs = (ctypes.c_void_p * n)()
+        for i, t in enumerate(scalars):
+            if t.numel() != 1 or t.device != out.device:
+                raise BdeKernelError("sum_scalars: one-element tensors on the output's device expected")
+            ptrs[i] = _ptr(t, "scalar")
+        if out.numel() != 1:
+            raise BdeKernelError("sum_scalars: out must hold one element")
+        if out.device.type == "cuda" and out.device.index != torch.cuda.current_device():
+            with torch.cuda.device(out.device):
+                _check(self.lib.bde_sum_scalars(ptrs, n, _ptr(out, "out"), _stream()), "bde_sum_scalars")
+            return
+        _check(self.lib.bde_sum_scalars(ptrs, n, _ptr(out, "out"), _stream()), "bde_sum_scalars")
+
     # ------------------------------------------------------------ SWAG --
     @_on_device_of
     def swag_update(self, theta, mean, sq, dev_row, n, d):

@@ -354,20 +354,32 @@ class SVGDOptimizer(BayesianOptimizer):
         row_off = local.start if self._exchange == "alltoall" else 0
         first, last = local.start, local.stop - 1
         pset.begin(first)
-        total_loss = None
+        losses = []
         for particle_idx in local:
             loss = forward_closure()
-            if total_loss is None:
-                total_loss = loss.detach().to(device=self._P.device if self._P is not None else self._Pown.device,
-                                              dtype=torch.float32, copy=True)
-            else:
-                total_loss += loss.detach()
+            losses.append(loss.detach())
             backward_closure(loss)
             if particle_idx != last:
                 pset.end_begin(particle_idx, table, particle_idx - row_off, m_tab, zero, particle_idx + 1)
             else:
                 pset.end(particle_idx, table, particle_idx - row_off, m_tab, zero)
-        return self._posterior_update(total_loss, None)
+        return self._posterior_update(self._sum_losses(losses), None)
+
+    def _sum_losses(self, losses):
+        """svgd.py:66,72: ``total_loss = tensor(0.0); total_loss += loss`` per particle -- the same fp32 sum in the same
+        order (0 + x == x bit for bit, so the first loss starts it), by ONE launch (bde_sum_scalars) when the losses are
+        fp32 scalars on the particles' device, by torch's adds otherwise (a half-precision or off-device loss).  A small
+        model's step is launch-bound: seven torch adds cost more host time than its whole posterior update."""
+        dev = self._P.device if self._P is not None else self._Pown.device
+        if 1 < len(losses) <= 64 and hasattr(self._ops, "sum_scalars") and all(
+                t.dtype == torch.float32 and t.numel() == 1 and t.device == dev for t in losses):
+            total = torch.empty((), dtype=torch.float32, device=dev)
+            self._ops.sum_scalars(losses, total)
+            return total
+        total = losses[0].to(device=dev, dtype=torch.float32, copy=True)
+        for t in losses[1:]:
+            total += t
+        return total
 
     def _particle_set(self):
         """The native object that runs the per-particle loops over its own tensor lists (csrc/host.cpp ParticleSet);

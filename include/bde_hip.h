@@ -186,6 +186,11 @@ int bde_svgd_fused_adam_seg(float* P, const void* const* seg_ptrs, const bde_seg
  * collective exchanges and the single-launch kernel read); pieces that already live there are skipped. */
 int bde_svgd_gather_seg(const void* const* seg_ptrs, const bde_seg_chunk* chunks, int64_t n_chunks, float* G, int M,
                         int row0, int n_rows, int64_t ld, void* stream);
+/* out[0] = ((*v[0] + *v[1]) + *v[2]) + ... in fp32, in this order: the loss a step returns (svgd.py:66,72 `total_loss +=
+ * loss` per particle, :105) summed by ONE launch instead of one torch add per particle.  ``scalars`` is a HOST array of n
+ * (1 <= n <= 64) device pointers to fp32 scalars; it is read during the call (the pointers travel in the kernel's
+ * argument block), so it may be a temporary.  `out` may be one of the inputs. */
+int bde_sum_scalars(const float* const* scalars, int n, float* out, void* stream);
 
 /* Shared-state base-optimizer apply for the M particles, in particle order
  * (svgd.py:92-103 with ONE torch.optim.SGD / Adam whose state is keyed on the

@@ -93,6 +93,12 @@ class OracleOps:
                 src = torch.frombuffer((ctypes.c_float * nflt).from_address(addr), dtype=torch.float32)
                 G[j, 4 * c4:4 * c4 + nflt] = src
 
+    def sum_scalars(self, scalars, out):
+        total = scalars[0].detach().reshape(()).clone()
+        for t in scalars[1:]:                                       # svgd.py:72: total_loss += loss, particle by particle
+            total += t.detach().reshape(())
+        out.reshape(()).copy_(total)
+
     def svgd_combine_seg(self, P, seg, out, d, kstat):
         self.svgd_combine(P, self._seg_rows(seg, P.shape[1], range(seg.m)), out, d, kstat)
 

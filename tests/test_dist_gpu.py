@@ -154,7 +154,20 @@ def _check_svgd_rccl_world1(tmp_path, name, m, kw):
         # alltoall: Gram reduced slice-wise through fp64 blocks; reuse_gram: the next step's Gram partials come out of the
         # fused kernel, whose flat-row form (sharded) and segmented form (single process) sum them chunk-wise in different
         # fixed orders -- 1-ulp differences in the statistics
-        np.testing.assert_allclose(r0["particles"], opt.particles.cpu().numpy(), rtol=1e-5, atol=2e-7)
+        a, b = r0["particles"].astype(np.float32), opt.particles.cpu().numpy().astype(np.float32)
+        # the size of the difference in units in the last place of the larger operand (recorded, so that the tolerance below
+        # is a measured figure: VERDICT r4 #2)
+        ulp = np.abs(a - b) / np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32))
+        line = (f"rccl_one_rank[{name}]: max |sharded - single| = {np.abs(a - b).max():.3e} = {ulp.max():.1f} ulp "
+                f"(mean {ulp.mean():.3f} ulp) over {a.size} particle elements after 4 steps")
+        print(line)
+        try:
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open("gpurun_out/rccl_one_rank_ulps.log", "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=2e-7)
         np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=2e-6)
     else:
         np.testing.assert_array_equal(r0["particles"], opt.particles.cpu().numpy())

@@ -35,6 +35,7 @@ DEFAULT = [
     "test_invalid_arguments_are_rejected", "test_randomized_shapes_against_oracle", "test_var_operand_kernels",
     "test_accumulating_unaligned_and_value_only_variants", "test_svgd_gram_load_flavour_split_does_not_change_results",
     "test_streaming_kernels_walk_several_grid_passes", "test_svgd_every_particle_count",
+    "test_r5_sum_scalars_is_the_sequential_fp32_sum",
 ]
 # ... and with BDE_EMU_FULL=1 (another ~3 minutes)
 SLOW = ["test_svgd_blocked_path_for_more_than_16_particles", "test_svgd_small_model_fused_step", "test_lrt_linear_forward",
@@ -128,7 +129,7 @@ def test_bbb_conv2d_channels_last_inputs_and_weights(emu, monkeypatch):
     monkeypatch.setattr(L, "_native_nodes", lambda ops: None)
     torch.manual_seed(2)
     prior = bde.GaussianPrior(0, 1.0)
-    conv = bde.BBBConv2d(6, 8, 3, prior, prior, padding=1, _ops=emu).train()
+    conv = bde.BBBConv2d(6, 8, 3, prior, prior, padding=1, fused_conv=True, _ops=emu).train()
     x = torch.randn(2, 6, 9, 9)
     noise = torch.randn(2, 8, 9, 9)
     monkeypatch.setattr(L, "normal_like", lambda t: noise)

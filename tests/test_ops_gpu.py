@@ -1491,3 +1491,34 @@ def test_lrt_linear_random_shapes(ops):
             # the backward is evaluated at OUR forward's variance (fp32, 1-2 ulp from the fp32 reference's): allow for it
             tol += 1e-6 * r64.abs().max().item()
             assert (ours.cpu().double() - r64).abs().max().item() <= tol, (name, b, i, o, bias)
+
+
+def test_r5_sum_scalars_is_the_sequential_fp32_sum(ops):
+    """bde_sum_scalars: out = ((s0 + s1) + s2) + ... in fp32 -- bit for bit the loss svgd.py:66,72 accumulates particle by
+    particle -- for every count 1..64, scalars that live in separate allocations / inside other tensors, out aliasing an
+    input; bad arguments are refused."""
+    from beyond_deep_ensembles_amd.ops import BdeKernelError
+    rng = np.random.default_rng(7)
+    for n in list(range(1, 18)) + [31, 32, 33, 63, 64]:
+        vals = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4, n)).astype(np.float32)
+        block = torch.from_numpy(vals).to(DEV)
+        # every other scalar is a view into one block, the others are their own 0-dim tensors
+        scalars = [block[i] if i % 2 else torch.tensor(float(vals[i]), dtype=torch.float32, device=DEV) for i in range(n)]
+        out = torch.full((), float("nan"), dtype=torch.float32, device=DEV)
+        ops.sum_scalars(scalars, out)
+        want = np.float32(vals[0])
+        for v in vals[1:]:
+            want = np.float32(want + v)
+        assert out.cpu().numpy() == want, (n, float(out), float(want))
+    a, b = torch.tensor(1.5, device=DEV), torch.tensor([2.25], device=DEV)
+    ops.sum_scalars([a, b], a)                                   # out aliases the first input
+    assert float(a) == 3.75
+    with pytest.raises(BdeKernelError):
+        ops.sum_scalars([], a)
+    with pytest.raises(BdeKernelError):
+        ops.sum_scalars([a] * 65, a)
+    with pytest.raises(BdeKernelError):
+        ops.sum_scalars([torch.zeros(2, device=DEV)], a)
+    with pytest.raises(BdeKernelError):
+        ops.sum_scalars([a.double()], a)
+

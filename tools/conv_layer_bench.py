@@ -27,7 +27,7 @@ def ev(fn, iters=30, warm=5):
 
 print(f"{'input':>22} {'elements':>10} {'torch us':>9} {'epilogue':>9} {'ep+x2':>9} {'all fused':>10}")
 for (n, c, hw) in [(128, 16, 32), (128, 64, 8), (128, 64, 32), (512, 64, 32), (64, 256, 56)]:
-    conv = bde.BBBConv2d(c, c, 3, prior, prior, padding=1, rng="philox").to(dev)
+    conv = bde.BBBConv2d(c, c, 3, prior, prior, padding=1, rng="philox", fused_conv=False).to(dev)
     x = torch.randn(n, c, hw, hw, device=dev, requires_grad=True)
     leaves = [x, conv.weight.mean, conv.weight.rho, conv.bias.mean, conv.bias.rho]
     ops = conv.weight._get_ops()
