@@ -214,6 +214,94 @@ def test_svgd_streaming_path_through_the_shell(backend, variant):
         assert float(base.state_dict()["state"][0]["step"]) == 3 * m
 
 
+# the 96 parameter tensors of the reference's CIFAR model (experiments/cifar/models.py: ResNet20(32, 3, 10, "swish", "frn"),
+# 273,610 elements; shapes read off the imported reference, written out here because the reference cannot travel)
+def _cifar_resnet20_shapes():
+    def conv_frn(cout, cin):                                     # a 3x3 convolution, then the FRN layer's four tensors
+        return [(cout, cin, 3, 3), (cout,)] + [(1, cout, 1, 1)] * 3
+    shapes = [(16, 3, 3, 3), (16,)]                              # stem
+    shapes += conv_frn(16, 16) * 6                               # stage 1: three blocks of two convolutions
+    shapes += conv_frn(32, 16) + conv_frn(32, 32) + [(32, 16, 1, 1)] + conv_frn(32, 32) * 4      # stage 2 (1x1 shortcut)
+    shapes += conv_frn(64, 32) + conv_frn(64, 64) + [(64, 32, 1, 1)] + conv_frn(64, 64) * 4      # stage 3
+    return shapes + [(10, 64), (10,)]                            # classifier
+
+
+@pytest.mark.parametrize("variant", ["default_sgd", "default_adam", "unfused_sgd"])
+def test_r5_cifar_resnet20_sized_svgd_step_through_the_shell(backend, variant):
+    """BASELINE configs[1] at its REAL size through the product shell: the 96 parameter tensors of the reference's CIFAR
+    ResNet-20 (273,610 elements), 8 particles, the base optimizer of cifar.yaml (nesterov SGD, momentum 0.9, weight decay) /
+    Adam -- i.e. gather_seg -> the small-model kernel's two launches with the fused shared-state optimizer applications
+    (default constructor), or its combine form + 8 torch steps (fuse_base_optimizer=False).  Two steps (the first and a later
+    application of the shared momentum), each checked against the oracle from the SAME particles and gradients in fp32 and
+    fp64: |ours - fp64| <= max(2 |ref32 - fp64|, 3e-6 max|step|) (svgd.py:14-32,82-103)."""
+    if getattr(backend[0], "name", "") == "hip_emu" and variant != "default_sgd":
+        pytest.skip("on the CPU model one of the three variants (40 s): the others run the same kernel's other template forms, "
+                    "which test_svgd_small_model_fused_step covers")
+    import oracle.bde_oracle as O
+    ops, dev = backend
+    torch.manual_seed(33)
+    shapes = _cifar_resnet20_shapes()
+    assert len(shapes) == 96 and sum(int(np.prod(sh)) for sh in shapes) == 273_610
+    params = [nn.Parameter(torch.randn(sh, device=dev) * 0.05) for sh in shapes]
+    m, n_data, l2 = 8, 50000.0, 3e-4
+
+    def reset():
+        with torch.no_grad():
+            for p in params:
+                p.copy_(torch.randn_like(p) * 0.05)
+
+    def make_base(ps):
+        if variant.endswith("adam"):
+            return torch.optim.Adam(ps, lr=1e-3, weight_decay=5e-4)
+        return torch.optim.SGD(ps, lr=0.1, momentum=0.9, nesterov=True, weight_decay=5e-4)
+    base = make_base(params)
+    kw = dict(fuse_base_optimizer=False) if variant.startswith("unfused") else {}
+    opt = bde.SVGDOptimizer(params, reset, base, particle_count=m, dataset_size=n_data, l2_reg=l2, _ops=ops, **kw)
+    assert ops.svgd_small_supported(m, opt._layout.d)              # the small-model kernel's range
+    assert bool(opt._fuse) == (not variant.startswith("unfused"))
+    numels = [p.numel() for p in params]
+
+    def split(row):
+        return [t.view(sh) for t, sh in zip(row.split(numels), shapes)]
+    tracks = {}
+    for dt in (torch.float32, torch.float64):
+        cpu_params = [torch.nn.Parameter(torch.zeros(sh, dtype=dt)) for sh in shapes]
+        tracks[dt] = (cpu_params, make_base(cpu_params))
+    coef = [torch.randn(sh, device=dev) * 0.01 for sh in shapes]
+    grads = []
+
+    def forward():                                                  # a loss whose gradient differs per particle: a + 0.3 p
+        return sum((a * p).sum() + 0.15 * (p * p).sum() for a, p in zip(coef, params))
+
+    def backward(loss):
+        loss.backward()
+        grads.append(torch.cat([p.grad.detach().reshape(-1) for p in params]).cpu())
+    for t in range(2):
+        before = opt.particles.cpu().clone()
+        grads.clear()
+        loss = opt.step(forward, backward)
+        assert torch.isfinite(loss)
+        G = torch.stack(grads)
+        after = opt.particles.cpu()
+        want = {}
+        for dt, (cpu_params, cpu_base) in tracks.items():
+            P = before.to(dt).clone()
+            neg_phi = -O.svgd_phi(P, G.to(dt), l2, 1.0, n_data)
+            rows = [split(P[i]) for i in range(m)]
+            O.svgd_apply_shared_optimizer(rows, [split(neg_phi[i]) for i in range(m)], cpu_params, cpu_base)
+            want[dt] = P
+        step_size = float((want[torch.float64] - before.double()).abs().max())
+        err_ref = float((want[torch.float32].double() - want[torch.float64]).abs().max())
+        err = float((after.double() - want[torch.float64]).abs().max())
+        assert step_size > 0
+        assert err <= max(2 * err_ref, 3e-6 * step_size), (variant, t, err, err_ref, step_size)
+        # the returned loss: mean of the particle losses (svgd.py:105), summed particle by particle in fp32
+        want_loss = float(sum(float(sum((a.cpu().double() * p).sum() + 0.15 * (p * p).sum()
+                                        for a, p in zip(coef, split(before[i].double())))) for i in range(m)) / m)
+        assert abs(float(loss) - want_loss) <= 2e-5 * abs(want_loss) + 1e-6, (float(loss), want_loss)
+    np.testing.assert_array_equal(flat(params).cpu().numpy(), opt.particles[m - 1].cpu().numpy())
+
+
 def test_step_hooks_and_profiler_ranges_still_work(backend):
     """BayesianOptimizer.step skips torch's per-call wrapper (profiler range + hook dispatch: a third of a small model's
     step in host time) only while it has nothing to do: a step pre / post hook registered on the optimizer (or globally)
