@@ -127,7 +127,7 @@ class StreamProbes:
         assert rc == 0, (shape, rc)
 
 
-def extras(ops, dev, quick):
+def extras(ops, dev, quick, on_section=None):
     """Secondary hot-path kernels: seconds per launch, algorithmic GB/s, fraction of the 8 TB/s HBM peak, and -- round 4 --
     beside every streaming kernel a no-arithmetic probe of the same read / write shape on the same tensors
     (probe_GBps, frac_of_probe = kernel rate / probe rate; StreamProbes)."""
@@ -179,16 +179,6 @@ def extras(ops, dev, quick):
     rec("svgd_step_M8_resnet50_independent_particles",
         time_loop(lambda: ops.svgd_step(Pi, Gi, outb, d, 0.0, 1.0, DATASET_SIZE, -1.0, ws, ks), it), 16 * M * d, 1, "steps_per_s")
     del Pi, Gi, P, G, outb
-    d20 = D_RESNET20
-    P2, G2 = make_svgd_inputs(d20, dev, 1234)
-    o2 = torch.empty_like(G2)
-    rec("svgd_step_M8_resnet20", time_loop(lambda: ops.svgd_step(P2, G2, o2, d20, 3e-4, 1.0, 50000.0, -1.0, ws, ks), 50),
-        16 * M * d20, 1, "steps_per_s")
-    b2 = torch.zeros(pad_ld(d20), device=dev)
-    t = time_loop(lambda: ops.svgd_step_small_sgd(P2, G2, b2, d20, 3e-4, 1.0, 50000.0, ws, ks, 1e-12, 0.9, 0.0, 3e-4,
-                                                  True, False), 50)
-    rec("svgd_full_step_fused_sgd_M8_resnet20_2_launches", t, (12 * M + 8) * d20, 1, "steps_per_s")
-    del P2, G2, o2, b2
     # --- SWAG: the K + 2 statistics rows are the rows of one [K + 2, ld] buffer (ring rows, then mean, then second moment)
     stat = torch.randn(K_SWAG + 2, ld, device=dev, generator=g) * 1e-3
     stat[K_SWAG] = torch.randn(ld, device=dev, generator=g) * 0.05
@@ -263,6 +253,20 @@ def extras(ops, dev, quick):
     rec("ivon_update_resnet50", time_loop(lambda: ops.ivon_update(mean2, mom, prec, ds, gm, d, lam=100.0 / DATASET_SIZE, n_eff=DATASET_SIZE, mc=2,
                                                                    beta1=0.9, beta2=0.999, t=1, lr=1e-12, damping=1e-3), it), 32 * d,
         probe=dict(shape=(2, 0, 3), n=d, rd=[ds, gm], rw=[mean2, mom, prec]))
+    if on_section is not None:
+        on_section(out)
+    # LAST: the small-model kernel was rewritten after its last run on an MI355X; what was measured
+    # above has been handed to `on_section` before it is launched
+    d20 = D_RESNET20
+    P2, G2 = make_svgd_inputs(d20, dev, 1234)
+    o2 = torch.empty_like(G2)
+    rec("svgd_step_M8_resnet20", time_loop(lambda: ops.svgd_step(P2, G2, o2, d20, 3e-4, 1.0, 50000.0, -1.0, ws, ks), 50),
+        16 * M * d20, 1, "steps_per_s")
+    b2 = torch.zeros(pad_ld(d20), device=dev)
+    t = time_loop(lambda: ops.svgd_step_small_sgd(P2, G2, b2, d20, 3e-4, 1.0, 50000.0, ws, ks, 1e-12, 0.9, 0.0, 3e-4,
+                                                  True, False), 50)
+    rec("svgd_full_step_fused_sgd_M8_resnet20_2_launches", t, (12 * M + 8) * d20, 1, "steps_per_s")
+    del P2, G2, o2, b2
     out["probe_note"] = ("probe_GBps / frac_of_probe: a no-arithmetic kernel with the SAME number of read / written / "
                          "read-modify-written rows on the SAME tensors (bench_probe/probe.hip), timed right beside the kernel: "
                          "frac_of_probe = kernel rate / probe rate; the probe walks its rows at the kernel's own addresses")
@@ -826,6 +830,115 @@ def config_extras(dev):
     return out
 
 
+def single_gpu_extras(ops, dev, args, sink=None):
+    """Everything under `extra` that one process on one GPU measures (every other kernel at ResNet-50 size, the product
+    shells' steps, the other BASELINE configs); each section catches its own exceptions.  ``sink``: a file that receives
+    the sections finished so far after each of them (the child process of extras_in_child: what was measured before a
+    fault survives it)."""
+    ex = {}
+
+    def checkpoint():
+        if sink:
+            with open(sink, "w") as fh:
+                json.dump(ex, fh)
+
+    def first_sections(part):
+        ex.update(part)
+        checkpoint()
+    try:
+        ex.update(extras(ops, dev, quick=False, on_section=first_sections))
+    except Exception as e:                  # the headline line above must survive a failing extra
+        import traceback
+        ex.update({"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]})
+        log(f"  extras failed: {ex['error']}")
+    checkpoint()
+    try:
+        ex["svgd_shell_step_ms"] = shell_step_ms(dev)
+        log(f"  svgd_shell_step_ms {ex['svgd_shell_step_ms']}")
+        if not args.no_config_extras:       # other sizes: kept out of the PMC passes (one size per kernel there)
+            ex["svgd_shell_step_densenet121_ms"] = shell_step_ms(dev, n_tensors=364, d=D_DENSENET)
+            log(f"  svgd_shell_step_densenet121_ms {ex['svgd_shell_step_densenet121_ms']}")
+    except Exception as e:
+        log(f"  svgd_shell_step_ms skipped: {e}")
+    checkpoint()
+    try:
+        ex["svgd_shell_step_real_grads_ms"] = shell_step_real_grads_ms(dev)
+        if not args.no_config_extras:
+            ex["svgd_shell_step_real_grads_densenet121_ms"] = \
+                shell_step_real_grads_ms(dev, 364, D_DENSENET)
+        log(f"  svgd_shell_step_real_grads_ms {ex['svgd_shell_step_real_grads_ms']}")
+        # the drop-in a user of the reference actually gets: the reference's own constructor call
+        ref_ctor = {"m8": shell_step_real_grads_ms(dev, ctor="reference"),
+                    "m8_fuse_base_optimizer_false": shell_step_real_grads_ms(dev, ctor="reference_unfused", steps=6),
+                    "m5_reference_particle_count": shell_step_real_grads_ms(dev, ctor="reference", particles=5)}
+        base_step = ex["svgd_shell_step_real_grads_ms"]["step_ms"]
+        ref_ctor["m8_vs_opt_in_step"] = round(ref_ctor["m8"]["step_ms"] / base_step, 3)
+        ref_ctor["what"] = ("SVGDOptimizer built exactly as experiments/iwildcam/models.py:120 builds it (Adam lr 3e-5, "
+                            "no extra keyword -> fuse_base_optimizer='auto'), real ResNet-50 tensor shapes, real "
+                            "gradients; m8_vs_opt_in_step = its step time / svgd_shell_step_real_grads_ms.step_ms "
+                            "(fused nesterov SGD + reuse_gram, opt-in keywords)")
+        ex["svgd_reference_constructor_step"] = ref_ctor
+        log(f"  svgd_reference_constructor_step {ref_ctor}")
+    except Exception as e:
+        log(f"  svgd_shell_step_real_grads_ms skipped: {type(e).__name__}: {e}")
+    checkpoint()
+    try:
+        ex["other_shell_steps_ms"] = other_shell_steps_ms(dev)
+        log(f"  other_shell_steps_ms {ex['other_shell_steps_ms']}")
+    except Exception as e:
+        log(f"  other_shell_steps_ms skipped: {type(e).__name__}: {e}")
+    checkpoint()
+    try:
+        # LAST: this section launches kernels that have never run on an MI355X (the fused BBBConv2d kernels, forced on)
+        if not args.no_config_extras:
+            ex["other_baseline_configs"] = config_extras(dev)
+            for k, v in ex["other_baseline_configs"].items():
+                log(f"  {k}: {v['ms']} ms")
+    except Exception as e:
+        log(f"  other_baseline_configs skipped: {type(e).__name__}: {e}")
+    checkpoint()
+    return ex
+
+
+def extras_in_child(args, dev_index, limit_s=1500):
+    """`extra` measured by a CHILD process (`python bench.py --extras-child FILE`): a Python exception in an extra is caught
+    section by section, but a GPU fault or a hang in one of them -- several run kernels that have never executed on an
+    MI355X -- would take the process down before the headline line is printed.  The parent has
+    finished (and freed) the headline workload when this starts; the child is a new process (no exec of this one), gets
+    `limit_s` seconds, and its exact PID is killed on a timeout."""
+    import subprocess
+    import tempfile
+    fd, path = tempfile.mkstemp(suffix=".json", prefix="bde_bench_extra_")
+    os.close(fd)
+    cmd = [sys.executable, os.path.abspath(__file__), "--extras-child", path, "--gpus", "1"]
+    if args.no_config_extras:
+        cmd.append("--no-config-extras")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GROUP_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env["BDE_BENCH_DEVICE"] = str(dev_index)
+    try:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL)       # its log lines go to our stderr
+        try:
+            rc = proc.wait(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.wait()
+            return {"error": f"the extras child did not finish within {limit_s} s and was killed"}
+        try:
+            with open(path) as f:
+                out = json.load(f)
+        except (OSError, ValueError):
+            out = {}
+        if rc != 0:
+            out["error"] = f"the extras child exited with code {rc}" + (" after writing these sections" if out else "")
+        return out
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
 def timed_blocks(step, steps, blocks, dist, dev):
     """`blocks` blocks of exactly `steps` steps, each bracketed by barrier + synchronize; MAX over ranks per block."""
     out = []
@@ -960,7 +1073,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config-extras", action="store_true",
                     help="skip extra.other_baseline_configs (smaller launches of the same kernels; PMC passes average per kernel)")
+    ap.add_argument("--extras-in-process", action="store_true",
+                    help="measure `extra` in this process instead of a child (profiling runs: rocprofv3 then sees those kernels "
+                         "in THIS process's trace; a GPU fault in an extra then costs the whole line)")
+    ap.add_argument("--extras-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.extras_child:                          # the child of extras_in_child(): `extra` only, written to a file
+        dev_index = int(os.environ.get("BDE_BENCH_DEVICE", "0"))
+        torch.cuda.set_device(dev_index)
+        from beyond_deep_ensembles_amd.ops import HipOps
+        dev = torch.device("cuda", dev_index)
+        single_gpu_extras(HipOps(), dev, args, sink=args.extras_child)      # writes the file section by section
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -1161,40 +1285,10 @@ def main():
             torch.cuda.empty_cache()
             if not args.no_extras and d == D_RESNET50:
                 log("extras ...")
-                try:
-                    res["extra"] = extras(ops, dev, quick=False)
-                except Exception as e:                  # the headline line above must survive a failing extra
-                    import traceback
-                    res["extra"] = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
-                    log(f"  extras failed: {res['extra']['error']}")
-                try:
-                    res["extra"]["svgd_shell_step_ms"] = shell_step_ms(dev)
-                    log(f"  svgd_shell_step_ms {res['extra']['svgd_shell_step_ms']}")
-                    if not args.no_config_extras:       # other sizes: kept out of the PMC passes (one size per kernel there)
-                        res["extra"]["svgd_shell_step_densenet121_ms"] = shell_step_ms(dev, n_tensors=364, d=D_DENSENET)
-                        log(f"  svgd_shell_step_densenet121_ms {res['extra']['svgd_shell_step_densenet121_ms']}")
-                except Exception as e:
-                    log(f"  svgd_shell_step_ms skipped: {e}")
-                try:
-                    res["extra"]["svgd_shell_step_real_grads_ms"] = shell_step_real_grads_ms(dev)
-                    if not args.no_config_extras:
-                        res["extra"]["svgd_shell_step_real_grads_densenet121_ms"] = \
-                            shell_step_real_grads_ms(dev, 364, D_DENSENET)
-                    log(f"  svgd_shell_step_real_grads_ms {res['extra']['svgd_shell_step_real_grads_ms']}")
-                    # the drop-in a user of the reference actually gets: the reference's own constructor call
-                    ref_ctor = {"m8": shell_step_real_grads_ms(dev, ctor="reference"),
-                                "m8_fuse_base_optimizer_false": shell_step_real_grads_ms(dev, ctor="reference_unfused", steps=6),
-                                "m5_reference_particle_count": shell_step_real_grads_ms(dev, ctor="reference", particles=5)}
-                    base_step = res["extra"]["svgd_shell_step_real_grads_ms"]["step_ms"]
-                    ref_ctor["m8_vs_opt_in_step"] = round(ref_ctor["m8"]["step_ms"] / base_step, 3)
-                    ref_ctor["what"] = ("SVGDOptimizer built exactly as experiments/iwildcam/models.py:120 builds it (Adam lr 3e-5, "
-                                        "no extra keyword -> fuse_base_optimizer='auto'), real ResNet-50 tensor shapes, real "
-                                        "gradients; m8_vs_opt_in_step = its step time / svgd_shell_step_real_grads_ms.step_ms "
-                                        "(fused nesterov SGD + reuse_gram, opt-in keywords)")
-                    res["extra"]["svgd_reference_constructor_step"] = ref_ctor
-                    log(f"  svgd_reference_constructor_step {ref_ctor}")
-                except Exception as e:
-                    log(f"  svgd_shell_step_real_grads_ms skipped: {type(e).__name__}: {e}")
+                if args.extras_in_process:
+                    res["extra"] = single_gpu_extras(ops, dev, args)
+                else:
+                    res["extra"] = extras_in_child(args, dev_index)
                 if dist is not None:
                     # one rank under torch.distributed.run: the product's multi-GPU update forced through the RCCL
                     # collectives (all_gather_into_tensor in place, the chunk pipeline, all_to_all_single)
@@ -1210,18 +1304,6 @@ def main():
                                    "multi-GPU step executes (self-exchange, no wire); exchange_ms is launch + copy cost")
                     res["extra"]["rccl_one_rank"] = one
                     log(f"  rccl_one_rank {one}")
-                try:
-                    res["extra"]["other_shell_steps_ms"] = other_shell_steps_ms(dev)
-                    log(f"  other_shell_steps_ms {res['extra']['other_shell_steps_ms']}")
-                except Exception as e:
-                    log(f"  other_shell_steps_ms skipped: {type(e).__name__}: {e}")
-                try:
-                    if not args.no_config_extras:
-                        res["extra"]["other_baseline_configs"] = config_extras(dev)
-                        for k, v in res["extra"]["other_baseline_configs"].items():
-                            log(f"  {k}: {v['ms']} ms")
-                except Exception as e:
-                    log(f"  other_baseline_configs skipped: {type(e).__name__}: {e}")
         print(json.dumps(res), flush=True)
     if dist:
         dist.barrier()

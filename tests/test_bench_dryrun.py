@@ -137,7 +137,9 @@ def test_main_prints_the_contract_line(dry, monkeypatch, capsys, launched):
         for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"),
                          ("MASTER_PORT", str(port)), ("BDE_BENCH_BACKEND", "gloo")):
             monkeypatch.setenv(key, val)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--blocks", "3", "--no-cpu-baseline"])
+    # --extras-in-process: the stub library lives in THIS process (the default runs `extra` in a child process, below)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--blocks", "3", "--no-cpu-baseline",
+                                      "--extras-in-process"])
     bench.main()
     lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -156,3 +158,50 @@ def test_main_prints_the_contract_line(dry, monkeypatch, capsys, launched):
         one = extra["rccl_one_rank"]
         for kind in ("allgather", "pipelined", "alltoall"):
             assert "error" not in one[kind] and one[kind]["step_ms"] > 0, (kind, one[kind])
+
+
+def test_a_dying_extras_child_does_not_cost_the_line(dry, monkeypatch, tmp_path):
+    """By default `extra` is measured by a child process (bench.extras_in_child): several extras launch kernels that have
+    never run on an MI355X, and a GPU fault there must not take the headline line with it.  The sections a child finished
+    before it died are kept, the death is reported under `error`; a child that hangs is killed (its exact PID) at the limit."""
+    import argparse
+    bench, ops, dev = dry
+    args = argparse.Namespace(no_config_extras=True)
+    script = tmp_path / "child.py"
+
+    def run(body, limit=60):
+        script.write_text("import json, os, sys, time\nout = sys.argv[sys.argv.index('--extras-child') + 1]\n" + body)
+        monkeypatch.setattr(bench, "__file__", str(script))
+        return bench.extras_in_child(args, 0, limit_s=limit)
+    whole = run("json.dump({'svgd_combine_M8_resnet50': {'ms': 0.4}}, open(out, 'w'))\n")
+    assert whole == {"svgd_combine_M8_resnet50": {"ms": 0.4}}
+    died = run("json.dump({'a': 1}, open(out, 'w'))\nos.abort()\n")            # as a GPU fault ends a process: SIGABRT
+    assert died["a"] == 1 and "exited with code" in died["error"]
+    nothing = run("os._exit(3)\n")
+    assert "exited with code 3" in nothing["error"]
+    hung = run("json.dump({'b': 2}, open(out, 'w'))\ntime.sleep(600)\n", limit=2)
+    assert "killed" in hung["error"]
+
+
+def test_the_real_extras_child_reports_sections_through_its_file(dry, monkeypatch, tmp_path):
+    """single_gpu_extras(sink=...) -- what the child process runs -- rewrites the file after every section: the first block
+    of kernels, each shell step, and LAST the sections that launch never-verified kernels."""
+    import argparse
+    import json
+    bench, ops, dev = dry
+    sink = tmp_path / "extra.json"
+    seen = []
+    real_shell = bench.shell_step_ms
+
+    def shell(*a, **k):
+        seen.append(sorted(json.load(open(sink))))                   # what had reached the file when the 2nd section began
+        return real_shell(*a, **k)
+    monkeypatch.setattr(bench, "shell_step_ms", shell)
+    monkeypatch.setattr(bench, "shell_step_real_grads_ms", lambda *a, **k: {"step_ms": 1.0})
+    monkeypatch.setattr(bench, "other_shell_steps_ms", lambda *a, **k: {"tensors": 1})
+    ex = bench.single_gpu_extras(ops, dev, argparse.Namespace(no_config_extras=True), sink=str(sink))
+    assert seen and "svgd_combine_M8_resnet50" in seen[0] and "svgd_full_step_fused_sgd_M8_resnet20_2_launches" in seen[0]
+    assert json.load(open(sink)) == json.loads(json.dumps(ex))
+    order = list(ex)
+    assert order.index("svgd_combine_M8_resnet50") < order.index("svgd_step_M8_resnet20")       # never-verified kernels last
+
