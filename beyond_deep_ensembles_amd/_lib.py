@@ -74,6 +74,11 @@ SIGNATURES = {
     "bde_conv_lrt_supported": (c_int, [c_int] * 11),
     "bde_conv_lrt_plan": (c_int, [c_int] * 12 + [_P]),
     "bde_conv_lrt_bwd_weight_plan": (c_int, [c_int] * 11 + [_P]),
+    "bde_conv_lrt_pass_geos": (c_int, [c_int, _P, _P, c_int]),
+    "bde_conv_lrt_candidates": (c_int, [_P, _P, c_int, _P]),
+    "bde_conv_lrt_set_tiling": (c_int, [_P, c_int, c_int, c_int, c_int]),
+    "bde_conv_lrt_wgrad_candidates": (c_int, [_P, _P, c_int, _P]),
+    "bde_conv_lrt_wgrad_set_tiling": (c_int, [_P, c_int, c_int, c_int, c_int]),
     "bde_conv_lrt_prep_floats": (c_size_t, [c_int] * 4),
     "bde_conv_lrt_prep": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "bde_conv_lrt_prep_strided": (c_int, [_P, _P, _P] + [c_int] * 8 + [_P, _P]),
@@ -96,7 +101,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 402        # csrc/version.hip, include/bde_hip.h
+ABI_VERSION = 403        # csrc/version.hip, include/bde_hip.h
 
 
 class BdeLibraryError(RuntimeError):

@@ -248,6 +248,8 @@ def _conv_profitable(x_shape, w_shape, stride, padding, ops, needs_grad) -> bool
             ops._abi_version = abi
         except AttributeError:
             pass
+    if hasattr(ops, "conv_lrt_set_tiling"):
+        conv_profit.apply_tilings(ops, tuple(x_shape), tuple(w_shape), stride, padding, abi)    # the autotuned tilings, once
     return conv_profit.profitable(tuple(x_shape), tuple(w_shape), stride, padding, needs_grad, abi)
 
 
@@ -460,10 +462,12 @@ class BBBConv2d(_LocalReparamLayer):
                 and hasattr(w._get_ops(), "conv_lrt_fwd"):
             ops = w._get_ops()
             stride, padding = _pair(self.stride), _pair(self.padding)
+            # (_conv_profitable also pins the tilings tools/conv_autotune.py recorded for this layer, forced path included)
             if ops.conv_lrt_supported(input.shape, w.mean.shape, stride, padding) and (
-                    self.fused_conv is True or _conv_profitable(
-                        input.shape, w.mean.shape, stride, padding, ops,
-                        torch.is_grad_enabled() and (input.requires_grad or w.mean.requires_grad or w.rho.requires_grad))):
+                    _conv_profitable(input.shape, w.mean.shape, stride, padding, ops,
+                                     torch.is_grad_enabled() and (input.requires_grad or w.mean.requires_grad
+                                                                  or w.rho.requires_grad))
+                    or self.fused_conv is True):
                 eps = None
                 if not (w.rng == "philox" and w.noise_source is None):
                     ho = (input.shape[2] + 2 * padding[0] - self.kernel_size) // stride[0] + 1

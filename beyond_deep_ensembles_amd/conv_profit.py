@@ -5,7 +5,9 @@ The rule (VERDICT r4 #3 / ADVICE r4): a geometry is fused by default only if a D
 shows them at least as fast as the reference's op sequence on the same MI355X -- ``bde_conv_lrt_supported`` only says that a
 tiling exists, not that it wins.  The measurements live in ``conv_profit.json`` beside this file, written by
 ``tools/conv_lrt_bench.py --table`` on the GPU box (one record per layer geometry: forward-only and forward + backward
-speed-ups over the reference's sequence, the kernel ABI version they were taken with, the profile they are filed under).
+speed-ups over the reference's sequence, the kernel ABI version they were taken with, the profile they are filed under);
+``tools/conv_autotune.py`` writes the same records after timing EVERY candidate tiling of each pass and adds the winners
+(``tilings``), which ``apply_tilings`` pins through the library's tuning hooks when the layer is first used.
 Records of another ABI version are ignored: a kernel rewritten since its measurement is unmeasured again.
 
 No record -> stock path.  ``fused_conv=True`` forces the fused kernels wherever they have a tiling (tests, benchmarks),
@@ -51,3 +53,37 @@ def profitable(x_shape, w_shape, stride, padding, needs_grad: bool, abi: int, ta
     if rec is None or int(x_shape[0]) * 4 < int(rec.get("batch", 1)):
         return False
     return float(rec.get("fwd_bwd" if needs_grad else "fwd", 0.0)) >= _MIN_GAIN
+
+
+_applied = set()
+
+
+def apply_tilings(ops, x_shape, w_shape, stride, padding, abi: int, table: dict = None) -> bool:
+    """Pin the tilings tools/conv_autotune.py recorded for this layer (forward, input gradient, weight gradient), once per
+    library handle and layer.  They are per LAUNCH geometry, batch size included: a record taken at another batch leaves the
+    planners' own choice in place.  A recorded tiling the current planner no longer offers is skipped."""
+    t = load() if table is None else table
+    if int(t.get("abi", 0)) != int(abi) or stride[0] != stride[1] or padding[0] != padding[1] or w_shape[2] != w_shape[3]:
+        return False
+    key = _key(x_shape[1], w_shape[0], w_shape[2], stride[0], padding[0], x_shape[2], x_shape[3])
+    rec = t["layers"].get(key)
+    if rec is None or int(rec.get("batch", -1)) != int(x_shape[0]) or not rec.get("tilings"):
+        return False
+    tag = (id(getattr(ops, "lib", ops)), key, int(x_shape[0]))
+    if tag in _applied:
+        return True
+    from .ops import BdeKernelError
+    til = rec["tilings"]
+    for row in til.get("launch", []):
+        try:
+            ops.conv_lrt_set_tiling(row[:15], row[15:19])
+        except (BdeKernelError, ValueError, IndexError):
+            pass
+    if til.get("wgrad"):
+        try:
+            ops.conv_lrt_wgrad_set_tiling(tuple(x_shape), tuple(w_shape), stride, padding, til["wgrad"])
+        except (BdeKernelError, ValueError, IndexError):
+            pass
+    _applied.add(tag)
+    return True
+

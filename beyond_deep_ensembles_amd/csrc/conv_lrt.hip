@@ -33,6 +33,10 @@
 // ConvGeo then describes THAT convolution: C = O', (H, W) = (Ho', Wo') before dilation (dh, dw), O = C',
 // (Ho, Wo) = (H', W').
 #include "bde_common.hpp"
+#include <array>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace bde {
 
@@ -446,19 +450,27 @@ struct FwdPlan {
 
 static inline int pad32(int v) { return (v + 31) / 32 * 32; }
 
-// Tile choice: enough workgroups to fill 256 CUs (>= 2 per CU where the layer allows), LDS <= 64 KB per workgroup
-// (two resident), 1 / 2 / 4 / 8 pixel tiles per wave.
-static bool plan_fwd(const ConvGeo& g, FwdPlan& p) {
+// ---- tilings.  fwd_candidates enumerates every tiling the kernel can run a launch geometry with: 4 waves = WP pixel-tile
+// groups x WK k-splits, a band of TH output rows (whole images or power-of-two bands) of NI images (several only for whole
+// small images), 1 / 2 / 4 / 8 pixel tiles per wave, the input channels in chunks of CC (the largest chunk that fits
+// 64 KB of LDS -- two workgroups per CU -- and half of it), each with a score:
+// chip fill first (up to 2 workgroups per CU), then idle waves / partial tiles, halo, chunks, k-split; re-staging the
+// weight tile per workgroup costs more the fewer products a workgroup does per chunk.  The planner takes the best score
+// unless a tiling has been PINNED for the launch geometry (bde_conv_lrt_set_tiling: tools/conv_autotune.py times every
+// candidate on the device and records the winners; the score's weights are hand-set and were never compared with one).
+struct FwdCand {
+  ConvTile t;
+  int pt;
+  size_t lds;
+  double score;
+};
+
+static void fwd_candidates(const ConvGeo& g, std::vector<FwdCand>& out) {
   const int mf = g.O <= 16 ? 16 : 32;
   const int pt_max = mf == 16 ? 8 : 4;
   const int ks = mf == 32 ? 2 : 4;
   const int regs = mf == 32 ? 16 : 4;
   const int khw = g.KH * g.KW;
-  ConvTile best{};
-  int best_pt = 0;
-  size_t best_lds = 0;
-  bool found = false;
-  double best_score = -1.0;
   const int otiles = (g.O + mf - 1) / mf;
   const size_t epi = sizeof(float) * 4ull * 2 * mf * (mf + 4);
   for (int wk = 1; wk <= 4; wk *= 2) {
@@ -474,7 +486,8 @@ static bool plan_fwd(const ConvGeo& g, FwdPlan& p) {
         while (pt * wpn < tiles) pt *= 2;
         if (pt > pt_max) continue;
         const int ph = (th - 1) * g.sh + g.KH, pwp = (g.Wo - 1) * g.sw + g.KW;
-        for (int cc = g.C; cc >= 1; cc = (cc > 8 ? cc / 2 : cc - 1)) {
+        int emitted = 0;
+        for (int cc = g.C; cc >= 1 && emitted < 2; cc = (cc > 8 ? cc / 2 : cc - 1)) {
           const int kc = cc * khw;
           const int kcpad = (kc + ks * wk - 1) / (ks * wk) * (ks * wk);
           const size_t lds = sizeof(float) * (2ull * ((static_cast<size_t>(ni) * cc * ph * pwp + 3) & ~size_t{3}) + 2ull * kcpad * mf + kcpad);
@@ -482,33 +495,64 @@ static bool plan_fwd(const ConvGeo& g, FwdPlan& p) {
           const size_t need = std::max(std::max(lds, red), epi);
           if (need > 64 * 1024) continue;
           const int64_t wgs = static_cast<int64_t>((g.N + ni - 1) / ni) * bands * otiles;
-          // score: chip fill first (up to 2 workgroups per CU), then idle waves / partial tiles, halo, chunks, k-split;
-          // re-staging the weight tile per workgroup costs more the fewer products a workgroup does per chunk
           const double fill = std::min(1.0, static_cast<double>(wgs) / 512.0);
           const double util = static_cast<double>(tiles) / (pt * wpn);
           const double halo = static_cast<double>(th) / ph;
           const double chunks = 1.0 / ((g.C + cc - 1) / cc);
           const double wreuse = std::min(1.0, static_cast<double>(tiles) / 8.0);
-          const double score = (0.25 + 0.75 * fill) * util * (0.6 + 0.4 * halo) * (0.8 + 0.2 * chunks) * (0.5 + 0.5 * wreuse) *
-                               (wk == 1 ? 1.0 : 0.9);
-          if (score > best_score) {
-            best_score = score;
-            best = ConvTile{ni, th, bands, cc, ph, pwp, wpn, wk, tiles_per_img, kcpad};
-            best_pt = pt;
-            best_lds = need;
-            found = true;
-          }
-          break;                                            // the largest chunk that fits is the one to take
+          double score = (0.25 + 0.75 * fill) * util * (0.6 + 0.4 * halo) * (0.8 + 0.2 * chunks) * (0.5 + 0.5 * wreuse) *
+                         (wk == 1 ? 1.0 : 0.9);
+          if (emitted == 1) score *= 0.999;               // the half chunk only ever wins when it is pinned
+          out.push_back(FwdCand{ConvTile{ni, th, bands, cc, ph, pwp, wpn, wk, tiles_per_img, kcpad}, pt, need, score});
+          ++emitted;                                        // the largest chunk that fits, then the next smaller one
         }
       }
     }
   }
-  if (!found) return false;
-  p.t = best;
+}
+
+// launch geometry -> pinned (WK, TH, NI, CC)
+using GeoKey = std::array<int, 15>;
+static GeoKey geo_key(const ConvGeo& g) {
+  return GeoKey{g.N, g.C, g.H, g.W, g.O, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, g.dh, g.dw, g.Ho, g.Wo};
+}
+static std::mutex& pin_mutex() {
+  static std::mutex m;
+  return m;
+}
+static std::map<GeoKey, std::array<int, 4>>& pins() {
+  static std::map<GeoKey, std::array<int, 4>> m;
+  return m;
+}
+
+static bool plan_fwd(const ConvGeo& g, FwdPlan& p, int* chosen_index = nullptr) {
+  std::vector<FwdCand> cands;
+  fwd_candidates(g, cands);
+  if (cands.empty()) return false;
+  int best = -1;
+  {
+    std::lock_guard<std::mutex> lock(pin_mutex());
+    const auto it = pins().find(geo_key(g));
+    if (it != pins().end()) {
+      for (size_t i = 0; i < cands.size(); ++i) {
+        const ConvTile& t = cands[i].t;
+        if (t.WK == it->second[0] && t.TH == it->second[1] && t.NI == it->second[2] && t.CC == it->second[3]) best = static_cast<int>(i);
+      }
+    }
+  }
+  if (best < 0) {
+    best = 0;
+    for (size_t i = 1; i < cands.size(); ++i)
+      if (cands[i].score > cands[best].score) best = static_cast<int>(i);
+  }
+  const FwdCand& c = cands[best];
+  const int mf = g.O <= 16 ? 16 : 32;
+  p.t = c.t;
   p.mf = mf;
-  p.pt = best_pt;
-  p.grid = dim3(static_cast<unsigned>(((g.N + best.NI - 1) / best.NI) * best.bands), static_cast<unsigned>(otiles));
-  p.lds = best_lds;
+  p.pt = c.pt;
+  p.grid = dim3(static_cast<unsigned>(((g.N + c.t.NI - 1) / c.t.NI) * c.t.bands), static_cast<unsigned>((g.O + mf - 1) / mf));
+  p.lds = c.lds;
+  if (chosen_index) *chosen_index = best;
   return true;
 }
 
@@ -615,6 +659,93 @@ extern "C" int bde_conv_lrt_plan(int which, int N, int C, int H, int W, int O, i
                      p.t.kcpad_max, static_cast<int>(p.grid.x), static_cast<int>(p.grid.y), static_cast<int>(p.lds), 0};
   for (int i = 0; i < 16; ++i) out[i] = v[i];
   return 0;
+}
+
+// ---- tuning hooks (tools/conv_autotune.py, tests): the launch geometries of a pass, the candidate tilings of a launch
+// geometry, pinning one.  A launch geometry is what ONE launch of conv_lrt_kernel convolves:
+// geo[15] = N, C, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw, Ho, Wo (dh, dw: dilation of the input image, > 1 only in the dilated
+// input-gradient pass; Ho, Wo: the output extent the launch writes -- the layer's input extent in the gradient passes, which
+// can exceed what the padded input alone would give).
+static bool geo_from_key(const int* k, ConvGeo& g) {
+  if (!k) return false;
+  for (int i = 0; i < 15; ++i)
+    if (k[i] < (i == 9 || i == 10 ? -64 : 1)) return false;    // (a phase's top / left padding can be negative: its first taps lie past the edge)
+  if (k[5] > 7 || k[6] > 7) return false;
+  g = ConvGeo{k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], k[8], k[9], k[10], k[13], k[14], k[11], k[12], pad32(k[4])};
+  g.OH = k[13];
+  g.OW = k[14];
+  return true;
+}
+
+extern "C" int bde_conv_lrt_pass_geos(int which, const int* layer, int* out, int max) {
+  ConvGeo l, g;
+  if (!layer || !out || max < 1 ||
+      !layer_geo(layer[0], layer[1], layer[2], layer[3], layer[4], layer[5], layer[6], layer[7], layer[8], layer[9], layer[10], l))
+    return BDE_ERR_INVALID;
+  int n = 0;
+  auto emit = [&](const ConvGeo& q) {
+    if (n < max) {
+      const GeoKey k = geo_key(q);
+      for (int i = 0; i < 15; ++i) out[15 * n + i] = k[i];
+    }
+    ++n;
+  };
+  if (which == 0) {
+    emit(l);
+  } else if (which == 1) {
+    if (!data_grad_geo(l, g)) return BDE_ERR_INVALID;
+    emit(g);
+  } else if (which == 2) {
+    if (l.ph > l.KH - 1 || l.pw > l.KW - 1) return BDE_ERR_INVALID;
+    for (int a = 0; a < l.sh; ++a)
+      for (int b = 0; b < l.sw; ++b) {
+        int64_t off;
+        if (phase_geo(l, a, b, g, off)) emit(g);
+      }
+  } else {
+    return BDE_ERR_INVALID;
+  }
+  return n;
+}
+
+// out[i][6] = WK, TH, NI, CC, PT, LDS bytes; *chosen = the index the planner runs (pinned or best score).  Returns the number
+// of candidates (possibly > max: only the first max are written), 0 when the geometry has no tiling.
+extern "C" int bde_conv_lrt_candidates(const int* geo, int* out, int max, int* chosen) {
+  ConvGeo g;
+  if (!geo_from_key(geo, g) || (max > 0 && !out)) return BDE_ERR_INVALID;
+  std::vector<FwdCand> cands;
+  fwd_candidates(g, cands);
+  for (int i = 0; i < static_cast<int>(cands.size()) && i < max; ++i) {
+    const FwdCand& c = cands[i];
+    const int v[6] = {c.t.WK, c.t.TH, c.t.NI, c.t.CC, c.pt, static_cast<int>(c.lds)};
+    for (int j = 0; j < 6; ++j) out[6 * i + j] = v[j];
+  }
+  if (chosen) {
+    FwdPlan p;
+    int idx = -1;
+    *chosen = plan_fwd(g, p, &idx) ? idx : -1;
+  }
+  return static_cast<int>(cands.size());
+}
+
+// Pin the tiling (WK, TH, NI, CC) of a launch geometry for this process; wk = 0 removes the pin.  BDE_ERR_INVALID when the tiling
+// is not one of the geometry's candidates (nothing is pinned then).
+extern "C" int bde_conv_lrt_set_tiling(const int* geo, int wk, int th, int ni, int cc) {
+  ConvGeo g;
+  if (!geo_from_key(geo, g)) return BDE_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(pin_mutex());
+  if (wk == 0) {
+    pins().erase(geo_key(g));
+    return 0;
+  }
+  std::vector<FwdCand> cands;
+  fwd_candidates(g, cands);
+  for (const FwdCand& c : cands)
+    if (c.t.WK == wk && c.t.TH == th && c.t.NI == ni && c.t.CC == cc) {
+      pins()[geo_key(g)] = {wk, th, ni, cc};
+      return 0;
+    }
+  return BDE_ERR_INVALID;
 }
 
 extern "C" size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW) {

@@ -13,6 +13,10 @@
 // LDS in wave order, and the block goes to a partials buffer [share][2][O][C KH KW]; bde's finish pass adds the shares
 // in order (fixed order everywhere: bit-reproducible) and applies the chain rule for rho.
 #include "bde_common.hpp"
+#include <array>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace bde {
 
@@ -274,65 +278,101 @@ struct WgPlan {
   size_t lds;
 };
 
-static bool plan_wgrad(const WgGeo& g, WgPlan& p) {
+// Candidate tilings: CT column tiles of the [O, C*KH*KW] gradient per workgroup (as many as the accumulators hold, fewer when
+// the input patches of the channels they span do not fit the LDS even for one output row: wide 1x1 layers on large images;
+// the tiles spread evenly over the column groups: 9 tiles with at most 4 per group run as 3 + 3 + 3, not 4 + 4 + 1), a band
+// of TH output rows (halving from the whole image) of NI images per item, PS shares of the items.  Shares: ONE resident set
+// of workgroups (256 CUs x 2 per CU = 512 slots; round 4 asked for 768, i.e. a second, half empty wave of workgroups and
+// half as many more partial blocks to write and re-read), every share the same number of items (+- 1).  The planner takes
+// the best score among the LARGEST feasible CT unless a tiling is pinned (bde_conv_lrt_wgrad_set_tiling).
+struct WgCand {
+  WgTile t;
+  size_t lds;
+  double score;
+  int ct_cap;
+};
+
+static void wgrad_candidates(const WgGeo& g, std::vector<WgCand>& out) {
   const int mf = g.O <= 16 ? 16 : 32;
   const int ct_max = mf == 16 ? 9 : 4;
   const int ks = mf == 32 ? 2 : 4;
   const int regs = mf == 32 ? 16 : 4;
   const int khw = g.KH * g.KW, ktot = g.C * khw;
   const int otiles = (g.O + mf - 1) / mf;
-  // (the wave reduction keeps two waves' blocks of ct tiles in LDS at a time: checked per candidate below)
-  bool found = false;
-  double best_score = -1.0;
-  WgTile best{};
-  size_t best_lds = 0;
-  // ct column tiles of the [O, C*KH*KW] gradient per workgroup: as many as the accumulators hold, fewer only when the input
-  // patches of the channels they span do not fit the LDS even for one output row (wide 1x1 layers on large images)
   const int coltiles = (ktot + mf - 1) / mf;
-  for (int ct_cap = std::min(ct_max, coltiles); ct_cap >= 1 && !found; --ct_cap) {
-  // the column tiles spread evenly over the groups (9 tiles with at most 4 per group: 3 + 3 + 3, not 4 + 4 + 1)
-  const int colgroups = (coltiles + ct_cap - 1) / ct_cap;
-  const int ct = (coltiles + colgroups - 1) / colgroups;
-  const int cmax = std::min(g.C, (ct * mf + khw - 2) / khw + 1);
-  for (int th = g.Ho; th >= 1; th = (th > 1 ? (th + 1) / 2 : 0)) {
-    const int bands = (g.Ho + th - 1) / th;
-    for (int ni = 8; ni >= 1; ni /= 2) {
-      if (ni > 1 && th != g.Ho) continue;
-      const int ph = (th - 1) * g.sh + g.KH, pwp = (g.Wo - 1) * g.sw + g.KW;
-      int npix = ni * th * g.Wo;
-      npix = (npix + ks * 4 - 1) / (ks * 4) * (ks * 4);
-      int gp = npix;
-      if (mf == 32) gp |= 1; else gp = (gp + 31) / 32 * 32 + 2;
-      const size_t lds = sizeof(float) * (2ull * ni * cmax * ph * pwp + 2ull * mf * gp + npix);
-      const size_t red = sizeof(float) * 2ull * ct * 2 * regs * 64;
-      if (std::max(lds, red) > 64 * 1024) continue;
-      const int items = ((g.N + ni - 1) / ni) * bands;
-      const int blocks = otiles * colgroups;
-      // Shares: ONE resident set of workgroups (256 CUs x 2 per CU = 512 slots; round 4 asked for 768, i.e. a second, half
-      // empty wave of workgroups and half as many more partial blocks to write and re-read), every share the same number
-      // of items (+- 1): ps = ceil(items / items_per_share)
-      const int ps_cap = std::max(1, std::min(items, 512 / blocks));
-      const int per_share = (items + ps_cap - 1) / ps_cap;
-      const int ps = (items + per_share - 1) / per_share;
-      const double fill = std::min(1.0, static_cast<double>(ps) * blocks / 512.0);
-      const double halo = static_cast<double>(th) / ph;
-      const double big = std::min(1.0, static_cast<double>(npix) / 256.0);      // enough k-steps per staging
-      const double score = fill * (0.5 + 0.5 * halo) * (0.5 + 0.5 * big);
-      if (score > best_score) {
-        best_score = score;
-        best = WgTile{ni, th, bands, ps, ct, colgroups, ph, pwp, cmax, gp, npix};
-        best_lds = std::max(lds, red);
-        found = true;
+  int last_ct = -1;
+  for (int ct_cap = std::min(ct_max, coltiles); ct_cap >= 1; --ct_cap) {
+    const int colgroups = (coltiles + ct_cap - 1) / ct_cap;
+    const int ct = (coltiles + colgroups - 1) / colgroups;
+    if (ct == last_ct) continue;                                // the same spread as a larger cap
+    last_ct = ct;
+    const int cmax = std::min(g.C, (ct * mf + khw - 2) / khw + 1);
+    for (int th = g.Ho; th >= 1; th = (th > 1 ? (th + 1) / 2 : 0)) {
+      const int bands = (g.Ho + th - 1) / th;
+      for (int ni = 8; ni >= 1; ni /= 2) {
+        if (ni > 1 && th != g.Ho) continue;
+        const int ph = (th - 1) * g.sh + g.KH, pwp = (g.Wo - 1) * g.sw + g.KW;
+        int npix = ni * th * g.Wo;
+        npix = (npix + ks * 4 - 1) / (ks * 4) * (ks * 4);
+        int gp = npix;
+        if (mf == 32) gp |= 1; else gp = (gp + 31) / 32 * 32 + 2;
+        const size_t lds = sizeof(float) * (2ull * ni * cmax * ph * pwp + 2ull * mf * gp + npix);
+        const size_t red = sizeof(float) * 2ull * ct * 2 * regs * 64;
+        if (std::max(lds, red) > 64 * 1024) continue;
+        const int items = ((g.N + ni - 1) / ni) * bands;
+        const int blocks = otiles * colgroups;
+        const int ps_cap = std::max(1, std::min(items, 512 / blocks));
+        const int per_share = (items + ps_cap - 1) / ps_cap;
+        const int ps = (items + per_share - 1) / per_share;
+        const double fill = std::min(1.0, static_cast<double>(ps) * blocks / 512.0);
+        const double halo = static_cast<double>(th) / ph;
+        const double big = std::min(1.0, static_cast<double>(npix) / 256.0);      // enough k-steps per staging
+        const double score = fill * (0.5 + 0.5 * halo) * (0.5 + 0.5 * big);
+        out.push_back(WgCand{WgTile{ni, th, bands, ps, ct, colgroups, ph, pwp, cmax, gp, npix}, std::max(lds, red), score, ct_cap});
       }
     }
   }
+}
+
+using WgKey = std::array<int, 11>;
+static WgKey wg_key(const WgGeo& g) { return WgKey{g.N, g.C, g.H, g.W, g.O, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw}; }
+static std::mutex& wg_pin_mutex() {
+  static std::mutex m;
+  return m;
+}
+static std::map<WgKey, std::array<int, 4>>& wg_pins() {               // (CT, TH, NI, PS)
+  static std::map<WgKey, std::array<int, 4>> m;
+  return m;
+}
+
+static bool plan_wgrad(const WgGeo& g, WgPlan& p, int* chosen_index = nullptr) {
+  std::vector<WgCand> cands;
+  wgrad_candidates(g, cands);
+  if (cands.empty()) return false;
+  int best = -1;
+  {
+    std::lock_guard<std::mutex> lock(wg_pin_mutex());
+    const auto it = wg_pins().find(wg_key(g));
+    if (it != wg_pins().end())
+      for (size_t i = 0; i < cands.size(); ++i) {
+        const WgTile& t = cands[i].t;
+        if (t.CT == it->second[0] && t.TH == it->second[1] && t.NI == it->second[2] && t.PS == it->second[3]) best = static_cast<int>(i);
+      }
   }
-  if (!found) return false;
-  p.t = best;
+  if (best < 0) {
+    // the largest CT that has a tiling at all (fewer column groups = fewer re-stagings of g / g_var), the best score within it
+    const int ct_first = cands[0].t.CT;
+    best = 0;
+    for (size_t i = 1; i < cands.size() && cands[i].t.CT == ct_first; ++i)
+      if (cands[i].score > cands[best].score) best = static_cast<int>(i);
+  }
+  const int mf = g.O <= 16 ? 16 : 32;
+  p.t = cands[best].t;
   p.mf = mf;
-  p.otiles = otiles;
-  p.grid = dim3(static_cast<unsigned>(best.PS), static_cast<unsigned>(otiles * best.colgroups));
-  p.lds = best_lds;
+  p.otiles = (g.O + mf - 1) / mf;
+  p.grid = dim3(static_cast<unsigned>(p.t.PS), static_cast<unsigned>(p.otiles * p.t.colgroups));
+  p.lds = cands[best].lds;
+  if (chosen_index) *chosen_index = best;
   return true;
 }
 
@@ -358,6 +398,49 @@ extern "C" int bde_conv_lrt_bwd_weight_plan(int N, int C, int H, int W, int O, i
                      p.t.cmax, p.t.GP, p.t.npix, static_cast<int>(p.grid.y), static_cast<int>(p.lds), p.otiles};
   for (int i = 0; i < 16; ++i) out[i] = v[i];
   return 0;
+}
+
+// Tuning hooks of the weight-gradient pass (tools/conv_autotune.py): the candidate tilings of a LAYER geometry
+// (layer[11] = N, C, H, W, O, KH, KW, sh, sw, ph, pw): out[i][5] = CT, TH, NI, PS, LDS bytes; *chosen = the planner's index.
+extern "C" int bde_conv_lrt_wgrad_candidates(const int* layer, int* out, int max, int* chosen) {
+  WgGeo g;
+  if (!layer || (max > 0 && !out) ||
+      !geo_ok(layer[0], layer[1], layer[2], layer[3], layer[4], layer[5], layer[6], layer[7], layer[8], layer[9], layer[10], g))
+    return BDE_ERR_INVALID;
+  std::vector<WgCand> cands;
+  wgrad_candidates(g, cands);
+  for (int i = 0; i < static_cast<int>(cands.size()) && i < max; ++i) {
+    const WgTile& t = cands[i].t;
+    const int v[5] = {t.CT, t.TH, t.NI, t.PS, static_cast<int>(cands[i].lds)};
+    for (int j = 0; j < 5; ++j) out[5 * i + j] = v[j];
+  }
+  if (chosen) {
+    WgPlan p;
+    int idx = -1;
+    *chosen = plan_wgrad(g, p, &idx) ? idx : -1;
+  }
+  return static_cast<int>(cands.size());
+}
+
+// Pin (CT, TH, NI, PS) for a layer geometry (process-wide); ct = 0 removes the pin; a tiling that is not a candidate is refused.
+// The caller's partials buffer must be sized AFTER pinning (bde_conv_lrt_bwd_weight_ws_bytes follows the pin).
+extern "C" int bde_conv_lrt_wgrad_set_tiling(const int* layer, int ct, int th, int ni, int ps) {
+  WgGeo g;
+  if (!layer || !geo_ok(layer[0], layer[1], layer[2], layer[3], layer[4], layer[5], layer[6], layer[7], layer[8], layer[9], layer[10], g))
+    return BDE_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(wg_pin_mutex());
+  if (ct == 0) {
+    wg_pins().erase(wg_key(g));
+    return 0;
+  }
+  std::vector<WgCand> cands;
+  wgrad_candidates(g, cands);
+  for (const WgCand& c : cands)
+    if (c.t.CT == ct && c.t.TH == th && c.t.NI == ni && c.t.PS == ps) {
+      wg_pins()[wg_key(g)] = {ct, th, ni, ps};
+      return 0;
+    }
+  return BDE_ERR_INVALID;
 }
 
 // bytes of the partials buffer bde_conv_lrt_bwd_weight needs (0: unsupported geometry)

@@ -563,6 +563,58 @@ class HipOps:
                                                 _ptr(g_wrho), *geo, _stream()), "bde_conv_lrt_bwd_weight")
         return ws
 
+    # ---- tuning hooks of the fused convolution (tools/conv_autotune.py, tests): candidate tilings, pinning
+    @staticmethod
+    def _layer_geo(x_shape, w_shape, stride, padding):
+        import ctypes
+        n, c, h, w = (int(v) for v in x_shape)
+        o, _, kh, kw = (int(v) for v in w_shape)
+        return (ctypes.c_int * 11)(n, c, h, w, o, kh, kw, int(stride[0]), int(stride[1]), int(padding[0]), int(padding[1]))
+
+    def conv_lrt_pass_geos(self, which, x_shape, w_shape, stride, padding):
+        """Launch geometries (15-tuples) of a pass of a layer: which = 0 forward, 1 dilated input gradient, 2 per-phase input
+        gradient."""
+        import ctypes
+        out = (ctypes.c_int * (15 * 64))()
+        n = int(self.lib.bde_conv_lrt_pass_geos(int(which), self._layer_geo(x_shape, w_shape, stride, padding), out, 64))
+        if n < 0:
+            raise BdeKernelError("bde_conv_lrt_pass_geos: unsupported layer geometry")
+        return [tuple(out[15 * i:15 * i + 15]) for i in range(min(n, 64))]
+
+    def conv_lrt_candidates(self, geo):
+        """([(WK, TH, NI, CC, PT, LDS bytes), ...], index the planner runs) for a launch geometry."""
+        import ctypes
+        g = (ctypes.c_int * 15)(*[int(v) for v in geo])
+        out, chosen = (ctypes.c_int * (6 * 512))(), ctypes.c_int(-1)
+        n = int(self.lib.bde_conv_lrt_candidates(g, out, 512, ctypes.byref(chosen)))
+        if n < 0:
+            raise BdeKernelError("bde_conv_lrt_candidates: invalid launch geometry")
+        return [tuple(out[6 * i:6 * i + 6]) for i in range(min(n, 512))], int(chosen.value)
+
+    def conv_lrt_set_tiling(self, geo, tiling=None):
+        """Pin (WK, TH, NI, CC) for a launch geometry (None: remove the pin)."""
+        import ctypes
+        g = (ctypes.c_int * 15)(*[int(v) for v in geo])
+        wk, th, ni, cc = (0, 0, 0, 0) if tiling is None else (int(v) for v in tiling[:4])
+        _check(self.lib.bde_conv_lrt_set_tiling(g, wk, th, ni, cc), "bde_conv_lrt_set_tiling")
+
+    def conv_lrt_wgrad_candidates(self, x_shape, w_shape, stride, padding):
+        """([(CT, TH, NI, PS, LDS bytes), ...], index the planner runs) for the weight-gradient pass of a layer."""
+        import ctypes
+        out, chosen = (ctypes.c_int * (5 * 512))(), ctypes.c_int(-1)
+        n = int(self.lib.bde_conv_lrt_wgrad_candidates(self._layer_geo(x_shape, w_shape, stride, padding), out, 512,
+                                                       ctypes.byref(chosen)))
+        if n < 0:
+            raise BdeKernelError("bde_conv_lrt_wgrad_candidates: invalid layer geometry")
+        return [tuple(out[5 * i:5 * i + 5]) for i in range(min(n, 512))], int(chosen.value)
+
+    def conv_lrt_wgrad_set_tiling(self, x_shape, w_shape, stride, padding, tiling=None):
+        """Pin (CT, TH, NI, PS) for a layer's weight-gradient pass (None: remove the pin).  Partials buffers sized before the
+        pin must not be reused (conv_lrt_bwd_weight re-checks the size)."""
+        ct, th, ni, ps = (0, 0, 0, 0) if tiling is None else (int(v) for v in tiling[:4])
+        _check(self.lib.bde_conv_lrt_wgrad_set_tiling(self._layer_geo(x_shape, w_shape, stride, padding), ct, th, ni, ps),
+               "bde_conv_lrt_wgrad_set_tiling")
+
     def lrt_linear_supported(self, b: int, i: int, o: int) -> bool:
         return bool(self.lib.bde_lrt_linear_supported(b, i, o))
 

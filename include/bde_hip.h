@@ -379,6 +379,26 @@ int bde_conv_lrt_plan(int which, int N, int C, int H, int W, int O, int KH, int 
                       int pad_w, int* out);
 int bde_conv_lrt_bwd_weight_plan(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h,
                                  int pad_w, int* out);
+/* Tuning hooks of the fused convolution (tools/conv_autotune.py; without them the planners' own scores decide).  The scores'
+ * weights are hand-set; on the device every candidate tiling of a layer can be timed and the winner pinned.
+ * A LAUNCH geometry is what one launch of the convolution kernel convolves: geo[15] = N, C, H, W, O, KH, KW, sh, sw, ph, pw,
+ * dh, dw, Ho, Wo (dh, dw: dilation of the input image, > 1 only in the dilated input-gradient pass; Ho, Wo: the output extent
+ * the launch writes).  A LAYER geometry is layer[11] = N, C, H, W, O, KH, KW, stride_h, stride_w, pad_h, pad_w.
+ *   bde_conv_lrt_pass_geos    the launch geometries of a pass of a layer -- which = 0 forward (one), 1 input gradient over the
+ *                             zero-dilated gradient (one), 2 input gradient per phase (up to sh * sw) -- into out[max][15];
+ *                             returns their number
+ *   bde_conv_lrt_candidates   every tiling the planner considers for a launch geometry: out[i][6] = WK, TH, NI, CC, PT, LDS bytes;
+ *                             *chosen = the index it runs (the pinned one, else the best score); returns the number of candidates
+ *   bde_conv_lrt_set_tiling   pins (WK, TH, NI, CC) for a launch geometry, process-wide; wk = 0 removes the pin; a tiling that is
+ *                             not a candidate is refused (BDE_ERR_INVALID)
+ *   bde_conv_lrt_wgrad_candidates / _set_tiling   the same for the weight-gradient pass, keyed by the layer geometry:
+ *                             out[i][5] = CT, TH, NI, PS, LDS bytes.  Size the partials buffer AFTER pinning
+ *                             (bde_conv_lrt_bwd_weight_ws_bytes follows the pin). */
+int bde_conv_lrt_pass_geos(int which, const int* layer, int* out, int max);
+int bde_conv_lrt_candidates(const int* geo, int* out, int max, int* chosen);
+int bde_conv_lrt_set_tiling(const int* geo, int wk, int th, int ni, int cc);
+int bde_conv_lrt_wgrad_candidates(const int* layer, int* out, int max, int* chosen);
+int bde_conv_lrt_wgrad_set_tiling(const int* layer, int ct, int th, int ni, int ps);
 size_t bde_conv_lrt_prep_floats(int O, int C, int KH, int KW);
 int bde_conv_lrt_prep(const float* w_mu, const float* w_rho, const float* b_rho, int O, int C, int KH, int KW, float* wbuf,
                       void* stream);

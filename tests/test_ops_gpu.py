@@ -1298,6 +1298,99 @@ def test_conv_lrt_backward(ops):
         assert torch.equal(gwm, gwm2) and torch.equal(gwr, gwr2) and torch.equal(gx, gx2), case
 
 
+def test_r5_conv_every_candidate_tiling_computes_the_same_layer(ops):
+    """The tuning hooks of the fused convolution (bde_conv_lrt_pass_geos / _candidates / _set_tiling and the weight-gradient
+    pair): EVERY tiling the planners enumerate for a layer -- not only the one their hand-set score picks -- is pinned in
+    turn and must compute the layer (forward, dilated and per-phase input gradient, weight gradient) to the tolerance of the
+    fp64 anchor; a tiling that is not a candidate is refused; removing the pin restores the planner's choice bit for bit.
+    This is what tools/conv_autotune.py relies on when it times the candidates on the device and pins the winners."""
+    import torch.nn.functional as F
+    from beyond_deep_ensembles_amd.ops import BdeKernelError
+    torch.manual_seed(41)
+    cases = [(2, 5, 9, 11, 7, 3, (1, 1), (0, 0)), (2, 16, 12, 12, 32, 3, (2, 2), (1, 1)), (3, 20, 10, 10, 16, 3, (1, 1), (1, 1)),
+             (2, 40, 6, 6, 40, 1, (1, 1), (0, 0)), (1, 8, 9, 9, 8, 3, (3, 3), (2, 2))]
+    total = 0
+    for n, c, h, w, o, k, stride, padding in cases:
+        x = torch.randn(n, c, h, w)
+        w_mu, w_rho = torch.randn(o, c, k, k) * 0.1, torch.randn(o, c, k, k) * 1.5 - 3.0
+        xs, ws = tuple(x.shape), tuple(w_mu.shape)
+
+        def run(dt):
+            leaves = [t.to(dt).clone().requires_grad_(True) for t in (x, w_mu, w_rho)]
+            xx, wm, wr = leaves
+            mean = F.conv2d(xx, wm, None, stride=stride, padding=padding)
+            var = F.conv2d((xx ** 2).clamp(min=1e-4), (F.softplus(wr) ** 2).clamp(min=1e-4), None, stride=stride, padding=padding)
+            return mean, var, leaves
+        m64, v64, l64 = run(torch.float64)
+        eps, gout = torch.randn(m64.shape, dtype=torch.float64), torch.randn(m64.shape, dtype=torch.float64)
+        g64 = [t.detach() for t in torch.autograd.grad(m64 + v64.sqrt() * eps, l64, gout)]
+        out64 = (m64 + v64.sqrt() * eps).detach()
+        dev = lambda t: t.to(DEV).float().contiguous()
+        xd, wm, wr, ed, gd = dev(x), dev(w_mu), dev(w_rho), dev(eps), dev(gout)
+        wbuf = ops.conv_lrt_wbuf(ws, DEV)
+        ops.conv_lrt_prep(wm, wr, wbuf, stride=stride, padding=padding)
+        shape = tuple(m64.shape)
+
+        def forward():
+            out, var = torch.full(shape, 9.0, device=DEV), torch.full(shape, 9.0, device=DEV)
+            ops.conv_lrt_fwd(xd, wbuf, ws, None, False, stride, padding, out, var, eps=ed)
+            return out, var
+        out0, var0 = forward()
+        gvar = torch.empty_like(gd)
+        ops.local_reparam_bwd(gd.view(-1), var0.view(-1), gvar.view(-1), gd.numel(), eps=ed.view(-1))
+
+        def bwd_data(phases):
+            gx = torch.full_like(xd, 9.0)
+            ops.conv_lrt_bwd_data(gd, gvar, wbuf, ws, xd, gx, stride, padding, phases=phases)
+            return gx
+
+        def bwd_weight():
+            gwm, gwr = torch.full_like(wm, 9.0), torch.full_like(wr, 9.0)
+            ops.conv_lrt_bwd_weight(xd, gd, gvar, wr, gwm, gwr, stride, padding)
+            return gwm, gwr
+
+        def close(got, want64, chain):
+            rel = 2e-5 * max(1.0, (chain / 1024.0) ** 0.5)
+            return (got.cpu().double() - want64).abs().max().item() <= rel * want64.abs().max().item()
+        passes = [(0, forward, lambda r: close(r[0], out64, c * k * k) and close(r[1], v64.detach(), c * k * k)),
+                  (1, lambda: bwd_data(False), lambda r: close(r, g64[0], o * k * k)),
+                  (2, lambda: bwd_data(True), lambda r: close(r, g64[0], o * k * k))]
+        for which, fn, ok in passes:
+            base = fn()
+            assert ok(base), (which, xs, ws)
+            for geo in ops.conv_lrt_pass_geos(which, xs, ws, stride, padding):
+                cands, chosen = ops.conv_lrt_candidates(geo)
+                assert cands and 0 <= chosen < len(cands), geo
+                for cand in cands:
+                    ops.conv_lrt_set_tiling(geo, cand)
+                    assert ops.conv_lrt_candidates(geo)[1] == cands.index(cand)
+                    assert ok(fn()), (which, geo, cand)
+                    total += 1
+                with pytest.raises(BdeKernelError):
+                    ops.conv_lrt_set_tiling(geo, (3, 1, 1, 1))                  # 3 k-splits: never a candidate
+                ops.conv_lrt_set_tiling(geo, None)
+                assert ops.conv_lrt_candidates(geo)[1] == chosen
+            again = fn()
+            for a, b in zip(base if isinstance(base, tuple) else (base,), again if isinstance(again, tuple) else (again,)):
+                assert torch.equal(a, b), (which, xs, ws)
+        ho, wo = shape[2:]
+        base = bwd_weight()
+        cands, chosen = ops.conv_lrt_wgrad_candidates(xs, ws, stride, padding)
+        assert cands and 0 <= chosen < len(cands)
+        for cand in cands:
+            ops.conv_lrt_wgrad_set_tiling(xs, ws, stride, padding, cand)
+            assert ops.conv_lrt_wgrad_candidates(xs, ws, stride, padding)[1] == cands.index(cand)
+            gwm, gwr = bwd_weight()
+            assert close(gwm, g64[1], n * ho * wo) and close(gwr, g64[2], n * ho * wo), (xs, ws, cand)
+            total += 1
+        with pytest.raises(BdeKernelError):
+            ops.conv_lrt_wgrad_set_tiling(xs, ws, stride, padding, (99, 1, 1, 1))
+        ops.conv_lrt_wgrad_set_tiling(xs, ws, stride, padding, None)
+        again = bwd_weight()
+        assert torch.equal(base[0], again[0]) and torch.equal(base[1], again[1])
+    assert total > 100                                                  # several hundred (pass, tiling) pairs in all
+
+
 def test_lrt_linear_backward(ops):
     """bde_lrt_linear_bwd (the autograd graph of bbb_layers.py:61-80 in three or four launches) against fp64 autograd
     over those lines; the allowance is twice the deviation of fp32 autograd over the same lines (CPU)."""

@@ -1402,6 +1402,25 @@ def test_r5_fused_conv_auto_follows_the_measured_table(backend, monkeypatch, tmp
         assert conv_profit.load(str(path))["layers"][key]["fwd"] == 2.0
         path.write_text("not json")
         assert conv_profit.load(str(path))["layers"] == {}
+        # a record with autotuned tilings: pinned through the library's hooks the first time the layer runs (backends with kernels)
+        if hasattr(ops, "conv_lrt_candidates"):
+            xs, ws_ = (8, 3, 6, 6), (4, 3, 3, 3)
+            geo = ops.conv_lrt_pass_geos(0, xs, ws_, (1, 1), (1, 1))[0]
+            cands, chosen = ops.conv_lrt_candidates(geo)
+            other = next(i for i in range(len(cands)) if i != chosen)
+            wc, wchosen = ops.conv_lrt_wgrad_candidates(xs, ws_, (1, 1), (1, 1))
+            tuned = {"abi": abi, "source": "t", "layers": {key: {"batch": 8, "fwd": 2.0, "fwd_bwd": 2.0, "tilings": {
+                "launch": [list(geo) + list(cands[other][:4])], "wgrad": list(wc[-1][:4])}}}}
+            layer.fused_conv = "auto"
+            conv_profit._applied.clear()
+            try:
+                assert used(tuned) == 1
+                assert ops.conv_lrt_candidates(geo)[1] == other
+                assert ops.conv_lrt_wgrad_candidates(xs, ws_, (1, 1), (1, 1))[1] == len(wc) - 1
+            finally:
+                ops.conv_lrt_set_tiling(geo, None)
+                ops.conv_lrt_wgrad_set_tiling(xs, ws_, (1, 1), (1, 1), None)
+                conv_profit._applied.clear()
         shipped = conv_profit.load(conv_profit._PATH)                        # the shipped table parses and is well formed
         for rec in shipped["layers"].values():
             assert {"batch", "fwd", "fwd_bwd"} <= set(rec)
