@@ -1096,6 +1096,11 @@ def main():
     dev_index = int(os.environ.get("BDE_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # the kernel library first: HipOps() loads every code object of libbde_hip.so on this device (bde_init) BEFORE any
+    # communicator thread exists (a first launch under in-flight collectives is the one ingredient of
+    # the illegal-instruction queue abort that is ours to avoid); raises if the library is missing -- no fallback
+    from beyond_deep_ensembles_amd.ops import HipOps
+    ops = HipOps()
     dist = None
     # launched by torch.distributed.run (RANK / MASTER_ADDR set): a process group even with ONE rank, so that
     # `torchrun --nproc-per-node 1 bench.py --gpus 1` drives barriers, the MAX reduction and extra.rccl_one_rank over RCCL
@@ -1113,8 +1118,6 @@ def main():
         if M % world:
             raise SystemExit(f"M={M} particles cannot be sharded over {world} ranks")
 
-    from beyond_deep_ensembles_amd.ops import HipOps
-    ops = HipOps()                                 # raises if libbde_hip.so is missing: no fallback
     d = args.dim
     per = M // world
     exchange_used, exchange_note = "none", None
