@@ -32,7 +32,7 @@
 // layer's C' input channels and H' x W' pixels at stride 1, and the epilogue applies the clamp's derivative with x.
 // ConvGeo then describes THAT convolution: C = O', (H, W) = (Ho', Wo') before dilation (dh, dw), O = C',
 // (Ho, Wo) = (H', W').
-#include "bde_common.hpp"
+#include "conv_common.hpp"
 #include <array>
 #include <map>
 #include <mutex>
@@ -54,6 +54,7 @@ struct ConvGeo {
 };
 struct ConvTile {
   int NI, TH, bands, CC, PH, PWP, WP, WK, tiles_per_img, kcpad_max;
+  float rcp_pwp;     // fl(1 / PWP): the staging pass splits a flat patch index into (row, column) with it (conv_common.hpp)
 };
 
 template <int MF> struct Mfma;
@@ -130,49 +131,14 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     const int kc = cc * khw;
     const int kcpad = (kc + KS * t.WK - 1) / (KS * t.WK) * (KS * t.WK);
     if (c0 > 0) __syncthreads();                           // the previous chunk's operand reads are done
-    // ---- the input patch, one (image, channel) plane per wave trip, a patch row per lane group: x and clamp(x^2)
-    //      (zero outside the image: padding is applied after the clamp); MODE 1: g and gvar, dilated
-    for (int rc = wave; rc < t.NI * cc; rc += 4) {
-      const int img = rc / cc, c = rc % cc;                // wave-uniform
-      const bool img_ok = img0 + img < g.N;
-      const int64_t plane = (static_cast<int64_t>(img_ok ? img0 + img : 0) * g.C + c0 + c) * g.H * g.W;
-      const float* src1 = x + plane;
-      const float* src2 = MODE == 1 ? x_second + plane : x;
-      float* d1 = xs + img * img_floats + c * row_elems;
-      float* d2 = x2s + img * img_floats + c * row_elems;
-      for (int px = lane; px < t.PWP; px += 64) {
-        int wi = px - g.pw;
-        bool col_ok = img_ok && wi >= 0;
-        if (MODE == 1 && g.dw != 1) {
-          col_ok = col_ok && wi % g.dw == 0;
-          wi /= g.dw;
-        }
-        col_ok = col_ok && wi < g.W;
-        for (int py0 = 0; py0 < t.PH; py0 += 4) {
-          float v[4], v2[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            int hi = hi0 + py0 + u;
-            bool ok = col_ok && py0 + u < t.PH && hi >= 0;
-            if (MODE == 1 && g.dh != 1) {
-              ok = ok && hi % g.dh == 0;
-              hi /= g.dh;
-            }
-            ok = ok && hi < g.H;
-            v[u] = ok ? src1[hi * g.W + wi] : 0.f;
-            if (MODE == 0) v2[u] = ok ? fmaxf(v[u] * v[u], 1e-4f) : 0.f;
-            else v2[u] = ok ? src2[hi * g.W + wi] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (py0 + u < t.PH) {
-              d1[(py0 + u) * t.PWP + px] = v[u];
-              d2[(py0 + u) * t.PWP + px] = v2[u];
-            }
-          }
-        }
-      }
-    }
+    // ---- the input patch of the chunk: x and clamp(x^2) (zero outside the image: padding is applied after the clamp);
+    //      MODE 1: g and gvar, dilated.  Flat over the lanes, eight loads in flight per lane (conv_common.hpp)
+    if (MODE == 1 && (g.dh != 1 || g.dw != 1))               // (uniform for the launch: the dilated input-gradient pass)
+      conv_stage_patch<1, true>(x, x_second, xs, x2s, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp, img_floats, img0, g.N,
+                                g.C, c0, g.H, g.W, hi0, g.pw, g.dh, g.dw);
+    else
+      conv_stage_patch<MODE, false>(x, MODE == 1 ? x_second : x, xs, x2s, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp,
+                                    img_floats, img0, g.N, g.C, c0, g.H, g.W, hi0, g.pw, 1, 1);
     // ---- the weight tile, k-major [k][MF] (conflict-free A-operand reads): aligned float4 copies of the pre-arranged
     //      [k][rp] matrices; k past the chunk is zero
     {
@@ -503,7 +469,7 @@ static void fwd_candidates(const ConvGeo& g, std::vector<FwdCand>& out) {
           double score = (0.25 + 0.75 * fill) * util * (0.6 + 0.4 * halo) * (0.8 + 0.2 * chunks) * (0.5 + 0.5 * wreuse) *
                          (wk == 1 ? 1.0 : 0.9);
           if (emitted == 1) score *= 0.999;               // the half chunk only ever wins when it is pinned
-          out.push_back(FwdCand{ConvTile{ni, th, bands, cc, ph, pwp, wpn, wk, tiles_per_img, kcpad}, pt, need, score});
+          out.push_back(FwdCand{ConvTile{ni, th, bands, cc, ph, pwp, wpn, wk, tiles_per_img, kcpad, 1.0f / static_cast<float>(pwp)}, pt, need, score});
           ++emitted;                                        // the largest chunk that fits, then the next smaller one
         }
       }

@@ -12,7 +12,7 @@
 // a pixel -> patch-offset table; its four waves take the k-steps (2 or 4 pixels each) round robin, are summed through
 // LDS in wave order, and the block goes to a partials buffer [share][2][O][C KH KW]; bde's finish pass adds the shares
 // in order (fixed order everywhere: bit-reproducible) and applies the chain rule for rho.
-#include "bde_common.hpp"
+#include "conv_common.hpp"
 #include <array>
 #include <map>
 #include <mutex>
@@ -28,6 +28,7 @@ struct WgGeo {
 };
 struct WgTile {
   int NI, TH, bands, PS, CT, colgroups, PH, PWP, cmax, GP, npix;
+  float rcp_pwp;     // fl(1 / PWP) for the flat patch staging (conv_common.hpp)
 };
 
 template <int MF> struct MfmaW;
@@ -93,49 +94,13 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     const int th = min(t.TH, geo.Ho - ho0);
     const int hi0 = ho0 * geo.sh - geo.ph;
     __syncthreads();
-    // the input patch of the block's channels: one (image, channel) plane per wave trip, lanes along a patch row
-    for (int rc = wave; rc < t.NI * cc; rc += 4) {
-      const int img = rc / cc, c = rc % cc;                    // wave-uniform
-      const bool img_ok = img0 + img < geo.N;
-      const float* src = x + (static_cast<int64_t>(img_ok ? img0 + img : 0) * geo.C + c_lo + c) * geo.H * geo.W;
-      float* d1 = xs + img * img_floats + c * row_elems;
-      float* d2 = x2s + img * img_floats + c * row_elems;
-      for (int px = lane; px < t.PWP; px += 64) {
-        const int wi = px - geo.pw;
-        const bool col_ok = img_ok && wi >= 0 && wi < geo.W;
-        for (int py0 = 0; py0 < t.PH; py0 += 4) {
-          float v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int hi = hi0 + py0 + u;
-            const bool ok = col_ok && py0 + u < t.PH && hi >= 0 && hi < geo.H;
-            v[u] = ok ? src[hi * geo.W + wi] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (py0 + u < t.PH) {
-              const int hi = hi0 + py0 + u;
-              const bool ok = col_ok && hi >= 0 && hi < geo.H;
-              d1[(py0 + u) * t.PWP + px] = v[u];
-              d2[(py0 + u) * t.PWP + px] = ok ? fmaxf(v[u] * v[u], 1e-4f) : 0.f;
-            }
-          }
-        }
-      }
-    }
-    // the block's rows of g and gvar, one (row, image) strip per wave trip (contiguous pixels of a band), and the
-    // pixel -> patch offset table
-    for (int ro = wave; ro < MF * t.NI; ro += 4) {
-      const int o = ro / t.NI, img = ro % t.NI;                // wave-uniform
-      const bool ok_row = img0 + img < geo.N && o0 + o < geo.O;
-      const int64_t src0 = (static_cast<int64_t>(ok_row ? img0 + img : 0) * geo.O + (ok_row ? o0 + o : 0)) * howo +
-                           static_cast<int64_t>(ho0) * geo.Wo;
-      for (int p = lane; p < bpi; p += 64) {
-        const bool ok = ok_row && p < th * geo.Wo;
-        gs[o * t.GP + img * bpi + p] = ok ? g[src0 + p] : 0.f;
-        gvs[o * t.GP + img * bpi + p] = ok ? gvar[src0 + p] : 0.f;
-      }
-    }
+    // the input patch of the block's channels as x and clamp(x^2): flat over the lanes, eight loads in flight per lane
+    // (conv_common.hpp)
+    conv_stage_patch<0, false>(x, x, xs, x2s, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp, img_floats, img0, geo.N, geo.C, c_lo,
+                        geo.H, geo.W, hi0, geo.pw, 1, 1);
+    // the block's rows of g and gvar ((row, image) strips of contiguous band pixels): flat items, sixteen loads in flight
+    conv_stage_rows(g, gvar, gs, gvs, wave, lane, MF * t.NI, t.NI, bpi, th * geo.Wo, t.GP, img0, geo.N, o0, geo.O, howo,
+                    static_cast<int64_t>(ho0) * geo.Wo);
     const int padn = t.npix - t.NI * bpi;                      // the padding behind the last image's strip
     for (int e = threadIdx.x; e < MF * padn; e += 256) {
       const int o = e / padn, pp = t.NI * bpi + e % padn;
@@ -328,7 +293,7 @@ static void wgrad_candidates(const WgGeo& g, std::vector<WgCand>& out) {
         const double halo = static_cast<double>(th) / ph;
         const double big = std::min(1.0, static_cast<double>(npix) / 256.0);      // enough k-steps per staging
         const double score = fill * (0.5 + 0.5 * halo) * (0.5 + 0.5 * big);
-        out.push_back(WgCand{WgTile{ni, th, bands, ps, ct, colgroups, ph, pwp, cmax, gp, npix}, std::max(lds, red), score, ct_cap});
+        out.push_back(WgCand{WgTile{ni, th, bands, ps, ct, colgroups, ph, pwp, cmax, gp, npix, 1.0f / static_cast<float>(pwp)}, std::max(lds, red), score, ct_cap});
       }
     }
   }

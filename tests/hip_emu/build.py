@@ -24,7 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "beyond_deep_ensembles_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-HEADERS = ["bde_common.hpp", "svgd_shared.hpp", "svgd_gram.hpp"]
+HEADERS = ["bde_common.hpp", "conv_common.hpp", "svgd_shared.hpp", "svgd_gram.hpp"]
 
 _EXTERN_LDS = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];")
 _ASM = re.compile(r"asm\s+volatile\s*\((?:[^()]|\((?:[^()]|\([^()]*\))*\))*\)\s*;")

@@ -129,3 +129,15 @@ def test_planner_supported_means_every_pass_has_a_tiling():
         assert lib.bde_conv_lrt_bwd_weight_ws_bytes(*geo) > 0, geo
     assert n_supported > 2500, n_supported                                 # the fused path is the rule, not the exception
     assert all(lib.bde_conv_lrt_supported(*g) for g in geos[:8])
+
+
+def test_flat_patch_index_split_is_exact():
+    """csrc/conv_common.hpp splits a flat patch-plane index e into (row, column) = (e // PWP, e % PWP) with ONE float multiply,
+    int((e + 0.5f) * fl(1 / PWP)), in fp32 as the kernel evaluates it.  A plane holds at most 8192 elements (two images of it
+    must fit 64 KB of LDS); the split must be exact for every e < 8192 and every row pitch 1 <= PWP <= 8192."""
+    e = np.arange(8192, dtype=np.int64)
+    ef = e.astype(np.float32) + np.float32(0.5)
+    for pwp in range(1, 8193):
+        rcp = np.float32(1.0) / np.float32(pwp)
+        py = (ef * rcp).astype(np.int32)                  # fp32 product, truncation
+        assert np.array_equal(py, e // pwp), pwp
