@@ -6,6 +6,7 @@ export PYTHONDONTWRITEBYTECODE=1 HSA_ENABLE_IPC_MODE_LEGACY=0
 # every candidate tiling of every pass timed, the winners pinned, the tuned layers measured against the reference's sequence
 timeout 1500 python tools/conv_autotune.py --out $O/conv_profit.json > $O/conv_autotune.txt 2>&1; grep -v amdgpu $O/conv_autotune.txt | tail -90
 timeout 2400 bash tools/gpu_profile.sh r05 > $O/gpu_profile.log 2>&1; tail -30 $O/gpu_profile.log | cut -c1-200
+timeout 300 python tools/graph_small_step_ab.py > $O/graph_small_step_ab.txt 2>&1; grep -v amdgpu $O/graph_small_step_ab.txt | tail -6
 timeout 600 python tools/gram_split_ab.py > $O/gram_split_ab.txt 2>&1; grep -v amdgpu $O/gram_split_ab.txt | tail -30
 for i in 1 2; do
 timeout 300 python tools/swag_batched_ab.py >> $O/swag_batched_rounds_ab.txt 2>&1
