@@ -2,7 +2,7 @@
 # round 5, first GPU call: HEAD of round 4 on hardware -- new kernels first, then the whole suite (no -x), conv bench, bench.py
 O=gpurun_out/r5a; mkdir -p $O
 export PYTHONDONTWRITEBYTECODE=1 HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q -k "conv_lrt or swag_batched or small_model" > $O/pytest_new_kernels.log 2>&1; echo "new kernels rc=$?"; tail -30 $O/pytest_new_kernels.log | cut -c1-220
+timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -q -k "conv_lrt or swag_batched or small_model or r5_" > $O/pytest_new_kernels.log 2>&1; echo "new kernels rc=$?"; tail -30 $O/pytest_new_kernels.log | cut -c1-220
 timeout 600 python tools/conv_lrt_bench.py > $O/conv_lrt_bench.txt 2>&1; grep -v amdgpu $O/conv_lrt_bench.txt | tail -60
 timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu_full.log 2>&1; echo "full suite rc=$?"; tail -40 $O/pytest_gpu_full.log | cut -c1-220
 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29612 \
