@@ -247,3 +247,64 @@ def test_the_model_notices_a_missing_dma_wait():
                 G.DEV = dev
     finally:
         emu_build._asm = real
+
+
+def test_conv_autotune_tool_end_to_end_on_the_cpu_model(emu, tmp_path, monkeypatch):
+    """tools/conv_autotune.py will get ONE run on the device: its whole logic -- candidate loops over forward / dilated and
+    per-phase input gradient / weight gradient, pinning, the reference sequence, the JSON it writes -- runs here on a tiny
+    stride-2 layer with a host clock, and the table it wrote is then consumed by a default BBBConv2d: the layer takes the
+    fused path (the record says it wins) with the recorded tilings pinned."""
+    import importlib.util
+    import json
+    import time
+    import beyond_deep_ensembles_amd as bde
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    from beyond_deep_ensembles_amd import conv_profit
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(root)
+    spec = importlib.util.spec_from_file_location("conv_autotune", os.path.join(root, "tools", "conv_autotune.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+
+    def host_clock(fn, iters):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+    out = tmp_path / "conv_profit.json"
+    layer_geo = (2, 4, 8, 8, 6, 3, 2, 1)
+    table = tool.main(["--out", str(out), "--iters", "1"], ops=emu, dev=torch.device("cpu"), layers=[layer_geo],
+                      time_loop=host_clock, device_name="the CPU model")
+    on_disk = json.load(open(out))
+    assert on_disk == json.loads(json.dumps(table)) and on_disk["abi"] == int(emu.lib.bde_version())
+    (key, rec), = on_disk["layers"].items()
+    assert key == conv_profit._key(4, 6, 3, 2, 1, 8, 8) and rec["batch"] == 2 and rec["fwd"] > 0 and rec["fwd_bwd"] > 0
+    til = rec["tilings"]
+    assert len(til["wgrad"]) == 4 and len(til["launch"]) >= 2 and all(len(row) == 19 for row in til["launch"])
+    # the tool removed its pins when it finished the layer
+    xs, ws = (2, 4, 8, 8), (6, 4, 3, 3)
+    geo = emu.conv_lrt_pass_geos(0, xs, ws, (2, 2), (1, 1))[0]
+    planner_choice = emu.conv_lrt_candidates(geo)[1]
+    # a default layer with this table: fused (the record is made a win), tilings re-pinned
+    rec["fwd"] = rec["fwd_bwd"] = 2.0
+    for row in til["launch"]:
+        if tuple(row[:15]) == tuple(geo):
+            cands, _ = emu.conv_lrt_candidates(geo)
+            other = next(c for i, c in enumerate(cands) if i != planner_choice)
+            row[15:19] = list(other[:4])
+    monkeypatch.setattr(conv_profit, "_table", on_disk)
+    monkeypatch.setattr(L, "_native_nodes", lambda ops: None)
+    conv_profit._applied.clear()
+    calls = []
+    real = emu.conv_lrt_fwd
+    monkeypatch.setattr(emu, "conv_lrt_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1], raising=False)
+    try:
+        prior = bde.GaussianPrior(0, 1.0)
+        layer = bde.BBBConv2d(4, 6, 3, prior, prior, stride=2, padding=1, _ops=emu)
+        y = layer(torch.randn(2, 4, 8, 8, requires_grad=True))
+        y.sum().backward()
+        assert calls and emu.conv_lrt_candidates(geo)[1] != planner_choice
+    finally:
+        for row in til["launch"]:
+            emu.conv_lrt_set_tiling(row[:15], None)
+        emu.conv_lrt_wgrad_set_tiling(xs, ws, (2, 2), (1, 1), None)
+        conv_profit._applied.clear()

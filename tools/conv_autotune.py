@@ -32,16 +32,20 @@ LAYERS = [  # (N, C, H, W, O, K, stride, padding): the CIFAR ResNet-20 layers of
     (32, 64, 56, 56, 64, 3, 1, 1), (32, 256, 14, 14, 256, 3, 1, 1), (32, 256, 56, 56, 64, 1, 1, 0), (32, 64, 56, 56, 256, 1, 1, 0)]
 
 
-def main():
+def main(argv=None, ops=None, dev=None, layers=None, time_loop=None, device_name=None):
+    """(the keyword arguments exist for tests/test_hip_emu.py, which runs this tool's whole logic on the CPU model with a tiny layer)"""
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/conv_profit.json")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--quick", action="store_true", help="the first four layers only")
-    a = ap.parse_args()
-    dev = torch.device("cuda", 0)
-    ops = HipOps()
-    table = {"abi": int(ops.lib.bde_version()), "source": "tools/conv_autotune.py on " + torch.cuda.get_device_name(0), "layers": {}}
-    for n, c, h, w, o, k, s, p in (LAYERS[:4] if a.quick else LAYERS):
+    a = ap.parse_args(argv)
+    dev = torch.device("cuda", 0) if dev is None else dev
+    ops = HipOps() if ops is None else ops
+    time_loop = bench.time_loop if time_loop is None else time_loop
+    layers = (LAYERS[:4] if a.quick else LAYERS) if layers is None else layers
+    table = {"abi": int(ops.lib.bde_version()), "layers": {},
+             "source": "tools/conv_autotune.py on " + (device_name or torch.cuda.get_device_name(0))}
+    for n, c, h, w, o, k, s, p in layers:
         xs, wsh, st, pd = (n, c, h, w), (o, c, k, k), (s, s), (p, p)
         if not ops.conv_lrt_supported(xs, wsh, st, pd):
             print(xs, wsh, "unsupported", flush=True)
@@ -82,14 +86,14 @@ def main():
                 times = []
                 for cand in cands:
                     ops.conv_lrt_set_tiling(geo, cand)
-                    times.append(bench.time_loop(fn, a.iters))
+                    times.append(time_loop(fn, a.iters))
                 best = min(range(len(cands)), key=lambda i: times[i])
                 ops.conv_lrt_set_tiling(geo, cands[best])
                 pinned.append((geo, cands[best][:4]))
                 print(f"    pass {which} geo {geo[5]}x{geo[6]} taps -> {geo[13]}x{geo[14]}: {len(cands)} tilings, planner's "
                       f"{cands[chosen][:4]} {times[chosen]*1e6:7.1f} us, best {cands[best][:4]} {times[best]*1e6:7.1f} us, worst "
                       f"{max(times)*1e6:7.1f} us", flush=True)
-            return bench.time_loop(fn, a.iters), pinned
+            return time_loop(fn, a.iters), pinned
         print(f"N{n} C{c} {h}x{w} O{o} k{k} s{s} p{p}", flush=True)
         t_f, pins_f = tune(0, fwd)
         t_dd, pins_dd = tune(1, dgrad_dilated)
@@ -98,13 +102,13 @@ def main():
         times = []
         for cand in cands:
             ops.conv_lrt_wgrad_set_tiling(xs, wsh, st, pd, cand)
-            times.append(bench.time_loop(wgrad, a.iters))
+            times.append(time_loop(wgrad, a.iters))
         best = min(range(len(cands)), key=lambda i: times[i])
         ops.conv_lrt_wgrad_set_tiling(xs, wsh, st, pd, cands[best])
         t_w = times[best]
         print(f"    weight gradient: {len(cands)} tilings, planner's {cands[chosen][:4]} {times[chosen]*1e6:7.1f} us, best "
               f"{cands[best][:4]} {t_w*1e6:7.1f} us, worst {max(times)*1e6:7.1f} us", flush=True)
-        t_g = bench.time_loop(gvar_pass, a.iters)
+        t_g = time_loop(gvar_pass, a.iters)
 
         # the reference's sequence on the same GPU: forward only, and forward + backward through autograd
         def torch_fwd():
@@ -120,8 +124,8 @@ def main():
             v = F.conv2d((xx ** 2).clamp(min=1e-4), (F.softplus(r_) ** 2).clamp(min=1e-4), F.softplus(br_) ** 2, stride=s, padding=p)
             torch.autograd.grad(mean + torch.sqrt(v) * noise, leaves, g)
         with torch.no_grad():
-            t_tf = bench.time_loop(torch_fwd, a.iters)
-        t_tfb = bench.time_loop(torch_fwd_bwd, a.iters)
+            t_tf = time_loop(torch_fwd, a.iters)
+        t_tfb = time_loop(torch_fwd_bwd, a.iters)
         ours = t_f + t_g + min(t_dd, t_dp) + t_w
         flops = 2 * 2.0 * n * o * ho * wo * c * k * k
         print(f"    tuned: forward {t_f*1e6:7.1f} us ({flops/t_f/1e12:5.1f} TFLOP/s) vs torch {t_tf*1e6:7.1f} us = {t_tf/t_f:5.2f}x;  "
@@ -140,6 +144,7 @@ def main():
     with open(a.out, "w") as f:
         json.dump(table, f, indent=1)
     print("wrote", a.out)
+    return table
 
 
 if __name__ == "__main__":
