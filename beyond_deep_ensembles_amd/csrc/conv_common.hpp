@@ -4,6 +4,19 @@
 
 namespace bde {
 
+// XCD-aware work assignment.  The hardware hands consecutive workgroups of a launch to the 8 XCDs round robin (workgroup L runs
+// on XCD L % 8), and every XCD has its own L2.  The kernels here have groups of `inner` workgroups that read the SAME input
+// (the channel tiles of one image band; the column groups of one share of items): this maps the launch's linear workgroup
+// index to a work index such that the workgroups of one XCD get CONSECUTIVE work indices -- with `inner` fastest, the
+// workgroups that share an input sit on one XCD, next to each other in time, and the second one finds the input in that L2.
+// A bijection on [0, total) for any total (XCD x owns (total - x + 7) / 8 of them).
+__device__ __forceinline__ int xcd_work_index(int linear, int total) {
+  constexpr int kXcds = 8;
+  const int q = total / kXcds, r = total % kXcds;
+  const int x = linear % kXcds;
+  return x * q + (x < r ? x : r) + linear / kXcds;
+}
+
 // Stage the patch of one channel chunk -- planes (image, channel) of PH x PWP elements each, LDS layout
 // [img][c][PH][PWP] -- as TWO images: xs <- the tensor (zero outside it), x2s <- clamp(x^2, 1e-4) of the same element
 // (MODE 0; zero in the padding: F.conv2d pads the clamped tensor) or the matching element of a second tensor (MODE 1:

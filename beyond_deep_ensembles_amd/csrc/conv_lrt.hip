@@ -98,8 +98,12 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane / MF, idx = lane % MF;
   const int wp = wave % t.WP, wk = wave / t.WP;
-  const int img0 = (blockIdx.x / t.bands) * t.NI, band = blockIdx.x % t.bands;
-  const int o0 = blockIdx.y * MF;
+  // work index -> (image group x band, channel tile), channel tile fastest: the channel tiles of one band read the same patch and
+  // run on one XCD back to back (xcd_work_index)
+  const int work = xcd_work_index(static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x), static_cast<int>(gridDim.x * gridDim.y));
+  const int bx = work / static_cast<int>(gridDim.y), by = work % static_cast<int>(gridDim.y);
+  const int img0 = (bx / t.bands) * t.NI, band = bx % t.bands;
+  const int o0 = by * MF;
   const int ho0 = band * t.TH;
   const int th = min(t.TH, g.Ho - ho0);
   const int band_pixels = th * g.Wo;

@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane / MF, idx = lane % MF;
-  const int otile = blockIdx.y / t.colgroups, cg = blockIdx.y % t.colgroups;
+  // work index -> (share of the items, block of the gradient matrices), block fastest: the blocks of one share stage the same
+  // patches and g rows and run on one XCD back to back (xcd_work_index)
+  const int work = xcd_work_index(static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x), static_cast<int>(gridDim.x * gridDim.y));
+  const int share = work / static_cast<int>(gridDim.y), yb = work % static_cast<int>(gridDim.y);
+  const int otile = yb / t.colgroups, cg = yb % t.colgroups;
   const int o0 = otile * MF, col0 = cg * CT * MF;                // (t.CT == CT: the host instantiates the planner's choice)
   const int col_end = min(ktot, col0 + CT * MF);
   const int c_lo = col0 / khw, c_hi = (col_end - 1) / khw, cc = c_hi - c_lo + 1;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
   const int bpi = t.TH * geo.Wo;                               // band pixels per image
   const int64_t howo = static_cast<int64_t>(geo.Ho) * geo.Wo;
   const int items = ((geo.N + t.NI - 1) / t.NI) * t.bands;
-  for (int item = blockIdx.x; item < items; item += t.PS) {
+  for (int item = share; item < items; item += t.PS) {
     const int img0 = (item / t.bands) * t.NI, band = item % t.bands;
     const int ho0 = band * t.TH;
     const int th = min(t.TH, geo.Ho - ho0);
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
   }
   if (wave != 0) return;
   // part [share][2][O][ktot]
-  float* pm = part + static_cast<int64_t>(blockIdx.x) * 2 * geo.O * ktot;
+  float* pm = part + static_cast<int64_t>(share) * 2 * geo.O * ktot;
   float* pv = pm + static_cast<int64_t>(geo.O) * ktot;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {

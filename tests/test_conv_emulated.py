@@ -141,3 +141,15 @@ def test_flat_patch_index_split_is_exact():
         rcp = np.float32(1.0) / np.float32(pwp)
         py = (ef * rcp).astype(np.int32)                  # fp32 product, truncation
         assert np.array_equal(py, e // pwp), pwp
+
+
+def test_xcd_work_index_is_a_bijection():
+    """csrc/conv_common.hpp xcd_work_index: workgroup L (dispatched to XCD L % 8) -> a work index such that one XCD's workgroups
+    own CONSECUTIVE work indices; it must be a bijection on [0, total) for every total."""
+    for total in list(range(1, 70)) + [255, 256, 257, 511, 512, 770, 1000]:
+        q, r = divmod(total, 8)
+        work = [(L % 8) * q + min(L % 8, r) + L // 8 for L in range(total)]
+        assert sorted(work) == list(range(total)), total
+        for x in range(min(8, total)):                               # the workgroups of XCD x: one contiguous range
+            mine = sorted(w for L, w in enumerate(work) if L % 8 == x)
+            assert mine == list(range(mine[0], mine[0] + len(mine))), (total, x)
