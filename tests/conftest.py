@@ -38,7 +38,8 @@ def pytest_collection_modifyitems(config, items):
 
 # Test functions that were part of the last full `-m gpu` suite that ran green on an MI355X under the driver (round 3,
 # GPUTEST_r03.json: 117 passed).  Everything else -- written while the GPU pool was closed, or re-run there only in part --
-# is collected BEHIND them, and the multi-rank files last: the driver runs `pytest -x`, and a failure in the least
+# is collected BEHIND them (the last suite's multi-rank tests before the new single-process tests, the new multi-rank tests
+# last): the driver runs `pytest -x`, and a failure in the least
 # verified tests must not leave the kernel parity tests "unreached" (the first GPU call of round 4
 # stopped at test 17 of the old order).  An ordering only -- nothing is skipped.
 _NEW_SINCE_LAST_GREEN_SUITE = {
@@ -57,13 +58,15 @@ _LAST_FILES = ["test_dist_gpu", "test_dist_fullsize_gpu"]
 
 
 def _order_key(nodeid: str, name: str):
+    """(group, file rank): 0 the kernel / shell tests of the last green suite, 1 its multi-rank tests, 2 kernel / shell tests
+    written since, 3 multi-rank tests written since."""
     fname = os.path.splitext(os.path.basename(nodeid.split("::")[0]))[0]
     base = name.split("[")[0]
-    if fname in _LAST_FILES:
-        return (3, _LAST_FILES.index(fname), base in _NEW_SINCE_LAST_GREEN_SUITE)
     new = base in _NEW_SINCE_LAST_GREEN_SUITE or base.startswith("test_r5_")
+    if fname in _LAST_FILES:
+        return (3 if new else 1, _LAST_FILES.index(fname))
     rank = _FILE_ORDER.index(fname) if fname in _FILE_ORDER else len(_FILE_ORDER)
-    return (1 if new else 0, rank, False)
+    return (2 if new else 0, rank)
 
 
 def _hardware_verified_first(items) -> None:
