@@ -362,3 +362,58 @@ def test_reference_checkpoint_resumes_on_two_ranks(tmp_path, kw):
     from tests.ckpt_resume import check
     mp.spawn(_resume_worker, args=(2, _free_port(), tuple(kw.items()), str(tmp_path)), nprocs=2, join=True)
     check(str(tmp_path))
+
+
+# ------------------------------------------------------------------ the RCCL one-rank matrix of tests/test_dist_gpu.py, on the CPU model --
+def _one_rank_matrix_worker(rank, world, port, m, kw, out_dir):
+    import tests.test_dist_gpu as G
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        with _backend("emu") as ops:
+            model, opt = G._make_svgd(100 + rank, m, torch.device("cpu"), pg=dist.group.WORLD, _ops=ops, **dict(kw))
+            losses = G._run_steps(model, opt, torch.device("cpu"))
+            np.savez(os.path.join(out_dir, f"rank{rank}.npz"), particles=opt.particles.numpy(), losses=np.array(losses))
+    finally:
+        dist.destroy_process_group()
+
+
+def _svgd_cases():
+    import tests.test_dist_gpu as G
+    return G.SVGD_CASES
+
+
+@pytest.mark.parametrize("name,m,kw", _svgd_cases(), ids=[c[0] for c in _svgd_cases()])
+def test_one_rank_forced_exchange_matrix_on_the_cpu_model(tmp_path, name, m, kw):
+    """tests/test_dist_gpu.py::test_svgd_rccl_one_rank_forced_exchange -- the nine exchange variants through a process group of
+    ONE rank with the collectives forced -- has run on the MI355X for one variant only (the pool closed).  Here the same nine
+    variants, the same model, optimizer and steps (its _make_svgd / _run_steps), the product's kernels on the CPU model, gloo
+    instead of RCCL: the result must equal the run without a process group exactly as the GPU test demands -- bit for bit for
+    the replicated exchanges, to 1e-5 / 2e-7 for the dimension-sharded exchange and reuse_gram, whose Gram partials are summed
+    in another fixed order; that difference is printed in ulps (the figure the device run will reproduce: same kernels, same
+    arithmetic)."""
+    import tests.test_dist_gpu as G
+    from tests.hip_emu import build
+    if not build.available():
+        pytest.skip("no host clang / HIP headers to build the CPU model with")
+    build.build(__import__("tests.hip_emu.emu_ops", fromlist=["ALL"]).ALL)
+    forced = dict(kw, _force_exchange=True)
+    mp.spawn(_one_rank_matrix_worker, args=(1, _free_port(), m, tuple(forced.items()), str(tmp_path)), nprocs=1, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    single_kw = {k: v for k, v in kw.items() if k not in ("exchange", "exchange_chunks", "overlap_backward")}
+    torch.set_num_threads(1)
+    with _backend("emu") as ops:
+        model, opt = G._make_svgd(100, m, torch.device("cpu"), single_launch=False, _ops=ops, **single_kw)
+        losses = G._run_steps(model, opt, torch.device("cpu"))
+        want = opt.particles.numpy().copy()
+    if kw.get("exchange") == "alltoall" or kw.get("reuse_gram"):
+        a, b = r0["particles"].astype(np.float32), want.astype(np.float32)
+        ulp = np.abs(a - b) / np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32))
+        print(f"one_rank_matrix[{name}] on the CPU model: max |sharded - single| = {np.abs(a - b).max():.3e} = {ulp.max():.1f} ulp")
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=2e-7)
+        np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=2e-6)
+    else:
+        np.testing.assert_array_equal(r0["particles"], want)
+        np.testing.assert_array_equal(r0["losses"], np.array(losses))
