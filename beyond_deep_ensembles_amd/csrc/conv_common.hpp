@@ -4,6 +4,8 @@
 
 namespace bde {
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
 // XCD-aware work assignment.  The hardware hands consecutive workgroups of a launch to the 8 XCDs round robin (workgroup L runs
 // on XCD L % 8), and every XCD has its own L2.  The kernels here have groups of `inner` workgroups that read the SAME input
 // (the channel tiles of one image band; the column groups of one share of items): this maps the launch's linear workgroup
@@ -18,9 +20,10 @@ __device__ __forceinline__ int xcd_work_index(int linear, int total) {
 }
 
 // Stage the patch of one channel chunk -- planes (image, channel) of PH x PWP elements each, LDS layout
-// [img][c][PH][PWP] -- as TWO images: xs <- the tensor (zero outside it), x2s <- clamp(x^2, 1e-4) of the same element
-// (MODE 0; zero in the padding: F.conv2d pads the clamped tensor) or the matching element of a second tensor (MODE 1:
-// g and g_var of the input-gradient pass, optionally zero-dilated by (dh, dw)).
+// [img][c][PH][PWP] of PAIRS: .x <- the tensor (zero outside it), .y <- clamp(x^2, 1e-4) of the same element (MODE 0; zero in
+// the padding: F.conv2d pads the clamped tensor) or the matching element of a second tensor (MODE 1: g and g_var of the
+// input-gradient pass, optionally zero-dilated by (dh, dw)).  The two products of the layer read their B operands at the same
+// element: interleaved, ONE ds_read_b64 (one address) serves both, and the staging pass writes one ds_write_b64 per element.
 //
 // Round 4 staged one plane per wave trip with the lanes along a patch ROW, four rows of loads in flight: a 10 x 10 patch
 // of an 8 x 8 image kept 10 of 64 lanes busy and put 12 load instructions of 4 in flight behind each other per plane --
@@ -40,7 +43,7 @@ __device__ __forceinline__ int xcd_work_index(int linear, int total) {
 // register written on two paths, separates the eight (sixteen) loads.
 template <int MODE, bool DIL>
 __device__ __forceinline__ void conv_stage_patch(const float* __restrict__ src1, const float* __restrict__ src2,
-                                                 float* __restrict__ xs, float* __restrict__ x2s, int wave, int lane,
+                                                 f32x2* __restrict__ xq, int wave, int lane,
                                                  int planes, int cc, int row_elems, int PWP, float rcp_pwp, int img_floats,
                                                  int img0, int N, int C, int c0, int H, int W, int hi0, int pw, int dh,
                                                  int dw) {
@@ -91,19 +94,21 @@ __device__ __forceinline__ void conv_stage_patch(const float* __restrict__ src1,
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (off[u] >= 0) {
-        xs[off[u]] = okv[u] ? v[u] : 0.f;
-        x2s[off[u]] = !okv[u] ? 0.f : (MODE == 1 ? v2[u] : fmaxf(v[u] * v[u], 1e-4f));
+        f32x2 pair;
+        pair.x = okv[u] ? v[u] : 0.f;
+        pair.y = !okv[u] ? 0.f : (MODE == 1 ? v2[u] : fmaxf(v[u] * v[u], 1e-4f));
+        xq[off[u]] = pair;
       }
     }
   }
 }
 
 // The weight-gradient kernel's A operands: rows (output channel o, image img) of g and g_var -- bpi contiguous pixels of a
-// band each -- into gs / gvs [o][GP] at column img * bpi + p; zero for rows / pixels outside the tensor.  The same scheme as
+// band each -- as PAIRS (g, g_var) into gq [o][GP] at column img * bpi + p; zero for rows / pixels outside the tensor.  The same scheme as
 // the patch: a wave's rows (wave, wave + 4, ...) x steps of 64 lanes as one sequence of items, eight items (sixteen loads) in
 // flight, straight-line (round 4: one row per trip, two loads in flight -- the staging latency exceeded the matrix work).
 __device__ __forceinline__ void conv_stage_rows(const float* __restrict__ g, const float* __restrict__ gvar,
-                                                float* __restrict__ gs, float* __restrict__ gvs, int wave, int lane, int rows,
+                                                f32x2* __restrict__ gq, int wave, int lane, int rows,
                                                 int NI, int bpi, int valid_pixels, int GP, int img0, int N, int o0, int O,
                                                 int64_t howo, int64_t band_at) {
   const int S = (bpi + 63) >> 6;
@@ -138,8 +143,10 @@ __device__ __forceinline__ void conv_stage_rows(const float* __restrict__ g, con
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (off[u] >= 0) {
-        gs[off[u]] = okv[u] ? a[u] : 0.f;
-        gvs[off[u]] = okv[u] ? b[u] : 0.f;
+        f32x2 pair;
+        pair.x = okv[u] ? a[u] : 0.f;
+        pair.y = okv[u] ? b[u] : 0.f;
+        gq[off[u]] = pair;
       }
     }
   }

@@ -72,8 +72,9 @@ template <> struct Mfma<16> {
   __device__ __forceinline__ static int row(int r, int h) { return 4 * h + r; }
 };
 
-// LDS: xs [NI][CC][PH][PWP] | x2s (same) | wm [kcpad][MF] | ws [kcpad][MF] | kofs [kcpad] (int); the epilogue reuses
-// the front of it: per wave 2 x [MF][MF + 4] floats.
+// LDS: xq [NI][CC][PH][PWP] pairs (x, clamp(x^2)) | wq [kcpad][MF] pairs (W_mu, sigma^2) | kofs [kcpad] (int); the epilogue
+// reuses the front of it: per wave 2 x [MF][MF + 4] floats.  Pairs: both products of a k-step read their operands at the
+// same element, so one ds_read_b64 (one address computation) serves both.
 template <int MF, int PT, bool RNG, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     const float* __restrict__ x, const float* __restrict__ x_second, const float* __restrict__ wt_mu,
@@ -88,11 +89,9 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
   const int row_elems = t.PH * t.PWP;
   const int img_floats = t.CC * row_elems;
   const int patch_floats = (t.NI * img_floats + 3) & ~3;    // the weight tiles behind the two patch images are written as float4
-  float* xs = lds;
-  float* x2s = lds + patch_floats;
-  float* wm = lds + 2 * patch_floats;
-  float* wsv = wm + t.kcpad_max * MF;
-  int* kofs = reinterpret_cast<int*>(wsv + t.kcpad_max * MF);
+  f32x2* xq = reinterpret_cast<f32x2*>(lds);
+  f32x2* wq = reinterpret_cast<f32x2*>(lds + 2 * patch_floats);
+  int* kofs = reinterpret_cast<int*>(lds + 2 * patch_floats + 2 * t.kcpad_max * MF);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -138,16 +137,17 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     // ---- the input patch of the chunk: x and clamp(x^2) (zero outside the image: padding is applied after the clamp);
     //      MODE 1: g and gvar, dilated.  Flat over the lanes, eight loads in flight per lane (conv_common.hpp)
     if (MODE == 1 && (g.dh != 1 || g.dw != 1))               // (uniform for the launch: the dilated input-gradient pass)
-      conv_stage_patch<1, true>(x, x_second, xs, x2s, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp, img_floats, img0, g.N,
+      conv_stage_patch<1, true>(x, x_second, xq, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp, img_floats, img0, g.N,
                                 g.C, c0, g.H, g.W, hi0, g.pw, g.dh, g.dw);
     else
-      conv_stage_patch<MODE, false>(x, MODE == 1 ? x_second : x, xs, x2s, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp,
+      conv_stage_patch<MODE, false>(x, MODE == 1 ? x_second : x, xq, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp,
                                     img_floats, img0, g.N, g.C, c0, g.H, g.W, hi0, g.pw, 1, 1);
-    // ---- the weight tile, k-major [k][MF] (conflict-free A-operand reads): aligned float4 copies of the pre-arranged
-    //      [k][rp] matrices; k past the chunk is zero
+    // ---- the weight tile, k-major [k][MF] pairs (conflict-free A-operand reads): aligned float4 copies of the pre-arranged
+    //      [k][rp] matrices, interleaved on the way; k past the chunk is zero
     {
       constexpr int Q = MF / 4;
       const int64_t k_base = static_cast<int64_t>(c0) * khw;
+      float* wflat = reinterpret_cast<float*>(wq);
       for (int e = threadIdx.x; e < kcpad * Q; e += 256) {
         const int k = e / Q, o4 = e % Q;
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
@@ -156,48 +156,38 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
           a = ld4(wt_mu + src);
           b = ld4(wt_s2 + src);
         }
-        st4(wm + k * MF + 4 * o4, a);
-        st4(wsv + k * MF + 4 * o4, b);
+        st4(wflat + 2 * (k * MF + 4 * o4), f32x4{a.x, b.x, a.y, b.y});
+        st4(wflat + 2 * (k * MF + 4 * o4) + 4, f32x4{a.z, b.z, a.w, b.w});
       }
     }
     __syncthreads();
     const int ksteps = kcpad / KS;
     const int ks0 = wk * (ksteps / t.WK), ks1 = ks0 + ksteps / t.WK;
-    // operands of step ks + 1 are requested before the products of step ks are issued
-    int kk = ks0 * KS + h;
-    int ko = kofs[kk];
-    float am = wm[kk * MF + idx], as = wsv[kk * MF + idx];
-    float b[PT], b2[PT];
+    // Two operand sets, used alternately: the operands of step ks + 1 are requested before the products of step ks are issued,
+    // and no register is copied (round 4 copied the prefetched set into the "current" one: 2 + 2 PT moves per step)
+    f32x2 a0, a1, b0[PT], b1[PT];
+    auto fetch = [&](int kk_, f32x2& a, f32x2(&b)[PT]) {
+      const int ko = kofs[kk_];
+      a = wq[kk_ * MF + idx];
 #pragma unroll
-    for (int i = 0; i < PT; ++i) {
-      b[i] = xs[pixoff[i] + ko];
-      b2[i] = x2s[pixoff[i] + ko];
-    }
-    for (int ks = ks0; ks < ks1; ++ks) {
-      const float cam = am, cas = as;
-      float cb[PT], cb2[PT];
+      for (int i = 0; i < PT; ++i) b[i] = xq[pixoff[i] + ko];
+    };
+    auto products = [&](const f32x2& a, const f32x2(&b)[PT]) {
 #pragma unroll
       for (int i = 0; i < PT; ++i) {
-        cb[i] = b[i];
-        cb2[i] = b2[i];
+        accm[i] = M::run(a.x, b[i].x, accm[i]);
+        accv[i] = M::run(a.y, b[i].y, accv[i]);
       }
-      if (ks + 1 < ks1) {
-        kk += KS;
-        ko = kofs[kk];
-        am = wm[kk * MF + idx];
-        as = wsv[kk * MF + idx];
-#pragma unroll
-        for (int i = 0; i < PT; ++i) {
-          b[i] = xs[pixoff[i] + ko];
-          b2[i] = x2s[pixoff[i] + ko];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < PT; ++i) {
-        accm[i] = M::run(cam, cb[i], accm[i]);
-        accv[i] = M::run(cas, cb2[i], accv[i]);
-      }
+    };
+    int ks = ks0, kk = ks0 * KS + h;
+    if (ks < ks1) fetch(kk, a0, b0);
+    for (; ks + 1 < ks1; ks += 2, kk += 2 * KS) {
+      fetch(kk + KS, a1, b1);
+      products(a0, b0);
+      if (ks + 2 < ks1) fetch(kk + 2 * KS, a0, b0);
+      products(a1, b1);
     }
+    if (ks < ks1) products(a0, b0);                         // an odd number of steps: the last set fetched is still pending
   }
 
   // ---- k-split: waves wk > 0 hand their accumulators to wave wk = 0 of the same pixel-tile group through LDS

@@ -45,7 +45,7 @@ template <> struct MfmaW<16> {
   __device__ __forceinline__ static int row(int r, int h) { return 4 * h + r; }
 };
 
-// LDS: xs [NI][cmax][PH][PWP] | x2s | gs [MF][GP] | gvs [MF][GP] | pixtab [npix]   (reused for the wave reduction)
+// LDS: xq [NI][cmax][PH][PWP] pairs (x, clamp(x^2)) | gq [MF][GP] pairs (g, g_var) | pixtab [npix]   (reused for the wave reduction)
 template <int MF, int CT>
 __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                 const float* __restrict__ gvar, float* __restrict__ part,
@@ -69,11 +69,9 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
   const int c_lo = col0 / khw, c_hi = (col_end - 1) / khw, cc = c_hi - c_lo + 1;
   const int img_floats = cc * row_elems;
   const int patch_floats = t.NI * t.cmax * row_elems;
-  float* xs = lds;
-  float* x2s = lds + patch_floats;
-  float* gs = lds + 2 * patch_floats;
-  float* gvs = gs + MF * t.GP;
-  int* pixtab = reinterpret_cast<int*>(gvs + MF * t.GP);
+  f32x2* xq = reinterpret_cast<f32x2*>(lds);                       // pairs (x, clamp(x^2)): one b64 read serves both products
+  f32x2* gq = reinterpret_cast<f32x2*>(lds + 2 * patch_floats);    // pairs (g, g_var) [MF][GP]
+  int* pixtab = reinterpret_cast<int*>(lds + 2 * patch_floats + 2 * MF * t.GP);
 
   int kofs[CT];
 #pragma unroll
@@ -98,18 +96,17 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     const int th = min(t.TH, geo.Ho - ho0);
     const int hi0 = ho0 * geo.sh - geo.ph;
     __syncthreads();
-    // the input patch of the block's channels as x and clamp(x^2): flat over the lanes, eight loads in flight per lane
+    // the input patch of the block's channels as pairs (x, clamp(x^2)): flat over the lanes, eight loads in flight per lane
     // (conv_common.hpp)
-    conv_stage_patch<0, false>(x, x, xs, x2s, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp, img_floats, img0, geo.N, geo.C, c_lo,
-                        geo.H, geo.W, hi0, geo.pw, 1, 1);
-    // the block's rows of g and gvar ((row, image) strips of contiguous band pixels): flat items, sixteen loads in flight
-    conv_stage_rows(g, gvar, gs, gvs, wave, lane, MF * t.NI, t.NI, bpi, th * geo.Wo, t.GP, img0, geo.N, o0, geo.O, howo,
+    conv_stage_patch<0, false>(x, x, xq, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp, img_floats, img0, geo.N, geo.C, c_lo,
+                               geo.H, geo.W, hi0, geo.pw, 1, 1);
+    // the block's rows of g and gvar ((row, image) strips of contiguous band pixels) as pairs: flat items, sixteen loads in flight
+    conv_stage_rows(g, gvar, gq, wave, lane, MF * t.NI, t.NI, bpi, th * geo.Wo, t.GP, img0, geo.N, o0, geo.O, howo,
                     static_cast<int64_t>(ho0) * geo.Wo);
     const int padn = t.npix - t.NI * bpi;                      // the padding behind the last image's strip
     for (int e = threadIdx.x; e < MF * padn; e += 256) {
       const int o = e / padn, pp = t.NI * bpi + e % padn;
-      gs[o * t.GP + pp] = 0.f;
-      gvs[o * t.GP + pp] = 0.f;
+      gq[o * t.GP + pp] = f32x2{0.f, 0.f};
     }
     for (int pp = threadIdx.x; pp < t.npix; pp += 256) {
       const int img = pp / bpi, p = pp % bpi;
@@ -118,49 +115,33 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     }
     __syncthreads();
     const int ksteps = t.npix / KS;
-    // the operands of this wave's NEXT k-step are requested before the products of the current one are issued (as in the
-    // forward kernel): the LDS round trip hides behind 2 CT MFMAs instead of stalling in front of them
-    int ks = wave;
-    int po = 0;
-    float am = 0.f, av = 0.f, b[CT], b2[CT];
+    // Two operand sets, used alternately (no register copies): the operands of this wave's NEXT k-step are requested before
+    // the products of the current one are issued -- the LDS round trip hides behind 2 CT MFMAs instead of stalling in front
+    // of them.  One ds_read_b64 per operand pair: 2 + CT reads (+ the pixel's patch offset) per 2 CT products.
+    f32x2 a0, a1, b0[CT], b1[CT];
+    auto fetch = [&](int ks_, f32x2& a, f32x2(&b)[CT]) {
+      const int pix = ks_ * KS + h;
+      const int po = pixtab[pix];
+      a = gq[idx * t.GP + pix];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) b[ct] = b2[ct] = 0.f;
-    if (ks < ksteps) {
-      const int pix = ks * KS + h;
-      po = pixtab[pix];
-      am = gs[idx * t.GP + pix];
-      av = gvs[idx * t.GP + pix];
+      for (int ct = 0; ct < CT; ++ct) b[ct] = xq[po + kofs[ct]];
+    };
+    auto products = [&](const f32x2& a, const f32x2(&b)[CT]) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        b[ct] = xs[po + kofs[ct]];
-        b2[ct] = x2s[po + kofs[ct]];
+        accm[ct] = M::run(a.x, b[ct].x, accm[ct]);
+        accv[ct] = M::run(a.y, b[ct].y, accv[ct]);
       }
+    };
+    int ks = wave;                                             // this wave's steps: wave, wave + 4, ...
+    if (ks < ksteps) fetch(ks, a0, b0);
+    for (; ks + 4 < ksteps; ks += 8) {
+      fetch(ks + 4, a1, b1);
+      products(a0, b0);
+      if (ks + 8 < ksteps) fetch(ks + 8, a0, b0);
+      products(a1, b1);
     }
-    for (; ks < ksteps; ks += 4) {
-      const float cam = am, cav = av;
-      float cb[CT], cb2[CT];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        cb[ct] = b[ct];
-        cb2[ct] = b2[ct];
-      }
-      if (ks + 4 < ksteps) {
-        const int pix = (ks + 4) * KS + h;
-        po = pixtab[pix];
-        am = gs[idx * t.GP + pix];
-        av = gvs[idx * t.GP + pix];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          b[ct] = xs[po + kofs[ct]];
-          b2[ct] = x2s[po + kofs[ct]];
-        }
-      }
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        accm[ct] = M::run(cam, cb[ct], accm[ct]);
-        accv[ct] = M::run(cav, cb2[ct], accv[ct]);
-      }
-    }
+    if (ks < ksteps) products(a0, b0);                         // an odd number of steps: the last set fetched is still pending
   }
 
   // ---- the four waves' blocks summed through LDS as a fixed two-round tree, (w0 + w1) + (w2 + w3): round 1 waves 1 and 3
