@@ -94,7 +94,7 @@ ROWS = {
     "lrt_bwd_x_finish_kernel": ("O-slice partials finish", "latency", "—", R3, "same"),
     # ---- BBBConv2d
     "conv_lrt_kernel": ("whole `BBBConv2d.forward` (`bbb_layers.py:146-154`) / its input gradient: dual-accumulator implicit GEMM", "`4·N·O·Ho·Wo·C·K²` flop",
-                        "version 1 only: 40.7 µs vs 102.3 µs torch at 16→16 32×32 b128, 0.8× at 64→64 `r04_conv_lrt_fwd_v1_bench.txt`; version 2 (HEAD): **unmeasured**",
+                        "version 1 only: 40.7 µs vs 102.3 µs torch at 16→16 32×32 b128, 0.8× at 64→64 `r04_conv_lrt_fwd_v1_bench.txt`; HEAD (round-4 version 2 + round 5: flat 8-deep staging, pair layout, alternating operand sets, XCD mapping): **unmeasured**",
                         NEVER + "; `fused_conv=\"auto\"` keeps it OFF until `conv_profit.json` holds a device measurement", "`test_conv_lrt_forward`, `test_conv_lrt_backward`"),
     "conv_lrt_prep_kernel": ("σ², dσ²/dρ, weight matrices in staging order, per-phase matrices", "`~40·O·C·K²` B", "unmeasured", NEVER, "same"),
     "conv_lrt_wgrad_kernel": ("both weight-gradient convolutions, reduction over pixels", "same flops as forward; partials ≤ 512 blocks (round 5: −1/3 … −1/2 of round 4's bytes)",
