@@ -592,7 +592,7 @@ def other_shell_steps_ms(dev, steps=10):
     return out
 
 
-def config_extras(dev):
+def config_extras(dev, on_section=None):
     """The other BASELINE.json configs through the PRODUCT shells (null closures: what is timed is the optimizer's
     own work -- kernels + host logic -- per step / per posterior sample):
       configs[1]  CIFAR ResNet-20 SVGD, 8 particles: SVGDOptimizer.step, SGD-nesterov base (cifar.yaml), unfused and fused;
@@ -696,55 +696,6 @@ def config_extras(dev):
             del o_, v_, gg, gx_, gwm_, gwr_, s2_, ds2_
         del layer
 
-    # ---- the BBBConv2d layers of the CIFAR ResNet-20 (BASELINE configs[1] model family, batch 128): the fused layer
-    # (bde_conv_lrt_fwd + bde_conv_lrt_bwd_data / _weight: each pair of convolutions of bbb_layers.py:146-147 as ONE
-    # dual-accumulator implicit GEMM) vs the reference's op sequence (two MIOpen convolutions + element-wise ops) and vs
-    # round 3's composition (stock convolutions, fused element-wise passes: fused_conv=False)
-    from beyond_deep_ensembles_amd import bbb_layers as _bl
-    conv_shapes = {"resnet20_layer_b128": (128, 16, 32, 32, 16, 3, 1, 1), "resnet20_first_b128": (128, 3, 32, 32, 16, 3, 1, 1),
-                   "resnet20_16to32_s2_b128": (128, 16, 32, 32, 32, 3, 2, 1), "resnet20_32ch_b128": (128, 32, 16, 16, 32, 3, 1, 1),
-                   "resnet20_32to64_s2_b128": (128, 32, 16, 16, 64, 3, 2, 1), "resnet20_64ch_b128": (128, 64, 8, 8, 64, 3, 1, 1)}
-    for cname, (cn, cc_, chh, cww, co, ck, cs, cp) in conv_shapes.items():
-        conv = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=True).to(dev)
-        conv3 = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=False).to(dev)
-        conv3.load_state_dict(conv.state_dict())
-        xc = torch.randn(cn, cc_, chh, cww, device=dev, requires_grad=True)
-
-        def leaves(layer):
-            return [xc, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho]
-
-        def conv_fused():
-            torch.autograd.grad(conv(xc).sum(), leaves(conv))
-
-        def conv_round3():
-            torch.autograd.grad(conv3(xc).sum(), leaves(conv3))
-
-        def conv_torch():                                            # bbb_layers.py:146-154
-            w, b = conv.weight, conv.bias
-            mean = F.conv2d(xc, w.mean, b.mean, stride=cs, padding=cp)
-            var = F.conv2d((xc ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), b.std ** 2, stride=cs, padding=cp)
-            torch.autograd.grad((mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)).sum(), leaves(conv))
-        with torch.no_grad():
-            t_ff = time_loop(lambda: conv(xc), 30)
-        t_f, t_3, t_t = time_loop(conv_fused, 30), time_loop(conv_round3, 30), time_loop(conv_torch, 30)
-        ho, wo = (chh + 2 * cp - ck) // cs + 1, (cww + 2 * cp - ck) // cs + 1
-        flops_fwd = 2 * 2.0 * cn * co * ho * wo * cc_ * ck * ck
-        out["bbb_conv2d_fwd_bwd_" + cname] = {
-            "ms": round(t_f * 1e3, 4), "torch_sequence_ms": round(t_t * 1e3, 4), "speedup": round(t_t / t_f, 2),
-            "round3_composition_ms": round(t_3 * 1e3, 4), "forward_only_ms": round(t_ff * 1e3, 4),
-            "forward_TFLOPs": round(flops_fwd / t_ff / 1e12, 2), "shape": {"N": cn, "C": cc_, "H": chh, "W": cww, "O": co, "K": ck,
-                                                                          "stride": cs, "padding": cp},
-            "what": "BBBConv2d forward + backward (all five gradients) through the layer: fused dual-accumulator implicit-GEMM "
-                    "kernels (1 forward launch; g_var + input-gradient + weight-gradient + finish launches backward) vs the "
-                    "reference's op sequence under autograd (two MIOpen convolutions forward, four backward, ~25 element-wise "
-                    "launches) and vs round 3's composition (stock convolutions + fused element-wise passes)",
-            "native_autograd_nodes": _bl._native_nodes(conv.weight._get_ops()) is not None,
-            # what BBBConv2d() without a keyword does at this geometry: the fused kernels only where conv_profit.json records
-            # a device measurement of this kernel version that beats the stock sequence (forward + backward)
-            "default_path": "fused" if _bl._conv_profitable((cn, cc_, chh, cww), (co, cc_, ck, ck), (cs, cs), (cp, cp),
-                                                             conv.weight._get_ops(), True) else "stock (round-3 composition)"}
-        del conv, conv3, xc
-
     # ---- configs[0]: BBBOptimizer.step on the UCI-housing MLP (13 -> 50 -> 1 BBBLinear, 5 MC samples, Adam), whole
     # step incl. forward/backward; beside it the reference's op sequence for the same step in plain PyTorch on this GPU
     def uci_model():
@@ -827,6 +778,57 @@ def config_extras(dev):
                 "(predict_distributed)"}
     del ens
     torch.cuda.empty_cache()
+    if on_section is not None:
+        on_section(out)                 # everything above has been measured; LAST: kernels that have never run on an MI355X
+    # ---- the BBBConv2d layers of the CIFAR ResNet-20 (BASELINE configs[1] model family, batch 128): the fused layer
+    # (bde_conv_lrt_fwd + bde_conv_lrt_bwd_data / _weight: each pair of convolutions of bbb_layers.py:146-147 as ONE
+    # dual-accumulator implicit GEMM) vs the reference's op sequence (two MIOpen convolutions + element-wise ops) and vs
+    # round 3's composition (stock convolutions, fused element-wise passes: fused_conv=False)
+    from beyond_deep_ensembles_amd import bbb_layers as _bl
+    conv_shapes = {"resnet20_layer_b128": (128, 16, 32, 32, 16, 3, 1, 1), "resnet20_first_b128": (128, 3, 32, 32, 16, 3, 1, 1),
+                   "resnet20_16to32_s2_b128": (128, 16, 32, 32, 32, 3, 2, 1), "resnet20_32ch_b128": (128, 32, 16, 16, 32, 3, 1, 1),
+                   "resnet20_32to64_s2_b128": (128, 32, 16, 16, 64, 3, 2, 1), "resnet20_64ch_b128": (128, 64, 8, 8, 64, 3, 1, 1)}
+    for cname, (cn, cc_, chh, cww, co, ck, cs, cp) in conv_shapes.items():
+        conv = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=True).to(dev)
+        conv3 = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=False).to(dev)
+        conv3.load_state_dict(conv.state_dict())
+        xc = torch.randn(cn, cc_, chh, cww, device=dev, requires_grad=True)
+
+        def leaves(layer):
+            return [xc, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho]
+
+        def conv_fused():
+            torch.autograd.grad(conv(xc).sum(), leaves(conv))
+
+        def conv_round3():
+            torch.autograd.grad(conv3(xc).sum(), leaves(conv3))
+
+        def conv_torch():                                            # bbb_layers.py:146-154
+            w, b = conv.weight, conv.bias
+            mean = F.conv2d(xc, w.mean, b.mean, stride=cs, padding=cp)
+            var = F.conv2d((xc ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), b.std ** 2, stride=cs, padding=cp)
+            torch.autograd.grad((mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)).sum(), leaves(conv))
+        with torch.no_grad():
+            t_ff = time_loop(lambda: conv(xc), 30)
+        t_f, t_3, t_t = time_loop(conv_fused, 30), time_loop(conv_round3, 30), time_loop(conv_torch, 30)
+        ho, wo = (chh + 2 * cp - ck) // cs + 1, (cww + 2 * cp - ck) // cs + 1
+        flops_fwd = 2 * 2.0 * cn * co * ho * wo * cc_ * ck * ck
+        out["bbb_conv2d_fwd_bwd_" + cname] = {
+            "ms": round(t_f * 1e3, 4), "torch_sequence_ms": round(t_t * 1e3, 4), "speedup": round(t_t / t_f, 2),
+            "round3_composition_ms": round(t_3 * 1e3, 4), "forward_only_ms": round(t_ff * 1e3, 4),
+            "forward_TFLOPs": round(flops_fwd / t_ff / 1e12, 2), "shape": {"N": cn, "C": cc_, "H": chh, "W": cww, "O": co, "K": ck,
+                                                                          "stride": cs, "padding": cp},
+            "what": "BBBConv2d forward + backward (all five gradients) through the layer: fused dual-accumulator implicit-GEMM "
+                    "kernels (1 forward launch; g_var + input-gradient + weight-gradient + finish launches backward) vs the "
+                    "reference's op sequence under autograd (two MIOpen convolutions forward, four backward, ~25 element-wise "
+                    "launches) and vs round 3's composition (stock convolutions + fused element-wise passes)",
+            "native_autograd_nodes": _bl._native_nodes(conv.weight._get_ops()) is not None,
+            # what BBBConv2d() without a keyword does at this geometry: the fused kernels only where conv_profit.json records
+            # a device measurement of this kernel version that beats the stock sequence (forward + backward)
+            "default_path": "fused" if _bl._conv_profitable((cn, cc_, chh, cww), (co, cc_, ck, ck), (cs, cs), (cp, cp),
+                                                             conv.weight._get_ops(), True) else "stock (round-3 composition)"}
+        del conv, conv3, xc
+
     return out
 
 
@@ -891,7 +893,10 @@ def single_gpu_extras(ops, dev, args, sink=None):
     try:
         # LAST: this section launches kernels that have never run on an MI355X (the fused BBBConv2d kernels, forced on)
         if not args.no_config_extras:
-            ex["other_baseline_configs"] = config_extras(dev)
+            def config_sections(part):
+                ex["other_baseline_configs"] = dict(part)
+                checkpoint()
+            ex["other_baseline_configs"] = config_extras(dev, on_section=config_sections)
             for k, v in ex["other_baseline_configs"].items():
                 log(f"  {k}: {v['ms']} ms")
     except Exception as e:
