@@ -1187,6 +1187,8 @@ CONV_CASES = [
     # few output channels / single images: the remaining (channel tile, pixel tiles per wave) instantiations of the kernel
     (1, 3, 48, 48, 4, 1, (2, 2), (0, 0), True), (1, 3, 32, 32, 4, 3, (1, 1), (1, 1), False), (1, 3, 48, 48, 40, 1, (1, 1), (0, 0), True),
     (8, 3, 32, 32, 4, 1, (1, 1), (0, 0), False), (1, 3, 16, 16, 4, 3, (1, 1), (1, 1), True),
+    # 7 and 8 column tiles of the weight gradient per workgroup (conv_lrt_wgrad_kernel<16, 7> / <16, 8>)
+    (2, 12, 8, 8, 8, 3, (1, 1), (1, 1), True), (2, 14, 8, 8, 6, 3, (1, 1), (1, 1), False),
 ]
 
 
