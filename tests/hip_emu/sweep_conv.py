@@ -4,6 +4,7 @@ over random layer geometries -- the bodies of test_conv_lrt_forward / test_conv_
     python -m tests.hip_emu.sweep_conv SEED COUNT          # random geometries (kernel 1..7, stride 1..3, padding 0..k-1)
     python -m tests.hip_emu.sweep_conv imagenet            # ResNet-18/50 layer shapes at batch 1-2
     python -m tests.hip_emu.sweep_conv batch128            # the CIFAR ResNet-20 layers at the benchmark's batch (the tilings depend on it)
+    python -m tests.hip_emu.sweep_conv tilings SEED COUNT  # EVERY candidate tiling (not only the planner's choice) of random small layers
 """
 import random
 import sys
@@ -37,7 +38,37 @@ def random_cases(seed, count):
     return cases
 
 
+def tilings(seed, count):
+    """EVERY candidate tiling of random small layers (what tools/conv_autotune.py may pin on the device): the body of
+    test_r5_conv_every_candidate_tiling_computes_the_same_layer with TILING_CASES replaced."""
+    rng = random.Random(seed)
+    G.DEV = "cpu"
+    G.TILING_MIN_PAIRS = 0
+    bad = 0
+    with emulated(ALL) as ops:
+        for _ in range(count):
+            k = rng.choice([1, 2, 3, 3, 3, 5])
+            s_ = rng.choice([1, 1, 2, 2, 3])
+            case = (rng.randint(1, 3), rng.choice([2, 3, 8, 16, 17, 33, 64]), rng.randint(max(k, 4), 14), rng.randint(max(k, 4), 14),
+                    rng.choice([2, 7, 16, 20, 32, 40, 64]), k, (s_, rng.choice([s_, 1])), (rng.randint(0, k - 1), rng.randint(0, k - 1)))
+            n, c, h, w, o, kk, st, pd = case
+            if not ops.conv_lrt_supported((n, c, h, w), (o, c, kk, kk), st, pd) or (h + 2 * pd[0] - kk) // st[0] + 1 < 1:
+                continue
+            G.TILING_CASES = [case]
+            t = time.time()
+            try:
+                G.test_r5_conv_every_candidate_tiling_computes_the_same_layer(ops)
+                print("ok", case, round(time.time() - t, 1), flush=True)
+            except AssertionError as e:
+                bad += 1
+                print("FAIL", case, str(e)[:200], flush=True)
+    print("failures:", bad)
+    return 1 if bad else 0
+
+
 def main(argv):
+    if argv[0] == "tilings":
+        return tilings(int(argv[1]), int(argv[2]))
     cases = IMAGENET if argv[0] == "imagenet" else BATCH128 if argv[0] == "batch128" else random_cases(int(argv[0]), int(argv[1]))
     G.DEV = "cpu"
     bad = 0

@@ -1300,6 +1300,7 @@ def test_conv_lrt_backward(ops):
         assert torch.equal(gwm, gwm2) and torch.equal(gwr, gwr2) and torch.equal(gx, gx2), case
 
 
+TILING_MIN_PAIRS = 20
 TILING_CASES = [(2, 5, 9, 11, 7, 3, (1, 1), (0, 0)), (2, 16, 12, 12, 32, 3, (2, 2), (1, 1)), (3, 20, 10, 10, 16, 3, (1, 1), (1, 1)),
                 (2, 40, 6, 6, 40, 1, (1, 1), (0, 0)), (1, 8, 9, 9, 8, 3, (3, 3), (2, 2))]
 
@@ -1392,7 +1393,7 @@ def test_r5_conv_every_candidate_tiling_computes_the_same_layer(ops):
         ops.conv_lrt_wgrad_set_tiling(xs, ws, stride, padding, None)
         again = bwd_weight()
         assert torch.equal(base[0], again[0]) and torch.equal(base[1], again[1])
-    assert total > 20 * len(TILING_CASES)                                # dozens of (pass, tiling) pairs per layer
+    assert total > TILING_MIN_PAIRS * len(TILING_CASES)                  # dozens of (pass, tiling) pairs per layer
 
 
 def test_lrt_linear_backward(ops):
