@@ -944,6 +944,74 @@ def extras_in_child(args, dev_index, limit_s=1500):
             pass
 
 
+def parse_pmc_counter(paths, counter, kernel_substring):
+    """Mean of `counter` over the dispatches of kernels whose name contains `kernel_substring` in rocprofv3
+    `*counter_collection.csv` files -> (mean, dispatches)."""
+    import csv
+    vals = []
+    for path in paths:
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == counter and kernel_substring in row.get("Kernel_Name", ""):
+                    vals.append(float(row["Counter_Value"]))
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def pmc_traffic_bytes(fetch_kib, write_kib):
+    """HBM bytes per launch from the two counters as MI355X_MICROARCH.md prescribes: both are in KiB; on gfx950 FETCH_SIZE
+    tallies exactly half the bytes of a wide coalesced streaming read (16 B per lane), so it is doubled."""
+    return int(round(2.0 * fetch_kib * 1024.0 + write_kib * 1024.0))
+
+
+def live_traffic(d, dev_index, limit_s=180):
+    """roofline.traffic measured IN THIS RUN (it used to be a constant recorded once per round): two CHILD
+    passes, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separately: the two do not fit one pass), each over
+    `python3 bench.py --traffic-child` = a few full-size steps of the headline's kernels; the combine kernel's mean counter
+    values -> bytes per launch.  Counters only (no trace flags), the program itself behind `--`, run from /tmp with TMPDIR=/tmp,
+    as the profiling guide prescribes.  Returns (bytes, source) or (None, reason): any failure leaves the recorded value in place."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return None, "this process is itself being profiled"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GROUP_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env["TMPDIR"] = "/tmp"
+    env["BDE_BENCH_DEVICE"] = str(dev_index)
+    means = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="bde_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--traffic-child", "--dim", str(d)]
+        try:
+            proc = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            try:
+                rc = proc.wait(timeout=limit_s)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+                proc.wait()
+                return None, f"the {counter} pass did not finish within {limit_s} s"
+            if rc != 0:
+                return None, f"the {counter} pass exited with code {rc}"
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            mean, n = parse_pmc_counter(files, counter, "svgd_combine_kernel")
+            if mean is None:
+                return None, f"no {counter} rows for the combine kernel"
+            means[counter] = (mean, n)
+        except OSError as e:
+            return None, f"{type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    nbytes = pmc_traffic_bytes(means["FETCH_SIZE"][0], means["WRITE_SIZE"][0])
+    return nbytes, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two separate child passes over "
+                    f"{means['FETCH_SIZE'][1]} / {means['WRITE_SIZE'][1]} launches of the kernel at this size (bench.py --traffic-child); "
+                    "KiB counters, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md")
+
+
 def timed_blocks(step, steps, blocks, dist, dev):
     """`blocks` blocks of exactly `steps` steps, each bracketed by barrier + synchronize; MAX over ranks per block."""
     out = []
@@ -1082,7 +1150,25 @@ def main():
                     help="measure `extra` in this process instead of a child (profiling runs: rocprofv3 then sees those kernels "
                          "in THIS process's trace; a GPU fault in an extra then costs the whole line)")
     ap.add_argument("--extras-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from profiles/roofline_traffic.json instead of two rocprofv3 --pmc child passes in this run")
     args = ap.parse_args()
+    if args.traffic_child:                         # the child of live_traffic(): a few full-size steps of the headline's kernels
+        dev_index = int(os.environ.get("BDE_BENCH_DEVICE", "0"))
+        torch.cuda.set_device(dev_index)
+        from beyond_deep_ensembles_amd.ops import HipOps
+        dev = torch.device("cuda", dev_index)
+        ops = HipOps()
+        P, G = make_svgd_inputs(args.dim, dev, 1234)
+        out = torch.empty_like(G)
+        ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
+        for _ in range(4):
+            ops.svgd_gram(P, args.dim, ws)
+            ops.svgd_kstats(ws, M, 0.0, 1.0, DATASET_SIZE, -1.0, ks)
+            ops.svgd_combine(P, G, out, args.dim, ks)
+        torch.cuda.synchronize()
+        return
     if args.extras_child:                          # the child of extras_in_child(): `extra` only, written to a file
         dev_index = int(os.environ.get("BDE_BENCH_DEVICE", "0"))
         torch.cuda.set_device(dev_index)
@@ -1234,6 +1320,13 @@ def main():
                         + " -- a recorded PMC measurement of this kernel at this size, not re-measured in this run"
                 except Exception:
                     traffic = None
+            if not args.no_live_traffic:
+                live, why = live_traffic(d, dev_index)
+                if live is not None:
+                    traffic, traffic_source = live, why
+                else:
+                    log(f"live traffic measurement skipped: {why}")
+                    traffic_source = (traffic_source or "none recorded") + f" (the in-run rocprofv3 passes were skipped: {why})"
             res["roofline"] = {"kernel": "svgd_combine_kernel<8,true>", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "traffic_source": traffic_source,

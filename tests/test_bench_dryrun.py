@@ -139,7 +139,7 @@ def test_main_prints_the_contract_line(dry, monkeypatch, capsys, launched):
             monkeypatch.setenv(key, val)
     # --extras-in-process: the stub library lives in THIS process (the default runs `extra` in a child process, below)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--blocks", "3", "--no-cpu-baseline",
-                                      "--extras-in-process"])
+                                      "--extras-in-process", "--no-live-traffic"])
     bench.main()
     lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -204,4 +204,28 @@ def test_the_real_extras_child_reports_sections_through_its_file(dry, monkeypatc
     assert json.load(open(sink)) == json.loads(json.dumps(ex))
     order = list(ex)
     assert order.index("svgd_combine_M8_resnet50") < order.index("svgd_step_M8_resnet20")       # never-verified kernels last
+
+
+def test_live_traffic_parsing_and_fallback(dry, monkeypatch, tmp_path):
+    """bench.live_traffic: roofline.traffic from two `rocprofv3 --pmc` child passes of THIS run.  (1) The counter arithmetic on
+    the round-1 PMC files committed under profiles/ (FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled on gfx950) reproduces
+    the per-launch bytes of the combine kernel recorded then, 1.000x its 12 M D algorithmic bytes.  (2) Without a working
+    profiler / GPU the function reports why and the recorded value stays."""
+    bench, ops, dev = dry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fetch, nf = bench.parse_pmc_counter([os.path.join(root, "profiles", "r01_b_pmc_FETCH_SIZE.csv")], "FETCH_SIZE", "svgd_combine_kernel")
+    write, nw = bench.parse_pmc_counter([os.path.join(root, "profiles", "r01_b_pmc_WRITE_SIZE.csv")], "WRITE_SIZE", "svgd_combine_kernel")
+    assert nf >= 3 and nw >= 3
+    nbytes = bench.pmc_traffic_bytes(fetch, write)
+    assert abs(nbytes / (12 * 8 * 23_880_950) - 1.0) < 2e-3, nbytes
+    assert bench.parse_pmc_counter([os.path.join(root, "profiles", "r01_b_pmc_FETCH_SIZE.csv")], "FETCH_SIZE", "no_such_kernel") == (None, 0)
+    # a profiler that fails / is absent / a profiled parent: (None, reason)
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/sh\nexit 7\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ.get("PATH", ""))
+    got, why = bench.live_traffic(1000, 0, limit_s=20)
+    assert got is None and "exited with code 7" in why
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert bench.live_traffic(1000, 0)[1] == "this process is itself being profiled"
 

@@ -6,14 +6,14 @@ O=gpurun_out/prof_$R; mkdir -p $O
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 export PYTHONDONTWRITEBYTECODE=1
 # (a) exactly the driver's command
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_full -o t -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_full_under_rocprof.json 2> $O/bench_full.err; echo "trace_full rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_full -o t -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-live-traffic > $O/bench_full_under_rocprof.json 2> $O/bench_full.err; echo "trace_full rc=$?"
 # (b) the timed loop alone: every launch of the three SVGD kernels in the CSV belongs to the headline
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_main -o t -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_main_under_rocprof.json 2> $O/bench_main.err; echo "trace_main rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_main -o t -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-live-traffic > $O/bench_main_under_rocprof.json 2> $O/bench_main.err; echo "trace_main rc=$?"
 # (c) PMC passes over the bench with extras (every kernel at ResNet-50 size), counters only; --extras-in-process: no child
 #     process under the counter-collecting profiler (its preloaded library has initialised the GPU: a spawn there is an exec)
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAVES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$tag -o p -- python3 bench.py --gpus 1 --steps 3 --warmup 1 --blocks 1 --no-cpu-baseline --no-config-extras --extras-in-process > $O/pmc_$tag.json 2> $O/pmc_$tag.err; echo "pmc $tag rc=$?"
+  rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$tag -o p -- python3 bench.py --gpus 1 --steps 3 --warmup 1 --blocks 1 --no-cpu-baseline --no-config-extras --extras-in-process --no-live-traffic > $O/pmc_$tag.json 2> $O/pmc_$tag.err; echo "pmc $tag rc=$?"
 done
 # (d) the wide BBBLinear kernels at 4096 x 4096, batch 64 (tools/lrt_bench.py): kernel trace + the same counter groups
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_lrt -o t -- python3 tools/lrt_bench.py 64x4096x4096 > $O/lrt_bench_under_rocprof.txt 2> $O/lrt_trace.err; echo "trace_lrt rc=$?"
