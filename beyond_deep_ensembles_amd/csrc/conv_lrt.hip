@@ -143,21 +143,36 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
       conv_stage_patch<MODE, false>(x, MODE == 1 ? x_second : x, xq, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp,
                                     img_floats, img0, g.N, g.C, c0, g.H, g.W, hi0, g.pw, 1, 1);
     // ---- the weight tile, k-major [k][MF] pairs (conflict-free A-operand reads): aligned float4 copies of the pre-arranged
-    //      [k][rp] matrices, interleaved on the way; k past the chunk is zero
+    //      [k][rp] matrices, interleaved on the way; k past the chunk is zero.  Four copies (eight loads) in flight per thread:
+    //      one copy at a time put a full memory round trip behind every 32 bytes (4-5 round trips per chunk at 16 channels)
     {
       constexpr int Q = MF / 4;
       const int64_t k_base = static_cast<int64_t>(c0) * khw;
       float* wflat = reinterpret_cast<float*>(wq);
-      for (int e = threadIdx.x; e < kcpad * Q; e += 256) {
-        const int k = e / Q, o4 = e % Q;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-        if (k < kc) {
-          const int64_t src = (k_base + k) * g.rp + o0 + 4 * o4;
-          a = ld4(wt_mu + src);
-          b = ld4(wt_s2 + src);
+      const int n_e = kcpad * Q;
+      for (int e0 = threadIdx.x; e0 < n_e; e0 += 4 * 256) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * 256;
+          const int k = e / Q, o4 = e % Q;
+          const bool live = e < n_e && k < kc;                 // (an unconditional load of row 0 stands in and is dropped)
+          const int64_t src = (k_base + (live ? k : 0)) * g.rp + o0 + 4 * o4;
+          a[u] = ld4(wt_mu + src);
+          b[u] = ld4(wt_s2 + src);
         }
-        st4(wflat + 2 * (k * MF + 4 * o4), f32x4{a.x, b.x, a.y, b.y});
-        st4(wflat + 2 * (k * MF + 4 * o4) + 4, f32x4{a.z, b.z, a.w, b.w});
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * 256;
+          if (e < n_e) {
+            const int k = e / Q, o4 = e % Q;
+            const bool live = k < kc;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 av = live ? a[u] : z, bv = live ? b[u] : z;
+            st4(wflat + 2 * (k * MF + 4 * o4), f32x4{av.x, bv.x, av.y, bv.y});
+            st4(wflat + 2 * (k * MF + 4 * o4) + 4, f32x4{av.z, bv.z, av.w, bv.w});
+          }
+        }
       }
     }
     __syncthreads();
