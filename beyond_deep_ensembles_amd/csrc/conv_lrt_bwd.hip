@@ -197,21 +197,53 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
   }
 }
 
-// shares summed in order; chain rule of sigma^2 = clamp(softplus(rho)^2, 1e-4) for the rho gradient
-__global__ __launch_bounds__(kBlock) void conv_lrt_wgrad_finish_kernel(const float* __restrict__ part, int shares, int64_t n,
-                                                                       const float* __restrict__ w_rho,
-                                                                       float* __restrict__ g_wmu, float* __restrict__ g_wrho) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float sm = 0.f, sv = 0.f;
-    for (int s = 0; s < shares; ++s) {
-      sm += part[(static_cast<int64_t>(s) * 2 + 0) * n + i];
-      sv += part[(static_cast<int64_t>(s) * 2 + 1) * n + i];
+// The per-share partial blocks summed in a FIXED order, then the chain rule of sigma^2 = clamp(softplus(rho)^2, 1e-4) for the rho
+// gradient.  A workgroup = 16 waves x 64 consecutive elements: wave w adds the shares w, w + 16, w + 32, ... of its 64 elements
+// in that order with eight shares (sixteen 4-byte loads, 256 contiguous bytes per wave each) in flight, the sixteen wave sums
+// are added in wave order through LDS.  (Round 4: one thread per element walking ALL shares, two loads and a full memory round
+// trip per share -- up to 768 dependent round trips, by the latency count several hundred microseconds for a 5 us job.)
+constexpr int kFinWaves = 16;
+__global__ __launch_bounds__(kFinWaves * 64) void conv_lrt_wgrad_finish_kernel(const float* __restrict__ part, int shares, int64_t n,
+                                                                            const float* __restrict__ w_rho,
+                                                                            float* __restrict__ g_wmu, float* __restrict__ g_wrho) {
+  __shared__ float red[2][kFinWaves][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 64 + lane;
+  const bool in = i < n;
+  const int64_t ii = in ? i : 0;                               // (a lane past the end reads element 0 and drops it)
+  float sm = 0.f, sv = 0.f;
+  for (int s0 = wave; s0 < shares; s0 += 8 * kFinWaves) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u * kFinWaves;
+      const int64_t sc = s < shares ? s : 0;                   // wave-uniform; a share past the end: share 0, dropped below
+      a[u] = part[(sc * 2 + 0) * n + ii];
+      b[u] = part[(sc * 2 + 1) * n + ii];
     }
-    g_wmu[i] = sm;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u * kFinWaves < shares) {
+        sm += a[u];
+        sv += b[u];
+      }
+    }
+  }
+  red[0][wave][lane] = sm;
+  red[1][wave][lane] = sv;
+  __syncthreads();
+  if (wave == 0 && in) {
+    float m = red[0][0][lane], v = red[1][0][lane];
+#pragma unroll
+    for (int w = 1; w < kFinWaves; ++w) {
+      m += red[0][w][lane];
+      v += red[1][w][lane];
+    }
+    g_wmu[i] = m;
     const SoftplusSigmoid ss = softplus_sigmoid(w_rho[i]);
     const float s2 = ss.sp * ss.sp;
-    g_wrho[i] = s2 >= 1e-4f ? sv * (2.0f * ss.sp * ss.sg) : 0.f;
+    g_wrho[i] = s2 >= 1e-4f ? v * (2.0f * ss.sp * ss.sg) : 0.f;
   }
 }
 
@@ -425,8 +457,8 @@ extern "C" int bde_conv_lrt_bwd_weight(const float* x, const float* g, const flo
 #undef BDE_WGRAD_CASE
   if (!launched) return BDE_ERR_INVALID;
   const int64_t n = static_cast<int64_t>(O) * C * KH * KW;
-  hipLaunchKernelGGL(conv_lrt_wgrad_finish_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, part, p.t.PS, n, w_rho, g_wmu,
-                     g_wrho);
+  hipLaunchKernelGGL(conv_lrt_wgrad_finish_kernel, dim3(static_cast<unsigned>((n + 63) / 64)), dim3(kFinWaves * 64), 0, s, part,
+                     p.t.PS, n, w_rho, g_wmu, g_wrho);
   return to_err(hipGetLastError());
 }
 
