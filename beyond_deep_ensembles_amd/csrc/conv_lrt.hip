@@ -55,6 +55,7 @@ struct ConvGeo {
 struct ConvTile {
   int NI, TH, bands, CC, PH, PWP, WP, WK, tiles_per_img, kcpad_max;
   float rcp_pwp;     // fl(1 / PWP): the staging pass splits a flat patch index into (row, column) with it (conv_common.hpp)
+  int bias_off;      // float offset of the 2 x MF bias terms in LDS (behind everything the main loop and the epilogue use)
 };
 
 template <int MF> struct Mfma;
@@ -128,6 +129,14 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     kofs[k] = c < t.CC ? c * row_elems + (rq / g.KW) * t.PWP + (rq % g.KW) : 0;
   }
 
+  // the tile's bias terms (forward: mean bias, bias variance) go to LDS once, behind everything else: the epilogue reads them
+  // with an LDS latency instead of a global one per pass (they become visible at the first barrier of the chunk loop)
+  float* bias_lds = lds + t.bias_off;
+  if (MODE == 0 && threadIdx.x < 2 * MF) {
+    const int c = threadIdx.x % MF, which = threadIdx.x / MF;
+    const float* src = which ? bvar : bmu;
+    bias_lds[threadIdx.x] = (src && o0 + c < g.O) ? src[o0 + c] : 0.f;
+  }
   const int hi0 = ho0 * g.sh - g.ph;                       // (dilated) input row of patch row 0
   for (int c0 = 0; c0 < g.C; c0 += t.CC) {
     const int cc = min(t.CC, g.C - c0);
@@ -249,6 +258,10 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
   float* tm = lds + wave * 2 * MF * RS;
   float* tv = tm + MF * RS;
   constexpr int Q = MF / 4;                                // float4 groups per tile row
+  constexpr int NPASS = MF * Q / 64;                       // float4 passes of a wave over a tile (4 at MF = 32, 1 at MF = 16)
+  // No global load of the epilogue sits where it is consumed: the bias terms come from LDS (above), the tile's x / noise operands
+  // are requested a batch ahead (before the tile's LDS transposition) -- a load issued at its use costs a memory round trip per
+  // pass / per accumulator register: up to 16 dependent round trips per tile, as long as the tile's products.
   // a rolled loop over the wave's tiles (its body with the Philox code is too large to replicate PT times: the compiler
   // then gives up unrolling and puts the accumulators into scratch): tile i's accumulators are picked by uniform branches
 #pragma unroll 1
@@ -266,6 +279,21 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
       }
     }
     if (vec) {
+      // the tile's global operands (x for the clamp's derivative, or the supplied noise) are requested PB passes at a time, the
+      // first batch before the transposition (in flight during it); PB = 1 where the accumulators fill the register file
+      constexpr bool kLoads = MODE == 1 || !RNG;
+      constexpr int PB = (PT * M::REGS >= 64 && NPASS > 1) ? 1 : NPASS;
+      f32x4 gop[PB];
+      auto request = [&](int pass0) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+          const int ch = (pass0 + u) * (64 / Q) + lane / Q, p4 = lane % Q;
+          const bool live = o0 + ch < g.O && p0 + 4 * p4 < band_pixels;
+          const int64_t e = base + (o0 + ch) * howo + 4 * p4;
+          if (kLoads) gop[u] = ld4((MODE == 1 ? bmu : eps) + (live ? e : int64_t{0}));   // (element 0 stands in, dropped)
+        }
+      };
+      request(0);
 #pragma unroll
       for (int r = 0; r < M::REGS; ++r) {
         tm[M::row(r, h) * RS + idx] = cm[r];
@@ -273,29 +301,33 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's own LDS writes have landed
 #pragma unroll
-      for (int pass = 0; pass < MF * Q / 64; ++pass) {
-        const int ch = pass * (64 / Q) + lane / Q, p4 = lane % Q;
-        const int o = o0 + ch;
-        if (o < g.O && p0 + 4 * p4 < band_pixels) {
-          const f32x4 m4 = ld4(tm + ch * RS + 4 * p4), v4 = ld4(tv + ch * RS + 4 * p4);
-          const int64_t e = base + o * howo + 4 * p4;
-          if (MODE == 1) {                                 // bmu = the layer's input x: d clamp(x^2, 1e-4) / dx = 2 x [x^2 >= 1e-4]
-            const f32x4 xv = ld4(bmu + e);
-            f32x4 d;
+      for (int pass0 = 0; pass0 < NPASS; pass0 += PB) {
+        if (pass0 > 0) request(pass0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d[c] = m4[c] + (xv[c] * xv[c] >= 1e-4f ? 2.0f * xv[c] * v4[c] : 0.f);
-            st4(out + e, d);
-          } else {
-            const float bm = bmu ? bmu[o] : 0.f, bv = bvar ? bvar[o] : 0.f;
-            const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag) : ld4(eps + e);
-            f32x4 res, var;
+        for (int u = 0; u < PB; ++u) {
+          const int pass = pass0 + u;
+          const int ch = pass * (64 / Q) + lane / Q, p4 = lane % Q;
+          if (o0 + ch < g.O && p0 + 4 * p4 < band_pixels) {
+            const f32x4 m4 = ld4(tm + ch * RS + 4 * p4), v4 = ld4(tv + ch * RS + 4 * p4);
+            const int64_t e = base + (o0 + ch) * howo + 4 * p4;
+            if (MODE == 1) {                               // bmu = the layer's input x: d clamp(x^2, 1e-4) / dx = 2 x [x^2 >= 1e-4]
+              const f32x4 xv = gop[u];
+              f32x4 d;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              var[c] = v4[c] + bv;
-              res[c] = (m4[c] + bm) + __builtin_sqrtf(var[c]) * z[c];
+              for (int c = 0; c < 4; ++c) d[c] = m4[c] + (xv[c] * xv[c] >= 1e-4f ? 2.0f * xv[c] * v4[c] : 0.f);
+              st4(out + e, d);
+            } else {
+              const float bm = bias_lds[ch], bv = bias_lds[MF + ch];
+              const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag) : gop[u];
+              f32x4 res, var;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                var[c] = v4[c] + bv;
+                res[c] = (m4[c] + bm) + __builtin_sqrtf(var[c]) * z[c];
+              }
+              st4(out + e, res);
+              st4(var_out + e, var);
             }
-            st4(out + e, res);
-            st4(var_out + e, var);
           }
         }
       }
@@ -307,27 +339,43 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
         const int prow = ho0 + p / g.Wo, pcol = p % g.Wo;
         const int64_t pix = static_cast<int64_t>(g.oh0 + g.osh * prow) * g.OW + g.ow0 + g.osw * pcol;
         const int64_t img_base = static_cast<int64_t>(img0 + img) * g.O * plane;
+        // four or eight accumulator registers (channels) at a time: their loads first (x, or the supplied noise), then the
+        // arithmetic and the stores
+        constexpr int GR = M::REGS < 8 ? M::REGS : (PT * M::REGS >= 64 ? 4 : 8);     // 4 where the accumulators fill the register file
 #pragma unroll
-        for (int r = 0; r < M::REGS; ++r) {
-          const int o = o0 + M::row(r, h);
-          if (o < g.O) {
-            const int64_t e = img_base + o * plane + pix;
-            if (MODE == 1) {
-              const float xv = bmu[e];
-              out[e] = cm[r] + (xv * xv >= 1e-4f ? 2.0f * xv * cv[r] : 0.f);
-            } else {
-              const float mean = cm[r] + (bmu ? bmu[o] : 0.f);
-              const float var = cv[r] + (bvar ? bvar[o] : 0.f);
-              float z;
-              if (RNG) {
-                const f32x4 zz = philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag);
-                const int c = static_cast<int>(e & 3);
-                z = c == 0 ? zz.x : c == 1 ? zz.y : c == 2 ? zz.z : zz.w;
+        for (int r0 = 0; r0 < M::REGS; r0 += GR) {
+          float l1[GR];
+#pragma unroll
+          for (int u = 0; u < GR; ++u) {
+            const int o = o0 + M::row(r0 + u, h);
+            const int64_t e = o < g.O ? img_base + o * plane + pix : int64_t{0};
+            l1[u] = 0.f;
+            if (MODE == 1) l1[u] = bmu[e];
+            else if (!RNG) l1[u] = eps[e];
+          }
+#pragma unroll
+          for (int u = 0; u < GR; ++u) {
+            const int r = r0 + u;
+            const int o = o0 + M::row(r, h);
+            if (o < g.O) {
+              const int64_t e = img_base + o * plane + pix;
+              if (MODE == 1) {
+                const float xv = l1[u];
+                out[e] = cm[r] + (xv * xv >= 1e-4f ? 2.0f * xv * cv[r] : 0.f);
               } else {
-                z = eps[e];
+                const float mean = cm[r] + bias_lds[M::row(r, h)];
+                const float var = cv[r] + bias_lds[MF + M::row(r, h)];
+                float z;
+                if (RNG) {
+                  const f32x4 zz = philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag);
+                  const int c = static_cast<int>(e & 3);
+                  z = c == 0 ? zz.x : c == 1 ? zz.y : c == 2 ? zz.z : zz.w;
+                } else {
+                  z = l1[u];
+                }
+                out[e] = mean + __builtin_sqrtf(var) * z;
+                var_out[e] = var;
               }
-              out[e] = mean + __builtin_sqrtf(var) * z;
-              var_out[e] = var;
             }
           }
         }
@@ -467,7 +515,8 @@ static void fwd_candidates(const ConvGeo& g, std::vector<FwdCand>& out) {
           const int kcpad = (kc + ks * wk - 1) / (ks * wk) * (ks * wk);
           const size_t lds = sizeof(float) * (2ull * ((static_cast<size_t>(ni) * cc * ph * pwp + 3) & ~size_t{3}) + 2ull * kcpad * mf + kcpad);
           const size_t red = wk > 1 ? sizeof(float) * 4ull * pt * 2 * regs * 64 : 0;
-          const size_t need = std::max(std::max(lds, red), epi);
+          const size_t before_bias = std::max(std::max(lds, red), epi);
+          const size_t need = before_bias + sizeof(float) * 2 * mf;       // + the tile's bias terms (mean, variance)
           if (need > 64 * 1024) continue;
           const int64_t wgs = static_cast<int64_t>((g.N + ni - 1) / ni) * bands * otiles;
           const double fill = std::min(1.0, static_cast<double>(wgs) / 512.0);
@@ -478,7 +527,9 @@ static void fwd_candidates(const ConvGeo& g, std::vector<FwdCand>& out) {
           double score = (0.25 + 0.75 * fill) * util * (0.6 + 0.4 * halo) * (0.8 + 0.2 * chunks) * (0.5 + 0.5 * wreuse) *
                          (wk == 1 ? 1.0 : 0.9);
           if (emitted == 1) score *= 0.999;               // the half chunk only ever wins when it is pinned
-          out.push_back(FwdCand{ConvTile{ni, th, bands, cc, ph, pwp, wpn, wk, tiles_per_img, kcpad, 1.0f / static_cast<float>(pwp)}, pt, need, score});
+          out.push_back(FwdCand{ConvTile{ni, th, bands, cc, ph, pwp, wpn, wk, tiles_per_img, kcpad, 1.0f / static_cast<float>(pwp),
+                                       static_cast<int>(before_bias / sizeof(float))},
+                              pt, need, score});
           ++emitted;                                        // the largest chunk that fits, then the next smaller one
         }
       }
