@@ -189,9 +189,12 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     const int ks0 = wk * (ksteps / t.WK), ks1 = ks0 + ksteps / t.WK;
     // Two operand sets, used alternately: the operands of step ks + 1 are requested before the products of step ks are issued,
     // and no register is copied (round 4 copied the prefetched set into the "current" one: 2 + 2 PT moves per step)
+    // The tap -> patch-offset entry of a step is read one step BEFORE its operands are requested (ko_next): an operand
+    // request then never waits for an LDS round trip of its own address -- with one pixel tile per wave a k-step is only two
+    // MFMAs long, and the dependent table read was as long as the step.
     f32x2 a0, a1, b0[PT], b1[PT];
-    auto fetch = [&](int kk_, f32x2& a, f32x2(&b)[PT]) {
-      const int ko = kofs[kk_];
+    const int kk_last = (ks1 - 1) * KS + h;                  // the last step's table index (reads past it are clamped to it)
+    auto fetch = [&](int kk_, int ko, f32x2& a, f32x2(&b)[PT]) {
       a = wq[kk_ * MF + idx];
 #pragma unroll
       for (int i = 0; i < PT; ++i) b[i] = xq[pixoff[i] + ko];
@@ -204,11 +207,19 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
       }
     };
     int ks = ks0, kk = ks0 * KS + h;
-    if (ks < ks1) fetch(kk, a0, b0);
+    int ko_next = 0;
+    if (ks < ks1) {
+      fetch(kk, kofs[kk], a0, b0);
+      ko_next = kofs[min(kk + KS, kk_last)];
+    }
     for (; ks + 1 < ks1; ks += 2, kk += 2 * KS) {
-      fetch(kk + KS, a1, b1);
+      fetch(kk + KS, ko_next, a1, b1);
+      ko_next = kofs[min(kk + 2 * KS, kk_last)];
       products(a0, b0);
-      if (ks + 2 < ks1) fetch(kk + 2 * KS, a0, b0);
+      if (ks + 2 < ks1) {
+        fetch(kk + 2 * KS, ko_next, a0, b0);
+        ko_next = kofs[min(kk + 3 * KS, kk_last)];
+      }
       products(a1, b1);
     }
     if (ks < ks1) products(a0, b0);                         // an odd number of steps: the last set fetched is still pending

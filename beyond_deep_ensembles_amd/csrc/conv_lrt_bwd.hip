@@ -118,11 +118,12 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     // Two operand sets, used alternately (no register copies): the operands of this wave's NEXT k-step are requested before
     // the products of the current one are issued -- the LDS round trip hides behind 2 CT MFMAs instead of stalling in front
     // of them.  One ds_read_b64 per operand pair: 2 + CT reads (+ the pixel's patch offset) per 2 CT products.
+    // The pixel -> patch-offset entry of a step is read one step BEFORE its operands are requested (po_next): an operand request
+    // never waits for the LDS round trip of its own address.
     f32x2 a0, a1, b0[CT], b1[CT];
-    auto fetch = [&](int ks_, f32x2& a, f32x2(&b)[CT]) {
-      const int pix = ks_ * KS + h;
-      const int po = pixtab[pix];
-      a = gq[idx * t.GP + pix];
+    const int pix_last = t.npix - KS + h;                      // the last k-step's pixel (table reads past it are clamped to it)
+    auto fetch = [&](int ks_, int po, f32x2& a, f32x2(&b)[CT]) {
+      a = gq[idx * t.GP + ks_ * KS + h];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) b[ct] = xq[po + kofs[ct]];
     };
@@ -134,11 +135,19 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
       }
     };
     int ks = wave;                                             // this wave's steps: wave, wave + 4, ...
-    if (ks < ksteps) fetch(ks, a0, b0);
+    int po_next = 0;
+    if (ks < ksteps) {
+      fetch(ks, pixtab[ks * KS + h], a0, b0);
+      po_next = pixtab[min((ks + 4) * KS + h, pix_last)];
+    }
     for (; ks + 4 < ksteps; ks += 8) {
-      fetch(ks + 4, a1, b1);
+      fetch(ks + 4, po_next, a1, b1);
+      po_next = pixtab[min((ks + 8) * KS + h, pix_last)];
       products(a0, b0);
-      if (ks + 8 < ksteps) fetch(ks + 8, a0, b0);
+      if (ks + 8 < ksteps) {
+        fetch(ks + 8, po_next, a0, b0);
+        po_next = pixtab[min((ks + 12) * KS + h, pix_last)];
+      }
       products(a1, b1);
     }
     if (ks < ksteps) products(a0, b0);                         // an odd number of steps: the last set fetched is still pending
