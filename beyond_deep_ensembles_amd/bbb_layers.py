@@ -283,9 +283,13 @@ class _ConvLrt(torch.autograd.Function):
         stride, padding, seed, stream_id, ops, phases = ctx.meta
         g = grad_out.contiguous()
         gvar = torch.empty_like(g)
-        # eps None: the kernel regenerates the forward's in-kernel noise (same element numbering over the flat output)
-        ops.local_reparam_bwd(g.view(-1), var.view(-1), gvar.view(-1), g.numel(), eps=None if eps is None else eps.view(-1),
-                              seed=seed, stream_id=stream_id)
+        g_bmu = g_brho = None
+        if b_rho is not None:
+            g_bmu, g_brho = torch.empty_like(b_rho), torch.empty_like(b_rho)
+        # ONE pass: g_var and (with a bias) both bias gradients -- the channel sums of g and g_var ride on it, the rho chain rule
+        # in its finish.  eps None: the kernel regenerates the forward's in-kernel noise (same element numbering)
+        ops.conv_lrt_gvar_bias(g, var, gvar, eps=eps, seed=seed, stream_id=stream_id,
+                               b_rho=None if b_rho is None else b_rho.detach().contiguous(), g_bmu=g_bmu, g_brho=g_brho)
         g_x = None
         if ctx.needs_input_grad[0]:
             g_x = torch.empty_like(x)
@@ -293,12 +297,6 @@ class _ConvLrt(torch.autograd.Function):
         wr = w_rho.detach().contiguous()
         g_wmu, g_wrho = torch.empty_like(wr), torch.empty_like(wr)
         ops.conv_lrt_bwd_weight(x, g, gvar, wr, g_wmu, g_wrho, stride, padding)
-        g_bmu = g_brho = None
-        if b_rho is not None:
-            g_bmu = g.sum(dim=(0, 2, 3))
-            g_bvar = gvar.sum(dim=(0, 2, 3))
-            g_brho = torch.empty_like(g_bvar)
-            ops.var_operand_bwd(g_bvar, b_rho.detach().contiguous(), 2, g_brho)
         return g_x, g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None, None, None, None
 
 

@@ -256,6 +256,82 @@ __global__ __launch_bounds__(kFinWaves * 64) void conv_lrt_wgrad_finish_kernel(c
   }
 }
 
+// The first pass of the layer's backward: g_var = g eps / (2 sqrt(var)) over the layer output [N, O, HW] (bbb_layers.py:148-154
+// through autograd; the noise is the forward's: supplied, or the Philox stream of the flat output's float4 group e >> 2 -- the
+// numbering of bde_local_reparam_bwd, which this pass replaces for the convolution layer) AND, riding on the same pass, the
+// channel sums the bias gradients need: sum g and sum g_var per output channel (two torch reductions over the whole
+// gradient + a kernel for the rho chain rule in round 4: two more passes over 2 x N O HW floats and three launches).
+// grid (O, NCH): workgroup (o, ch) walks the planes (n, o) of the images n = ch, ch + NCH, ... in order; thread sums in fp32
+// in a fixed order, workgroup sums in fp64 in a fixed order (block_sum) -> part [2][NCH][O] doubles; the finish pass adds the
+// NCH partials of a channel in order and applies d softplus(b_rho)^2 / d b_rho (the bias variance is not clamped: line 147).
+template <bool RNG>
+__global__ __launch_bounds__(kBlock) void conv_lrt_gvar_kernel(const float* __restrict__ g, const float* __restrict__ var,
+                                                              const float* __restrict__ eps, uint64_t seed, uint64_t stream_id,
+                                                              float* __restrict__ gvar, double* __restrict__ part, int N, int O,
+                                                              int64_t HW, int NCH, int vec) {
+  __shared__ double smem[kBlock / 64];
+  const int o = blockIdx.x, ch = blockIdx.y;
+  float sm = 0.f, sv = 0.f;
+  for (int n = ch; n < N; n += NCH) {
+    const int64_t base = (static_cast<int64_t>(n) * O + o) * HW;
+    if (vec) {                                                   // HW % 4 == 0 and 16-byte aligned tensors: float4 groups stay inside a plane
+      for (int64_t i = threadIdx.x; i < (HW >> 2); i += kBlock) {
+        const int64_t e = base + 4 * i;
+        const f32x4 go = ld4_nt(g + e), v = ld4_nt(var + e);
+        const f32x4 z = RNG ? philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag) : ld4_nt(eps + e);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r[j] = (go[j] * z[j]) / (2.0f * __builtin_sqrtf(v[j]));
+          sm += go[j];
+          sv += r[j];
+        }
+        st4_nt(gvar + e, r);
+      }
+    } else {
+      for (int64_t i = threadIdx.x; i < HW; i += kBlock) {
+        const int64_t e = base + i;
+        float z;
+        if (RNG) {
+          const f32x4 zz = philox_normal4(seed, stream_id, static_cast<uint64_t>(e >> 2), kDomainDiag);
+          const int c = static_cast<int>(e & 3);
+          z = c == 0 ? zz.x : c == 1 ? zz.y : c == 2 ? zz.z : zz.w;
+        } else {
+          z = eps[e];
+        }
+        const float go = g[e];
+        const float r = (go * z) / (2.0f * __builtin_sqrtf(var[e]));
+        gvar[e] = r;
+        sm += go;
+        sv += r;
+      }
+    }
+  }
+  if (part) {
+    const double tm = block_sum(static_cast<double>(sm), smem);
+    const double tv = block_sum(static_cast<double>(sv), smem);
+    if (threadIdx.x == 0) {
+      part[(0 * static_cast<int64_t>(NCH) + ch) * O + o] = tm;
+      part[(1 * static_cast<int64_t>(NCH) + ch) * O + o] = tv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void conv_lrt_bias_finish_kernel(const double* __restrict__ part, int NCH, int O,
+                                                                     const float* __restrict__ b_rho,
+                                                                     float* __restrict__ g_bmu, float* __restrict__ g_brho) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= O) return;
+  double tm = 0.0, tv = 0.0;
+  for (int ch = 0; ch < NCH; ++ch) {                            // (NCH <= 64 values of 8 bytes per channel: one round of loads)
+    tm += part[(0 * static_cast<int64_t>(NCH) + ch) * O + o];
+    tv += part[(1 * static_cast<int64_t>(NCH) + ch) * O + o];
+  }
+  g_bmu[o] = static_cast<float>(tm);
+  const SoftplusSigmoid ss = softplus_sigmoid(b_rho[o]);
+  g_brho[o] = static_cast<float>(tv) * (2.0f * ss.sp * ss.sg);
+}
+
 }  // namespace bde
 
 using namespace bde;
@@ -432,6 +508,37 @@ extern "C" int bde_conv_lrt_wgrad_set_tiling(const int* layer, int ct, int th, i
       return 0;
     }
   return BDE_ERR_INVALID;
+}
+
+static int gvar_chunks(int N, int O) {
+  // about 1024 workgroups (4 per CU), at most 64 partials per channel, never more than N
+  return std::max(1, std::min(std::min(N, 64), (1024 + O - 1) / O));
+}
+
+extern "C" size_t bde_conv_lrt_gvar_ws_bytes(int N, int O) {
+  if (N < 1 || O < 1) return 0;
+  return sizeof(double) * 2 * static_cast<size_t>(gvar_chunks(N, O)) * O;
+}
+
+// g_var of BBBConv2d's backward + (b_rho != NULL) the bias gradients g_bmu / g_brho, one pass over the output gradient.
+extern "C" int bde_conv_lrt_gvar_bias(const float* g, const float* var, const float* eps, uint64_t seed, uint64_t stream_id,
+                                      float* gvar, const float* b_rho, float* g_bmu, float* g_brho, void* ws, int N, int O,
+                                      int64_t HW, void* stream) {
+  if (!g || !var || !gvar || N < 1 || O < 1 || HW < 1) return BDE_ERR_INVALID;
+  if (b_rho && (!g_bmu || !g_brho || !ws || (reinterpret_cast<uintptr_t>(ws) & 7))) return BDE_ERR_INVALID;
+  const int nch = gvar_chunks(N, O);
+  const int vec = (HW & 3) == 0 && aligned16(g) && aligned16(var) && aligned16(gvar) && (!eps || aligned16(eps));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* part = b_rho ? static_cast<double*>(ws) : nullptr;
+  const dim3 grid(static_cast<unsigned>(O), static_cast<unsigned>(nch));
+  if (eps)
+    hipLaunchKernelGGL(conv_lrt_gvar_kernel<false>, grid, dim3(kBlock), 0, s, g, var, eps, seed, stream_id, gvar, part, N, O, HW, nch, vec);
+  else
+    hipLaunchKernelGGL(conv_lrt_gvar_kernel<true>, grid, dim3(kBlock), 0, s, g, var, eps, seed, stream_id, gvar, part, N, O, HW, nch, vec);
+  if (b_rho)
+    hipLaunchKernelGGL(conv_lrt_bias_finish_kernel, dim3((O + kBlock - 1) / kBlock), dim3(kBlock), 0, s, part, nch, O, b_rho, g_bmu,
+                       g_brho);
+  return to_err(hipGetLastError());
 }
 
 // bytes of the partials buffer bde_conv_lrt_bwd_weight needs (0: unsupported geometry)

@@ -224,9 +224,20 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
     const at::Tensor g = grad_outputs[0].contiguous();
     at::Tensor gvar = at::empty_like(g);
     void* stream = current_stream(x);
-    int rc = bde_local_reparam_bwd(ptr(g), ptr(var), ptr(eps), static_cast<uint64_t>(ctx->saved_data["seed"].toInt()),
-                                   static_cast<uint64_t>(ctx->saved_data["stream_id"].toInt()), mptr(gvar), g.numel(), stream);
-    TORCH_CHECK(rc == 0, "bde_local_reparam_bwd failed with code ", rc);
+    // ONE pass: g_var and (with a bias) both bias gradients (channel sums of g / g_var + the rho chain rule in the finish)
+    at::Tensor g_bmu, g_brho, br, gws;
+    if (b_rho.defined()) {
+      br = b_rho.detach().contiguous();
+      g_bmu = at::empty_like(br);
+      g_brho = at::empty_like(br);
+      gws = at::empty({static_cast<int64_t>(bde_conv_lrt_gvar_ws_bytes(N, O) / 8)}, x.options().dtype(at::kDouble));
+    }
+    int rc = bde_conv_lrt_gvar_bias(ptr(g), ptr(var), ptr(eps), static_cast<uint64_t>(ctx->saved_data["seed"].toInt()),
+                                    static_cast<uint64_t>(ctx->saved_data["stream_id"].toInt()), mptr(gvar),
+                                    br.defined() ? ptr(br) : nullptr, g_bmu.defined() ? mptr(g_bmu) : nullptr,
+                                    g_brho.defined() ? mptr(g_brho) : nullptr, gws.defined() ? gws.data_ptr() : nullptr, N, O,
+                                    g.size(2) * g.size(3), stream);
+    TORCH_CHECK(rc == 0, "bde_conv_lrt_gvar_bias failed with code ", rc);
     at::Tensor g_x;
     if (ctx->needs_input_grad(0)) {
       g_x = at::empty_like(x);
@@ -242,14 +253,6 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
     rc = bde_conv_lrt_bwd_weight(ptr(x), ptr(g), ptr(gvar), ptr(wr), ws.data_ptr(), mptr(g_wmu), mptr(g_wrho), N, C, H, W, O, KH,
                                  KW, sh, sw, ph, pw, stream);
     TORCH_CHECK(rc == 0, "bde_conv_lrt_bwd_weight failed with code ", rc);
-    at::Tensor g_bmu, g_brho;
-    if (b_rho.defined()) {
-      g_bmu = g.sum({0, 2, 3});
-      const at::Tensor g_bvar = gvar.sum({0, 2, 3}), br = b_rho.detach().contiguous();
-      g_brho = at::empty_like(g_bvar);
-      rc = bde_var_operand_bwd(ptr(g_bvar), ptr(br), 2, mptr(g_brho), br.numel(), stream);     // d softplus(rho)^2 / d rho
-      TORCH_CHECK(rc == 0, "bde_var_operand_bwd failed with code ", rc);
-    }
     return {g_x, g_wmu, g_wrho, g_bmu, g_brho, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
             at::Tensor(), at::Tensor(), at::Tensor()};
   }

@@ -547,6 +547,27 @@ class HipOps:
                "bde_conv_lrt_bwd_data_phases" if phases else "bde_conv_lrt_bwd_data")
 
     @_on_device_of
+    def conv_lrt_gvar_bias(self, g_out, var, g_var, eps=None, seed=0, stream_id=0, b_rho=None, g_bmu=None, g_brho=None):
+        """First pass of BBBConv2d's backward: g_var = g eps / (2 sqrt(var)) over the layer output [N, O, Ho, Wo] (supplied
+        noise, or the forward's Philox stream) and -- with ``b_rho`` -- the bias gradients g_bmu / g_brho in the same pass."""
+        if g_out.dim() != 4:
+            raise BdeKernelError("conv_lrt_gvar_bias: g_out must be [N, O, Ho, Wo]")
+        shape = tuple(g_out.shape)
+        n, o = int(shape[0]), int(shape[1])
+        for t, name in ((g_out, "g_out"), (var, "var"), (g_var, "g_var"), (eps, "eps")):
+            self._dense(t, shape, name)
+        ws = None
+        if b_rho is not None:
+            for t, name in ((b_rho, "b_rho"), (g_bmu, "g_bmu"), (g_brho, "g_brho")):
+                if t is None:
+                    raise BdeKernelError("conv_lrt_gvar_bias: b_rho, g_bmu and g_brho come together")
+                self._dense(t, (o,), name)
+            ws = torch.empty(int(self.lib.bde_conv_lrt_gvar_ws_bytes(n, o)) // 8, dtype=torch.float64, device=g_out.device)
+        _check(self.lib.bde_conv_lrt_gvar_bias(_ptr(g_out, "g_out"), _ptr(var), _ptr(eps), seed, stream_id, _ptr(g_var),
+                                               _ptr(b_rho), _ptr(g_bmu), _ptr(g_brho), None if ws is None else _ptr64(ws, "ws"),
+                                               n, o, int(shape[2]) * int(shape[3]), _stream()), "bde_conv_lrt_gvar_bias")
+
+    @_on_device_of
     def conv_lrt_bwd_weight(self, x, g_out, g_var, w_rho, g_wmu, g_wrho, stride, padding, ws=None):
         """g_wmu / g_wrho of BBBConv2d: two weight-gradient convolutions + the rho chain rule in two launches."""
         geo, oshape = self._conv_geo(x, tuple(w_rho.shape), stride, padding)

@@ -418,6 +418,14 @@ int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, int h
                      int stride_h, int stride_w, int pad_h, int pad_w, void* stream);
 int bde_conv_lrt_bwd_data(const float* g_out, const float* g_var, const float* wbuf, const float* x, float* g_x, int N, int C,
                           int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, void* stream);
+/* The first pass of BBBConv2d's backward: g_var = g eps / (2 sqrt(var)) over the layer output [N, O, HW] (eps supplied, or the
+ * forward's Philox stream: float4 group e >> 2 of the flat output, as bde_local_reparam_bwd) and, in the same pass, the bias
+ * gradients (b_rho != NULL): g_bmu[o] = sum g, g_brho[o] = (sum g_var) 2 softplus(b_rho) sigmoid(b_rho) -- the reference's
+ * autograd does two reductions over the gradient and the chain rule of bbb_layers.py:147 separately.  ws:
+ * bde_conv_lrt_gvar_ws_bytes(N, O) bytes, 8-byte aligned (fixed-order fp64 partials). */
+size_t bde_conv_lrt_gvar_ws_bytes(int N, int O);
+int bde_conv_lrt_gvar_bias(const float* g, const float* var, const float* eps, uint64_t seed, uint64_t stream_id, float* gvar,
+                           const float* b_rho, float* g_bmu, float* g_brho, void* ws, int N, int O, int64_t HW, void* stream);
 size_t bde_conv_lrt_bwd_weight_ws_bytes(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h,
                                         int pad_w);
 int bde_conv_lrt_bwd_weight(const float* x, const float* g_out, const float* g_var, const float* w_rho, void* ws,

@@ -263,6 +263,14 @@ class OracleOps:
         gv = torch.nn.grad.conv2d_input(x.shape, s2, g_var, stride=stride, padding=padding)
         g_x.copy_(gm + torch.where(x * x >= 1e-4, 2.0 * x * gv, torch.zeros_like(x)))
 
+    def conv_lrt_gvar_bias(self, g_out, var, g_var, eps=None, seed=0, stream_id=0, b_rho=None, g_bmu=None, g_brho=None):
+        z = eps if eps is not None else _philox(seed, stream_id, g_out.numel()).view(g_out.shape)
+        g_var.copy_((g_out * z) / (2 * torch.sqrt(var)))                         # autograd of bbb_layers.py:148-154
+        if b_rho is not None:
+            g_bmu.copy_(g_out.sum(dim=(0, 2, 3)))                                # the bias of the mean convolution (:146)
+            sp = F.softplus(b_rho)
+            g_brho.copy_(g_var.sum(dim=(0, 2, 3)) * 2.0 * sp * torch.sigmoid(b_rho))   # softplus(b_rho)^2, not clamped (:147)
+
     def conv_lrt_bwd_weight(self, x, g_out, g_var, w_rho, g_wmu, g_wrho, stride, padding, ws=None):
         g_wmu.copy_(torch.nn.grad.conv2d_weight(x, w_rho.shape, g_out, stride=stride, padding=padding))
         gs2 = torch.nn.grad.conv2d_weight((x ** 2).clamp(min=1e-4), w_rho.shape, g_var, stride=stride, padding=padding)

@@ -36,6 +36,7 @@ DEFAULT = [
     "test_accumulating_unaligned_and_value_only_variants", "test_svgd_gram_load_flavour_split_does_not_change_results",
     "test_streaming_kernels_walk_several_grid_passes", "test_svgd_every_particle_count",
     "test_r5_sum_scalars_is_the_sequential_fp32_sum", "test_r5_conv_every_candidate_tiling_computes_the_same_layer",
+    "test_r5_conv_gvar_and_bias_gradients_in_one_pass",
 ]
 # ... and with BDE_EMU_FULL=1 (another ~3 minutes)
 SLOW = ["test_svgd_blocked_path_for_more_than_16_particles", "test_svgd_small_model_fused_step", "test_lrt_linear_forward",

@@ -1300,6 +1300,44 @@ def test_conv_lrt_backward(ops):
         assert torch.equal(gwm, gwm2) and torch.equal(gwr, gwr2) and torch.equal(gx, gx2), case
 
 
+def test_r5_conv_gvar_and_bias_gradients_in_one_pass(ops):
+    """bde_conv_lrt_gvar_bias: g_var = g eps / (2 sqrt(var)) over the layer output -- bit for bit what bde_local_reparam_bwd
+    writes (same arithmetic, same Philox stream) -- and the two bias gradients of bbb_layers.py:146-147 from the same pass,
+    against fp64 (channel sums of g and g_var, the rho chain rule of the UNclamped bias variance), for plane sizes that are
+    and are not multiples of 4, supplied and in-kernel noise, with and without a bias."""
+    import torch.nn.functional as F
+    torch.manual_seed(52)
+    for n, o, ho, wo in [(3, 5, 4, 4), (2, 7, 3, 5), (8, 16, 32, 32), (5, 33, 8, 8), (1, 3, 1, 1), (70, 4, 6, 6)]:
+        g = torch.randn(n, o, ho, wo)
+        var = torch.rand(n, o, ho, wo) + 0.05
+        b_rho = torch.randn(o) - 2.0
+        dev = lambda t: t.to(DEV).contiguous()
+        gd, vd = dev(g), dev(var)
+        for supplied in (True, False):
+            eps = torch.randn(n, o, ho, wo) if supplied else None
+            want = torch.empty_like(gd)
+            ops.local_reparam_bwd(gd.view(-1), vd.view(-1), want.view(-1), gd.numel(), eps=None if eps is None else dev(eps).view(-1),
+                                  seed=11, stream_id=3)
+            for bias in (True, False):
+                gvar = torch.full_like(gd, 9.0)
+                g_bmu, g_brho = (torch.full((o,), 9.0, device=DEV), torch.full((o,), 9.0, device=DEV)) if bias else (None, None)
+                ops.conv_lrt_gvar_bias(gd, vd, gvar, eps=None if eps is None else dev(eps), seed=11, stream_id=3,
+                                       b_rho=dev(b_rho) if bias else None, g_bmu=g_bmu, g_brho=g_brho)
+                assert torch.equal(gvar, want), (n, o, ho, wo, supplied, bias)
+                if bias:
+                    gv64 = want.cpu().double()
+                    sp = F.softplus(b_rho.double())
+                    want_bmu = g.double().sum(dim=(0, 2, 3))
+                    want_brho = gv64.sum(dim=(0, 2, 3)) * 2.0 * sp * torch.sigmoid(b_rho.double())
+                    scale = max(1.0, float(n * ho * wo) ** 0.5)
+                    assert (g_bmu.cpu().double() - want_bmu).abs().max().item() <= 2e-6 * scale * max(1.0, g.abs().max().item())
+                    assert (g_brho.cpu().double() - want_brho).abs().max().item() <= 2e-6 * scale * max(1.0, gv64.abs().max().item())
+                    again_m, again_r = torch.empty_like(g_bmu), torch.empty_like(g_brho)        # deterministic
+                    ops.conv_lrt_gvar_bias(gd, vd, gvar, eps=None if eps is None else dev(eps), seed=11, stream_id=3,
+                                           b_rho=dev(b_rho), g_bmu=again_m, g_brho=again_r)
+                    assert torch.equal(again_m, g_bmu) and torch.equal(again_r, g_brho)
+
+
 TILING_MIN_PAIRS = 20
 TILING_CASES = [(2, 5, 9, 11, 7, 3, (1, 1), (0, 0)), (2, 16, 12, 12, 32, 3, (2, 2), (1, 1)), (3, 20, 10, 10, 16, 3, (1, 1), (1, 1)),
                 (2, 40, 6, 6, 40, 1, (1, 1), (0, 0)), (1, 8, 9, 9, 8, 3, (3, 3), (2, 2))]

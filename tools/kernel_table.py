@@ -99,6 +99,9 @@ ROWS = {
     "conv_lrt_prep_kernel": ("σ², dσ²/dρ, weight matrices in staging order, per-phase matrices", "`~40·O·C·K²` B", "unmeasured", NEVER, "same"),
     "conv_lrt_wgrad_kernel": ("both weight-gradient convolutions, reduction over pixels", "same flops as forward; partials ≤ 512 blocks (round 5: −1/3 … −1/2 of round 4's bytes)",
                               "**unmeasured**", NEVER, "`test_conv_lrt_backward`"),
+    "conv_lrt_gvar_kernel": ("first pass of the layer's backward: g_var = g·eps/(2√var) + the channel sums the bias gradients need (round 5; replaces `local_reparam_bwd` + two torch reductions)",
+                             "`16·N·O·Ho·Wo` B", "unmeasured", NEVER, "`test_r5_conv_gvar_and_bias_gradients_in_one_pass`"),
+    "conv_lrt_bias_finish_kernel": ("channel partials in order + ρ chain rule of the bias variance (`bbb_layers.py:147`)", "latency", "unmeasured", NEVER, "same test"),
     "conv_lrt_wgrad_finish_kernel": ("shares summed in order + ρ chain rule", "partials once", "unmeasured", NEVER, "same"),
     # ---- iVON
     "ivon_sample_kernel": ("`ivorn.py:102-115`", "`20·D` B", "0.0737 ms = 6.48 TB/s (0.81); r4", R3, "`test_ivon_golden_bit_exact`"),
