@@ -73,8 +73,10 @@ def main(argv=None, ops=None, dev=None, layers=None, time_loop=None, device_name
         def wgrad():
             ops.conv_lrt_bwd_weight(x, g, gvar, wr, gwm, gwr, st, pd)          # (sizes its partials buffer per call: follows the pin)
 
-        def gvar_pass():
-            ops.local_reparam_bwd(g.view(-1), var.view(-1), gvar.view(-1), g.numel(), seed=1, stream_id=2)
+        gbm, gbr = torch.empty_like(bm), torch.empty_like(br)
+
+        def gvar_pass():                                           # g_var + both bias gradients, one pass (what the layer's backward runs)
+            ops.conv_lrt_gvar_bias(g, var, gvar, seed=1, stream_id=2, b_rho=br, g_bmu=gbm, g_brho=gbr)
         fwd()
         gvar_pass()
 

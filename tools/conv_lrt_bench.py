@@ -70,8 +70,10 @@ for n, c, h, w, o, k, s, p in shapes:
     def bwd_weight():
         wws[0] = ops.conv_lrt_bwd_weight(x, g, gvar, wr, gwm, gwr, (s, s), (p, p), ws=wws[0])
 
-    def gvar_pass():
-        ops.local_reparam_bwd(g.view(-1), var.view(-1), gvar.view(-1), g.numel(), seed=1, stream_id=2)
+    gbm, gbr = torch.empty_like(bm), torch.empty_like(br)
+
+    def gvar_pass():                                           # g_var + both bias gradients, one pass (what the layer's backward runs)
+        ops.conv_lrt_gvar_bias(g, var, gvar, seed=1, stream_id=2, b_rho=br, g_bmu=gbm, g_brho=gbr)
     leaves = [t.clone().requires_grad_(True) for t in (x, wm, wr, bm, br)]
     noise = torch.randn_like(out)
 
