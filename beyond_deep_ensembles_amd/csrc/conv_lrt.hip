@@ -143,6 +143,37 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     const int kc = cc * khw;
     const int kcpad = (kc + KS * t.WK - 1) / (KS * t.WK) * (KS * t.WK);
     if (c0 > 0) __syncthreads();                           // the previous chunk's operand reads are done
+    // ---- the weight tile, k-major [k][MF] pairs (conflict-free A-operand reads): aligned float4 copies of the pre-arranged
+    //      [k][rp] matrices, interleaved on the way; k past the chunk is zero.  Several copies in flight per thread (one copy at a
+    //      time put a full memory round trip behind every 32 bytes).  With one or two pixel tiles per wave the registers are
+    //      there to REQUEST the first eight copies of a thread before the patch is staged and to store them after it: the
+    //      tile's round trip then overlaps the patch's instead of following it (at the 32- and 64-channel CIFAR layers the
+    //      weight tile was two of the three round trips of a chunk, and a chunk's products are shorter than one).
+    constexpr int Q = MF / 4;
+    constexpr int WB = PT <= 2 ? 8 : 0;                      // copies requested ahead of the patch (registers permitting)
+    const int64_t k_base = static_cast<int64_t>(c0) * khw;
+    float* wflat = reinterpret_cast<float*>(wq);
+    const int n_e = kcpad * Q;
+    auto w_src = [&](int e) {                                // (a copy past the tile / the chunk: row 0 stands in, dropped at the store)
+      const int k = e / Q, o4 = e % Q;
+      return (k_base + ((e < n_e && k < kc) ? k : 0)) * g.rp + o0 + 4 * o4;
+    };
+    auto w_store = [&](int e, const f32x4& a, const f32x4& b) {
+      if (e < n_e) {
+        const int k = e / Q, o4 = e % Q;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 av = k < kc ? a : z, bv = k < kc ? b : z;
+        st4(wflat + 2 * (k * MF + 4 * o4), f32x4{av.x, bv.x, av.y, bv.y});
+        st4(wflat + 2 * (k * MF + 4 * o4) + 4, f32x4{av.z, bv.z, av.w, bv.w});
+      }
+    };
+    f32x4 wa[WB > 0 ? WB : 1], wb[WB > 0 ? WB : 1];
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+      const int64_t src = w_src(static_cast<int>(threadIdx.x) + u * 256);
+      wa[u] = ld4(wt_mu + src);
+      wb[u] = ld4(wt_s2 + src);
+    }
     // ---- the input patch of the chunk: x and clamp(x^2) (zero outside the image: padding is applied after the clamp);
     //      MODE 1: g and gvar, dilated.  Flat over the lanes, eight loads in flight per lane (conv_common.hpp)
     if (MODE == 1 && (g.dh != 1 || g.dw != 1))               // (uniform for the launch: the dilated input-gradient pass)
@@ -151,38 +182,18 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     else
       conv_stage_patch<MODE, false>(x, MODE == 1 ? x_second : x, xq, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp,
                                     img_floats, img0, g.N, g.C, c0, g.H, g.W, hi0, g.pw, 1, 1);
-    // ---- the weight tile, k-major [k][MF] pairs (conflict-free A-operand reads): aligned float4 copies of the pre-arranged
-    //      [k][rp] matrices, interleaved on the way; k past the chunk is zero.  Four copies (eight loads) in flight per thread:
-    //      one copy at a time put a full memory round trip behind every 32 bytes (4-5 round trips per chunk at 16 channels)
-    {
-      constexpr int Q = MF / 4;
-      const int64_t k_base = static_cast<int64_t>(c0) * khw;
-      float* wflat = reinterpret_cast<float*>(wq);
-      const int n_e = kcpad * Q;
-      for (int e0 = threadIdx.x; e0 < n_e; e0 += 4 * 256) {
-        f32x4 a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * 256;
-          const int k = e / Q, o4 = e % Q;
-          const bool live = e < n_e && k < kc;                 // (an unconditional load of row 0 stands in and is dropped)
-          const int64_t src = (k_base + (live ? k : 0)) * g.rp + o0 + 4 * o4;
-          a[u] = ld4(wt_mu + src);
-          b[u] = ld4(wt_s2 + src);
-        }
+    for (int u = 0; u < WB; ++u) w_store(static_cast<int>(threadIdx.x) + u * 256, wa[u], wb[u]);
+    for (int e0 = static_cast<int>(threadIdx.x) + WB * 256; e0 < n_e; e0 += 4 * 256) {     // the rest, four copies in flight
+      f32x4 a[4], b4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * 256;
-          if (e < n_e) {
-            const int k = e / Q, o4 = e % Q;
-            const bool live = k < kc;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 av = live ? a[u] : z, bv = live ? b[u] : z;
-            st4(wflat + 2 * (k * MF + 4 * o4), f32x4{av.x, bv.x, av.y, bv.y});
-            st4(wflat + 2 * (k * MF + 4 * o4) + 4, f32x4{av.z, bv.z, av.w, bv.w});
-          }
-        }
+      for (int u = 0; u < 4; ++u) {
+        const int64_t src = w_src(e0 + u * 256);
+        a[u] = ld4(wt_mu + src);
+        b4[u] = ld4(wt_s2 + src);
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w_store(e0 + u * 256, a[u], b4[u]);
     }
     __syncthreads();
     const int ksteps = kcpad / KS;
