@@ -37,11 +37,12 @@ __device__ __forceinline__ int xcd_work_index(int linear, int total) {
 // images of it must fit 64 KB): the product's relative error is below 2^-23, i.e. below 9.8e-4 / PWP absolute for
 // e / PWP <= 8192 / PWP, while (e + 0.5) / PWP is at least 0.5 / PWP away from an integer (tests/test_conv_emulated.py
 // checks every (e, PWP) exhaustively).
+// DEPTH: items (loads) in flight per lane and batch: 8, or 16 where the caller has the registers.
 // DIL: the source images are zero-dilated by (dh, dw) (the single-launch input gradient of a strided layer): the per-element
 // modulo / division only exists in that instantiation.  The batch is straight-line code: the cursor over (plane, step) items
 // advances with wave-uniform selects, an item past the last plane is a dropped load of element 0 -- no branch, and no
 // register written on two paths, separates the eight (sixteen) loads.
-template <int MODE, bool DIL>
+template <int MODE, bool DIL, int DEPTH = 8>
 __device__ __forceinline__ void conv_stage_patch(const float* __restrict__ src1, const float* __restrict__ src2,
                                                  f32x2* __restrict__ xq, int wave, int lane,
                                                  int planes, int cc, int row_elems, int PWP, float rcp_pwp, int img_floats,
@@ -52,11 +53,11 @@ __device__ __forceinline__ void conv_stage_patch(const float* __restrict__ src1,
   const int dq = 4 / cc, dr = 4 % cc;                       // a wave's next plane is 4 further: (image, channel) += (dq, dr)
   int pl = wave, img = wave / cc, c = wave % cc, step = 0;  // the cursor: wave-uniform
   while (pl < planes) {
-    float v[8], v2[8];
-    int off[8];
-    bool okv[8];
+    float v[DEPTH], v2[DEPTH];
+    int off[DEPTH];
+    bool okv[DEPTH];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < DEPTH; ++u) {
       // wave-uniform part: is there an item, and the plane it reads (plane 0 stands in when there is none: its element 0 is
       // loaded and dropped) -- a scalar base pointer, the lane adds a 32-bit element offset
       const bool plane_ok = pl < planes && img0 + img < N;
@@ -92,7 +93,7 @@ __device__ __forceinline__ void conv_stage_patch(const float* __restrict__ src1,
       img = wrap ? img_next : img;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < DEPTH; ++u) {
       if (off[u] >= 0) {
         f32x2 pair;
         pair.x = okv[u] ? v[u] : 0.f;
@@ -107,6 +108,7 @@ __device__ __forceinline__ void conv_stage_patch(const float* __restrict__ src1,
 // band each -- as PAIRS (g, g_var) into gq [o][GP] at column img * bpi + p; zero for rows / pixels outside the tensor.  The same scheme as
 // the patch: a wave's rows (wave, wave + 4, ...) x steps of 64 lanes as one sequence of items, eight items (sixteen loads) in
 // flight, straight-line (round 4: one row per trip, two loads in flight -- the staging latency exceeded the matrix work).
+template <int DEPTH = 8>
 __device__ __forceinline__ void conv_stage_rows(const float* __restrict__ g, const float* __restrict__ gvar,
                                                 f32x2* __restrict__ gq, int wave, int lane, int rows,
                                                 int NI, int bpi, int valid_pixels, int GP, int img0, int N, int o0, int O,
@@ -115,11 +117,11 @@ __device__ __forceinline__ void conv_stage_rows(const float* __restrict__ g, con
   const int dq = 4 / NI, dr = 4 % NI;                       // row r = o * NI + img; the wave's next row is 4 further
   int r = wave, o = wave / NI, img = wave % NI, step = 0;   // the cursor: wave-uniform
   while (r < rows) {
-    float a[8], b[8];
-    int off[8];
-    bool okv[8];
+    float a[DEPTH], b[DEPTH];
+    int off[DEPTH];
+    bool okv[DEPTH];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < DEPTH; ++u) {
       const bool row_ok = r < rows && img0 + img < N && o0 + o < O;
       const int64_t row_at = row_ok ? (static_cast<int64_t>(img0 + img) * O + o0 + o) * howo + band_at : int64_t{0};
       const float* __restrict__ p1 = g + row_at;
@@ -141,7 +143,7 @@ __device__ __forceinline__ void conv_stage_rows(const float* __restrict__ g, con
       o = wrap ? o_next : o;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < DEPTH; ++u) {
       if (off[u] >= 0) {
         f32x2 pair;
         pair.x = okv[u] ? a[u] : 0.f;

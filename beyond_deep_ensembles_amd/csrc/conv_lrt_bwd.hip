@@ -98,10 +98,11 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     __syncthreads();
     // the input patch of the block's channels as pairs (x, clamp(x^2)): flat over the lanes, eight loads in flight per lane
     // (conv_common.hpp)
-    conv_stage_patch<0, false>(x, x, xq, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp, img_floats, img0, geo.N, geo.C, c_lo,
+    constexpr int kDepth = CT * M::REGS <= 48 ? 16 : 8;           // sixteen items in flight where the accumulators leave the registers
+    conv_stage_patch<0, false, kDepth>(x, x, xq, wave, lane, t.NI * cc, cc, row_elems, t.PWP, t.rcp_pwp, img_floats, img0, geo.N, geo.C, c_lo,
                                geo.H, geo.W, hi0, geo.pw, 1, 1);
     // the block's rows of g and gvar ((row, image) strips of contiguous band pixels) as pairs: flat items, sixteen loads in flight
-    conv_stage_rows(g, gvar, gq, wave, lane, MF * t.NI, t.NI, bpi, th * geo.Wo, t.GP, img0, geo.N, o0, geo.O, howo,
+    conv_stage_rows<kDepth>(g, gvar, gq, wave, lane, MF * t.NI, t.NI, bpi, th * geo.Wo, t.GP, img0, geo.N, o0, geo.O, howo,
                     static_cast<int64_t>(ho0) * geo.Wo);
     const int padn = t.npix - t.NI * bpi;                      // the padding behind the last image's strip
     for (int e = threadIdx.x; e < MF * padn; e += 256) {
