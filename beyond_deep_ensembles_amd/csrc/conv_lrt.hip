@@ -7,12 +7,18 @@
 //
 // The reference runs two cuDNN/MIOpen convolutions over the same input windows plus ~8 element-wise launches.  Here
 // both products are one implicit GEMM with TWO accumulators per output tile: the input patch of a band of output rows
-// is staged ONCE into LDS as x and as clamp(x^2) (zero padding applied AFTER the clamp, as F.conv2d pads the clamped
-// tensor), the weight tile as W_mu and sigma^2, and every k-step issues a pair of f32 MFMAs -- (W_mu, x) and
-// (sigma^2, clamp(x^2)) -- whose B operands sit at the same LDS offset of the two patch images.  The epilogue
-// transposes each accumulator tile through LDS so that a lane owns 4 consecutive pixels of one channel, adds the bias
-// terms, draws eps (Philox, the stream of bde_local_reparam_fwd: float4 group e >> 2 of the flat NCHW output) or
-// reads it, and writes output and total variance (the backward needs sqrt(var)) as 16-byte stores.
+// is staged ONCE into LDS as PAIRS (x, clamp(x^2)) (zero padding applied AFTER the clamp, as F.conv2d pads the clamped
+// tensor), the weight tile as pairs (W_mu, sigma^2), and every k-step issues a pair of f32 MFMAs -- (W_mu, x) and
+// (sigma^2, clamp(x^2)) -- whose operands arrive with ONE ds_read_b64 each.  The epilogue transposes each accumulator tile
+// through LDS so that a lane owns 4 consecutive pixels of one channel, adds the bias terms, draws eps (Philox, the stream of
+// bde_local_reparam_fwd: float4 group e >> 2 of the flat NCHW output) or reads it, and writes output and total variance
+// (the backward needs sqrt(var)) as 16-byte stores.
+//
+// Round 5 (the kernel has still not run on an MI355X; what guided these was the latency count and the ISA): staging flat over
+// the lanes with eight loads in flight and no branch between them (conv_common.hpp), the weight tile requested ahead of the
+// patch where the registers allow, two operand sets used alternately (no register copies), the tap -> offset entry read a
+// step ahead, no global load of the epilogue at its point of use (bias terms through LDS), XCD-aware work assignment,
+// every candidate tiling enumerable and pinnable (tools/conv_autotune.py).
 //
 // GEMM view: rows = output channels (MF = 32 per tile on v_mfma_f32_32x32x2_f32, 16 on v_mfma_f32_16x16x4_f32 for
 // layers with <= 16 channels), columns = MF consecutive output pixels of one image (flattened ho * Wo + wo),
@@ -26,7 +32,7 @@
 //
 // MODE 1: the INPUT gradient as the same implicit GEMM,
 //   dx = convT(g, W_mu) + 2 x [x^2 >= 1e-4] * convT(gvar, sigma^2)
-// (g = gradient of the layer output, gvar = g eps / (2 sqrt(var)) from bde_local_reparam_bwd): the "input" images are
+// (g = gradient of the layer output, gvar = g eps / (2 sqrt(var)) from bde_conv_lrt_gvar_bias): the "input" images are
 // g and gvar [N, O', Ho', Wo'] (two tensors instead of x and clamp(x^2)), dilated by the layer's stride (zeros between
 // the samples: a stride-s layer spends s^2 times the products here) and padded by K - 1 - p, the "output" has the
 // layer's C' input channels and H' x W' pixels at stride 1, and the epilogue applies the clamp's derivative with x.
