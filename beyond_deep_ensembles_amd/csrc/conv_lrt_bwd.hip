@@ -4,14 +4,17 @@
 //   dS2   [o, c, r, q] = sum_{n, ho, wo} gvar[n, o, ho, wo] * clamp(x^2) [n, c, ...]              (0 in the padding)
 //   dW_rho = dS2 * [softplus(rho)^2 >= 1e-4] * 2 softplus(rho) sigmoid(rho)
 //
-// (g = gradient of the layer output, gvar = g eps / (2 sqrt(var)) from bde_local_reparam_bwd) -- what autograd computes
-// with two weight-gradient convolutions plus the element-wise chain in the reference.  One implicit GEMM with two
-// accumulators: rows = output channels, columns = (c, r, q), reduction over the output PIXELS.  A workgroup owns a
-// [MF rows x CT * MF columns] block of both gradient matrices and a share of the (image group, row band) items; per
-// item it stages the input patch of the block's channels once as x and clamp(x^2), the block's rows of g and gvar, and
-// a pixel -> patch-offset table; its four waves take the k-steps (2 or 4 pixels each) round robin, are summed through
-// LDS in wave order, and the block goes to a partials buffer [share][2][O][C KH KW]; bde's finish pass adds the shares
-// in order (fixed order everywhere: bit-reproducible) and applies the chain rule for rho.
+// (g = gradient of the layer output, gvar = g eps / (2 sqrt(var)) from the first pass of the backward, conv_lrt_gvar_kernel
+// below, which also delivers the bias gradients) -- what autograd computes with two weight-gradient convolutions plus the
+// element-wise chain in the reference.  One implicit GEMM with two accumulators: rows = output channels, columns =
+// (c, r, q), reduction over the output PIXELS.  A workgroup owns a [MF rows x CT * MF columns] block of both gradient
+// matrices (one instantiation per CT) and a share of the (image group, row band) items -- shares sized to ONE resident set of
+// workgroups; per item it stages the input patch of the block's channels once as pairs (x, clamp(x^2)), the block's rows of
+// g and gvar as pairs, and a pixel -> patch-offset table (flat over the lanes, 8-16 loads in flight: conv_common.hpp); its four
+// waves take the k-steps (2 or 4 pixels each) round robin with two alternating operand sets, are summed through LDS as a
+// fixed two-round tree, and the block goes to a partials buffer [share][2][O][C KH KW]; the finish pass (16 waves per 64
+// elements, eight shares in flight per wave) adds the shares in a fixed order (bit-reproducible) and applies the chain
+// rule for rho.
 #include "conv_common.hpp"
 #include <array>
 #include <map>
