@@ -256,18 +256,18 @@ def _conv_profitable(x_shape, w_shape, stride, padding, ops, needs_grad) -> bool
 class _ConvLrt(torch.autograd.Function):
     """The whole forward of a mean-field convolution layer in local-reparameterisation form (bbb_layers.py:146-154) as
     ONE fused op (bde_conv_lrt_fwd: both convolutions as one dual-accumulator implicit GEMM over the same staged input
-    windows, the sampling epilogue fused); the backward is bde_local_reparam_bwd (g_var) + bde_conv_lrt_bwd_data +
-    bde_conv_lrt_bwd_weight (+ two channel sums for the bias) instead of autograd's four convolutions and ~20
-    element-wise launches."""
+    windows, the sampling epilogue fused); the backward is bde_conv_lrt_gvar_bias (g_var + both bias gradients, one pass) +
+    bde_conv_lrt_bwd_data + bde_conv_lrt_bwd_weight instead of autograd's four convolutions and ~20 element-wise launches."""
 
     @staticmethod
-    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, stride, padding, eps, seed, stream_id, ops, wbuf, phases=False):
+    def forward(ctx, x, w_mu, w_rho, b_mu, b_rho, stride, padding, eps, seed, stream_id, ops, wbuf, phases=False, want_var=True):
         xc = x.detach().contiguous()
         n, o = xc.shape[0], w_mu.shape[0]
         ho = (xc.shape[2] + 2 * padding[0] - w_mu.shape[2]) // stride[0] + 1
         wo = (xc.shape[3] + 2 * padding[1] - w_mu.shape[3]) // stride[1] + 1
         out = torch.empty((n, o, ho, wo), dtype=torch.float32, device=x.device)
-        var = torch.empty_like(out)
+        # the total variance is what the backward needs (sqrt(var)): a forward nobody will differentiate does not write it
+        var = torch.empty_like(out) if want_var else None
         e = None if eps is None else eps.reshape(out.shape).contiguous()
         # the bias variance softplus(b_rho)^2 (not clamped, line 147) was evaluated by the preparation pass
         ops.conv_lrt_fwd(xc, wbuf, tuple(w_mu.shape), None if b_mu is None else b_mu.detach().contiguous(), b_rho is not None,
@@ -297,7 +297,7 @@ class _ConvLrt(torch.autograd.Function):
         wr = w_rho.detach().contiguous()
         g_wmu, g_wrho = torch.empty_like(wr), torch.empty_like(wr)
         ops.conv_lrt_bwd_weight(x, g, gvar, wr, g_wmu, g_wrho, stride, padding)
-        return g_x, g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None, None, None, None
+        return g_x, g_wmu, g_wrho, g_bmu, g_brho, None, None, None, None, None, None, None, None, None
 
 
 class _LocalReparamLayer(nn.Module):
@@ -473,13 +473,16 @@ class BBBConv2d(_LocalReparamLayer):
                     eps = normal_like(input.new_empty((input.shape[0], self.out_channels, ho, wo)))
                 wbuf = self._conv_weights.get(w.mean, w.rho, b.rho if b is not None else None, ops, stride, padding)
                 native = _native_nodes(ops)
+                want_var = torch.is_grad_enabled() and (input.requires_grad or any(
+                    t is not None and t.requires_grad for t in (w.mean, w.rho, b.mean if b is not None else None,
+                                                                b.rho if b is not None else None)))
                 if native is not None and hasattr(native, "conv_lrt"):
                     return native.conv_lrt(input, w.mean, w.rho, b.mean if b is not None else None,
                                            b.rho if b is not None else None, stride[0], stride[1], padding[0], padding[1], eps,
-                                           w.seed, next(_philox_stream), wbuf, True)
+                                           w.seed, next(_philox_stream), wbuf, True, want_var)
                 return _ConvLrt.apply(input, w.mean, w.rho, b.mean if b is not None else None,
                                       b.rho if b is not None else None, stride, padding, eps, w.seed, next(_philox_stream), ops,
-                                      wbuf, True)
+                                      wbuf, True, want_var)
         mean = F.conv2d(input, w.mean, b.mean if b is not None else None, stride=self.stride, padding=self.padding)
         x2, s2, vb = self._var_operands(input, clamp_bias=False)     # the conv layer does not clamp its bias variance
         var = F.conv2d(x2, s2, vb, stride=self.stride, padding=self.padding)

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
                 res[c] = (m4[c] + bm) + __builtin_sqrtf(var[c]) * z[c];
               }
               st4(out + e, res);
-              st4(var_out + e, var);
+              if (var_out) st4(var_out + e, var);        // (NULL: a forward nobody will differentiate)
             }
           }
         }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
                   z = l1[u];
                 }
                 out[e] = mean + __builtin_sqrtf(var) * z;
-                var_out[e] = var;
+                if (var_out) var_out[e] = var;
               }
             }
           }
@@ -829,7 +829,7 @@ extern "C" int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* 
                                 int O, int KH, int KW, int sh, int sw, int ph, int pw, void* stream) {
   ConvGeo g;
   FwdPlan p;
-  if (!x || !wbuf || !out || !var_out || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) || !plan_fwd(g, p))
+  if (!x || !wbuf || !out || !layer_geo(N, C, H, W, O, KH, KW, sh, sw, ph, pw, g) || !plan_fwd(g, p))     // var_out may be NULL
     return BDE_ERR_INVALID;
   if (!aligned16(wbuf)) return BDE_ERR_INVALID;           // out / var_out / eps: 16-byte alignment only selects the float4 epilogue
   const WBuf w = wbuf_parts(wbuf, O, C, KH * KW);

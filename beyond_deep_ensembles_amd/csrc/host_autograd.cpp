@@ -174,7 +174,7 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho,
                             const c10::optional<at::Tensor>& b_mu_, const c10::optional<at::Tensor>& b_rho_, int64_t sh,
                             int64_t sw, int64_t ph, int64_t pw, const c10::optional<at::Tensor>& eps_, int64_t seed,
-                            int64_t stream_id, const at::Tensor& wbuf, bool phases) {
+                            int64_t stream_id, const at::Tensor& wbuf, bool phases, bool want_var) {
     at::Tensor b_mu = opt(b_mu_), b_rho = opt(b_rho_), eps = opt(eps_);
     check_f32_cuda(x, "x");
     check_f32_cuda(w_mu, "w_mu");
@@ -192,7 +192,9 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
                 "conv_lrt: wbuf does not belong to a layer of this shape");
     const int64_t Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
     TORCH_CHECK(Ho >= 1 && Wo >= 1, "conv_lrt: empty output");
-    at::Tensor out = at::empty({N, O, Ho, Wo}, xc.options()), var = at::empty({N, O, Ho, Wo}, xc.options());
+    // the total variance is what the backward needs: a forward nobody will differentiate (want_var false) does not write it
+    at::Tensor out = at::empty({N, O, Ho, Wo}, xc.options()), var;
+    if (want_var) var = at::empty({N, O, Ho, Wo}, xc.options());
     at::Tensor e;
     if (eps.defined()) e = eps.reshape(out.sizes()).contiguous();
     at::Tensor bm;
@@ -254,7 +256,7 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
                                  KW, sh, sw, ph, pw, stream);
     TORCH_CHECK(rc == 0, "bde_conv_lrt_bwd_weight failed with code ", rc);
     return {g_x, g_wmu, g_wrho, g_bmu, g_brho, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-            at::Tensor(), at::Tensor(), at::Tensor()};
+            at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
@@ -277,12 +279,14 @@ void bind_autograd_nodes(py::module_& m) {
   m.def("conv_lrt",
         [](const at::Tensor& x, const at::Tensor& w_mu, const at::Tensor& w_rho, const c10::optional<at::Tensor>& b_mu,
            const c10::optional<at::Tensor>& b_rho, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
-           const c10::optional<at::Tensor>& eps, int64_t seed, int64_t stream_id, const at::Tensor& wbuf, bool phases) {
-          return ConvLrt::apply(x, w_mu, w_rho, b_mu, b_rho, sh, sw, ph, pw, eps, seed, stream_id, wbuf, phases);
+           const c10::optional<at::Tensor>& eps, int64_t seed, int64_t stream_id, const at::Tensor& wbuf, bool phases,
+           bool want_var) {
+          return ConvLrt::apply(x, w_mu, w_rho, b_mu, b_rho, sh, sw, ph, pw, eps, seed, stream_id, wbuf, phases, want_var);
         },
         "BBBConv2d forward (local reparameterisation, fused) with its fused backward", py::arg("x"), py::arg("w_mu"),
         py::arg("w_rho"), py::arg("b_mu"), py::arg("b_rho"), py::arg("sh"), py::arg("sw"), py::arg("ph"), py::arg("pw"),
-        py::arg("eps"), py::arg("seed"), py::arg("stream_id"), py::arg("wbuf"), py::arg("phases") = false);
+        py::arg("eps"), py::arg("seed"), py::arg("stream_id"), py::arg("wbuf"), py::arg("phases") = false,
+        py::arg("want_var") = true);
   m.def("var_operand", [](const at::Tensor& v, int64_t mode) { return VarOperand::apply(v, mode); },
         "clamp(v^2) / clamp(softplus(v)^2) / softplus(v)^2", py::arg("v"), py::arg("mode"));
 }

@@ -526,7 +526,7 @@ class HipOps:
         geo, oshape = self._conv_geo(x, w_shape, stride, padding)
         self._conv_wbuf_ok(wbuf, geo)
         self._dense(out, oshape, "out")
-        self._dense(var_out, oshape, "var_out")
+        self._dense(var_out, oshape, "var_out")            # None: a forward nobody differentiates (no variance written)
         self._dense(eps, oshape, "eps")
         self._dense(b_mu, (geo[4],), "b_mu")
         _check(self.lib.bde_conv_lrt_fwd(_ptr(x, "x"), _ptr(wbuf), _ptr(b_mu), int(bool(bias_var)), _ptr(eps), seed, stream_id,

@@ -413,6 +413,7 @@ int bde_conv_lrt_prep_strided(const float* w_mu, const float* w_rho, const float
 int bde_conv_lrt_bwd_data_phases(const float* g_out, const float* g_var, const float* wbuf, const float* x, float* g_x, int N,
                                  int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w,
                                  void* stream);
+/* (var_out may be NULL: a forward pass nobody will differentiate -- torch.no_grad() -- does not write the variance.) */
 int bde_conv_lrt_fwd(const float* x, const float* wbuf, const float* b_mu, int has_bias_var, const float* eps, uint64_t seed,
                      uint64_t stream_id, float* out, float* var_out, int N, int C, int H, int W, int O, int KH, int KW,
                      int stride_h, int stride_w, int pad_h, int pad_w, void* stream);

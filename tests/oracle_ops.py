@@ -255,7 +255,8 @@ class OracleOps:
         var = F.conv2d((x ** 2).clamp(min=1e-4), s2, b_var, stride=stride, padding=padding)  # :147
         z = eps if eps is not None else _philox(seed, stream_id, out.numel()).view(out.shape)
         out.copy_(mean + torch.sqrt(var) * z)
-        var_out.copy_(var)
+        if var_out is not None:                                      # None: a forward nobody differentiates
+            var_out.copy_(var)
 
     def conv_lrt_bwd_data(self, g_out, g_var, wbuf, w_shape, x, g_x, stride, padding, phases=False):
         w_mu, s2 = self._conv_w[wbuf.data_ptr()][:2]

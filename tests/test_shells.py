@@ -1428,6 +1428,44 @@ def test_r5_fused_conv_auto_follows_the_measured_table(backend, monkeypatch, tmp
         ops.conv_lrt_fwd = real_fwd
 
 
+def test_r5_fused_conv_forward_without_gradients_writes_no_variance(backend, monkeypatch):
+    """The fused forward stores the total variance only for its backward (sqrt(var)): under torch.no_grad() -- or when nothing
+    requires a gradient -- bde_conv_lrt_fwd gets var_out = NULL (one output-sized store less) and returns the same sample."""
+    import beyond_deep_ensembles_amd.bbb_layers as BL
+    ops, dev = backend
+    if not hasattr(ops, "conv_lrt_fwd"):
+        pytest.skip("backend without the fused convolution")
+    torch.manual_seed(8)
+    prior = bde.GaussianPrior(0, 1.0)
+    layer = bde.BBBConv2d(3, 4, 3, prior, prior, padding=1, fused_conv=True, _ops=ops).to(dev)
+    x = torch.randn(2, 3, 6, 6, device=dev)
+    noise = torch.randn(2, 4, 6, 6)
+    monkeypatch.setattr(BL, "normal_like", lambda t: noise.to(t.device))
+    seen = []
+    real = ops.conv_lrt_fwd
+
+    def spy(x_, wbuf, w_shape, b_mu, bias_var, stride, padding, out, var_out, **kw):
+        seen.append(var_out is not None)
+        return real(x_, wbuf, w_shape, b_mu, bias_var, stride, padding, out, var_out, **kw)
+    native = BL._native_nodes(ops)
+    if native is not None and hasattr(native, "conv_lrt"):
+        monkeypatch.setattr(BL, "_native_nodes", lambda o: None)       # the Python Function: its ops call can be observed
+    ops.conv_lrt_fwd = spy
+    try:
+        with_grad = layer(x)
+        with torch.no_grad():
+            without = layer(x)
+        assert seen == [True, False]
+        assert torch.equal(with_grad.detach(), without)
+    finally:
+        ops.conv_lrt_fwd = real
+    if native is not None and hasattr(native, "conv_lrt"):             # the C++ node takes the flag as an argument
+        monkeypatch.setattr(BL, "_native_nodes", lambda o: native)
+        with torch.no_grad():
+            assert torch.equal(layer(x), without)
+        assert torch.equal(layer(x).detach(), without)
+
+
 def test_bbb_group_draw_is_one_launch_per_forward(backend):
     """With rng="philox" the Gaussian parameters owned by a BBBOptimizer are drawn by ONE bde_gauss_draw_fwd launch
     over the group's flat buffers per forward pass (and ONE bde_gauss_draw_bwd per backward), and the result is
