@@ -582,9 +582,18 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
 extern "C" {
 void __tsan_init() {}
 #define HIP_EMU_PC reinterpret_cast<uintptr_t>(__builtin_return_address(0))
+// The compiler calls the plain hooks where the access's type promises n-byte alignment (a float4 / f32x2 load is ONE
+// b128 / b64 instruction on the device and the LDS forms of those need the alignment): a kernel that breaks the promise
+// stops here instead of working by accident on the host.
+static inline void hip_emu_aligned(void* a, int n, bool write) {
+  if (reinterpret_cast<uintptr_t>(a) % static_cast<uintptr_t>(n) != 0) {
+    std::fprintf(stderr, "hip_emu: misaligned %d-byte %s at %p in a kernel\n", n, write ? "store" : "load", a);
+    std::abort();
+  }
+}
 #define HIP_EMU_HOOK(n)                                                                              \
-  void __tsan_read##n(void* a) { hip_emu::on_access(a, n, false, HIP_EMU_PC); }                      \
-  void __tsan_write##n(void* a) { hip_emu::on_access(a, n, true, HIP_EMU_PC); }                      \
+  void __tsan_read##n(void* a) { hip_emu_aligned(a, n, false); hip_emu::on_access(a, n, false, HIP_EMU_PC); }   \
+  void __tsan_write##n(void* a) { hip_emu_aligned(a, n, true); hip_emu::on_access(a, n, true, HIP_EMU_PC); }    \
   void __tsan_unaligned_read##n(void* a) { hip_emu::on_access(a, n, false, HIP_EMU_PC); }            \
   void __tsan_unaligned_write##n(void* a) { hip_emu::on_access(a, n, true, HIP_EMU_PC); }
 HIP_EMU_HOOK(1)

@@ -250,6 +250,20 @@ def test_the_model_notices_a_missing_dma_wait():
         emu_build._asm = real
 
 
+def test_the_model_stops_at_a_misaligned_vector_access():
+    """A float4 / f32x2 access is one b128 / b64 instruction on the device (the LDS forms need the alignment); on the host
+    it would work by accident.  The model's access hook aborts on one: call it with an address 4 past an 8-byte boundary."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from tests.hip_emu import build as B; from tests.hip_emu.emu_ops import ALL; "
+            "lib = ctypes.CDLL(B.build(ALL)); buf = ctypes.create_string_buffer(64); "
+            "a = (ctypes.addressof(buf) + 15) // 16 * 16; lib.__tsan_read8(ctypes.c_void_p(a + 8)); print('aligned ok', flush=True); "
+            "lib.__tsan_read8(ctypes.c_void_p(a + 4)); print('not reached')" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "aligned ok" in r.stdout and "not reached" not in r.stdout, (r.stdout, r.stderr)
+    assert "misaligned 8-byte load" in r.stderr
+
+
 def test_conv_autotune_tool_end_to_end_on_the_cpu_model(emu, tmp_path, monkeypatch):
     """tools/conv_autotune.py will get ONE run on the device: its whole logic -- candidate loops over forward / dilated and
     per-phase input gradient / weight gradient, pinning, the reference sequence, the JSON it writes -- runs here on a tiny
