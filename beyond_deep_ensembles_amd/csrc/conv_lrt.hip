@@ -58,6 +58,8 @@ struct ConvGeo {
   // input gradient of a strided layer, which write every sh-th row / sw-th column of g_x.
   int osh = 1, osw = 1, oh0 = 0, ow0 = 0, OH = 0, OW = 0;
 };
+constexpr int kConvTablePad = 16;   // zero entries behind the tap table (the product loop looks up to 3 k-steps = 12 entries ahead)
+
 struct ConvTile {
   int NI, TH, bands, CC, PH, PWP, WP, WK, tiles_per_img, kcpad_max;
   float rcp_pwp;     // fl(1 / PWP): the staging pass splits a flat patch index into (row, column) with it (conv_common.hpp)
@@ -79,7 +81,7 @@ template <> struct Mfma<16> {
   __device__ __forceinline__ static int row(int r, int h) { return 4 * h + r; }
 };
 
-// LDS: xq [NI][CC][PH][PWP] pairs (x, clamp(x^2)) | wq [kcpad][MF] pairs (W_mu, sigma^2) | kofs [kcpad] (int); the epilogue
+// LDS: xq [NI][CC][PH][PWP] pairs (x, clamp(x^2)) | wq [kcpad][MF] pairs (W_mu, sigma^2) | kofs [kcpad + 16] (int, byte offsets); the epilogue
 // reuses the front of it: per wave 2 x [MF][MF + 4] floats.  Pairs: both products of a k-step read their operands at the
 // same element, so one ds_read_b64 (one address computation) serves both.
 template <int MF, int PT, bool RNG, int MODE>
@@ -116,23 +118,24 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
   const int khw = g.KH * g.KW;
 
   // a wave's PT tiles are consecutive: tile = wp * PT + i
-  int pixoff[PT];
+  int pixoff[PT];                                          // BYTE offsets of the pairs (the table's entries too: one add per request)
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
     const int tile = wp * PT + i;
     const int img = tile / t.tiles_per_img, p = (tile % t.tiles_per_img) * MF + idx;
     const bool ok = img < t.NI && img0 + img < g.N && p < band_pixels;
     const int hl = ok ? p / g.Wo : 0, wo = ok ? p % g.Wo : 0;
-    pixoff[i] = (ok ? img : 0) * img_floats + hl * g.sh * t.PWP + wo * g.sw;
+    pixoff[i] = 8 * ((ok ? img : 0) * img_floats + hl * g.sh * t.PWP + wo * g.sw);
   }
   Acc accm[PT], accv[PT];
 #pragma unroll
   for (int i = 0; i < PT; ++i) accm[i] = accv[i] = Acc{};
 
-  // patch offset of tap k = (c, r, q), chunk-relative: the same for every chunk
-  for (int k = threadIdx.x; k < t.kcpad_max; k += 256) {
+  // patch offset (in bytes of pairs) of tap k = (c, r, q), chunk-relative: the same for every chunk.  kConvTablePad entries past
+  // the chunk are zero: the product loop reads its table entry up to three steps ahead without clamping the index
+  for (int k = threadIdx.x; k < t.kcpad_max + kConvTablePad; k += 256) {
     const int c = k / khw, rq = k % khw;
-    kofs[k] = c < t.CC ? c * row_elems + (rq / g.KW) * t.PWP + (rq % g.KW) : 0;
+    kofs[k] = (k < t.kcpad_max && c < t.CC) ? 8 * (c * row_elems + (rq / g.KW) * t.PWP + (rq % g.KW)) : 0;
   }
 
   // the tile's bias terms (forward: mean bias, bias variance) go to LDS once, behind everything else: the epilogue reads them
@@ -210,11 +213,10 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     // request then never waits for an LDS round trip of its own address -- with one pixel tile per wave a k-step is only two
     // MFMAs long, and the dependent table read was as long as the step.
     f32x2 a0, a1, b0[PT], b1[PT];
-    const int kk_last = (ks1 - 1) * KS + h;                  // the last step's table index (reads past it are clamped to it)
     auto fetch = [&](int kk_, int ko, f32x2& a, f32x2(&b)[PT]) {
       a = wq[kk_ * MF + idx];
 #pragma unroll
-      for (int i = 0; i < PT; ++i) b[i] = xq[pixoff[i] + ko];
+      for (int i = 0; i < PT; ++i) b[i] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(xq) + (pixoff[i] + ko));
     };
     auto products = [&](const f32x2& a, const f32x2(&b)[PT]) {
 #pragma unroll
@@ -227,15 +229,15 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_kernel(
     int ko_next = 0;
     if (ks < ks1) {
       fetch(kk, kofs[kk], a0, b0);
-      ko_next = kofs[min(kk + KS, kk_last)];
+      ko_next = kofs[kk + KS];
     }
     for (; ks + 1 < ks1; ks += 2, kk += 2 * KS) {
       fetch(kk + KS, ko_next, a1, b1);
-      ko_next = kofs[min(kk + 2 * KS, kk_last)];
+      ko_next = kofs[kk + 2 * KS];
       products(a0, b0);
       if (ks + 2 < ks1) {
         fetch(kk + 2 * KS, ko_next, a0, b0);
-        ko_next = kofs[min(kk + 3 * KS, kk_last)];
+        ko_next = kofs[kk + 3 * KS];
       }
       products(a1, b1);
     }
@@ -541,7 +543,7 @@ static void fwd_candidates(const ConvGeo& g, std::vector<FwdCand>& out) {
         for (int cc = g.C; cc >= 1 && emitted < 2; cc = (cc > 8 ? cc / 2 : cc - 1)) {
           const int kc = cc * khw;
           const int kcpad = (kc + ks * wk - 1) / (ks * wk) * (ks * wk);
-          const size_t lds = sizeof(float) * (2ull * ((static_cast<size_t>(ni) * cc * ph * pwp + 3) & ~size_t{3}) + 2ull * kcpad * mf + kcpad);
+          const size_t lds = sizeof(float) * (2ull * ((static_cast<size_t>(ni) * cc * ph * pwp + 3) & ~size_t{3}) + 2ull * kcpad * mf + kcpad + kConvTablePad);
           const size_t red = wk > 1 ? sizeof(float) * 4ull * pt * 2 * regs * 64 : 0;
           const size_t before_bias = std::max(std::max(lds, red), epi);
           const size_t need = before_bias + sizeof(float) * 2 * mf;       // + the tile's bias terms (mean, variance)

@@ -29,6 +29,8 @@ using f32x4w = __attribute__((ext_vector_type(4))) float;
 struct WgGeo {
   int N, C, H, W, O, KH, KW, sh, sw, ph, pw, Ho, Wo;
 };
+constexpr int kWgTablePad = 48;   // zero entries behind the pixel table (the product loop looks up to 12 k-steps' worth ahead)
+
 struct WgTile {
   int NI, TH, bands, PS, CT, colgroups, PH, PWP, cmax, GP, npix;
   float rcp_pwp;     // fl(1 / PWP) for the flat patch staging (conv_common.hpp)
@@ -48,7 +50,7 @@ template <> struct MfmaW<16> {
   __device__ __forceinline__ static int row(int r, int h) { return 4 * h + r; }
 };
 
-// LDS: xq [NI][cmax][PH][PWP] pairs (x, clamp(x^2)) | gq [MF][GP] pairs (g, g_var) | pixtab [npix]   (reused for the wave reduction)
+// LDS: xq [NI][cmax][PH][PWP] pairs (x, clamp(x^2)) | gq [MF][GP] pairs (g, g_var) | pixtab [npix + 48] (byte offsets)   (reused for the wave reduction)
 template <int MF, int CT>
 __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                 const float* __restrict__ gvar, float* __restrict__ part,
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     kofs[ct] = 0;
     if (col < ktot) {                                            // a column past the matrix multiplies patch element 0: never stored
       const int c = col / khw - c_lo, rq = col % khw;
-      kofs[ct] = c * row_elems + (rq / geo.KW) * t.PWP + (rq % geo.KW);
+      kofs[ct] = 8 * (c * row_elems + (rq / geo.KW) * t.PWP + (rq % geo.KW));    // bytes of pairs, like the pixel table's entries
     }
   }
   Acc accm[CT], accv[CT];
@@ -112,10 +114,10 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
       const int o = e / padn, pp = t.NI * bpi + e % padn;
       gq[o * t.GP + pp] = f32x2{0.f, 0.f};
     }
-    for (int pp = threadIdx.x; pp < t.npix; pp += 256) {
+    for (int pp = threadIdx.x; pp < t.npix + kWgTablePad; pp += 256) {   // (zero entries behind the table: read ahead, never used)
       const int img = pp / bpi, p = pp % bpi;
       const int hl = p / geo.Wo, wo = p % geo.Wo;
-      pixtab[pp] = (img < t.NI && hl < th) ? img * img_floats + hl * geo.sh * t.PWP + wo * geo.sw : 0;
+      pixtab[pp] = (pp < t.npix && img < t.NI && hl < th) ? 8 * (img * img_floats + hl * geo.sh * t.PWP + wo * geo.sw) : 0;
     }
     __syncthreads();
     const int ksteps = t.npix / KS;
@@ -125,11 +127,10 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     // The pixel -> patch-offset entry of a step is read one step BEFORE its operands are requested (po_next): an operand request
     // never waits for the LDS round trip of its own address.
     f32x2 a0, a1, b0[CT], b1[CT];
-    const int pix_last = t.npix - KS + h;                      // the last k-step's pixel (table reads past it are clamped to it)
     auto fetch = [&](int ks_, int po, f32x2& a, f32x2(&b)[CT]) {
       a = gq[idx * t.GP + ks_ * KS + h];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) b[ct] = xq[po + kofs[ct]];
+      for (int ct = 0; ct < CT; ++ct) b[ct] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(xq) + (po + kofs[ct]));
     };
     auto products = [&](const f32x2& a, const f32x2(&b)[CT]) {
 #pragma unroll
@@ -142,15 +143,15 @@ __global__ __launch_bounds__(256, 2) void conv_lrt_wgrad_kernel(const float* __r
     int po_next = 0;
     if (ks < ksteps) {
       fetch(ks, pixtab[ks * KS + h], a0, b0);
-      po_next = pixtab[min((ks + 4) * KS + h, pix_last)];
+      po_next = pixtab[(ks + 4) * KS + h];
     }
     for (; ks + 4 < ksteps; ks += 8) {
       fetch(ks + 4, po_next, a1, b1);
-      po_next = pixtab[min((ks + 8) * KS + h, pix_last)];
+      po_next = pixtab[(ks + 8) * KS + h];
       products(a0, b0);
       if (ks + 8 < ksteps) {
         fetch(ks + 8, po_next, a0, b0);
-        po_next = pixtab[min((ks + 12) * KS + h, pix_last)];
+        po_next = pixtab[(ks + 12) * KS + h];
       }
       products(a1, b1);
     }
@@ -387,7 +388,7 @@ static void wgrad_candidates(const WgGeo& g, std::vector<WgCand>& out) {
         npix = (npix + ks * 4 - 1) / (ks * 4) * (ks * 4);
         int gp = npix;
         if (mf == 32) gp |= 1; else gp = (gp + 31) / 32 * 32 + 2;
-        const size_t lds = sizeof(float) * (2ull * ni * cmax * ph * pwp + 2ull * mf * gp + npix);
+        const size_t lds = sizeof(float) * (2ull * ni * cmax * ph * pwp + 2ull * mf * gp + npix + kWgTablePad);
         const size_t red = sizeof(float) * 2ull * ct * 2 * regs * 64;
         if (std::max(lds, red) > 64 * 1024) continue;
         const int items = ((g.N + ni - 1) / ni) * bands;
