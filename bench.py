@@ -905,7 +905,7 @@ def single_gpu_extras(ops, dev, args, sink=None):
     return ex
 
 
-def extras_in_child(args, dev_index, limit_s=1500):
+def extras_in_child(args, dev_index, limit_s=600):
     """`extra` measured by a CHILD process (`python bench.py --extras-child FILE`): a Python exception in an extra is caught
     section by section, but a GPU fault or a hang in one of them -- several run kernels that have never executed on an
     MI355X -- would take the process down before the headline line is printed.  The parent has
@@ -923,18 +923,22 @@ def extras_in_child(args, dev_index, limit_s=1500):
     env["BDE_BENCH_DEVICE"] = str(dev_index)
     try:
         proc = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL)       # its log lines go to our stderr
+        timed_out = False
         try:
             rc = proc.wait(timeout=limit_s)
         except subprocess.TimeoutExpired:
+            timed_out = True
             proc.kill()
-            proc.wait()
-            return {"error": f"the extras child did not finish within {limit_s} s and was killed"}
+            rc = proc.wait()
         try:
-            with open(path) as f:
+            with open(path) as f:                                              # (the child rewrites it after every section)
                 out = json.load(f)
         except (OSError, ValueError):
             out = {}
-        if rc != 0:
+        if timed_out:
+            out["error"] = (f"the extras child did not finish within {limit_s} s and was killed" +
+                            (" after writing these sections" if out else ""))
+        elif rc != 0:
             out["error"] = f"the extras child exited with code {rc}" + (" after writing these sections" if out else "")
         return out
     finally:
@@ -963,7 +967,7 @@ def pmc_traffic_bytes(fetch_kib, write_kib):
     return int(round(2.0 * fetch_kib * 1024.0 + write_kib * 1024.0))
 
 
-def live_traffic(d, dev_index, limit_s=180):
+def live_traffic(d, dev_index, limit_s=120):
     """roofline.traffic measured IN THIS RUN (it used to be a constant recorded once per round): two CHILD
     passes, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separately: the two do not fit one pass), each over
     `python3 bench.py --traffic-child` = a few full-size steps of the headline's kernels; the combine kernel's mean counter
