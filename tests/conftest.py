@@ -25,6 +25,10 @@ def pytest_collection_modifyitems(config, items):
         for item in items:
             if "test_hip_emu" in item.nodeid or "[emu" in item.nodeid or "cpu_model" in item.nodeid:
                 item.add_marker(pytest.mark.timeout(1500, method="thread"))
+            elif "gpu" in item.keywords:
+                # a kernel that never returns (several have not run on an MI355X yet) ends the run with a stack dump after 15
+                # minutes instead of holding the box until the caller's limit (the whole green suite of round 3 took under 4)
+                item.add_marker(pytest.mark.timeout(900, method="thread"))
     except ImportError:
         pass
     _hardware_verified_first(items)
