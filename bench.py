@@ -780,6 +780,29 @@ def config_extras(dev, on_section=None):
     torch.cuda.empty_cache()
     if on_section is not None:
         on_section(out)                 # everything above has been measured; LAST: kernels that have never run on an MI355X
+    # ---- configs[1] again with SVGDOptimizer(graph_replay=True): the step's launches recorded in a hipGraph per (staging slot,
+    # step scalars) and replayed (opt-in, never run on an MI355X: a failure here must not cost the sections behind it)
+    try:
+        params = tensors(D_RESNET20, 65)
+        base = torch.optim.SGD(params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=3e-4)
+
+        def reset_last():
+            with torch.no_grad():
+                params[-1].normal_(0, 0.05)
+        opt = bde.SVGDOptimizer(params, reset_last, base, particle_count=M, dataset_size=50000.0, l2_reg=3e-4, graph_replay=True)
+        for _ in range(8):                                           # the eager first steps + one recording per staging slot
+            opt.step(lambda: zero, lambda loss: None)
+        t = timed(lambda: opt.step(lambda: zero, lambda loss: None), 30)
+        out["svgd_step_cifar_resnet20_shell_fused_graph_replay"] = {
+            "ms": round(t * 1e3, 4), "steps_per_s": round(1.0 / t, 1), "replayed_steps": opt._graph_replays,
+            "recordings": opt._graph_captures,
+            "what": "as svgd_step_cifar_resnet20_shell_fused with graph_replay=True: table upload + gradient packing + the "
+                    "update's two launches as ONE hipGraph launch per step"}
+        del opt, params, base
+    except Exception as e:                                           # noqa: BLE001 -- reported, the other sections go on
+        out["svgd_step_cifar_resnet20_shell_fused_graph_replay"] = {"error": f"{type(e).__name__}: {e}"}
+    if on_section is not None:
+        on_section(out)
     # ---- the BBBConv2d layers of the CIFAR ResNet-20 (BASELINE configs[1] model family, batch 128): the fused layer
     # (bde_conv_lrt_fwd + bde_conv_lrt_bwd_data / _weight: each pair of convolutions of bbb_layers.py:146-147 as ONE
     # dual-accumulator implicit GEMM) vs the reference's op sequence (two MIOpen convolutions + element-wise ops) and vs

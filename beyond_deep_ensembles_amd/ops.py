@@ -137,8 +137,12 @@ class SegTable:
 
     def upload(self) -> None:
         """Host table -> device (stream-ordered, asynchronous from pinned memory)."""
-        h = self.host[self._slot]
-        self.ptrs.copy_(h, non_blocking=True)
+        self.ptrs.copy_(self.host[self._slot], non_blocking=True)
+        self.uploaded()
+
+    def uploaded(self) -> None:
+        """The current staging slot's copy has been enqueued (by upload(), or by a replayed graph that contains it): mark
+        the slot busy until that point of the stream and move on to the next one."""
         if self.ptrs.is_cuda:
             ev = torch.cuda.Event()
             ev.record()

@@ -117,8 +117,8 @@ class SVGDOptimizer(BayesianOptimizer):
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
                  kernel_grad_scale=1.0, *, process_group=None, exchange="allgather", exchange_chunks=1,
-                 overlap_backward=False, fuse_base_optimizer="auto", reuse_gram=False, single_launch=None, _ops=None,
-                 _force_exchange=False):
+                 overlap_backward=False, fuse_base_optimizer="auto", reuse_gram=False, single_launch=None,
+                 graph_replay=False, _ops=None, _force_exchange=False):
         # one param group per tensor, like the reference (svgd.py:50): groups distinguish tensors, not particles
         super().__init__([{"params": p} for p in params], {})
         self._ops = _ops or _default_ops()
@@ -195,6 +195,10 @@ class SVGDOptimizer(BayesianOptimizer):
         if single_launch not in (None, False, "two"):
             raise ValueError("single_launch must be None, 'two' or False")
         self._single_launch = single_launch
+        # opt-in: the small-model step's launches (table upload, gradient packing, the two launches of the update) recorded
+        # ONCE per set of step scalars in a hipGraph and replayed (see _replay_small_sgd)
+        self._graph_replay = bool(graph_replay)
+        self._graphs, self._graph_eager_steps, self._graph_captures, self._graph_replays = {}, 0, 0, 0
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
         # 17 <= particle_count <= 64: -phi by the blocked update kernel, then ONE launch applies the base optimizer to all
         # particles in order with its shared state (bde_svgd_apply_sgd / adam) instead of particle_count torch steps
@@ -514,6 +518,10 @@ class SVGDOptimizer(BayesianOptimizer):
         # The Gram pass and the kernel statistics need only the (replicated) particles: they run while the
         # gradient all-gather is in flight.  (Skipped when the previous fused kernel already left the Gram.)
         single_launch = pending is None and self._single_launch is not False and self._ops.svgd_small_supported(m, d)
+        if fused and single_launch and self._graph_replay and self._replay_small_sgd(base, m, d):
+            self._gram_valid = False
+            self._use_particle(m - 1)
+            return total_loss
         if single_launch or m > 16:
             self._grads_to_rows(self._G, 0, m)                           # these kernels read flat rows
         if fused and single_launch:
@@ -559,6 +567,58 @@ class SVGDOptimizer(BayesianOptimizer):
                 self._apply_base_optimizer(base, grad_scaler)
         self._release_grads()
         return total_loss
+
+    def _replay_small_sgd(self, base, m, d) -> bool:
+        """``graph_replay=True``: a small model's step on one GPU is host-bound -- ~15 us of kernels behind four launches
+        (segment-table upload, gradient packing, the update's two launches).  With torch.optim.SGD as the base optimizer
+        every scalar those launches take is constant between LR-scheduler steps (the reference's CIFAR loop steps its
+        scheduler once per epoch, experiments/cifar/cifar.py:169-172), so the sequence is recorded once per (staging slot of
+        the table, scalars) in a hipGraph and replayed: one launch per step.  Same kernels, same arguments, same order -- the
+        results are those of the eager path bit for bit.  Returns False (caller runs the eager path) for another base
+        optimizer, without a segment table of this step, on the first steps (the library's lazy initialisation must not
+        run inside a capture; the momentum buffers' first step has scalars of its own) and when the scalars change too
+        often for a recording to pay (a per-STEP scheduler)."""
+        if (not isinstance(base, torch.optim.SGD) or self._seg_host is None or not self._graphs_possible()
+                or self._graph_captures > 8 + self._graph_replays // 64):
+            return False
+        g0 = self._fused_hyper(base)
+        if g0.get("maximize", False):
+            raise RuntimeError("fuse_base_optimizer: maximize=True is not supported")
+        st = self._fused_buffers(base, "sgd")
+        if st["first"] or self._graph_eager_steps < 3:
+            self._graph_eager_steps += 1
+            return False
+        seg = self._seg
+        slot = seg._slot
+        l2, scale, n, _ = self._stat_args()
+        scalars = (float(g0["lr"]), float(g0["momentum"]), float(g0["dampening"]), float(g0["weight_decay"]),
+                   bool(g0["nesterov"]), l2, scale, n)
+        graph = self._graphs.get((slot, scalars))
+        if graph is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._small_sgd_launches(slot, scalars, st["buf"], m, d)
+            if len(self._graphs) >= 12:                                 # (a handful of learning rates x three slots)
+                self._graphs.clear()
+            self._graphs[(slot, scalars)] = graph
+            self._graph_captures += 1
+        graph.replay()
+        self._graph_replays += 1
+        seg.uploaded()                                                   # what SegTable.upload does around its copy
+        self._seg_host = None
+        self._release_grads()
+        self._fused_advance()
+        return True
+
+    def _graphs_possible(self) -> bool:
+        return self._P.is_cuda
+
+    def _small_sgd_launches(self, slot, scalars, buf, m, d) -> None:
+        """What _grads_to_rows + _fused_apply(single_launch=True) enqueue for an SGD base optimizer after its first step."""
+        seg = self._seg
+        seg.ptrs.copy_(seg.host[slot], non_blocking=True)               # (read from the pinned table at every replay)
+        self._ops.svgd_gather_seg(self._G, seg, 0, m)
+        self._ops.svgd_step_small_sgd(self._P, self._G, buf, d, *scalars[5:], self._ws, self._kstat, *scalars[:5], False)
 
     def _apply_base_optimizer(self, base, grad_scaler):
         """svgd.py:92-103: hand row i of -phi to the base optimizer as the gradient of particle i, for every i."""

@@ -216,6 +216,86 @@ def test_svgd_streaming_path_through_the_shell(backend, variant):
 
 # the 96 parameter tensors of the reference's CIFAR model (experiments/cifar/models.py: ResNet20(32, 3, 10, "swish", "frn"),
 # 273,610 elements; shapes read off the imported reference, written out here because the reference cannot travel)
+@pytest.mark.parametrize("backend", ["emu", pytest.param("hip", marks=pytest.mark.gpu)], indirect=True)
+def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkeypatch):
+    """SVGDOptimizer(graph_replay=True): the small-model step's launches (table upload, gradient packing, the update's two
+    launches) recorded once per (staging slot, step scalars) and replayed -- the reference's CIFAR loop
+    (experiments/cifar/cifar.py:155-172: SGD, one scheduler step per epoch).  Same kernels, same arguments: the particles
+    after every step equal the eager path's bit for bit, through a learning-rate change, and the step really is replayed.
+    On the device the recording is a hipGraph; on the CPU model a stand-in that re-issues the recorded launches (the
+    bookkeeping around it -- slot rotation, eager first steps, keys, the optimizer's state -- is the product's)."""
+    ops, dev = backend
+    from beyond_deep_ensembles_amd.svgd import SVGDOptimizer
+    if dev.type == "cpu":
+        state = {"capturing": None}
+
+        class Recording:
+            def __init__(self):
+                self.launches = None
+
+            def replay(self):
+                self.launches()
+
+        class recording_into:
+            def __init__(self, graph):
+                self.graph = graph
+
+            def __enter__(self):
+                state["capturing"] = self.graph
+
+            def __exit__(self, *exc):
+                state["capturing"] = None
+        real = SVGDOptimizer._small_sgd_launches
+
+        def launches(self, *a):
+            if state["capturing"] is None:
+                return real(self, *a)
+            state["capturing"].launches = lambda: real(self, *a)           # recorded, not executed (as under a capture)
+        monkeypatch.setattr(SVGDOptimizer, "_small_sgd_launches", launches)
+        monkeypatch.setattr(SVGDOptimizer, "_graphs_possible", lambda self: True)
+        monkeypatch.setattr(torch.cuda, "CUDAGraph", Recording)
+        monkeypatch.setattr(torch.cuda, "graph", recording_into)
+    torch.manual_seed(5)
+    x, y = torch.randn(64, 13, device=dev), torch.randn(64, 1, device=dev)
+    init = [torch.randn(13 * 50 + 50 + 50 + 1) * 0.1 for _ in range(4)]
+
+    def run(graph_replay):
+        model = make_mlp().to(dev)
+        params = list(model.parameters())
+        set_flat(params, init[0].to(dev))
+        k = [0]
+
+        def reset():
+            k[0] += 1
+            set_flat(params, init[k[0]].to(dev))
+        base = torch.optim.SGD(model.parameters(), lr=0.004, momentum=0.9, nesterov=True, weight_decay=3e-4)
+        opt = bde.SVGDOptimizer(model.parameters(), reset, base, particle_count=4, dataset_size=64, l2_reg=1e-3, _ops=ops,
+                                graph_replay=graph_replay)
+        assert opt._fuse and ops.svgd_small_supported(4, opt._layout.d)
+        out, losses = [], []
+        for t in range(14):
+            if t == 9:                                                      # the scheduler's epoch step
+                for group in base.param_groups:
+                    group["lr"] = 0.002
+            xb, yb = x[(t % 4) * 16:(t % 4 + 1) * 16], y[(t % 4) * 16:(t % 4 + 1) * 16]
+            losses.append(opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward()).item())
+            out.append(opt.particles.cpu().clone())
+        return out, losses, opt, base
+    eager, eager_losses, opt_e, _ = run(False)
+    replayed, losses, opt, base = run(True)
+    assert opt_e._graph_replays == 0
+    # three eager steps (the momentum buffers' first one among them), then one recording per staging slot and learning
+    # rate: 3 + 3 recordings, every step from the fourth on replayed
+    assert opt._graph_replays == 11 and opt._graph_captures == 6, (opt._graph_replays, opt._graph_captures)
+    for t, (a, b) in enumerate(zip(eager, replayed)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), t
+    assert losses == eager_losses
+    # the base optimizer's published state is the fused buffers', as on the eager path
+    assert torch.equal(torch.cat([base.state[p]["momentum_buffer"].reshape(-1) for p in opt._plist]).cpu(),
+                       torch.cat([opt_e.state["__base_optimizer"].state[p]["momentum_buffer"].reshape(-1)
+                                  for p in opt_e._plist]).cpu())
+
+
 def _cifar_resnet20_shapes():
     def conv_frn(cout, cin):                                     # a 3x3 convolution, then the FRN layer's four tensors
         return [(cout, cin, 3, 3), (cout,)] + [(1, cout, 1, 1)] * 3

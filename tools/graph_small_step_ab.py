@@ -9,7 +9,10 @@ SGD) is launch cost that a hipGraph replay would remove?
   (c) the same sequence captured ONCE in a torch.cuda.CUDAGraph and replayed (SGD's per-step scalars are constant between
       LR-scheduler steps, so no device-resident scalars are needed for this base optimizer; `first` is False after step 1)
 
-(a) - (b) is the shell's Python; (b) - (c) is what graph replay can buy.  Prints microseconds per iteration (host loop of
+  (d) the product step with SVGDOptimizer(graph_replay=True) (round 5: table upload + packing + the two launches replayed
+      from one hipGraph per (staging slot, step scalars); the loss sum stays a launch of its own)
+
+(a) - (b) is the shell's Python; (b) - (c) is what graph replay can buy; (a) - (d) is what the product's option buys.  Prints microseconds per iteration (host loop of
 200 iterations + one synchronize; the kernels are ~15 us, so every variant is host-bound).
 
     python tools/graph_small_step_ab.py
@@ -90,6 +93,19 @@ def main():
         print(f"shell Python (a - b) {t_a - t_b:6.1f} us;   launch cost a replay removes (b - c) {t_b - t_c:6.1f} us")
     except Exception as e:
         print(f"(c) capture failed: {type(e).__name__}: {e}")
+    params2 = [torch.nn.Parameter(torch.randn(s, device=dev) * 0.05) for s in sizes]
+    base2 = torch.optim.SGD(params2, lr=0.1, momentum=0.9, nesterov=True, weight_decay=5e-4)
+
+    def reset2():
+        with torch.no_grad():
+            params2[-1].normal_(0, 0.05)
+    try:
+        opt2 = bde.SVGDOptimizer(params2, reset2, base2, particle_count=M, dataset_size=50000.0, l2_reg=3e-4, graph_replay=True)
+        t_d = timed(lambda: opt2.step(lambda: zero, lambda loss: None))
+        print(f"(d) SVGDOptimizer(graph_replay=True).step, null closures:       {t_d:7.1f} us   ({opt2._graph_replays} replays, "
+              f"{opt2._graph_captures} recordings)")
+    except Exception as e:
+        print(f"(d) failed: {type(e).__name__}: {e}")
 
 
 if __name__ == "__main__":
