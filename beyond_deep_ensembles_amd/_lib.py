@@ -54,6 +54,7 @@ SIGNATURES = {
                                         c_double, c_double, c_double, c_int64, _P, _P]),
     "bde_svgd_gather_seg": (c_int, [_P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, _P]),
     "bde_sum_scalars": (c_int, [_P, c_int, _P, _P]),
+    "bde_mean_scalars": (c_int, [_P, c_int, c_float, _P, _P]),
     "bde_swag_update": (c_int, [_P, _P, _P, _P, c_int64, c_int64, _P]),
     "bde_swag_sample": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_uint64, c_uint64, _P, c_int64, _P]),
     "bde_swag_sample_batched": (c_int, [_P, _P, _P, c_int, c_int64, c_int, _P, _P, c_int64, c_uint64, c_uint64, _P, c_int64,
@@ -103,7 +104,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 404        # csrc/version.hip, include/bde_hip.h
+ABI_VERSION = 405        # csrc/version.hip, include/bde_hip.h
 
 
 class BdeLibraryError(RuntimeError):

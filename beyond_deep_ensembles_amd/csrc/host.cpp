@@ -245,6 +245,28 @@ class ParticleSet {
   std::vector<std::vector<at::Tensor>> keep_;
 };
 
+// The value SVGDOptimizer.step returns (svgd.py:66,72,105: the particles' losses summed in order, divided by their count) by
+// ONE call of bde_mean_scalars: the per-tensor checks and the pointer array without a Python loop (8 losses: ~9 us of a
+// ~65 us step in Python).  `entry` is the address of bde_mean_scalars in the kernel library the caller uses (the device
+// library; the tests' CPU model or stub), `stream` its stream handle.  Returns false -- the caller then takes torch's adds
+// -- when the losses are not fp32 one-element tensors on `out`'s device (a half-precision or off-device loss).
+bool mean_losses(const std::vector<at::Tensor>& losses, at::Tensor out, double divisor, int64_t entry, int64_t stream) {
+  const int64_t n = static_cast<int64_t>(losses.size());
+  if (n < 1 || n > 64 || entry == 0 || !(divisor > 0.0)) return false;
+  if (!out.defined() || out.scalar_type() != at::kFloat || out.numel() != 1) return false;
+  const float* ptrs[64];
+  for (int64_t i = 0; i < n; ++i) {
+    const at::Tensor& t = losses[i];
+    if (!t.defined() || t.scalar_type() != at::kFloat || t.numel() != 1 || t.device() != out.device()) return false;
+    ptrs[i] = t.data_ptr<float>();
+  }
+  using Fn = int (*)(const float* const*, int, float, float*, void*);
+  const int rc = reinterpret_cast<Fn>(entry)(ptrs, static_cast<int>(n), static_cast<float>(divisor), out.data_ptr<float>(),
+                                            reinterpret_cast<void*>(stream));
+  TORCH_CHECK(rc == 0, "bde_mean_scalars failed with code ", rc);
+  return true;
+}
+
 }  // namespace
 
 void bind_autograd_nodes(py::module_& m);   // host_autograd.cpp: the Bayesian layers' autograd nodes
@@ -265,6 +287,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("release", &ParticleSet::release);
   m.def("repoint", &repoint, "param.data / param.grad = views, for whole parameter lists", py::arg("params"),
         py::arg("datas"), py::arg("grads"));
+  m.def("mean_losses", &mean_losses, "sum of fp32 scalar tensors / divisor by one bde_mean_scalars call; False: not applicable",
+        py::arg("losses"), py::arg("out"), py::arg("divisor"), py::arg("entry"), py::arg("stream"));
   m.def("clear_grads", &clear_grads, "param.grad = None for a whole parameter list");
   m.def("collect_grads", &collect_grads, "record where the gradients live (no copy); returns the tensors taken by reference",
         py::arg("params"), py::arg("views"), py::arg("table"), py::arg("j"), py::arg("M"), py::arg("zero_addr") = 0,

@@ -683,8 +683,9 @@ namespace bde {
 struct ScalarPtrs {
   const float* v[64];
 };
-// every lane fetches one scalar (all loads in flight at once), lane 0 adds them in index order
-__global__ __launch_bounds__(64) void sum_scalars_kernel(ScalarPtrs p, int n, float* __restrict__ out) {
+// every lane fetches one scalar (all loads in flight at once), lane 0 adds them in index order; the sum is divided by
+// `divisor` (IEEE fp32 division; 1 leaves the sum as it is): svgd.py:105 `total_loss / particle_count` in the same launch
+__global__ __launch_bounds__(64) void sum_scalars_kernel(ScalarPtrs p, int n, float divisor, float* __restrict__ out) {
   __shared__ float vals[64];
   const int i = threadIdx.x;
   vals[i] = i < n ? *p.v[i] : 0.f;
@@ -692,19 +693,23 @@ __global__ __launch_bounds__(64) void sum_scalars_kernel(ScalarPtrs p, int n, fl
   if (i == 0) {
     float s = vals[0];
     for (int j = 1; j < n; ++j) s += vals[j];
-    out[0] = s;
+    out[0] = s / divisor;
   }
 }
 }  // namespace bde
 
-extern "C" int bde_sum_scalars(const float* const* scalars, int n, float* out, void* stream) {
-  if (!scalars || !out || n < 1 || n > 64) return BDE_ERR_INVALID;
+extern "C" int bde_mean_scalars(const float* const* scalars, int n, float divisor, float* out, void* stream) {
+  if (!scalars || !out || n < 1 || n > 64 || !(divisor > 0.f)) return BDE_ERR_INVALID;
   bde::ScalarPtrs p;
   for (int i = 0; i < 64; ++i) p.v[i] = i < n ? scalars[i] : nullptr;
   for (int i = 0; i < n; ++i)
     if (!p.v[i]) return BDE_ERR_INVALID;
-  hipLaunchKernelGGL(bde::sum_scalars_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), p, n, out);
+  hipLaunchKernelGGL(bde::sum_scalars_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), p, n, divisor, out);
   return bde::to_err(hipGetLastError());
+}
+
+extern "C" int bde_sum_scalars(const float* const* scalars, int n, float* out, void* stream) {
+  return bde_mean_scalars(scalars, n, 1.f, out, stream);
 }
 
 extern "C" int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld, float l2_reg,

@@ -351,10 +351,17 @@ class HipOps:
     def sum_scalars(self, scalars, out) -> None:
         """out[()] = ((s0 + s1) + s2) + ... in fp32, this order, ONE launch (bde_sum_scalars): the returned loss of a
         step (svgd.py:66,72: ``total_loss += loss`` per particle).  ``scalars``: 1..64 fp32 one-element device tensors."""
+        self.mean_scalars(scalars, out, 1.0)
+
+    def mean_scalars(self, scalars, out, divisor) -> None:
+        """The same sum divided by ``divisor`` (IEEE fp32 division) in the same launch (bde_mean_scalars): svgd.py:105
+        ``total_loss / particle_count``."""
         import ctypes
         n = len(scalars)
         if not 1 <= n <= 64:
             raise BdeKernelError("sum_scalars: 1..64 scalars expected")
+        if not float(divisor) > 0.0:
+            raise BdeKernelError("mean_scalars: the divisor must be positive")
         ptrs = (ctypes.c_void_p * n)()
         for i, t in enumerate(scalars):
             if t.numel() != 1 or t.device != out.device:
@@ -364,9 +371,15 @@ class HipOps:
             raise BdeKernelError("sum_scalars: out must hold one element")
         if out.device.type == "cuda" and out.device.index != torch.cuda.current_device():
             with torch.cuda.device(out.device):
-                _check(self.lib.bde_sum_scalars(ptrs, n, _ptr(out, "out"), _stream()), "bde_sum_scalars")
+                _check(self.lib.bde_mean_scalars(ptrs, n, float(divisor), _ptr(out, "out"), _stream()), "bde_mean_scalars")
             return
-        _check(self.lib.bde_sum_scalars(ptrs, n, _ptr(out, "out"), _stream()), "bde_sum_scalars")
+        _check(self.lib.bde_mean_scalars(ptrs, n, float(divisor), _ptr(out, "out"), _stream()), "bde_mean_scalars")
+
+    def mean_scalars_entry(self) -> int:
+        """Address of this library's bde_mean_scalars, for the native host helper (csrc/host.cpp ``mean_losses``: the
+        argument checks and the call without Python in between)."""
+        import ctypes
+        return ctypes.cast(self.lib.bde_mean_scalars, ctypes.c_void_p).value
 
     # ------------------------------------------------------------ SWAG --
     @_on_device_of

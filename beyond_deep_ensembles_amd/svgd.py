@@ -47,6 +47,17 @@ from .algo import (BayesianOptimizer, FlatLayout, adopt_grads, check_params, cle
 from .ops import pad4
 
 
+def _raw_stream_of(dev) -> int:
+    """hipStream_t of torch's current stream when ``dev`` is the current GPU; 0 for CPU tensors (the tests' backends);
+    -1: another GPU than the current one (the caller takes the path that switches devices)."""
+    if dev.type != "cuda":
+        return 0
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        return -1
+    from . import ops as _ops_mod
+    return int(_ops_mod._stream() or 0)
+
+
 def rbf(particles: torch.Tensor, h_override=None, _ops=None):
     """Pairwise RBF kernel with the median heuristic and its repulsive gradient
     (drop-in for ``src/algos/svgd.py:14-32``): returns ``(kernel [M, M],
@@ -198,6 +209,7 @@ class SVGDOptimizer(BayesianOptimizer):
         # opt-in: the small-model step's launches (table upload, gradient packing, the two launches of the update) recorded
         # ONCE per set of step scalars in a hipGraph and replayed (see _replay_small_sgd)
         self._graph_replay = bool(graph_replay)
+        self._mean_losses = None
         self._graphs, self._graph_eager_steps, self._graph_captures, self._graph_replays = {}, 0, 0, 0
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
         # 17 <= particle_count <= 64: -phi by the blocked update kernel, then ONE launch applies the base optimizer to all
@@ -367,23 +379,50 @@ class SVGDOptimizer(BayesianOptimizer):
                 pset.end_begin(particle_idx, table, particle_idx - row_off, m_tab, zero, particle_idx + 1)
             else:
                 pset.end(particle_idx, table, particle_idx - row_off, m_tab, zero)
+        if not self._sharded and self._chunks is None:
+            # one GPU: nothing is exchanged, the returned mean (svgd.py:105) comes out of the same launch as the sum
+            m = self.state["__particle_count"]
+            return self._posterior_update(self._sum_losses(losses, divisor=m), None, mean_taken=True)
         return self._posterior_update(self._sum_losses(losses), None)
 
-    def _sum_losses(self, losses):
+    def _sum_losses(self, losses, divisor=1):
         """svgd.py:66,72: ``total_loss = tensor(0.0); total_loss += loss`` per particle -- the same fp32 sum in the same
-        order (0 + x == x bit for bit, so the first loss starts it), by ONE launch (bde_sum_scalars) when the losses are
+        order (0 + x == x bit for bit, so the first loss starts it), by ONE launch (bde_mean_scalars) when the losses are
         fp32 scalars on the particles' device, by torch's adds otherwise (a half-precision or off-device loss).  A small
-        model's step is launch-bound: seven torch adds cost more host time than its whole posterior update."""
+        model's step is launch-bound: seven torch adds cost more host time than its whole posterior update.  ``divisor``:
+        svgd.py:105's ``/ particle_count`` in the same launch (IEEE fp32 division: what torch computes on the CPU; torch's
+        GPU kernel multiplies by fl(1 / count) instead, equal for the usual power-of-two counts and within one ulp of it
+        otherwise).  With the native host helper the checks and the call are one C++ function (host.cpp mean_losses)."""
         dev = self._P.device if self._P is not None else self._Pown.device
-        if 1 < len(losses) <= 64 and hasattr(self._ops, "sum_scalars") and all(
-                t.dtype == torch.float32 and t.numel() == 1 and t.device == dev for t in losses):
-            total = torch.empty((), dtype=torch.float32, device=dev)
-            self._ops.sum_scalars(losses, total)
-            return total
+        n = len(losses)
+        if 1 < n <= 64 and hasattr(self._ops, "mean_scalars"):
+            native = self._native_mean_losses()
+            stream = _raw_stream_of(dev) if native is not None else -1
+            if stream >= 0:
+                total = torch.empty((), dtype=torch.float32, device=dev)
+                if native[0](losses, total, float(divisor), native[1], stream):
+                    return total
+            elif all(t.dtype == torch.float32 and t.numel() == 1 and t.device == dev for t in losses):
+                total = torch.empty((), dtype=torch.float32, device=dev)
+                self._ops.mean_scalars(losses, total, float(divisor))
+                return total
         total = losses[0].to(device=dev, dtype=torch.float32, copy=True)
         for t in losses[1:]:
             total += t
-        return total
+        return total if divisor == 1 else total / divisor
+
+    def _native_mean_losses(self):
+        """(host.cpp mean_losses, address of this backend's bde_mean_scalars), or None: no host helper / a backend without a
+        C entry point (the tests' checker)."""
+        if self._mean_losses is None:
+            self._mean_losses = False
+            entry = getattr(self._ops, "mean_scalars_entry", None)
+            if entry is not None:
+                from . import _host
+                native = _host.load()
+                if native is not None and hasattr(native, "mean_losses"):
+                    self._mean_losses = (native.mean_losses, int(entry()))
+        return self._mean_losses or None
 
     def _particle_set(self):
         """The native object that runs the per-particle loops over its own tensor lists (csrc/host.cpp ParticleSet);
@@ -481,10 +520,11 @@ class SVGDOptimizer(BayesianOptimizer):
         if self._pset:
             self._pset.release()
 
-    def _posterior_update(self, total_loss, grad_scaler=None):
+    def _posterior_update(self, total_loss, grad_scaler=None, mean_taken=False):
         """Everything after the forward/backward passes (svgd.py:82-105): gradient exchange (multi-GPU), kernel
-        statistics, -phi and the base-optimizer applications.  ``total_loss`` = sum of this rank's particle losses;
-        returns the mean loss over all particles.  (bench.py times exactly this.)"""
+        statistics, -phi and the base-optimizer applications.  ``total_loss`` = sum of this rank's particle losses
+        (``mean_taken``: already divided by the particle count, single-GPU fast path); returns the mean loss over all
+        particles.  (bench.py times exactly this.)"""
         base = self.state["__base_optimizer"]
         m = self.state["__particle_count"]
         with torch.no_grad():
@@ -501,7 +541,7 @@ class SVGDOptimizer(BayesianOptimizer):
             else:
                 total_loss = self._step_replicated(total_loss, base, fused and self._fuse, grad_scaler,
                                                    staged_apply=fused and self._fuse_staged)
-        return total_loss / m
+        return total_loss if mean_taken else total_loss / m
 
     # ---- replicated particles: one gather (or none), then the update ----------------------------------------
     def _stat_args(self):

@@ -191,6 +191,9 @@ int bde_svgd_gather_seg(const void* const* seg_ptrs, const bde_seg_chunk* chunks
  * (1 <= n <= 64) device pointers to fp32 scalars; it is read during the call (the pointers travel in the kernel's
  * argument block), so it may be a temporary.  `out` may be one of the inputs. */
 int bde_sum_scalars(const float* const* scalars, int n, float* out, void* stream);
+/* The same sum divided by `divisor` (> 0; IEEE fp32 division) in the same launch: the value SVGDOptimizer.step returns,
+ * svgd.py:105 `total_loss / particle_count`, without a second launch (ABI 405).  With divisor = 1 it is bde_sum_scalars. */
+int bde_mean_scalars(const float* const* scalars, int n, float divisor, float* out, void* stream);
 
 /* Shared-state base-optimizer apply for the M particles, in particle order
  * (svgd.py:92-103 with ONE torch.optim.SGD / Adam whose state is keyed on the

@@ -99,6 +99,10 @@ class OracleOps:
             total += t.detach().reshape(())
         out.reshape(()).copy_(total)
 
+    def mean_scalars(self, scalars, out, divisor):                  # svgd.py:105: total_loss / particle_count
+        self.sum_scalars(scalars, out)
+        out.reshape(()).div_(float(divisor))
+
     def svgd_combine_seg(self, P, seg, out, d, kstat):
         self.svgd_combine(P, self._seg_rows(seg, P.shape[1], range(seg.m)), out, d, kstat)
 

@@ -1646,6 +1646,12 @@ def test_r5_sum_scalars_is_the_sequential_fp32_sum(ops):
         for v in vals[1:]:
             want = np.float32(want + v)
         assert out.cpu().numpy() == want, (n, float(out), float(want))
+        # bde_mean_scalars: the same sum / divisor (IEEE fp32 division), svgd.py:105 -- the particle counts 1..16 and the
+        # scalar count itself
+        for div in (1, 3, 5, 8, 13, n):
+            mean = torch.full((), float("nan"), dtype=torch.float32, device=DEV)
+            ops.mean_scalars(scalars, mean, div)
+            assert mean.cpu().numpy() == np.float32(want / np.float32(div)), (n, div)
     a, b = torch.tensor(1.5, device=DEV), torch.tensor([2.25], device=DEV)
     ops.sum_scalars([a, b], a)                                   # out aliases the first input
     assert float(a) == 3.75
@@ -1657,4 +1663,6 @@ def test_r5_sum_scalars_is_the_sequential_fp32_sum(ops):
         ops.sum_scalars([torch.zeros(2, device=DEV)], a)
     with pytest.raises(BdeKernelError):
         ops.sum_scalars([a.double()], a)
+    with pytest.raises(BdeKernelError):
+        ops.mean_scalars([a, b], a, 0.0)
 

@@ -51,7 +51,7 @@ ROWS = {
     "svgd_gram_finish_kernel": ("dimension-sharded exchange: slice Gram partials → fp64 block", "257 doubles / rank", "latency", R3,
                                 "`test_svgd_sharded_hip_two_ranks_one_device[alltoall*]`"),
     "svgd_kstats_gmat_kernel": ("the ranks' fp64 blocks summed in rank order → identical statistics on every rank", "latency", "—", R3, "same test"),
-    "sum_scalars_kernel": ("the returned loss (`svgd.py:66,72,105`): M−1 torch adds → one launch (round 5)", "M scalars", "unmeasured",
+    "sum_scalars_kernel": ("the returned loss (`svgd.py:66,72,105`): M−1 torch adds and the division by M → one launch (round 5)", "M scalars", "unmeasured",
                            "**no** -- new in round 5; CPU model green", "`test_r5_sum_scalars_is_the_sequential_fp32_sum`"),
     # ---- SVGD, small models (BASELINE configs[1])
     "svgd_step_small_kernel": ("the whole of `svgd.py:86-103` for M ≤ 8, D ≤ 524,288: two launches of one kernel", "`12·M·D` B (one pass over P)",
