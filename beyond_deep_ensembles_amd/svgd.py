@@ -210,6 +210,7 @@ class SVGDOptimizer(BayesianOptimizer):
         # ONCE per set of step scalars in a hipGraph and replayed (see _replay_small_sgd)
         self._graph_replay = bool(graph_replay)
         self._mean_losses = None
+        self._small_ok = None
         self._graphs, self._graph_eager_steps, self._graph_captures, self._graph_replays = {}, 0, 0, 0
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
         # 17 <= particle_count <= 64: -phi by the blocked update kernel, then ONE launch applies the base optimizer to all
@@ -557,7 +558,9 @@ class SVGDOptimizer(BayesianOptimizer):
             pending = self._start_gradient_exchange(total_loss)
         # The Gram pass and the kernel statistics need only the (replicated) particles: they run while the
         # gradient all-gather is in flight.  (Skipped when the previous fused kernel already left the Gram.)
-        single_launch = pending is None and self._single_launch is not False and self._ops.svgd_small_supported(m, d)
+        if self._small_ok is None:                                       # (a property of M, D and the device: asked once)
+            self._small_ok = bool(self._ops.svgd_small_supported(m, d))
+        single_launch = pending is None and self._single_launch is not False and self._small_ok
         if fused and single_launch and self._graph_replay and self._replay_small_sgd(base, m, d):
             self._gram_valid = False
             self._use_particle(m - 1)
