@@ -297,6 +297,44 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
                                   for p in opt_e._plist]).cpu())
 
 
+@pytest.mark.parametrize("loss_dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("m", [3, 8])
+def test_r5_returned_loss_is_the_reference_accumulation(backend, loss_dtype, m):
+    """svgd.py:66,72,105: ``total_loss = tensor(0.0); total_loss += loss`` per particle; ``return total_loss / particle_count``.
+    fp32 losses take ONE launch (bde_mean_scalars through host.cpp mean_losses where the backend has a C entry point), any
+    other loss type torch's adds -- both must return exactly what the reference's accumulation gives on the same losses
+    (on the GPU torch divides by multiplying with fl(1 / count): equal for m = 8, within one ulp for m = 3)."""
+    ops, dev = backend
+    torch.manual_seed(11)
+    model = make_mlp().to(dev)
+    x, y = torch.randn(16, 13, device=dev), torch.randn(16, 1, device=dev)
+    base = torch.optim.SGD(model.parameters(), lr=1e-3)
+
+    def reset():
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn_like(p) * 0.05)
+    opt = bde.SVGDOptimizer(model.parameters(), reset, base, particle_count=m, dataset_size=64, _ops=ops)
+    seen = []
+
+    def forward():
+        loss = F.mse_loss(model(x), y).to(loss_dtype)
+        seen.append(loss.detach().clone())
+        return loss
+    for _ in range(2):
+        seen.clear()
+        got = opt.step(forward, lambda l: l.backward())
+        total = torch.tensor(0.0, device=dev)
+        for l in seen:
+            total += l
+        want = total / m
+        assert got.dtype == torch.float32 and len(seen) == m
+        if dev.type == "cpu" or m == 8:
+            assert torch.equal(got.cpu(), want.cpu()), (float(got), float(want))
+        else:
+            assert abs(float(got) - float(want)) <= 2.4e-7 * abs(float(want))
+
+
 def _cifar_resnet20_shapes():
     def conv_frn(cout, cin):                                     # a 3x3 convolution, then the FRN layer's four tensors
         return [(cout, cin, 3, 3), (cout,)] + [(1, cout, 1, 1)] * 3
