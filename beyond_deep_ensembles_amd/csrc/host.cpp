@@ -267,6 +267,71 @@ bool mean_losses(const std::vector<at::Tensor>& losses, at::Tensor out, double d
   return true;
 }
 
+// A small model's posterior update on one GPU is host-bound (~15 us of kernels): its two C-ABI calls -- bde_svgd_gather_seg
+// (gradients -> flat rows) and bde_svgd_step_small_sgd / _adam (statistics, -phi, the M shared-state optimizer applications)
+// -- issued from ONE native function instead of two Python wrappers + ctypes marshalling (~13 us of a ~55 us step).  The
+// entry addresses are those of the kernel library the caller uses (device library, the tests' CPU model, the stub); the
+// tensors are the optimizer's own persistent buffers, validated where they are created (ops.py), re-checked cheaply here.
+struct SmallStepArgs {
+  float *P, *G, *s0, *s1;
+  void* ws;
+  float* kstat;
+  int m;
+  int64_t ld;
+};
+
+SmallStepArgs small_step_common(int64_t e_gather, const at::Tensor& seg_ptrs, const at::Tensor& chunks, const at::Tensor& P,
+                                const at::Tensor& G, const at::Tensor& s0, const c10::optional<at::Tensor>& s1,
+                                const at::Tensor& ws, const at::Tensor& kstat, int64_t d, int64_t stream) {
+  TORCH_CHECK(P.dim() == 2 && G.dim() == 2 && P.scalar_type() == at::kFloat && G.scalar_type() == at::kFloat &&
+                  P.stride(1) == 1 && G.stride(1) == 1 && P.stride(0) == G.stride(0) && P.size(0) == G.size(0) &&
+                  d >= 1 && d <= P.size(1), "small_step: P and G must be fp32 [M, ld] with one leading dimension");
+  TORCH_CHECK(seg_ptrs.scalar_type() == at::kLong && chunks.scalar_type() == at::kLong && chunks.dim() == 2 &&
+                  chunks.size(1) == 4 && chunks.is_contiguous() && seg_ptrs.is_contiguous(), "small_step: segment table");
+  const auto dev = P.device();
+  TORCH_CHECK(G.device() == dev && s0.device() == dev && ws.device() == dev && kstat.device() == dev &&
+                  seg_ptrs.device() == dev && chunks.device() == dev && (!s1 || s1->device() == dev),
+              "small_step: every buffer must live on the particles' device");
+  TORCH_CHECK(s0.scalar_type() == at::kFloat && s0.numel() >= d && (!s1 || (s1->scalar_type() == at::kFloat && s1->numel() >= d)) &&
+                  kstat.scalar_type() == at::kFloat, "small_step: optimizer state / statistics buffers");
+  SmallStepArgs a{P.data_ptr<float>(), G.data_ptr<float>(), s0.data_ptr<float>(), s1 ? s1->data_ptr<float>() : nullptr,
+                  ws.data_ptr(), kstat.data_ptr<float>(), static_cast<int>(P.size(0)), P.stride(0)};
+  using Gather = int (*)(const void* const*, const void*, int64_t, float*, int, int, int, int64_t, void*);
+  const int rc = reinterpret_cast<Gather>(e_gather)(reinterpret_cast<const void* const*>(seg_ptrs.data_ptr<int64_t>()),
+                                                    chunks.data_ptr<int64_t>(), chunks.size(0), a.G, a.m, 0, a.m, a.ld,
+                                                    reinterpret_cast<void*>(stream));
+  TORCH_CHECK(rc == 0, "bde_svgd_gather_seg failed with code ", rc);
+  return a;
+}
+
+void small_step_sgd(int64_t e_gather, int64_t e_step, at::Tensor seg_ptrs, at::Tensor chunks, at::Tensor P, at::Tensor G,
+                    at::Tensor buf, at::Tensor ws, at::Tensor kstat, int64_t d, double l2_reg, double kernel_grad_scale,
+                    double dataset_size, double lr, double momentum, double dampening, double weight_decay, bool nesterov,
+                    bool first, int64_t stream) {
+  const SmallStepArgs a = small_step_common(e_gather, seg_ptrs, chunks, P, G, buf, c10::nullopt, ws, kstat, d, stream);
+  using Step = int (*)(float*, const float*, float*, int, int64_t, int64_t, float, float, float, double, double, double, double,
+                       int, int, void*, float*, void*);
+  const int rc = reinterpret_cast<Step>(e_step)(a.P, a.G, a.s0, a.m, d, a.ld, static_cast<float>(l2_reg),
+                                                static_cast<float>(kernel_grad_scale), static_cast<float>(dataset_size), lr,
+                                                momentum, dampening, weight_decay, nesterov ? 1 : 0, first ? 1 : 0, a.ws,
+                                                a.kstat, reinterpret_cast<void*>(stream));
+  TORCH_CHECK(rc == 0, "bde_svgd_step_small_sgd failed with code ", rc);
+}
+
+void small_step_adam(int64_t e_gather, int64_t e_step, at::Tensor seg_ptrs, at::Tensor chunks, at::Tensor P, at::Tensor G,
+                     at::Tensor exp_avg, at::Tensor exp_avg_sq, at::Tensor ws, at::Tensor kstat, int64_t d, double l2_reg,
+                     double kernel_grad_scale, double dataset_size, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int64_t step0, int64_t stream) {
+  const SmallStepArgs a = small_step_common(e_gather, seg_ptrs, chunks, P, G, exp_avg, exp_avg_sq, ws, kstat, d, stream);
+  using Step = int (*)(float*, const float*, float*, float*, int, int64_t, int64_t, float, float, float, double, double, double,
+                       double, double, int64_t, void*, float*, void*);
+  const int rc = reinterpret_cast<Step>(e_step)(a.P, a.G, a.s0, a.s1, a.m, d, a.ld, static_cast<float>(l2_reg),
+                                                static_cast<float>(kernel_grad_scale), static_cast<float>(dataset_size), lr,
+                                                beta1, beta2, eps, weight_decay, step0, a.ws, a.kstat,
+                                                reinterpret_cast<void*>(stream));
+  TORCH_CHECK(rc == 0, "bde_svgd_step_small_adam failed with code ", rc);
+}
+
 }  // namespace
 
 void bind_autograd_nodes(py::module_& m);   // host_autograd.cpp: the Bayesian layers' autograd nodes
@@ -289,6 +354,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("datas"), py::arg("grads"));
   m.def("mean_losses", &mean_losses, "sum of fp32 scalar tensors / divisor by one bde_mean_scalars call; False: not applicable",
         py::arg("losses"), py::arg("out"), py::arg("divisor"), py::arg("entry"), py::arg("stream"));
+  m.def("small_step_sgd", &small_step_sgd, "bde_svgd_gather_seg + bde_svgd_step_small_sgd on the optimizer's buffers");
+  m.def("small_step_adam", &small_step_adam, "bde_svgd_gather_seg + bde_svgd_step_small_adam on the optimizer's buffers");
   m.def("clear_grads", &clear_grads, "param.grad = None for a whole parameter list");
   m.def("collect_grads", &collect_grads, "record where the gradients live (no copy); returns the tensors taken by reference",
         py::arg("params"), py::arg("views"), py::arg("table"), py::arg("j"), py::arg("M"), py::arg("zero_addr") = 0,

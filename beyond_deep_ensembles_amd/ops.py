@@ -375,11 +375,14 @@ class HipOps:
             return
         _check(self.lib.bde_mean_scalars(ptrs, n, float(divisor), _ptr(out, "out"), _stream()), "bde_mean_scalars")
 
-    def mean_scalars_entry(self) -> int:
-        """Address of this library's bde_mean_scalars, for the native host helper (csrc/host.cpp ``mean_losses``: the
-        argument checks and the call without Python in between)."""
+    def entry(self, name: str) -> int:
+        """Address of C-ABI entry point ``name`` in this backend's library, for the native host helper (csrc/host.cpp
+        ``mean_losses`` / ``small_step_*``: argument checks and the calls without Python or ctypes marshalling in between)."""
         import ctypes
-        return ctypes.cast(self.lib.bde_mean_scalars, ctypes.c_void_p).value
+        return ctypes.cast(getattr(self.lib, name), ctypes.c_void_p).value
+
+    def mean_scalars_entry(self) -> int:
+        return self.entry("bde_mean_scalars")
 
     # ------------------------------------------------------------ SWAG --
     @_on_device_of

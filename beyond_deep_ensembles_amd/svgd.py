@@ -211,6 +211,7 @@ class SVGDOptimizer(BayesianOptimizer):
         self._graph_replay = bool(graph_replay)
         self._mean_losses = None
         self._small_ok = None
+        self._small_step_native = None
         self._graphs, self._graph_eager_steps, self._graph_captures, self._graph_replays = {}, 0, 0, 0
         self._fuse = bool(fuse_base_optimizer) and particle_count <= 16     # fused kernels: single-tile path only
         # 17 <= particle_count <= 64: -phi by the blocked update kernel, then ONE launch applies the base optimizer to all
@@ -565,6 +566,10 @@ class SVGDOptimizer(BayesianOptimizer):
             self._gram_valid = False
             self._use_particle(m - 1)
             return total_loss
+        if fused and single_launch and self._native_small_step(base, m, d):
+            self._gram_valid = False
+            self._use_particle(m - 1)
+            return total_loss
         if single_launch or m > 16:
             self._grads_to_rows(self._G, 0, m)                           # these kernels read flat rows
         if fused and single_launch:
@@ -649,6 +654,52 @@ class SVGDOptimizer(BayesianOptimizer):
         self._graph_replays += 1
         seg.uploaded()                                                   # what SegTable.upload does around its copy
         self._seg_host = None
+        self._release_grads()
+        self._fused_advance()
+        return True
+
+    def _native_small_step(self, base, m, d) -> bool:
+        """The small-model update of a step whose gradients sit in the segment table -- upload, bde_svgd_gather_seg,
+        bde_svgd_step_small_sgd / _adam -- with both C-ABI calls issued by ONE native function (host.cpp small_step_*)
+        instead of two Python wrappers: the step is host-bound, and this is what _grads_to_rows + _fused_apply(single_launch)
+        enqueue, argument for argument.  False: no host helper / table / plain SGD or Adam -- the caller takes that path."""
+        if self._seg_host is None:
+            return False
+        native = self._small_step_native
+        if native is None:
+            native = False
+            if hasattr(self._ops, "entry"):
+                from . import _host
+                mod = _host.load()
+                if mod is not None and hasattr(mod, "small_step_sgd"):
+                    native = (mod, self._ops.entry("bde_svgd_gather_seg"), self._ops.entry("bde_svgd_step_small_sgd"),
+                              self._ops.entry("bde_svgd_step_small_adam"))
+            self._small_step_native = native
+        if native is False:
+            return False
+        sgd = isinstance(base, torch.optim.SGD)
+        if not sgd and type(base) is not torch.optim.Adam:
+            return False
+        g0 = self._fused_hyper(base)
+        if g0.get("maximize", False) or (not sgd and (g0.get("amsgrad", False) or g0.get("decoupled_weight_decay", False))):
+            return False                                                 # (_fused_apply raises, naming the option)
+        stream = _raw_stream_of(self._P.device)
+        if stream < 0:
+            return False
+        mod, e_gather, e_sgd, e_adam = native
+        st = self._fused_buffers(base, "sgd" if sgd else "adam")
+        seg = self._seg
+        seg.upload()
+        self._seg_host = None
+        l2, scale, n, _ = self._stat_args()
+        if sgd:
+            mod.small_step_sgd(e_gather, e_sgd, seg.ptrs, seg.chunks, self._P, self._G, st["buf"], self._ws, self._kstat, d, l2,
+                               scale, n, float(g0["lr"]), g0["momentum"], g0["dampening"], g0["weight_decay"], bool(g0["nesterov"]),
+                               bool(st["first"]), stream)
+        else:
+            mod.small_step_adam(e_gather, e_adam, seg.ptrs, seg.chunks, self._P, self._G, st["exp_avg"], st["exp_avg_sq"],
+                                self._ws, self._kstat, d, l2, scale, n, float(g0["lr"]), g0["betas"][0], g0["betas"][1],
+                                g0["eps"], g0["weight_decay"], int(st["step"]), stream)
         self._release_grads()
         self._fused_advance()
         return True

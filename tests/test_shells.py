@@ -285,6 +285,7 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
     replayed, losses, opt, base = run(True)
     assert opt_e._graph_replays == 0
     assert opt._native_mean_losses() is not None     # the returned mean loss came from host.cpp mean_losses -> bde_mean_scalars
+    assert opt_e._small_step_native                  # the eager steps went through host.cpp small_step_sgd
     # three eager steps (the momentum buffers' first one among them), then one recording per staging slot and learning
     # rate: 3 + 3 recordings, every step from the fourth on replayed
     assert opt._graph_replays == 11 and opt._graph_captures == 6, (opt._graph_replays, opt._graph_captures)
