@@ -114,6 +114,7 @@ class SegTable:
         if on_gpu:
             self.host = [h.pin_memory() for h in self.host]
         self._events = [None] * len(self.host)
+        self._event_pool = [None] * len(self.host)
         self._slot = 0
 
     def piece_range(self, c0: int, c1: int):
@@ -144,7 +145,9 @@ class SegTable:
         """The current staging slot's copy has been enqueued (by upload(), or by a replayed graph that contains it): mark
         the slot busy until that point of the stream and move on to the next one."""
         if self.ptrs.is_cuda:
-            ev = torch.cuda.Event()
+            ev = self._event_pool[self._slot]                 # one event per slot, re-recorded (creating one costs ~2 us a step)
+            if ev is None:
+                ev = self._event_pool[self._slot] = torch.cuda.Event()
             ev.record()
             self._events[self._slot] = ev
         self._slot = (self._slot + 1) % len(self.host)
