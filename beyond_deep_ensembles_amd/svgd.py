@@ -365,7 +365,8 @@ class SVGDOptimizer(BayesianOptimizer):
         """The same loop for the common case -- no GradScaler, no overlapped exchange, native ParticleSet: nothing but
         the closures, the loss sum and ONE native call per particle (end of particle i + begin of particle i + 1)
         between two forward passes.  A small model's step is host-bound (BENCH extra svgd_step_cifar_resnet20_shell_fused:
-        ~115 us per step around 15 us of kernels in round 3)."""
+        ~115 us per step around 15 us of kernels in round 3; on a stub library in the build container 529 us (round 3) ->
+        321 (round 4) -> ~40 (round 5: this loop, the loss mean and the update's launches each ONE native call))."""
         if self._seg_host is None:
             self._seg_host = self._seg.staging()
         table, m_tab, zero = self._seg_host, self._seg.m, self._zeros.data_ptr()
