@@ -259,7 +259,7 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
     x, y = torch.randn(64, 13, device=dev), torch.randn(64, 1, device=dev)
     init = [torch.randn(13 * 50 + 50 + 50 + 1) * 0.1 for _ in range(4)]
 
-    def run(graph_replay):
+    def run(graph_replay, per_step_schedule=False, steps=14):
         model = make_mlp().to(dev)
         params = list(model.parameters())
         set_flat(params, init[0].to(dev))
@@ -273,10 +273,13 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
                                 graph_replay=graph_replay)
         assert opt._fuse and ops.svgd_small_supported(4, opt._layout.d)
         out, losses = [], []
-        for t in range(14):
-            if t == 9:                                                      # the scheduler's epoch step
+        for t in range(steps):
+            if t == 9 and not per_step_schedule:                            # the scheduler's epoch step
                 for group in base.param_groups:
                     group["lr"] = 0.002
+            if per_step_schedule:                                           # a scheduler that steps with every batch
+                for group in base.param_groups:
+                    group["lr"] = 0.004 * 0.97 ** t
             xb, yb = x[(t % 4) * 16:(t % 4 + 1) * 16], y[(t % 4) * 16:(t % 4 + 1) * 16]
             losses.append(opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward()).item())
             out.append(opt.particles.cpu().clone())
@@ -292,6 +295,13 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
     for t, (a, b) in enumerate(zip(eager, replayed)):
         assert torch.isfinite(a).all() and torch.equal(a, b), t
     assert losses == eager_losses
+    # a per-STEP scheduler: every step has scalars of its own, a recording never pays -- the option turns itself off after a
+    # few recordings (and the results are the eager path's all along)
+    eager_s, _, _, _ = run(False, per_step_schedule=True, steps=20)
+    replayed_s, _, opt_s, _ = run(True, per_step_schedule=True, steps=20)
+    assert 8 <= opt_s._graph_captures <= 10 and opt_s._graph_replays == opt_s._graph_captures
+    for t, (a, b) in enumerate(zip(eager_s, replayed_s)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), t
     # the base optimizer's published state is the fused buffers', as on the eager path
     assert torch.equal(torch.cat([base.state[p]["momentum_buffer"].reshape(-1) for p in opt._plist]).cpu(),
                        torch.cat([opt_e.state["__base_optimizer"].state[p]["momentum_buffer"].reshape(-1)
