@@ -89,7 +89,7 @@ SIGNATURES = {
     "bde_conv_lrt_gvar_ws_bytes": (c_size_t, [c_int, c_int]),
     "bde_conv_lrt_gvar_bias": (c_int, [_P, _P, _P, c_uint64, c_uint64, _P, _P, _P, _P, _P, c_int, c_int, c_int64, _P]),
     "bde_conv_lrt_bwd_weight_ws_bytes": (c_size_t, [c_int] * 11),
-    "bde_conv_lrt_bwd_weight": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 11 + [_P]),
+    "bde_conv_lrt_bwd_weight": (c_int, [_P, _P, _P, _P, _P, c_size_t, _P, _P] + [c_int] * 11 + [_P]),
     "bde_lrt_linear_supported": (c_int, [c_int, c_int, c_int]),
     "bde_lrt_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "bde_lrt_linear_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, c_int, _P, c_uint64, c_uint64, _P, _P, c_int, c_int, c_int,
@@ -104,7 +104,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 405        # csrc/version.hip, include/bde_hip.h
+ABI_VERSION = 406        # csrc/version.hip, include/bde_hip.h
 
 
 class BdeLibraryError(RuntimeError):

@@ -556,13 +556,15 @@ extern "C" size_t bde_conv_lrt_bwd_weight_ws_bytes(int N, int C, int H, int W, i
 }
 
 extern "C" int bde_conv_lrt_bwd_weight(const float* x, const float* g, const float* gvar, const float* w_rho, void* ws,
-                                       float* g_wmu, float* g_wrho, int N, int C, int H, int W, int O, int KH, int KW, int sh,
-                                       int sw, int ph, int pw, void* stream) {
+                                       size_t ws_bytes, float* g_wmu, float* g_wrho, int N, int C, int H, int W, int O, int KH,
+                                       int KW, int sh, int sw, int ph, int pw, void* stream) {
   WgGeo geo;
   WgPlan p;
   if (!x || !g || !gvar || !w_rho || !ws || !g_wmu || !g_wrho || !geo_ok(N, C, H, W, O, KH, KW, sh, sw, ph, pw, geo) ||
       !plan_wgrad(geo, p))
     return BDE_ERR_INVALID;
+  // the plan of THIS launch (a tiling may have been pinned since the caller sized `ws`) must fit the caller's buffer
+  if (ws_bytes < sizeof(float) * static_cast<size_t>(p.t.PS) * 2 * O * C * KH * KW) return BDE_ERR_INVALID;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(ws);
   // one instantiation per (tile size, column tiles per workgroup): the product loop carries no per-tile branch

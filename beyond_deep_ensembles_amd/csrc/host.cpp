@@ -9,6 +9,11 @@
 
 #include <vector>
 
+// the C ABI the native calls below go through: their function-pointer types are TAKEN from these declarations
+// (decltype(&bde_...)), so an edit of the header that this file does not follow fails to compile instead of passing
+// arguments in the wrong slots; tests/test_abi.py pins the same three signatures against _lib.py
+#include "../../include/bde_hip.h"
+
 namespace {
 
 // param.data = view.  All particle views of one parameter live in ONE storage with ONE shape (rows of the flat
@@ -260,7 +265,7 @@ bool mean_losses(const std::vector<at::Tensor>& losses, at::Tensor out, double d
     if (!t.defined() || t.scalar_type() != at::kFloat || t.numel() != 1 || t.device() != out.device()) return false;
     ptrs[i] = t.data_ptr<float>();
   }
-  using Fn = int (*)(const float* const*, int, float, float*, void*);
+  using Fn = decltype(&bde_mean_scalars);
   const int rc = reinterpret_cast<Fn>(entry)(ptrs, static_cast<int>(n), static_cast<float>(divisor), out.data_ptr<float>(),
                                             reinterpret_cast<void*>(stream));
   TORCH_CHECK(rc == 0, "bde_mean_scalars failed with code ", rc);
@@ -296,9 +301,11 @@ SmallStepArgs small_step_common(int64_t e_gather, const at::Tensor& seg_ptrs, co
                   kstat.scalar_type() == at::kFloat, "small_step: optimizer state / statistics buffers");
   SmallStepArgs a{P.data_ptr<float>(), G.data_ptr<float>(), s0.data_ptr<float>(), s1 ? s1->data_ptr<float>() : nullptr,
                   ws.data_ptr(), kstat.data_ptr<float>(), static_cast<int>(P.size(0)), P.stride(0)};
-  using Gather = int (*)(const void* const*, const void*, int64_t, float*, int, int, int, int64_t, void*);
+  using Gather = decltype(&bde_svgd_gather_seg);
+  static_assert(sizeof(bde_seg_chunk) == 4 * sizeof(int64_t), "a segment-table row is four int64 (ops.SegTable)");
   const int rc = reinterpret_cast<Gather>(e_gather)(reinterpret_cast<const void* const*>(seg_ptrs.data_ptr<int64_t>()),
-                                                    chunks.data_ptr<int64_t>(), chunks.size(0), a.G, a.m, 0, a.m, a.ld,
+                                                    reinterpret_cast<const bde_seg_chunk*>(chunks.data_ptr<int64_t>()),
+                                                    chunks.size(0), a.G, a.m, 0, a.m, a.ld,
                                                     reinterpret_cast<void*>(stream));
   TORCH_CHECK(rc == 0, "bde_svgd_gather_seg failed with code ", rc);
   return a;
@@ -309,8 +316,7 @@ void small_step_sgd(int64_t e_gather, int64_t e_step, at::Tensor seg_ptrs, at::T
                     double dataset_size, double lr, double momentum, double dampening, double weight_decay, bool nesterov,
                     bool first, int64_t stream) {
   const SmallStepArgs a = small_step_common(e_gather, seg_ptrs, chunks, P, G, buf, c10::nullopt, ws, kstat, d, stream);
-  using Step = int (*)(float*, const float*, float*, int, int64_t, int64_t, float, float, float, double, double, double, double,
-                       int, int, void*, float*, void*);
+  using Step = decltype(&bde_svgd_step_small_sgd);
   const int rc = reinterpret_cast<Step>(e_step)(a.P, a.G, a.s0, a.m, d, a.ld, static_cast<float>(l2_reg),
                                                 static_cast<float>(kernel_grad_scale), static_cast<float>(dataset_size), lr,
                                                 momentum, dampening, weight_decay, nesterov ? 1 : 0, first ? 1 : 0, a.ws,
@@ -323,8 +329,7 @@ void small_step_adam(int64_t e_gather, int64_t e_step, at::Tensor seg_ptrs, at::
                      double kernel_grad_scale, double dataset_size, double lr, double beta1, double beta2, double eps,
                      double weight_decay, int64_t step0, int64_t stream) {
   const SmallStepArgs a = small_step_common(e_gather, seg_ptrs, chunks, P, G, exp_avg, exp_avg_sq, ws, kstat, d, stream);
-  using Step = int (*)(float*, const float*, float*, float*, int, int64_t, int64_t, float, float, float, double, double, double,
-                       double, double, int64_t, void*, float*, void*);
+  using Step = decltype(&bde_svgd_step_small_adam);
   const int rc = reinterpret_cast<Step>(e_step)(a.P, a.G, a.s0, a.s1, a.m, d, a.ld, static_cast<float>(l2_reg),
                                                 static_cast<float>(kernel_grad_scale), static_cast<float>(dataset_size), lr,
                                                 beta1, beta2, eps, weight_decay, step0, a.ws, a.kstat,

@@ -252,8 +252,8 @@ struct ConvLrt : public torch::autograd::Function<ConvLrt> {
     const size_t ws_bytes = bde_conv_lrt_bwd_weight_ws_bytes(N, C, H, W, O, KH, KW, sh, sw, ph, pw);
     TORCH_CHECK(ws_bytes > 0, "conv_lrt: unsupported geometry in the weight-gradient pass");
     at::Tensor ws = at::empty({static_cast<int64_t>((ws_bytes + 3) / 4)}, x.options());
-    rc = bde_conv_lrt_bwd_weight(ptr(x), ptr(g), ptr(gvar), ptr(wr), ws.data_ptr(), mptr(g_wmu), mptr(g_wrho), N, C, H, W, O, KH,
-                                 KW, sh, sw, ph, pw, stream);
+    rc = bde_conv_lrt_bwd_weight(ptr(x), ptr(g), ptr(gvar), ptr(wr), ws.data_ptr(), static_cast<size_t>(ws.nbytes()), mptr(g_wmu),
+                                 mptr(g_wrho), N, C, H, W, O, KH, KW, sh, sw, ph, pw, stream);
     TORCH_CHECK(rc == 0, "bde_conv_lrt_bwd_weight failed with code ", rc);
     return {g_x, g_wmu, g_wrho, g_bmu, g_brho, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
             at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};

@@ -683,8 +683,10 @@ namespace bde {
 struct ScalarPtrs {
   const float* v[64];
 };
-// every lane fetches one scalar (all loads in flight at once), lane 0 adds them in index order; the sum is divided by
-// `divisor` (IEEE fp32 division; 1 leaves the sum as it is): svgd.py:105 `total_loss / particle_count` in the same launch
+// every lane fetches one scalar (all loads in flight at once), lane 0 adds them in index order; svgd.py:105
+// `total_loss / particle_count` in the same launch, rounded as torch's GPU kernel for `tensor / python_number` rounds it
+// (the sum TIMES fl(1 / divisor) -- not an IEEE division: the two differ by one ulp for e.g. the reference's 5 particles,
+// iwildcam.yaml:218); divisor 1 leaves the sum as it is
 __global__ __launch_bounds__(64) void sum_scalars_kernel(ScalarPtrs p, int n, float divisor, float* __restrict__ out) {
   __shared__ float vals[64];
   const int i = threadIdx.x;
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(64) void sum_scalars_kernel(ScalarPtrs p, int n, fl
   if (i == 0) {
     float s = vals[0];
     for (int j = 1; j < n; ++j) s += vals[j];
-    out[0] = s / divisor;
+    out[0] = divisor == 1.f ? s : s * (1.f / divisor);
   }
 }
 }  // namespace bde
@@ -715,9 +717,9 @@ extern "C" int bde_sum_scalars(const float* const* scalars, int n, float* out, v
 extern "C" int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld, float l2_reg,
                              float kernel_grad_scale, float dataset_size, float sign, void* ws, float* kstat,
                              void* stream) {
+  // the three streaming stages at EVERY size: the small-model kernel (bde_svgd_step_small*) is the caller's explicit choice,
+  // made by the host side only for sources whose parity tests have been green on a device (device_verified.py)
   if (!G) return BDE_ERR_INVALID;
-  if (bde_svgd_small_supported(M, D))
-    return bde_svgd_step_small(P, G, out, M, D, ld, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, ws, kstat, stream);
   int rc = bde_svgd_gram(P, M, D, ld, ws, stream);
   if (rc) return rc;
   rc = bde_svgd_kstats(ws, M, l2_reg, kernel_grad_scale, dataset_size, sign, 0.f, 0, kstat, stream);

@@ -1,5 +1,5 @@
 #include "bde_common.hpp"
-extern "C" int bde_version(void) { return 405; /* 0.4.4: + bde_conv_lrt_gvar_bias (g_var and the bias gradients in one pass) (0.4.3: + conv tuning hooks (bde_conv_lrt_pass_geos / _candidates / _set_tiling, _wgrad_candidates / _wgrad_set_tiling) (0.4.2: + bde_sum_scalars; conv weight gradient: one instantiation per column-tile count, 512-slot shares, tree reduction (0.4.1: + bde_conv_lrt_prep_strided / bde_conv_lrt_bwd_data_phases (0.4.0: contiguous SWAG rows again, LDS-DMA batched sampler, bde_conv_lrt_*, single-launch protocol gone)))) */ }
+extern "C" int bde_version(void) { return 406; /* 0.4.5: bde_svgd_step streams at every size (the small-model kernel is the caller's explicit choice), bde_mean_scalars multiplies by fl(1/divisor) like torch's GPU division, bde_conv_lrt_bwd_weight takes ws_bytes (0.4.4: + bde_conv_lrt_gvar_bias (g_var and the bias gradients in one pass) (0.4.3: + conv tuning hooks (bde_conv_lrt_pass_geos / _candidates / _set_tiling, _wgrad_candidates / _wgrad_set_tiling) (0.4.2: + bde_sum_scalars; conv weight gradient: one instantiation per column-tile count, 512-slot shares, tree reduction (0.4.1: + bde_conv_lrt_prep_strided / bde_conv_lrt_bwd_data_phases (0.4.0: contiguous SWAG rows again, LDS-DMA batched sampler, bde_conv_lrt_*, single-launch protocol gone))))) */ }
 extern "C" const char* bde_arch(void) { return "gfx950"; }
 
 extern "C" {

@@ -234,7 +234,8 @@ class HipOps:
 
     @_on_device_of
     def svgd_step(self, P, G, out, d, l2_reg, kernel_grad_scale, dataset_size, sign, ws, kstat):
-        """out = sign * phi (svgd.py:86-89); out may alias G."""
+        """out = sign * phi (svgd.py:86-89) by the three streaming launches, at every size; out may alias G.  (The
+        small-model kernel is svgd_step_small: an explicit choice, see device_verified.py.)"""
         m = P.shape[0]
         if _ld(G) != _ld(P) or _ld(out) != _ld(P):
             raise BdeKernelError("P, G, out must share one leading dimension")
@@ -357,8 +358,8 @@ class HipOps:
         self.mean_scalars(scalars, out, 1.0)
 
     def mean_scalars(self, scalars, out, divisor) -> None:
-        """The same sum divided by ``divisor`` (IEEE fp32 division) in the same launch (bde_mean_scalars): svgd.py:105
-        ``total_loss / particle_count``."""
+        """The same sum times fl(1 / ``divisor``) in the same launch (bde_mean_scalars): svgd.py:105 ``total_loss /
+        particle_count`` as torch's GPU kernel rounds a division by a Python number."""
         import ctypes
         n = len(scalars)
         if not 1 <= n <= 64:
@@ -603,8 +604,9 @@ class HipOps:
             raise BdeKernelError("bde_conv_lrt_bwd_weight: unsupported geometry")
         if ws is None or ws.numel() * ws.element_size() < need:
             ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
-        _check(self.lib.bde_conv_lrt_bwd_weight(_ptr(x, "x"), _ptr(g_out), _ptr(g_var), _ptr(w_rho), _ptr(ws), _ptr(g_wmu),
-                                                _ptr(g_wrho), *geo, _stream()), "bde_conv_lrt_bwd_weight")
+        _check(self.lib.bde_conv_lrt_bwd_weight(_ptr(x, "x"), _ptr(g_out), _ptr(g_var), _ptr(w_rho), _ptr(ws),
+                                                ws.numel() * ws.element_size(), _ptr(g_wmu), _ptr(g_wrho), *geo, _stream()),
+               "bde_conv_lrt_bwd_weight")
         return ws
 
     # ---- tuning hooks of the fused convolution (tools/conv_autotune.py, tests): candidate tilings, pinning

@@ -58,10 +58,12 @@ def _raw_stream_of(dev) -> int:
     return int(_ops_mod._stream() or 0)
 
 
-def rbf(particles: torch.Tensor, h_override=None, _ops=None):
+def rbf(particles: torch.Tensor, h_override=None, _ops=None, _small=None):
     """Pairwise RBF kernel with the median heuristic and its repulsive gradient
     (drop-in for ``src/algos/svgd.py:14-32``): returns ``(kernel [M, M],
-    grad_kernel [M, D])`` for ``particles [M, D]`` on the GPU."""
+    grad_kernel [M, D])`` for ``particles [M, D]`` on the GPU.  ``_small``: True = the small-model kernel where it
+    supports the problem, False = the streaming kernels, None = the small-model kernel once it is device-verified
+    (device_verified.py)."""
     ops = _ops or _default_ops()
     m, d = particles.shape
     layout_ld = (d + 63) // 64 * 64
@@ -73,7 +75,10 @@ def rbf(particles: torch.Tensor, h_override=None, _ops=None):
     ws, ks = ops.svgd_ws(m, P.device), ops.svgd_kstat(m, P.device)
     out = torch.zeros_like(P)
     h = float(h_override) if h_override is not None else 0.0
-    if ops.svgd_small_supported(m, d):
+    if _small is None:
+        from . import device_verified
+        _small = device_verified.enabled("svgd_small")
+    if _small and ops.svgd_small_supported(m, d):
         ops.svgd_step_small(P, None, out, d, 0.0, 1.0, 1.0, 1.0, ws, ks, h_override=h, mode=1)   # two small launches
     else:
         ops.svgd_gram(P, d, ws)
@@ -119,17 +124,25 @@ class SVGDOptimizer(BayesianOptimizer):
           reuse_gram          with fuse_base_optimizer: the fused kernel also emits the Gram partials of the updated
                               particles, so the next step skips the Gram pass.  Only valid while nothing but this
                               optimizer modifies the particles between two steps (call invalidate_gram() otherwise).
-          single_launch       None (default): small models on one GPU (bde_svgd_small_supported: M <= 8, D <= 524,288) run
-                              the whole update with the small-model kernel (bde_svgd_step_small*: two launches).  False: the
-                              streaming kernels (Gram -> statistics -> combine / fused) at every size.  (Rounds 2-3 also
+          single_launch       which kernels update a small model on one GPU (bde_svgd_small_supported: M <= 8,
+                              D <= 524,288).  False: the streaming kernels (Gram -> statistics -> combine / fused), as at
+                              every other size.  "two": the small-model kernel (bde_svgd_step_small*: the whole update in two
+                              launches).  None (default): "two" once that kernel's parity tests have been green on an MI355X
+                              for the sources in this tree (device_verified.py, family "svgd_small"), False until then --
+                              a default-constructed optimizer only launches device-verified kernels.  (Rounds 2-3 also
                               offered True = one persistent launch with an in-kernel hand-off; it was no faster than the two
                               launches once its wait was bounded, and is gone.)
+          host_fast_paths     the native host paths written since the last device run -- the per-particle loop with one
+                              native call per particle (ParticleSet.end_begin), the loss mean by one launch
+                              (bde_mean_scalars), the small-model step's two C-ABI calls from one native function
+                              (host.cpp small_step_*).  None (default): each one only once device_verified.py holds a
+                              record for it; True / False: all on / all off (tests, A/B runs).
     '''
 
     def __init__(self, params, reset_params_closure, base_optimizer, particle_count, dataset_size, l2_reg=0.0,
                  kernel_grad_scale=1.0, *, process_group=None, exchange="allgather", exchange_chunks=1,
                  overlap_backward=False, fuse_base_optimizer="auto", reuse_gram=False, single_launch=None,
-                 graph_replay=False, _ops=None, _force_exchange=False):
+                 graph_replay=False, host_fast_paths=None, _ops=None, _force_exchange=False):
         # one param group per tensor, like the reference (svgd.py:50): groups distinguish tensors, not particles
         super().__init__([{"params": p} for p in params], {})
         self._ops = _ops or _default_ops()
@@ -206,6 +219,10 @@ class SVGDOptimizer(BayesianOptimizer):
         if single_launch not in (None, False, "two"):
             raise ValueError("single_launch must be None, 'two' or False")
         self._single_launch = single_launch
+        if host_fast_paths not in (None, True, False):
+            raise ValueError("host_fast_paths must be None, True or False")
+        self._host_fast_paths = host_fast_paths
+        self._gates = {}
         # opt-in: the small-model step's launches (table upload, gradient packing, the two launches of the update) recorded
         # ONCE per set of step scalars in a hipGraph and replayed (see _replay_small_sgd)
         self._graph_replay = bool(graph_replay)
@@ -336,7 +353,8 @@ class SVGDOptimizer(BayesianOptimizer):
         local = self._local_particles()
         if grad_scaler is None or not grad_scaler.is_enabled():
             pset = self._particle_set()
-            if pset is not None and self._seg is not None and not self._overlap and hasattr(pset, "end_begin"):
+            if pset is not None and self._seg is not None and not self._overlap and hasattr(pset, "end_begin") \
+                    and self._gate("fast_loop"):
                 return self._step_fast(forward_closure, backward_closure, local, pset)
         OptState = _opt_state()
         base = self.state["__base_optimizer"]
@@ -360,6 +378,19 @@ class SVGDOptimizer(BayesianOptimizer):
             self._end_particle(particle_idx)
 
         return self._posterior_update(total_loss, grad_scaler)
+
+    def _gate(self, family: str) -> bool:
+        """May this optimizer take the path of ``family`` (device_verified.FAMILIES)?  host_fast_paths=True / False answers
+        for every family; None asks the device-verification table (once per family and optimizer)."""
+        hit = self._gates.get(family)
+        if hit is None:
+            if self._host_fast_paths is not None and family != "svgd_small":
+                hit = bool(self._host_fast_paths)
+            else:
+                from . import device_verified
+                hit = device_verified.enabled(family)
+            self._gates[family] = hit
+        return hit
 
     def _step_fast(self, forward_closure, backward_closure, local, pset):
         """The same loop for the common case -- no GradScaler, no overlapped exchange, native ParticleSet: nothing but
@@ -393,12 +424,12 @@ class SVGDOptimizer(BayesianOptimizer):
         order (0 + x == x bit for bit, so the first loss starts it), by ONE launch (bde_mean_scalars) when the losses are
         fp32 scalars on the particles' device, by torch's adds otherwise (a half-precision or off-device loss).  A small
         model's step is launch-bound: seven torch adds cost more host time than its whole posterior update.  ``divisor``:
-        svgd.py:105's ``/ particle_count`` in the same launch (IEEE fp32 division: what torch computes on the CPU; torch's
-        GPU kernel multiplies by fl(1 / count) instead, equal for the usual power-of-two counts and within one ulp of it
-        otherwise).  With the native host helper the checks and the call are one C++ function (host.cpp mean_losses)."""
+        svgd.py:105's ``/ particle_count`` in the same launch, rounded like torch's GPU kernel for it (sum * fl(1 / count)).
+        With the native host helper the checks and the call are one C++ function (host.cpp mean_losses).  The launch is
+        taken only behind its device-verification gate ("mean_scalars"); torch's adds and division are the default."""
         dev = self._P.device if self._P is not None else self._Pown.device
         n = len(losses)
-        if 1 < n <= 64 and hasattr(self._ops, "mean_scalars"):
+        if 1 < n <= 64 and hasattr(self._ops, "mean_scalars") and self._gate("mean_scalars"):
             native = self._native_mean_losses()
             stream = _raw_stream_of(dev) if native is not None else -1
             if stream >= 0:
@@ -558,31 +589,16 @@ class SVGDOptimizer(BayesianOptimizer):
             per = m // self._world
             self._grads_to_rows(self._G, self._rank * per, per)          # own rows packed for the collective: one launch
             pending = self._start_gradient_exchange(total_loss)
+        elif self._small_model(m, d):
+            self._step_small_model(base, fused, grad_scaler, m, d)
+            return total_loss
         # The Gram pass and the kernel statistics need only the (replicated) particles: they run while the
         # gradient all-gather is in flight.  (Skipped when the previous fused kernel already left the Gram.)
-        if self._small_ok is None:                                       # (a property of M, D and the device: asked once)
-            self._small_ok = bool(self._ops.svgd_small_supported(m, d))
-        single_launch = pending is None and self._single_launch is not False and self._small_ok
-        if fused and single_launch and self._graph_replay and self._replay_small_sgd(base, m, d):
-            self._gram_valid = False
-            self._use_particle(m - 1)
-            return total_loss
-        if fused and single_launch and self._native_small_step(base, m, d):
-            self._gram_valid = False
-            self._use_particle(m - 1)
-            return total_loss
-        if single_launch or m > 16:
-            self._grads_to_rows(self._G, 0, m)                           # these kernels read flat rows
-        if fused and single_launch:
-            # small model on one GPU: statistics, -phi and the M shared-state optimizer applications by the small-model kernel
-            self._fused_apply(base, [(self._P, self._G, d, 0)], single_launch=True)
-            self._gram_valid = False
-            self._use_particle(m - 1)
-            return total_loss
-        if not single_launch:
-            if not (fused and self._reuse_gram and self._gram_valid):
-                self._ops.svgd_gram(self._P, d, self._ws)
-            self._ops.svgd_kstats(self._ws, m, *self._stat_args(), self._kstat)
+        if m > 16:
+            self._grads_to_rows(self._G, 0, m)                           # the blocked kernels read flat rows
+        if not (fused and self._reuse_gram and self._gram_valid):
+            self._ops.svgd_gram(self._P, d, self._ws)
+        self._ops.svgd_kstats(self._ws, m, *self._stat_args(), self._kstat)
         if pending is not None:
             total_loss = self._finish_gradient_exchange(pending)
         seg = self._take_segments()                                      # None: the gradients are in the flat rows
@@ -594,10 +610,7 @@ class SVGDOptimizer(BayesianOptimizer):
         else:
             self._gram_valid = False
             # svgd.py:86-89: -phi overwrites the gradient rows
-            if single_launch:
-                # small model on one GPU: Gram, statistics and combine by the small-model kernel (two launches)
-                self._ops.svgd_step(self._P, self._G, self._G, d, *self._stat_args(), self._ws, self._kstat)
-            elif seg is not None:
+            if seg is not None:
                 self._ops.svgd_combine_seg(self._P, seg, self._G, d, self._kstat)
             elif m <= 16:
                 self._ops.svgd_combine(self._P, self._G, self._G, d, self._kstat)
@@ -616,6 +629,36 @@ class SVGDOptimizer(BayesianOptimizer):
                 self._apply_base_optimizer(base, grad_scaler)
         self._release_grads()
         return total_loss
+
+    # ---- small models on one GPU: the whole update by the small-model kernel (two launches) -------------------
+    def _small_model(self, m, d) -> bool:
+        """Does this optimizer update with the small-model kernel?  ``single_launch="two"`` asks for it, ``None`` takes it
+        once its device-verification record exists (see the class docstring); either way only where the kernel supports the
+        problem on this device (a property of M, D and the device: asked once)."""
+        if self._small_ok is None:
+            want = self._single_launch == "two" or (self._single_launch is None and self._gate("svgd_small"))
+            self._small_ok = bool(want) and bool(self._ops.svgd_small_supported(m, d))
+        return self._small_ok
+
+    def _step_small_model(self, base, fused, grad_scaler, m, d) -> None:
+        """ONE default and ONE fallback per case.  Fused base optimizer: statistics, -phi and the M shared-state optimizer
+        applications by bde_svgd_step_small_sgd / _adam -- issued together with the gradient packing by one native call
+        (host.cpp small_step_*) behind its gate, by the two Python wrappers otherwise (same C-ABI calls, same arguments);
+        graph_replay=True (opt-in) replays a recording of exactly those launches.  Any other base optimizer: -phi by
+        bde_svgd_step_small, then the torch loop."""
+        self._gram_valid = False
+        if fused:
+            if not (self._graph_replay and self._replay_small_sgd(base, m, d)) and \
+                    not (self._gate("small_step_host") and self._native_small_step(base, m, d)):
+                self._grads_to_rows(self._G, 0, m)                       # this kernel reads flat rows
+                self._fused_apply(base, [(self._P, self._G, d, 0)], single_launch=True)
+            self._use_particle(m - 1)
+            return
+        self._grads_to_rows(self._G, 0, m)
+        # svgd.py:86-89: -phi overwrites the gradient rows
+        self._ops.svgd_step_small(self._P, self._G, self._G, d, *self._stat_args(), self._ws, self._kstat)
+        self._apply_base_optimizer(base, grad_scaler)
+        self._release_grads()
 
     def _replay_small_sgd(self, base, m, d) -> bool:
         """``graph_replay=True``: a small model's step on one GPU is host-bound -- ~15 us of kernels behind four launches
@@ -642,14 +685,19 @@ class SVGDOptimizer(BayesianOptimizer):
         l2, scale, n, _ = self._stat_args()
         scalars = (float(g0["lr"]), float(g0["momentum"]), float(g0["dampening"]), float(g0["weight_decay"]),
                    bool(g0["nesterov"]), l2, scale, n)
-        graph = self._graphs.get((slot, scalars))
+        # a recording holds the ADDRESSES it was made with: the key carries them, so a buffer that was re-allocated
+        # (load_state_dict builds a new momentum buffer, set_particles under dimension sharding new rows) can never
+        # meet a recording of its predecessor
+        key = (slot, scalars, st["buf"].data_ptr(), self._P.data_ptr(), self._G.data_ptr(), self._ws.data_ptr(),
+               self._kstat.data_ptr(), seg.ptrs.data_ptr())
+        graph = self._graphs.get(key)
         if graph is None:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._small_sgd_launches(slot, scalars, st["buf"], m, d)
+            graph = self._record_small_sgd(slot, scalars, st["buf"], m, d)
+            if graph is None:
+                return False                                             # the eager path performs this step
             if len(self._graphs) >= 12:                                 # (a handful of learning rates x three slots)
                 self._graphs.clear()
-            self._graphs[(slot, scalars)] = graph
+            self._graphs[key] = graph
             self._graph_captures += 1
         graph.replay()
         self._graph_replays += 1
@@ -658,6 +706,29 @@ class SVGDOptimizer(BayesianOptimizer):
         self._release_grads()
         self._fused_advance()
         return True
+
+    def _record_small_sgd(self, slot, scalars, buf, m, d):
+        """One recording of _small_sgd_launches, or None: a capture that fails -- another thread made a HIP call the capture
+        mode forbids, the runtime refused a node -- switches graph replay OFF for this optimizer instead of aborting the
+        training step (nothing was enqueued: the caller's eager path runs the step).  ``thread_local``: only THIS thread's
+        calls are policed, so a DataLoader's pinning thread cannot invalidate the capture."""
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self._small_sgd_launches(slot, scalars, buf, m, d)
+        except Exception as e:                                            # noqa: BLE001 -- whatever the runtime raised
+            import warnings
+            warnings.warn(f"SVGDOptimizer(graph_replay=True): recording the step failed ({type(e).__name__}: {e}); "
+                          "continuing with eager launches")
+            self._drop_graphs()
+            self._graph_replay = False
+            return None
+        return graph
+
+    def _drop_graphs(self) -> None:
+        """Forget every recording (their buffers are about to change) and start over with eager steps."""
+        self._graphs.clear()
+        self._graph_eager_steps = 0
 
     def _native_small_step(self, base, m, d) -> bool:
         """The small-model update of a step whose gradients sit in the segment table -- upload, bde_svgd_gather_seg,
@@ -1194,6 +1265,7 @@ class SVGDOptimizer(BayesianOptimizer):
         # shared optimizer state of the fused path: re-adopted (and re-published into base.state) at the next step
         self._fused_loaded = self.state.pop("__fused", None)
         self._fused_state = None
+        self._drop_graphs()                                # recordings hold the old buffers' addresses
         self._fused_decision = None
         m = self.state["__particle_count"]
         if self._exchange == "alltoall":

@@ -118,8 +118,10 @@ int bde_svgd_kstats_gmat(const double* gmats, int n_mats, int64_t mat_stride, in
 int bde_svgd_combine(const float* P, const float* G, float* out, int M, int64_t D,
                      int64_t ld, int64_t ldg, const float* kstat, void* stream);
 
-/* One SVGD posterior update (svgd.py:86-89) on `stream`: the small-model kernel (two launches) when
- * bde_svgd_small_supported(M, D), otherwise the three stages back to back. */
+/* One SVGD posterior update (svgd.py:86-89) on `stream`: the three stages back to back, at every size.  (Until ABI 405
+ * this entry point chose the small-model kernel by itself when bde_svgd_small_supported(M, D); that choice now belongs
+ * to the caller -- bde_svgd_step_small* below -- so that a default call never reaches a kernel that has not been
+ * parity-tested on a device: beyond_deep_ensembles_amd/device_verified.py.) */
 int bde_svgd_step(const float* P, const float* G, float* out, int M, int64_t D, int64_t ld,
                   float l2_reg, float kernel_grad_scale, float dataset_size, float sign,
                   void* ws, float* kstat, void* stream);
@@ -191,8 +193,10 @@ int bde_svgd_gather_seg(const void* const* seg_ptrs, const bde_seg_chunk* chunks
  * (1 <= n <= 64) device pointers to fp32 scalars; it is read during the call (the pointers travel in the kernel's
  * argument block), so it may be a temporary.  `out` may be one of the inputs. */
 int bde_sum_scalars(const float* const* scalars, int n, float* out, void* stream);
-/* The same sum divided by `divisor` (> 0; IEEE fp32 division) in the same launch: the value SVGDOptimizer.step returns,
- * svgd.py:105 `total_loss / particle_count`, without a second launch (ABI 405).  With divisor = 1 it is bde_sum_scalars. */
+/* The same sum "divided" by `divisor` (> 0) in the same launch: the value SVGDOptimizer.step returns, svgd.py:105
+ * `total_loss / particle_count`, without a second launch (ABI 405).  Rounded as the reference rounds it ON A GPU: torch's
+ * kernel for `tensor / python_number` multiplies by fl(1 / divisor), so this computes sum * fl(1.f / divisor) (ABI 406;
+ * 405 divided in IEEE fp32, one ulp off for e.g. 5 particles).  With divisor = 1 it is bde_sum_scalars. */
 int bde_mean_scalars(const float* const* scalars, int n, float divisor, float* out, void* stream);
 
 /* Shared-state base-optimizer apply for the M particles, in particle order
@@ -432,9 +436,12 @@ int bde_conv_lrt_gvar_bias(const float* g, const float* var, const float* eps, u
                            const float* b_rho, float* g_bmu, float* g_brho, void* ws, int N, int O, int64_t HW, void* stream);
 size_t bde_conv_lrt_bwd_weight_ws_bytes(int N, int C, int H, int W, int O, int KH, int KW, int stride_h, int stride_w, int pad_h,
                                         int pad_w);
+/* `ws_bytes` (ABI 406): the size of `ws` as the caller allocated it.  The launch re-plans, so a tiling pinned between
+ * the sizing call and the launch (bde_conv_lrt_wgrad_set_tiling from another thread) may need more partial slots than
+ * the buffer holds: that is refused with BDE_ERR_INVALID instead of written out of bounds. */
 int bde_conv_lrt_bwd_weight(const float* x, const float* g_out, const float* g_var, const float* w_rho, void* ws,
-                            float* g_wmu, float* g_wrho, int N, int C, int H, int W, int O, int KH, int KW, int stride_h,
-                            int stride_w, int pad_h, int pad_w, void* stream);
+                            size_t ws_bytes, float* g_wmu, float* g_wrho, int N, int C, int H, int W, int O, int KH, int KW,
+                            int stride_h, int stride_w, int pad_h, int pad_w, void* stream);
 
 /* The whole local-reparameterisation forward of a mean-field LINEAR layer (bbb_layers.py:61-80, sampling =
  * "activations") for small batches (B <= 128): W_mu / W_rho [O, I] row-major are streamed ONCE, sigma^2 =

@@ -52,8 +52,32 @@ class _Shadows:
         self.live.clear()
 
 
+LOADED = {}            # path -> library handle of every CPU-model build this process has loaded (launched_kernels)
+
+
+def launched_kernels() -> dict:
+    """{kernel name (the __global__ function, without template arguments): launches so far} over every CPU-model build this
+    process has loaded -- what tests/conftest.py's reach guard compares before and after a test."""
+    import re
+    import tempfile
+    total = {}
+    for lib in LOADED.values():
+        with tempfile.NamedTemporaryFile("r", suffix=".txt") as fh:
+            lib.hip_emu_launch_report(fh.name.encode())
+            for line in fh.read().splitlines():
+                sym, _, count = line.rpartition(" ")
+                m = re.match(r"_ZN3bde(\d+)", sym)                # bde::<name><...>: Itanium length-prefixed identifier
+                if m:
+                    n = int(m.group(1))
+                    sym = sym[m.end():m.end() + n]
+                total[sym] = total.get(sym, 0) + int(count)
+    return total
+
+
 def load(sources, defines=()):
-    lib = ctypes.CDLL(B.build(sources, defines))
+    path = B.build(sources, defines)
+    lib = ctypes.CDLL(path)
+    LOADED[path] = lib
     for name, (res, args) in _lib.SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is not None:

@@ -5,6 +5,8 @@ sharding, gradient hand-over) without a GPU, and lets world_size-2 gloo tests
 run here.  The product never constructs it."""
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -101,7 +103,8 @@ class OracleOps:
 
     def mean_scalars(self, scalars, out, divisor):                  # svgd.py:105: total_loss / particle_count
         self.sum_scalars(scalars, out)
-        out.reshape(()).div_(float(divisor))
+        if float(divisor) != 1.0:                                   # torch on a GPU: tensor / number = tensor * fl(1 / number)
+            out.reshape(()).mul_(float(np.float32(1.0) / np.float32(divisor)))
 
     def svgd_combine_seg(self, P, seg, out, d, kstat):
         self.svgd_combine(P, self._seg_rows(seg, P.shape[1], range(seg.m)), out, d, kstat)

@@ -1646,12 +1646,13 @@ def test_r5_sum_scalars_is_the_sequential_fp32_sum(ops):
         for v in vals[1:]:
             want = np.float32(want + v)
         assert out.cpu().numpy() == want, (n, float(out), float(want))
-        # bde_mean_scalars: the same sum / divisor (IEEE fp32 division), svgd.py:105 -- the particle counts 1..16 and the
-        # scalar count itself
+        # bde_mean_scalars: the same sum * fl(1 / divisor) (torch's GPU rounding of svgd.py:105's `/ particle_count`) -- a
+        # few particle counts and the scalar count itself
         for div in (1, 3, 5, 8, 13, n):
             mean = torch.full((), float("nan"), dtype=torch.float32, device=DEV)
             ops.mean_scalars(scalars, mean, div)
-            assert mean.cpu().numpy() == np.float32(want / np.float32(div)), (n, div)
+            expect = want if div == 1 else np.float32(want * (np.float32(1.0) / np.float32(div)))
+            assert mean.cpu().numpy() == expect, (n, div)
     a, b = torch.tensor(1.5, device=DEV), torch.tensor([2.25], device=DEV)
     ops.sum_scalars([a, b], a)                                   # out aliases the first input
     assert float(a) == 3.75

@@ -7,6 +7,8 @@ Each test runs twice:
     -- with the arithmetic done by the CPU oracle (tests/oracle_ops.py);
   * backend "hip" (`-m gpu`): the product path, libbde_hip.so on cuda:0.
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -237,10 +239,13 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
                 self.launches()
 
         class recording_into:
-            def __init__(self, graph):
+            def __init__(self, graph, capture_error_mode=None):
+                assert capture_error_mode == "thread_local"                  # another thread's HIP calls must not break it
                 self.graph = graph
 
             def __enter__(self):
+                if state.get("fail"):
+                    raise RuntimeError("operation not permitted when stream is capturing")
                 state["capturing"] = self.graph
 
             def __exit__(self, *exc):
@@ -259,7 +264,7 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
     x, y = torch.randn(64, 13, device=dev), torch.randn(64, 1, device=dev)
     init = [torch.randn(13 * 50 + 50 + 50 + 1) * 0.1 for _ in range(4)]
 
-    def run(graph_replay, per_step_schedule=False, steps=14):
+    def run(graph_replay, per_step_schedule=False, steps=14, reload_at=None):
         model = make_mlp().to(dev)
         params = list(model.parameters())
         set_flat(params, init[0].to(dev))
@@ -270,10 +275,18 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
             set_flat(params, init[k[0]].to(dev))
         base = torch.optim.SGD(model.parameters(), lr=0.004, momentum=0.9, nesterov=True, weight_decay=3e-4)
         opt = bde.SVGDOptimizer(model.parameters(), reset, base, particle_count=4, dataset_size=64, l2_reg=1e-3, _ops=ops,
-                                graph_replay=graph_replay)
+                                graph_replay=graph_replay, single_launch="two", host_fast_paths=True)
         assert opt._fuse and ops.svgd_small_supported(4, opt._layout.d)
         out, losses = [], []
         for t in range(steps):
+            if t == reload_at:
+                # an in-process reload mid-run: load_state_dict gives the fused update NEW momentum buffers; a
+                # recording made with the old ones must never be replayed (stale addresses: freed memory on the device)
+                saved = copy.deepcopy(opt.state_dict())
+                old_buf = opt._fused_state["buf"]
+                opt.load_state_dict(saved)
+                assert not opt._graphs and opt._graph_eager_steps == 0
+                keep_alive.append(old_buf)                                   # (so that the allocator cannot hand it out again)
             if t == 9 and not per_step_schedule:                            # the scheduler's epoch step
                 for group in base.param_groups:
                     group["lr"] = 0.002
@@ -284,6 +297,7 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
             losses.append(opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward()).item())
             out.append(opt.particles.cpu().clone())
         return out, losses, opt, base
+    keep_alive = []
     eager, eager_losses, opt_e, _ = run(False)
     replayed, losses, opt, base = run(True)
     assert opt_e._graph_replays == 0
@@ -302,6 +316,24 @@ def test_r5_graph_replay_of_the_small_model_step_changes_nothing(backend, monkey
     assert 8 <= opt_s._graph_captures <= 10 and opt_s._graph_replays == opt_s._graph_captures
     for t, (a, b) in enumerate(zip(eager_s, replayed_s)):
         assert torch.isfinite(a).all() and torch.equal(a, b), t
+    # load_state_dict in the middle of a replayed run: recordings dropped, eager steps again, then new recordings that hold
+    # the NEW buffers -- the trajectory is the uninterrupted eager one, and the published momentum buffers keep advancing
+    reloaded, losses_r, opt_r, base_r = run(True, reload_at=8)
+    for t, (a, b) in enumerate(zip(eager, reloaded)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), t
+    assert losses_r == eager_losses and opt_r._graph_replays >= 5
+    assert all(key[2] == opt_r._fused_state["buf"].data_ptr() for key in opt_r._graphs)
+    assert torch.equal(torch.cat([base_r.state[p]["momentum_buffer"].reshape(-1) for p in opt_r._plist]).cpu(),
+                       torch.cat([base.state[p]["momentum_buffer"].reshape(-1) for p in opt._plist]).cpu())
+    if dev.type == "cpu":
+        # a capture the runtime refuses: the option switches itself off with a warning, the step is run eagerly, results unchanged
+        state["fail"] = True
+        with pytest.warns(UserWarning, match="recording the step failed"):
+            failed, losses_f, opt_f, _ = run(True)
+        state["fail"] = False
+        assert opt_f._graph_replay is False and opt_f._graph_replays == 0
+        for t, (a, b) in enumerate(zip(eager, failed)):
+            assert torch.equal(a, b), t
     # the base optimizer's published state is the fused buffers', as on the eager path
     assert torch.equal(torch.cat([base.state[p]["momentum_buffer"].reshape(-1) for p in opt._plist]).cpu(),
                        torch.cat([opt_e.state["__base_optimizer"].state[p]["momentum_buffer"].reshape(-1)
