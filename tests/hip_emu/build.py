@@ -179,7 +179,12 @@ def load_host_nodes(sources):
     spec = importlib.util.spec_from_file_location("_bde_host_emu", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    import ctypes
+    LOADED[path] = ctypes.CDLL(path)          # the module carries its own copy of the model: its launches count too
     return mod
+
+
+LOADED = {}            # path -> ctypes handle of every CPU-model library this process has loaded (emu_ops.launched_kernels)
 
 
 if __name__ == "__main__":

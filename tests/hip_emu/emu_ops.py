@@ -52,7 +52,7 @@ class _Shadows:
         self.live.clear()
 
 
-LOADED = {}            # path -> library handle of every CPU-model build this process has loaded (launched_kernels)
+LOADED = B.LOADED      # path -> library handle of every CPU-model build this process has loaded (launched_kernels)
 
 
 def launched_kernels() -> dict:

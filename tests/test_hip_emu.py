@@ -34,6 +34,7 @@ DEFAULT = [
     "test_invalid_arguments_are_rejected", "test_randomized_shapes_against_oracle", "test_var_operand_kernels",
     "test_accumulating_unaligned_and_value_only_variants", "test_svgd_gram_load_flavour_split_does_not_change_results",
     "test_streaming_kernels_walk_several_grid_passes", "test_svgd_every_particle_count",
+    "test_svgd_every_particle_count_small_model_kernel",
     "test_r5_sum_scalars_is_the_sequential_fp32_sum", "test_r5_conv_every_candidate_tiling_computes_the_same_layer",
     "test_r5_conv_gvar_and_bias_gradients_in_one_pass",
 ]
@@ -328,7 +329,8 @@ def test_conv_autotune_tool_end_to_end_on_the_cpu_model(emu, tmp_path, monkeypat
 def test_the_model_reproduces_the_smoke_figure_the_driver_recorded_on_the_mi355x(emu):
     """A pin of the CPU model AND of the small-model kernel at HEAD: the driver's smoke() runs of rounds 1-3 on the MI355X
     (GPUTEST_r01/r02/r03.json, `smoke_tail`) printed "svgd err 1.147e-08 (reference fp32 err 1.127e-07)" for the seeded
-    8 x 40,003 problem of __graft_entry__.smoke_body, which bde_svgd_step then ran with the small-model kernel.  That kernel
+    8 x 40,003 problem of __graft_entry__.smoke_body, which bde_svgd_step then ran with the small-model kernel (until ABI 406
+    it chose that kernel by itself; bde_svgd_step_small is called explicitly here).  That kernel
     lost its single-launch protocol after its last device run (round 4, -223 lines); on the model the kernel at HEAD prints
     the same figure to the digit, and so do the three streaming launches round 5's smoke uses."""
     from oracle import bde_oracle as O
@@ -346,7 +348,7 @@ def test_the_model_reproduces_the_smoke_figure_the_driver_recorded_on_the_mi355x
         ws, ks = emu.svgd_ws(m, "cpu"), emu.svgd_kstat(m, "cpu")
         if small:
             assert emu.svgd_small_supported(m, d)
-            emu.svgd_step(Pb, Gb, Gb, d, 0.01, 1.0, 50000.0, -1.0, ws, ks)
+            emu.svgd_step_small(Pb, Gb, Gb, d, 0.01, 1.0, 50000.0, -1.0, ws, ks)
         else:
             emu.svgd_gram(Pb, d, ws)
             emu.svgd_kstats(ws, m, 0.01, 1.0, 50000.0, -1.0, ks)
