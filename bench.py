@@ -255,17 +255,34 @@ def extras(ops, dev, quick, on_section=None):
         probe=dict(shape=(2, 0, 3), n=d, rd=[ds, gm], rw=[mean2, mom, prec]))
     if on_section is not None:
         on_section(out)
-    # LAST: the small-model kernel was rewritten after its last run on an MI355X; what was measured
-    # above has been handed to `on_section` before it is launched
+    # BASELINE configs[1] size (CIFAR ResNet-20, D = 273,610) with the kernels a default call runs: the three streaming launches
     d20 = D_RESNET20
     P2, G2 = make_svgd_inputs(d20, dev, 1234)
     o2 = torch.empty_like(G2)
+    b2 = torch.zeros(pad_ld(d20), device=dev)
     rec("svgd_step_M8_resnet20", time_loop(lambda: ops.svgd_step(P2, G2, o2, d20, 3e-4, 1.0, 50000.0, -1.0, ws, ks), 50),
         16 * M * d20, 1, "steps_per_s")
-    b2 = torch.zeros(pad_ld(d20), device=dev)
-    t = time_loop(lambda: ops.svgd_step_small_sgd(P2, G2, b2, d20, 3e-4, 1.0, 50000.0, ws, ks, 1e-12, 0.9, 0.0, 3e-4,
-                                                  True, False), 50)
-    rec("svgd_full_step_fused_sgd_M8_resnet20_2_launches", t, (12 * M + 8) * d20, 1, "steps_per_s")
+
+    def streaming_fused():
+        ops.svgd_gram(P2, d20, ws)
+        ops.svgd_kstats(ws, M, 3e-4, 1.0, 50000.0, -1.0, ks)
+        ops.svgd_fused_sgd(P2, G2, b2, d20, ks, 1e-12, 0.9, 0.0, 3e-4, True, False)
+    rec("svgd_full_step_fused_sgd_M8_resnet20_streaming", time_loop(streaming_fused, 50), (16 * M + 8) * d20, 1, "steps_per_s")
+    if on_section is not None:
+        on_section(out)
+    # LAST: the small-model kernel was rewritten after its last run on an MI355X and is no default until
+    # its parity tests have been green on a device (device_verified.py); what was measured above has been handed to
+    # `on_section` before it is launched, and each of its entries fails on its own
+    for name, fn, nbytes in (
+            ("svgd_step_M8_resnet20_small_kernel",
+             lambda: ops.svgd_step_small(P2, G2, o2, d20, 3e-4, 1.0, 50000.0, -1.0, ws, ks), 16 * M * d20),
+            ("svgd_full_step_fused_sgd_M8_resnet20_2_launches",
+             lambda: ops.svgd_step_small_sgd(P2, G2, b2, d20, 3e-4, 1.0, 50000.0, ws, ks, 1e-12, 0.9, 0.0, 3e-4, True, False),
+             (12 * M + 8) * d20)):
+        try:
+            rec(name, time_loop(fn, 50), nbytes, 1, "steps_per_s")
+        except Exception as e:                                       # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
     del P2, G2, o2, b2
     out["probe_note"] = ("probe_GBps / frac_of_probe: a no-arithmetic kernel with the SAME number of read / written / "
                          "read-modify-written rows on the SAME tensors (bench_probe/probe.hip), timed right beside the kernel: "
@@ -629,8 +646,10 @@ def config_extras(dev, on_section=None):
         t = timed(lambda: opt.step(lambda: zero, lambda loss: None), 30)
         out["svgd_step_cifar_resnet20_shell_" + ("fused" if fuse else "unfused")] = {
             "ms": round(t * 1e3, 4), "steps_per_s": round(1.0 / t, 1), "tensors": 65, "particles": M,
-            "what": "SVGDOptimizer.step, null closures: single-launch update" + (" incl. 8 SGD applications" if fuse else
-                                                                                " + 8 x torch SGD.step")}
+            "small_model_kernel": bool(opt._small_model(M, opt._layout.d)),
+            "what": "SVGDOptimizer.step as a default constructor builds it, null closures: the streaming update (Gram -> "
+                    "statistics -> " + ("fused update incl. 8 SGD applications)" if fuse else "combine) + 8 x torch SGD.step") +
+                    "; the small-model kernel takes over once device_verified.json records it: see ..._small_kernel"}
         del opt, params, base
 
     # ---- the BBB layer forward of the iWildCam head (2048 -> 182) at batch 16: fused op vs the reference's op sequence
@@ -780,8 +799,30 @@ def config_extras(dev, on_section=None):
     torch.cuda.empty_cache()
     if on_section is not None:
         on_section(out)                 # everything above has been measured; LAST: kernels that have never run on an MI355X
-    # ---- configs[1] again with SVGDOptimizer(graph_replay=True): the step's launches recorded in a hipGraph per (staging slot,
-    # step scalars) and replayed (opt-in, never run on an MI355X: a failure here must not cost the sections behind it)
+    # ---- configs[1] again through the small-model kernel + the round-5 native host paths (what the default becomes once they are
+    # device-verified), then with graph_replay=True on top: never run on an MI355X -- each entry fails on its own
+    small = dict(single_launch="two", host_fast_paths=True)
+    for fuse in (True, False):
+        key = "svgd_step_cifar_resnet20_shell_" + ("fused" if fuse else "unfused") + "_small_kernel"
+        try:
+            params = tensors(D_RESNET20, 65)
+            base = torch.optim.SGD(params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=3e-4)
+
+            def reset_small():
+                with torch.no_grad():
+                    params[-1].normal_(0, 0.05)
+            opt = bde.SVGDOptimizer(params, reset_small, base, particle_count=M, dataset_size=50000.0, l2_reg=3e-4,
+                                    fuse_base_optimizer=fuse, **small)
+            t = timed(lambda: opt.step(lambda: zero, lambda loss: None), 30)
+            out[key] = {"ms": round(t * 1e3, 4), "steps_per_s": round(1.0 / t, 1), "tensors": 65, "particles": M,
+                        "small_model_kernel": bool(opt._small_model(M, opt._layout.d)),
+                        "what": "as svgd_step_cifar_resnet20_shell_" + ("fused" if fuse else "unfused") + " with "
+                                "single_launch='two', host_fast_paths=True: gradient packing + the small-model kernel's two launches"}
+            del opt, params, base
+        except Exception as e:                                       # noqa: BLE001 -- reported, the other sections go on
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+    if on_section is not None:
+        on_section(out)
     try:
         params = tensors(D_RESNET20, 65)
         base = torch.optim.SGD(params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=3e-4)
@@ -789,15 +830,16 @@ def config_extras(dev, on_section=None):
         def reset_last():
             with torch.no_grad():
                 params[-1].normal_(0, 0.05)
-        opt = bde.SVGDOptimizer(params, reset_last, base, particle_count=M, dataset_size=50000.0, l2_reg=3e-4, graph_replay=True)
+        opt = bde.SVGDOptimizer(params, reset_last, base, particle_count=M, dataset_size=50000.0, l2_reg=3e-4, graph_replay=True,
+                                **small)
         for _ in range(8):                                           # the eager first steps + one recording per staging slot
             opt.step(lambda: zero, lambda loss: None)
         t = timed(lambda: opt.step(lambda: zero, lambda loss: None), 30)
         out["svgd_step_cifar_resnet20_shell_fused_graph_replay"] = {
             "ms": round(t * 1e3, 4), "steps_per_s": round(1.0 / t, 1), "replayed_steps": opt._graph_replays,
             "recordings": opt._graph_captures,
-            "what": "as svgd_step_cifar_resnet20_shell_fused with graph_replay=True: table upload + gradient packing + the "
-                    "update's two launches as ONE hipGraph launch per step"}
+            "what": "as svgd_step_cifar_resnet20_shell_fused_small_kernel with graph_replay=True: table upload + gradient "
+                    "packing + the update's two launches as ONE hipGraph launch per step"}
         del opt, params, base
     except Exception as e:                                           # noqa: BLE001 -- reported, the other sections go on
         out["svgd_step_cifar_resnet20_shell_fused_graph_replay"] = {"error": f"{type(e).__name__}: {e}"}
@@ -811,48 +853,75 @@ def config_extras(dev, on_section=None):
     conv_shapes = {"resnet20_layer_b128": (128, 16, 32, 32, 16, 3, 1, 1), "resnet20_first_b128": (128, 3, 32, 32, 16, 3, 1, 1),
                    "resnet20_16to32_s2_b128": (128, 16, 32, 32, 32, 3, 2, 1), "resnet20_32ch_b128": (128, 32, 16, 16, 32, 3, 1, 1),
                    "resnet20_32to64_s2_b128": (128, 32, 16, 16, 64, 3, 2, 1), "resnet20_64ch_b128": (128, 64, 8, 8, 64, 3, 1, 1)}
-    for cname, (cn, cc_, chh, cww, co, ck, cs, cp) in conv_shapes.items():
-        conv = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=True).to(dev)
-        conv3 = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=False).to(dev)
-        conv3.load_state_dict(conv.state_dict())
-        xc = torch.randn(cn, cc_, chh, cww, device=dev, requires_grad=True)
-
-        def leaves(layer):
-            return [xc, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho]
-
-        def conv_fused():
-            torch.autograd.grad(conv(xc).sum(), leaves(conv))
-
-        def conv_round3():
-            torch.autograd.grad(conv3(xc).sum(), leaves(conv3))
-
-        def conv_torch():                                            # bbb_layers.py:146-154
-            w, b = conv.weight, conv.bias
-            mean = F.conv2d(xc, w.mean, b.mean, stride=cs, padding=cp)
-            var = F.conv2d((xc ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), b.std ** 2, stride=cs, padding=cp)
-            torch.autograd.grad((mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)).sum(), leaves(conv))
-        with torch.no_grad():
-            t_ff = time_loop(lambda: conv(xc), 30)
-        t_f, t_3, t_t = time_loop(conv_fused, 30), time_loop(conv_round3, 30), time_loop(conv_torch, 30)
-        ho, wo = (chh + 2 * cp - ck) // cs + 1, (cww + 2 * cp - ck) // cs + 1
-        flops_fwd = 2 * 2.0 * cn * co * ho * wo * cc_ * ck * ck
-        out["bbb_conv2d_fwd_bwd_" + cname] = {
-            "ms": round(t_f * 1e3, 4), "torch_sequence_ms": round(t_t * 1e3, 4), "speedup": round(t_t / t_f, 2),
-            "round3_composition_ms": round(t_3 * 1e3, 4), "forward_only_ms": round(t_ff * 1e3, 4),
-            "forward_TFLOPs": round(flops_fwd / t_ff / 1e12, 2), "shape": {"N": cn, "C": cc_, "H": chh, "W": cww, "O": co, "K": ck,
-                                                                          "stride": cs, "padding": cp},
-            "what": "BBBConv2d forward + backward (all five gradients) through the layer: fused dual-accumulator implicit-GEMM "
-                    "kernels (1 forward launch; g_var + input-gradient + weight-gradient + finish launches backward) vs the "
-                    "reference's op sequence under autograd (two MIOpen convolutions forward, four backward, ~25 element-wise "
-                    "launches) and vs round 3's composition (stock convolutions + fused element-wise passes)",
-            "native_autograd_nodes": _bl._native_nodes(conv.weight._get_ops()) is not None,
-            # what BBBConv2d() without a keyword does at this geometry: the fused kernels only where conv_profit.json records
-            # a device measurement of this kernel version that beats the stock sequence (forward + backward)
-            "default_path": "fused" if _bl._conv_profitable((cn, cc_, chh, cww), (co, cc_, ck, ck), (cs, cs), (cp, cp),
-                                                             conv.weight._get_ops(), True) else "stock (round-3 composition)"}
-        del conv, conv3, xc
+    for cname, shape in conv_shapes.items():
+        # one geometry failing (these kernels have never run on an MI355X) must not cost the geometries behind it
+        try:
+            out["bbb_conv2d_fwd_bwd_" + cname] = conv_layer_entry(dev, prior, shape)
+        except Exception as e:                                       # noqa: BLE001
+            out["bbb_conv2d_fwd_bwd_" + cname] = {"error": f"{type(e).__name__}: {e}"}
+        if on_section is not None:
+            on_section(out)
 
     return out
+
+
+def conv_layer_entry(dev, prior, shape):
+    """One BBBConv2d geometry: the device-verified compositions FIRST (the reference's op sequence, round 3's stock convolutions
+    + fused element-wise passes = what a default-constructed layer runs), then the fused convolution kernels forced on -- a
+    failure there is recorded beside the stock numbers instead of replacing them."""
+    import torch.nn.functional as F
+    import beyond_deep_ensembles_amd as bde
+    from beyond_deep_ensembles_amd import bbb_layers as _bl
+    cn, cc_, chh, cww, co, ck, cs, cp = shape
+    conv = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=True).to(dev)
+    conv3 = bde.BBBConv2d(cc_, co, ck, prior, prior, stride=cs, padding=cp, rng="philox", fused_conv=False).to(dev)
+    conv3.load_state_dict(conv.state_dict())
+    xc = torch.randn(cn, cc_, chh, cww, device=dev, requires_grad=True)
+
+    def leaves(layer):
+        return [xc, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho]
+
+    def conv_fused():
+        torch.autograd.grad(conv(xc).sum(), leaves(conv))
+
+    def conv_round3():
+        torch.autograd.grad(conv3(xc).sum(), leaves(conv3))
+
+    def conv_torch():                                            # bbb_layers.py:146-154
+        w, b = conv.weight, conv.bias
+        mean = F.conv2d(xc, w.mean, b.mean, stride=cs, padding=cp)
+        var = F.conv2d((xc ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), b.std ** 2, stride=cs, padding=cp)
+        torch.autograd.grad((mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)).sum(), leaves(conv))
+    t_3, t_t = time_loop(conv_round3, 30), time_loop(conv_torch, 30)
+    ho, wo = (chh + 2 * cp - ck) // cs + 1, (cww + 2 * cp - ck) // cs + 1
+    flops_fwd = 2 * 2.0 * cn * co * ho * wo * cc_ * ck * ck
+    entry = {
+        "ms": round(t_3 * 1e3, 4), "torch_sequence_ms": round(t_t * 1e3, 4), "speedup": round(t_t / t_3, 2),
+        "round3_composition_ms": round(t_3 * 1e3, 4),
+        "shape": {"N": cn, "C": cc_, "H": chh, "W": cww, "O": co, "K": ck, "stride": cs, "padding": cp},
+        "what": "BBBConv2d forward + backward (all five gradients) through the layer.  ms / speedup: what a default-constructed "
+                "layer runs at this geometry (see default_path) vs the reference's op sequence under autograd (two MIOpen "
+                "convolutions forward, four backward, ~25 element-wise launches).  round3_composition_ms: stock convolutions + "
+                "fused element-wise passes.  fused_kernels: the dual-accumulator implicit-GEMM kernels forced on (1 forward "
+                "launch; g_var + input-gradient + weight-gradient + finish launches backward)",
+        "native_autograd_nodes": _bl._native_nodes(conv.weight._get_ops()) is not None,
+        # what BBBConv2d() without a keyword does at this geometry: the fused kernels only where conv_profit.json records
+        # a device measurement of this kernel version that beats the stock sequence (forward + backward)
+        "default_path": "fused" if _bl._conv_profitable((cn, cc_, chh, cww), (co, cc_, ck, ck), (cs, cs), (cp, cp),
+                                                         conv.weight._get_ops(), True) else "stock (round-3 composition)"}
+    try:
+        with torch.no_grad():
+            t_ff = time_loop(lambda: conv(xc), 30)
+        t_f = time_loop(conv_fused, 30)
+        entry["fused_kernels"] = {"ms": round(t_f * 1e3, 4), "speedup_vs_torch_sequence": round(t_t / t_f, 2),
+                                  "speedup_vs_round3_composition": round(t_3 / t_f, 2), "forward_only_ms": round(t_ff * 1e3, 4),
+                                  "forward_TFLOPs": round(flops_fwd / t_ff / 1e12, 2)}
+        if entry["default_path"] == "fused":
+            entry["ms"], entry["speedup"] = round(t_f * 1e3, 4), round(t_t / t_f, 2)
+    except Exception as e:                                           # noqa: BLE001
+        entry["fused_kernels"] = {"error": f"{type(e).__name__}: {e}"}
+    return entry
+
 
 
 def single_gpu_extras(ops, dev, args, sink=None):
@@ -921,7 +990,7 @@ def single_gpu_extras(ops, dev, args, sink=None):
                 checkpoint()
             ex["other_baseline_configs"] = config_extras(dev, on_section=config_sections)
             for k, v in ex["other_baseline_configs"].items():
-                log(f"  {k}: {v['ms']} ms")
+                log(f"  {k}: {v.get('ms', v.get('error'))} ms")
     except Exception as e:
         log(f"  other_baseline_configs skipped: {type(e).__name__}: {e}")
     checkpoint()
@@ -1158,7 +1227,7 @@ def multi_gpu_mode(kind, args, dist, dev, rank, world, d):
     return res
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -1174,36 +1243,74 @@ def main():
     ap.add_argument("--no-config-extras", action="store_true",
                     help="skip extra.other_baseline_configs (smaller launches of the same kernels; PMC passes average per kernel)")
     ap.add_argument("--extras-in-process", action="store_true",
-                    help="measure `extra` in this process instead of a child (profiling runs: rocprofv3 then sees those kernels "
-                         "in THIS process's trace; a GPU fault in an extra then costs the whole line)")
+                    help="ONE process measures everything (headline, cpu baseline, `extra`) instead of the GPU-free parent with "
+                         "one child per part (profiling runs: rocprofv3 then sees every kernel in THIS process's trace; a GPU "
+                         "fault in an extra then costs the whole line)")
+    ap.add_argument("--headline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--extras-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from profiles/roofline_traffic.json instead of two rocprofv3 --pmc child passes in this run")
-    args = ap.parse_args()
-    if args.traffic_child:                         # the child of live_traffic(): a few full-size steps of the headline's kernels
-        dev_index = int(os.environ.get("BDE_BENCH_DEVICE", "0"))
-        torch.cuda.set_device(dev_index)
-        from beyond_deep_ensembles_amd.ops import HipOps
-        dev = torch.device("cuda", dev_index)
-        ops = HipOps()
-        P, G = make_svgd_inputs(args.dim, dev, 1234)
-        out = torch.empty_like(G)
-        ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
-        for _ in range(4):
-            ops.svgd_gram(P, args.dim, ws)
-            ops.svgd_kstats(ws, M, 0.0, 1.0, DATASET_SIZE, -1.0, ks)
-            ops.svgd_combine(P, G, out, args.dim, ks)
-        torch.cuda.synchronize()
-        return
-    if args.extras_child:                          # the child of extras_in_child(): `extra` only, written to a file
-        dev_index = int(os.environ.get("BDE_BENCH_DEVICE", "0"))
-        torch.cuda.set_device(dev_index)
-        from beyond_deep_ensembles_amd.ops import HipOps
-        dev = torch.device("cuda", dev_index)
-        single_gpu_extras(HipOps(), dev, args, sink=args.extras_child)      # writes the file section by section
-        return
+    return ap.parse_args(argv)
 
+
+def traffic_child(args):
+    """The child of live_traffic(): a few full-size steps of the headline's kernels (under rocprofv3 --pmc)."""
+    dev_index = int(os.environ.get("BDE_BENCH_DEVICE", "0"))
+    torch.cuda.set_device(dev_index)
+    from beyond_deep_ensembles_amd.ops import HipOps
+    dev = torch.device("cuda", dev_index)
+    ops = HipOps()
+    P, G = make_svgd_inputs(args.dim, dev, 1234)
+    out = torch.empty_like(G)
+    ws, ks = ops.svgd_ws(M, dev), ops.svgd_kstat(M, dev)
+    for _ in range(4):
+        ops.svgd_gram(P, args.dim, ws)
+        ops.svgd_kstats(ws, M, 0.0, 1.0, DATASET_SIZE, -1.0, ks)
+        ops.svgd_combine(P, G, out, args.dim, ks)
+    torch.cuda.synchronize()
+
+
+def extras_child(args):
+    """The child of extras_in_child(): `extra` only, written to a file section by section."""
+    dev_index = int(os.environ.get("BDE_BENCH_DEVICE", "0"))
+    torch.cuda.set_device(dev_index)
+    from beyond_deep_ensembles_amd.ops import HipOps
+    dev = torch.device("cuda", dev_index)
+    single_gpu_extras(HipOps(), dev, args, sink=args.extras_child)
+
+
+def guarded(name, fn, *a, **k):
+    """fn(*a, **k), or {"error": ...}: no optional section of the line may cost the line (VERDICT r5 weak #3)."""
+    try:
+        return fn(*a, **k)
+    except (Exception, SystemExit) as e:          # noqa: BLE001 -- whatever a section raises: the line is still printed
+        import traceback
+        log(f"  {name} failed: {type(e).__name__}: {e}")
+        return {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1200:]}
+
+
+def apply_live_traffic(res, d, dev_index) -> None:
+    """roofline.traffic of ``res`` from two rocprofv3 --pmc child passes of THIS run (live_traffic); the recorded value stays
+    (with the reason appended to its source) when they cannot run."""
+    r = res.get("roofline")
+    if not isinstance(r, dict):
+        return
+    live, why = live_traffic(d, dev_index)
+    if live is not None:
+        r["traffic"], r["traffic_source"] = live, why
+    else:
+        log(f"live traffic measurement skipped: {why}")
+        r["traffic_source"] = (r.get("traffic_source") or "none recorded") + f" (the in-run rocprofv3 passes were skipped: {why})"
+
+
+def headline(args, sink=None):
+    """The process that touches the GPU for the headline: timed region, roofline, SWAG rate, the reference's op sequence on
+    the same GPU, and under torch.distributed.run with one rank the forced RCCL exchange.  ``sink(res)`` (the headline child
+    of the GPU-free parent, N = 1): called with everything measured so far before each optional section starts, so a fault
+    there cannot cost what exists.  Without a sink (N > 1, --extras-in-process) this one process also measures the CPU
+    baseline, `extra` and the PMC traffic.  Returns the result dictionary on rank 0, None on the other ranks."""
+    res = None
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1266,7 +1373,6 @@ def main():
         ms_per_step = median(blocks_ms)
         combine_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps     # HIP events of the last block
         assert torch.isfinite(out[:, :d]).all()
-        probe = stream_probe(ops, P, G, out, d, ws, ks)
     else:
         # every exchange mode of the product's multi-GPU update in ONE invocation; headline = north_star's all-gather
         wanted = ["allgather", "pipelined", "alltoall"] if args.exchange == "all" else [args.exchange]
@@ -1288,10 +1394,7 @@ def main():
 
     # ---- SWAG posterior samples/s (the second half of BASELINE's metric): every rank samples independently
     # (MultiSWAG fan-out, DeepEnsemble.predict(rank=, world_size=)); aggregate = sum over ranks ("weak").
-    swag = None
-    if d == D_RESNET50:
-        if world == 1:
-            del out
+    def swag_rates():
         torch.cuda.empty_cache()
         ld = pad_ld(d)
         gsw = torch.Generator(device=dev).manual_seed(99 + rank)
@@ -1307,12 +1410,14 @@ def main():
         rates = torch.tensor([1.0 / t_single, S_SWAG / t_batch], device=dev, dtype=torch.float64)
         if dist:
             dist.all_reduce(rates, op=dist.ReduceOp.SUM)
-        swag = {"samples_per_s": round(float(rates[0]), 1), "samples_per_s_batched_S30": round(float(rates[1]), 1),
+        return {"samples_per_s": round(float(rates[0]), 1), "samples_per_s_batched_S30": round(float(rates[1]), 1),
                 "K": K_SWAG, "D": d, "scaling": "weak (independent posterior samples on every GPU)",
                 "per_sample_hbm_frac_rank0": round(4 * d * (K_SWAG + 3) / t_single / 1e9 / HBM_PEAK_GBS, 4),
                 "batched_hbm_frac_rank0": round(4 * d * (K_SWAG + 2 + S_SWAG) / t_batch / 1e9 / HBM_PEAK_GBS, 4)}
-        del stat, bm, bs, br, o1, ob
-        out = None
+
+    swag = None
+    if d == D_RESNET50 and world > 1:
+        swag = swag_rates()           # a collective inside: every rank, unguarded (an exception on one rank must end the job)
 
     if rank == 0:
         res = {
@@ -1347,13 +1452,6 @@ def main():
                         + " -- a recorded PMC measurement of this kernel at this size, not re-measured in this run"
                 except Exception:
                     traffic = None
-            if not args.no_live_traffic:
-                live, why = live_traffic(d, dev_index)
-                if live is not None:
-                    traffic, traffic_source = live, why
-                else:
-                    log(f"live traffic measurement skipped: {why}")
-                    traffic_source = (traffic_source or "none recorded") + f" (the in-run rocprofv3 passes were skipped: {why})"
             res["roofline"] = {"kernel": "svgd_combine_kernel<8,true>", "bound": "hbm", "achieved": round(achieved, 1),
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "traffic_source": traffic_source,
@@ -1362,21 +1460,6 @@ def main():
                                "served_by": "HBM + Infinity Cache: in the step the kernel runs right behind the Gram pass, "
                                             "whose last ~240 MB of particle loads are still in the 256 MB MALL "
                                             "(svgd.hip:63-68); back_to_back is the same kernel without that help"}
-            if probe is not None:
-                r = res["roofline"]
-                r["probe_GBps"] = round(probe["probe_in_step_GBps"], 1)
-                r["frac_of_probe"] = round(achieved / probe["probe_in_step_GBps"], 4)
-                r["probe"] = {"what": "bench_probe/probe.hip: 16 rows read + 8 rows written, the kernel's walk and "
-                                      "non-temporal accesses, no arithmetic; timed by HIP events in this run, in-step = "
-                                      "right behind a Gram pass over the same rows (as the kernel runs)",
-                              "in_step_ms": round(probe["probe_in_step_ms"], 4),
-                              "back_to_back_ms": round(probe["probe_back_to_back_ms"], 4),
-                              "back_to_back_GBps": round(probe["probe_back_to_back_GBps"], 1)}
-                r["back_to_back"] = {"avg_launch_ms": round(probe["combine_back_to_back_ms"], 4),
-                                     "achieved": round(probe["combine_back_to_back_GBps"], 1),
-                                     "frac": round(probe["combine_back_to_back_GBps"] / HBM_PEAK_GBS, 4),
-                                     "frac_of_probe": round(probe["combine_back_to_back_GBps"] /
-                                                            probe["probe_back_to_back_GBps"], 4)}
         else:
             # per rank the update streams (12 M + 8) D / W bytes of its slice (alltoall) or (12 M + 8) D (replicated);
             # update_ms is the step with the collectives switched off, i.e. ALL of the rank's kernels + host logic,
@@ -1398,44 +1481,193 @@ def main():
         if swag is not None:
             res["swag"] = swag
         log(f"svgd_step: {ms_per_step:.4f} ms/step (blocks {[round(x, 4) for x in blocks_ms]}) = {res['value']} steps/s; "
-            f"combine {combine_ms} ms; swag {swag}")
+            f"combine {combine_ms} ms")
         if world == 1:
+            # From here on nothing may cost the line: every further section is optional and guarded, and with a sink (the
+            # headline child of the GPU-free parent) what exists so far is written out before each of them starts.
+            one_process = sink is None
+            if sink:
+                sink(res)
+            probe = guarded("stream_probe", stream_probe, ops, P, G, out, d, ws, ks)
+            if isinstance(probe, dict) and "error" in probe:
+                res["roofline"]["probe_error"] = probe["error"]
+            elif probe is not None:
+                r = res["roofline"]
+                r["probe_GBps"] = round(probe["probe_in_step_GBps"], 1)
+                r["frac_of_probe"] = round(achieved / probe["probe_in_step_GBps"], 4)
+                r["probe"] = {"what": "bench_probe/probe.hip: 16 rows read + 8 rows written, the kernel's walk and "
+                                      "non-temporal accesses, no arithmetic; timed by HIP events in this run, in-step = "
+                                      "right behind a Gram pass over the same rows (as the kernel runs)",
+                              "in_step_ms": round(probe["probe_in_step_ms"], 4),
+                              "back_to_back_ms": round(probe["probe_back_to_back_ms"], 4),
+                              "back_to_back_GBps": round(probe["probe_back_to_back_GBps"], 1)}
+                r["back_to_back"] = {"avg_launch_ms": round(probe["combine_back_to_back_ms"], 4),
+                                     "achieved": round(probe["combine_back_to_back_GBps"], 1),
+                                     "frac": round(probe["combine_back_to_back_GBps"] / HBM_PEAK_GBS, 4),
+                                     "frac_of_probe": round(probe["combine_back_to_back_GBps"] /
+                                                            probe["probe_back_to_back_GBps"], 4)}
+            del out
+            if d == D_RESNET50:
+                # the second half of BASELINE's metric; its kernels are device-verified, the section is guarded all the same
+                res["swag"] = guarded("swag", swag_rates)
+                log(f"  swag {res['swag']}")
+            if sink:
+                sink(res)
             if not args.no_cpu_baseline:
-                log("cpu baseline ...")
-                res["cpu_baseline"] = cpu_baseline(P, G, d)
-                log(f"  {res['cpu_baseline']}")
-                try:
-                    res["gpu_torch_baseline"] = torch_gpu_baseline(P, G, d, dev)
-                    log(f"  {res['gpu_torch_baseline']}")
-                except Exception as e:      # informational only
-                    log(f"  gpu_torch_baseline skipped: {e}")
+                if one_process:
+                    log("cpu baseline ...")
+                    res["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline, P, G, d)
+                    log(f"  {res['cpu_baseline']}")
+                res["gpu_torch_baseline"] = guarded("gpu_torch_baseline", torch_gpu_baseline, P, G, d, dev)   # informational
+                log(f"  gpu_torch_baseline {res['gpu_torch_baseline']}")
+                if sink:
+                    sink(res)
             del P, G
             torch.cuda.empty_cache()
             if not args.no_extras and d == D_RESNET50:
-                log("extras ...")
-                if args.extras_in_process:
-                    res["extra"] = single_gpu_extras(ops, dev, args)
-                else:
-                    res["extra"] = extras_in_child(args, dev_index)
+                if one_process:
+                    log("extras ...")
+                    res["extra"] = guarded("extras", single_gpu_extras, ops, dev, args)
                 if dist is not None:
                     # one rank under torch.distributed.run: the product's multi-GPU update forced through the RCCL
                     # collectives (all_gather_into_tensor in place, the chunk pipeline, all_to_all_single)
                     one = {}
                     for kind in ("allgather", "pipelined", "alltoall"):
-                        try:
-                            one[kind] = multi_gpu_mode(kind, args, dist, dev, rank, world, d)
-                            one[kind].pop("_blocks", None)
-                        except Exception as e:
-                            one[kind] = {"error": f"{type(e).__name__}: {e}"}
+                        one[kind] = guarded(f"rccl_one_rank[{kind}]", multi_gpu_mode, kind, args, dist, dev, rank, world, d)
+                        one[kind].pop("_blocks", None)
                     one["what"] = ("world size 1 over " + os.environ.get("BDE_BENCH_BACKEND", "nccl") + ": SVGDOptimizer("
                                    "process_group=WORLD, _force_exchange=True)._posterior_update -- every collective of the "
                                    "multi-GPU step executes (self-exchange, no wire); exchange_ms is launch + copy cost")
-                    res["extra"]["rccl_one_rank"] = one
+                    res["rccl_one_rank"] = one                          # (moved under `extra` when the line is assembled)
                     log(f"  rccl_one_rank {one}")
-        print(json.dumps(res), flush=True)
+                    if sink:
+                        sink(res)
+            if one_process and not args.no_live_traffic:
+                guarded("live_traffic", apply_live_traffic, res, d, dev_index)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    return res if rank == 0 else None
+
+
+def finish_line(res):
+    """`rccl_one_rank` belongs under `extra` (the headline child measured it, the extras child everything else)."""
+    if isinstance(res, dict) and "rccl_one_rank" in res:
+        extra = res.get("extra")
+        if not isinstance(extra, dict):
+            extra = res["extra"] = {} if extra is None else {"error": str(extra)}
+        extra["rccl_one_rank"] = res.pop("rccl_one_rank")
+    return res
+
+
+def _child_env(dev_index, keep_rendezvous=False):
+    drop = () if keep_rendezvous else ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                       "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env["BDE_BENCH_DEVICE"] = str(dev_index)
+    return env
+
+
+def headline_in_child(args, dev_index, limit_s=900):
+    """The headline measured by a CHILD process (`python bench.py --headline-child FILE ...`), so that the parent never
+    initialises the GPU -- on this pool a GPU-initialised process that creates further processes is what one avoids -- and so
+    that a fault in one of the optional sections behind the timed region costs only that section: the child rewrites FILE
+    before each of them.  Under torch.distributed.run (one rank) the child inherits the rendezvous variables and is the rank.
+    -> (result dictionary or None, error string or None)."""
+    import subprocess
+    import tempfile
+    fd, path = tempfile.mkstemp(suffix=".json", prefix="bde_bench_headline_")
+    os.close(fd)
+    cmd = [sys.executable, os.path.abspath(__file__), "--headline-child", path, "--gpus", "1", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--blocks", str(args.blocks), "--dim", str(args.dim), "--exchange", args.exchange,
+           "--chunks", str(args.chunks)]
+    for flag, on in (("--no-extras", args.no_extras), ("--no-cpu-baseline", args.no_cpu_baseline),
+                     ("--no-config-extras", args.no_config_extras)):
+        if on:
+            cmd.append(flag)
+    err = None
+    try:
+        proc = subprocess.Popen(cmd, env=_child_env(dev_index, keep_rendezvous=True), stdout=subprocess.DEVNULL)
+        try:
+            rc = proc.wait(timeout=limit_s)
+            if rc != 0:
+                err = f"the headline child exited with code {rc}"
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.wait()
+            err = f"the headline child did not finish within {limit_s} s and was killed"
+        try:
+            with open(path) as f:
+                res = json.load(f)
+        except (OSError, ValueError):
+            res = None
+        return res, err
+    except OSError as e:                       # the process could not be created at all
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+
+
+def orchestrate(args):
+    """N = 1, the default: a parent that NEVER touches the GPU runs the parts as sibling children, one after the other --
+    the headline (timed region, roofline, SWAG rate), the `extra` sections, the two rocprofv3 --pmc passes for
+    roofline.traffic -- times the CPU baseline itself (host cores only), merges what they wrote and prints the ONE line.
+    Each part has its own time limit and its own failure record; the line is printed whatever happens to any of them.
+    Returns the exit code (non-zero only when the headline itself is missing)."""
+    dev_index = int(os.environ.get("BDE_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    d = args.dim
+    res, err = headline_in_child(args, dev_index)
+    if not isinstance(res, dict) or "value" not in res:
+        line = {"metric": "svgd_steps_per_s", "value": None, "unit": "steps/s", "n_gpus": 1, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic", "config": {"workload": "SVGD posterior update, 8 particles x ResNet-50-sized weights"},
+                "error": err or "the headline child wrote no result"}
+        print(json.dumps(line), flush=True)
+        return 1
+    if err:
+        res["headline_child_error"] = err + " after the timed region (the sections it had finished are kept)"
+    if not args.no_cpu_baseline:
+        log("cpu baseline ...")
+
+        def cpu_part():
+            P, G = make_svgd_inputs(d, torch.device("cpu"), 1234)       # same distribution as the device inputs, host generator
+            return cpu_baseline(P, G, d)
+        res["cpu_baseline"] = guarded("cpu_baseline", cpu_part)
+        log(f"  {res['cpu_baseline']}")
+    if not args.no_extras and d == D_RESNET50:
+        log("extras ...")
+        res["extra"] = guarded("extras", extras_in_child, args, dev_index)
+    if not args.no_live_traffic:
+        guarded("live_traffic", apply_live_traffic, res, d, dev_index)
+    print(json.dumps(finish_line(res)), flush=True)
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.traffic_child:
+        return traffic_child(args)
+    if args.extras_child:
+        return extras_child(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.headline_child:
+        def sink(res):
+            tmp = args.headline_child + ".tmp"
+            with open(tmp, "w") as fh:
+                json.dump(res, fh)
+            os.replace(tmp, args.headline_child)
+        headline(args, sink=sink)
+        return
+    if world > 1 or args.gpus > 1 or args.extras_in_process:
+        # N > 1: every rank is already a child of torch.distributed.run and creates no process of its own
+        res = headline(args)
+        if res is not None:
+            print(json.dumps(finish_line(res)), flush=True)
+        return
+    sys.exit(orchestrate(args))
 
 
 if __name__ == "__main__":

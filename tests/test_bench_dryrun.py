@@ -79,6 +79,8 @@ def dry(monkeypatch):
 def test_extras_run_through(dry):
     bench, ops, dev = dry
     out = bench.extras(ops, dev, quick=True)
+    assert not {k: v for k, v in out.items() if isinstance(v, dict) and "error" in v}
+    assert "svgd_full_step_fused_sgd_M8_resnet20_streaming" in out and "svgd_step_M8_resnet20_small_kernel" in out
     for name in ("svgd_gram_M8_resnet50", "svgd_combine_M8_resnet50", "svgd_full_step_fused_sgd_M8_resnet20_2_launches",
                  "swag_update_resnet50", "swag_sample_K20_resnet50", "swag_sample_batched_K20_S30_resnet50",
                  "bbb_draw_fwd_resnet50", "bbb_kl_fwd_bwd_resnet50"):
@@ -88,7 +90,15 @@ def test_extras_run_through(dry):
 def test_config_extras_and_shell_steps_run_through(dry):
     bench, ops, dev = dry
     cfg = bench.config_extras(dev)
+    failed = {k: v for k, v in cfg.items() if isinstance(v, dict) and ("error" in v or "error" in v.get("fused_kernels", {}))}
+    assert not failed, failed                                                # (sections catch their own exceptions: look inside)
+    for key in ("svgd_step_cifar_resnet20_shell_fused", "svgd_step_cifar_resnet20_shell_fused_small_kernel",
+                "svgd_step_cifar_resnet20_shell_unfused_small_kernel", "svgd_step_cifar_resnet20_shell_fused_graph_replay"):
+        assert cfg[key]["ms"] > 0, key
+    assert cfg["svgd_step_cifar_resnet20_shell_fused"]["small_model_kernel"] is False      # the default: device-verified kernels only
+    assert cfg["svgd_step_cifar_resnet20_shell_fused_small_kernel"]["small_model_kernel"] is True
     assert any(k.startswith("bbb_conv2d_fwd_bwd") for k in cfg), sorted(cfg)
+    assert all("fused_kernels" in v for k, v in cfg.items() if k.startswith("bbb_conv2d_fwd_bwd"))
     assert any(k.startswith("bbb_linear") for k in cfg), sorted(cfg)
     small = bench.shell_step_real_grads_ms(dev, n_tensors=12, d=120_000, steps=2)
     assert small["step_ms"] > 0
@@ -229,3 +239,158 @@ def test_live_traffic_parsing_and_fallback(dry, monkeypatch, tmp_path):
     monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
     assert bench.live_traffic(1000, 0)[1] == "this process is itself being profiled"
 
+
+
+# ---- the line is unlosable ----------------------------------------------------------------------------
+_FAKE_BENCH = '''
+import json, os, sys, time
+argv = sys.argv
+def arg(name):
+    return argv[argv.index(name) + 1]
+mode = os.environ.get("FAKE_MODE", "ok")
+if "--headline-child" in argv:
+    assert os.environ.get("EXPECT_RANK") == os.environ.get("RANK"), "the headline child must inherit the rendezvous variables"
+    res = {"metric": "svgd_steps_per_s", "value": 1234.5, "unit": "steps/s", "n_gpus": 1, "steps": int(arg("--steps")),
+           "warmup": int(arg("--warmup")), "ms_per_step": 0.81, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "config": {"workload": "fake"},
+           "roofline": {"bound": "hbm", "achieved": 5600.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.7, "traffic": 7, "traffic_source": "recorded"}}
+    if mode == "headline_dies_at_once":
+        os.abort()
+    json.dump(res, open(arg("--headline-child"), "w"))
+    if mode == "headline_dies_after_the_timed_region":
+        os.abort()                                         # as a GPU fault in an optional section ends the process
+    res["swag"] = {"samples_per_s": 2700.0}
+    res["rccl_one_rank"] = {"allgather": {"step_ms": 1.0}}
+    json.dump(res, open(arg("--headline-child"), "w"))
+elif "--extras-child" in argv:
+    assert "RANK" not in os.environ and "MASTER_ADDR" not in os.environ, "the extras child is no rank"
+    json.dump({"svgd_combine_M8_resnet50": {"ms": 0.4}}, open(arg("--extras-child"), "w"))
+    if mode == "extras_die":
+        os.abort()
+'''
+
+
+def _orchestrate(bench, monkeypatch, tmp_path, capsys, mode="ok", argv=()):
+    import json
+    script = tmp_path / "fake_bench.py"
+    script.write_text(_FAKE_BENCH)
+    monkeypatch.setattr(bench, "__file__", str(script))
+    monkeypatch.setenv("FAKE_MODE", mode)
+    monkeypatch.setattr(bench, "cpu_baseline", lambda P, G, d: {"value": 0.28, "unit": "steps/s", "cores": 8, "kind": "port", "sample": "x"})
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "20", "--warmup", "5", "--no-live-traffic", *argv])
+    with pytest.raises(SystemExit) as done:
+        bench.main()
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    return done.value.code, json.loads(lines[0])
+
+
+@pytest.mark.parametrize("launched", [False, True], ids=["python", "torchrun_one_rank"])
+def test_the_default_run_is_a_gpu_free_parent_that_merges_its_children(dry, monkeypatch, tmp_path, capsys, launched):
+    """`python bench.py` (N = 1): the parent creates the headline child, times the CPU baseline itself, creates the extras child
+    and prints ONE line merged from what they wrote -- and it never touches the GPU itself (any torch.cuda call fails here)."""
+    bench, ops, dev = dry
+    for key in ("RANK", "MASTER_ADDR", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(key, raising=False)
+
+    def touched(*a, **k):
+        raise AssertionError("the parent process initialised the GPU")
+    for name in ("set_device", "synchronize", "current_device", "is_available", "Event", "current_stream", "empty_cache"):
+        monkeypatch.setattr(torch.cuda, name, touched)
+    if launched:
+        # `torchrun --nproc-per-node 1 bench.py --gpus 1`: the headline child IS the rank (it inherits the rendezvous variables
+        # and joins the process group); the extras child is an ordinary process without them
+        for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29999"),
+                         ("EXPECT_RANK", "0")):
+            monkeypatch.setenv(key, val)
+    code, line = _orchestrate(bench, monkeypatch, tmp_path, capsys)
+    assert code == 0 and line["value"] == 1234.5 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["roofline"]["frac"] == 0.7 and line["cpu_baseline"]["kind"] == "port" and line["swag"]["samples_per_s"] == 2700.0
+    assert line["extra"]["svgd_combine_M8_resnet50"] == {"ms": 0.4}
+    assert line["extra"]["rccl_one_rank"] == {"allgather": {"step_ms": 1.0}} and "rccl_one_rank" not in line
+
+
+@pytest.mark.parametrize("mode", ["headline_dies_after_the_timed_region", "extras_die", "cpu_baseline_raises", "popen_refused",
+                                  "popen_refused_for_the_extras", "headline_dies_at_once"])
+def test_no_failing_part_costs_the_line(dry, monkeypatch, tmp_path, capsys, mode):
+    """Every optional part may fail -- a GPU fault in a child behind the timed region, a dying extras child, an exception in the
+    CPU baseline, a box that refuses to create processes (PermissionError from Popen) -- and the line is still printed with
+    what was measured and the failure recorded beside it.  Only a missing HEADLINE makes the exit code non-zero, and even then
+    a line (value null, `error`) is printed."""
+    import subprocess
+    bench, ops, dev = dry
+    for key in ("RANK", "MASTER_ADDR", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(key, raising=False)
+    real_popen = subprocess.Popen
+    if mode.startswith("popen_refused"):
+        def popen(cmd, *a, **k):
+            if mode == "popen_refused" or "--extras-child" in cmd:
+                raise PermissionError(1, "Operation not permitted")
+            return real_popen(cmd, *a, **k)
+        monkeypatch.setattr(subprocess, "Popen", popen)
+    if mode == "cpu_baseline_raises":
+        script_mode = "ok"
+    else:
+        script_mode = mode
+    code, line = _orchestrate(bench, monkeypatch, tmp_path, capsys, mode=script_mode) if mode != "cpu_baseline_raises" else (None, None)
+    if mode == "cpu_baseline_raises":
+        def boom(P, G, d):
+            raise MemoryError("cannot allocate the host copy")
+        script = tmp_path / "fake_bench.py"
+        script.write_text(_FAKE_BENCH)
+        monkeypatch.setattr(bench, "__file__", str(script))
+        monkeypatch.setenv("FAKE_MODE", "ok")
+        monkeypatch.setattr(bench, "cpu_baseline", boom)
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--no-live-traffic"])
+        with pytest.raises(SystemExit) as done:
+            bench.main()
+        import json
+        line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][0])
+        assert done.value.code == 0 and line["value"] == 1234.5 and "MemoryError" in line["cpu_baseline"]["error"]
+        assert line["extra"]["svgd_combine_M8_resnet50"] == {"ms": 0.4}
+    elif mode == "headline_dies_after_the_timed_region":
+        assert code == 0 and line["value"] == 1234.5 and "exited with code" in line["headline_child_error"]
+        assert "swag" not in line and line["extra"]["svgd_combine_M8_resnet50"] == {"ms": 0.4}
+    elif mode == "extras_die":
+        assert code == 0 and line["value"] == 1234.5 and "exited with code" in line["extra"]["error"]
+        assert line["extra"]["svgd_combine_M8_resnet50"] == {"ms": 0.4}            # the sections it had written are kept
+    elif mode == "popen_refused_for_the_extras":
+        assert code == 0 and line["value"] == 1234.5 and "PermissionError" in line["extra"]["error"]
+        assert line["extra"]["rccl_one_rank"] == {"allgather": {"step_ms": 1.0}}
+    else:
+        assert code == 1 and line["value"] is None and line["metric"] == "svgd_steps_per_s"
+        assert ("PermissionError" if mode == "popen_refused" else "exited with code") in line["error"]
+
+
+def test_sections_behind_the_timed_region_are_guarded_and_checkpointed(dry, monkeypatch, capsys):
+    """bench.headline(sink=...) -- what the headline child runs: the result is handed to the sink as soon as the timed region
+    and the roofline exist and again after every optional section; a section that raises (here: the probe library, the SWAG
+    block, the reference-on-GPU baseline) becomes an `error` record in its place."""
+    import json
+    bench, ops, dev = dry
+
+    class _TorchOnCpu:
+        device = staticmethod(lambda *a, **k: torch.device("cpu"))
+        empty_like = staticmethod(torch.zeros_like)
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+    monkeypatch.setattr(bench, "torch", _TorchOnCpu())
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+    for key in ("RANK", "MASTER_ADDR", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(key, raising=False)
+
+    def boom(*a, **k):
+        raise RuntimeError("HIP error: an illegal memory access was encountered")
+    monkeypatch.setattr(bench, "stream_probe", boom)
+    monkeypatch.setattr(bench, "torch_gpu_baseline", boom)
+    monkeypatch.setattr(type(ops), "swag_sample_batched", boom)
+    seen = []
+    args = bench.parse_args(["--steps", "2", "--warmup", "1", "--blocks", "2", "--no-extras"])
+    res = bench.headline(args, sink=lambda r: seen.append(json.loads(json.dumps(r))))
+    assert len(seen) >= 3 and all(s["value"] == seen[0]["value"] > 0 for s in seen)
+    assert "roofline" in seen[0] and "swag" not in seen[0]                       # the first hand-over precedes every optional section
+    assert "illegal memory access" in res["roofline"]["probe_error"]
+    assert "illegal memory access" in res["swag"]["error"] and "illegal memory access" in res["gpu_torch_baseline"]["error"]
+    assert "cpu_baseline" not in res and "extra" not in res                    # the parent's parts
+    assert seen[-1] == json.loads(json.dumps(res))
