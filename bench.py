@@ -26,6 +26,16 @@ each bracketed by barrier + synchronize and reduced with MAX over ranks;
 ms_per_step is the MEDIAN block (all blocks are reported).
 
 One JSON line on stdout (rank 0); progress goes to stderr.
+
+Processes.  N = 1 (the default): the process started here NEVER touches the GPU.  It runs the parts as children, one
+after the other -- `--headline-child` (timed region, roofline with HIP-event launch times and the in-run probe, SWAG
+rates, the reference's op sequence on the same GPU; under torchrun with one rank also the forced RCCL exchange),
+`--extras-child` (every other kernel, the shells, the other BASELINE configs) and two `rocprofv3 --pmc ... -- python3
+bench.py --traffic-child` passes for roofline.traffic -- times the CPU baseline itself on the host cores, merges what
+the children wrote and prints the line.  Every part has a time limit and a failure record of its own (`error`
+beside what was measured); only a missing headline makes the exit code non-zero.  N > 1, `--extras-in-process` and
+runs under rocprofv3 (whose preloaded library has initialised the GPU already) measure everything in the one
+process, with every optional section guarded the same way.
 """
 import argparse
 import json
@@ -715,6 +725,38 @@ def config_extras(dev, on_section=None):
             del o_, v_, gg, gx_, gwm_, gwr_, s2_, ds2_
         del layer
 
+    # ---- BBBLinear ABOVE the fused op's 128 rows per launch: ceil(B / 128) launches of the same (device-verified) kernels
+    # (fused_linear_max_rows) vs what a default-constructed layer runs there (two stock GEMMs + fused element-wise passes) vs the
+    # reference's op sequence -- the measurement that decides whether the default limit moves (BBBLinear)
+    for bsz in (256, 512, 1024):
+        key = f"bbb_linear_fwd_bwd_mlp_4096x4096_b{bsz}_row_tiles"
+        try:
+            tiled = bde.BBBLinear(4096, 4096, prior, prior, rng="philox", fused_linear_max_rows=1024).to(dev)
+            stock = bde.BBBLinear(4096, 4096, prior, prior, rng="philox").to(dev)
+            stock.load_state_dict(tiled.state_dict())
+            xg = torch.randn(bsz, 4096, device=dev, requires_grad=True)
+
+            def fb(layer):
+                torch.autograd.grad(layer(xg).sum(), [xg, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho])
+
+            def torch_fb():
+                w, b = stock.weight, stock.bias
+                mean = F.linear(xg, w.mean, b.mean)
+                var = F.linear((xg ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), (b.std ** 2).clamp(min=1e-4))
+                torch.autograd.grad((mean + torch.sqrt(var) * torch.empty_like(mean).normal_(0, 1)).sum(),
+                                    [xg, w.mean, w.rho, b.mean, b.rho])
+            t_tiled, t_stock, t_torch = time_loop(lambda: fb(tiled), 20), time_loop(lambda: fb(stock), 20), time_loop(torch_fb, 20)
+            out[key] = {"ms": round(t_tiled * 1e3, 4), "default_layer_ms": round(t_stock * 1e3, 4),
+                        "torch_sequence_ms": round(t_torch * 1e3, 4), "speedup_vs_default_layer": round(t_stock / t_tiled, 2),
+                        "speedup_vs_torch_sequence": round(t_torch / t_tiled, 2), "B": bsz, "I": 4096, "O": 4096,
+                        "tiles": (bsz + 127) // 128, "TFLOPs": round(12.0 * bsz * 4096 * 4096 / t_tiled / 1e12, 1),
+                        "what": "BBBLinear(fused_linear_max_rows=1024) forward + backward in row tiles of 128 (bde_lrt_linear_fwd / "
+                                "_bwd per tile, weight gradients accumulated by autograd) vs the default layer at this batch (stock "
+                                "GEMMs + fused element-wise passes) vs the reference's op sequence"}
+            del tiled, stock, xg
+        except Exception as e:                                       # noqa: BLE001
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- configs[0]: BBBOptimizer.step on the UCI-housing MLP (13 -> 50 -> 1 BBBLinear, 5 MC samples, Adam), whole
     # step incl. forward/backward; beside it the reference's op sequence for the same step in plain PyTorch on this GPU
     def uci_model():
@@ -1040,6 +1082,12 @@ def extras_in_child(args, dev_index, limit_s=600):
             pass
 
 
+def being_profiled() -> bool:
+    """Is this process running under rocprofv3 (its tool library preloaded)?  Such a process has initialised the GPU before
+    main() starts and must not create further processes."""
+    return "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))
+
+
 def parse_pmc_counter(paths, counter, kernel_substring):
     """Mean of `counter` over the dispatches of kernels whose name contains `kernel_substring` in rocprofv3
     `*counter_collection.csv` files -> (mean, dispatches)."""
@@ -1072,7 +1120,7 @@ def live_traffic(d, dev_index, limit_s=120):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
-    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or os.environ.get("ROCP_TOOL_LIBRARIES"):
+    if being_profiled():
         return None, "this process is itself being profiled"
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
                                                             "GROUP_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
@@ -1661,8 +1709,10 @@ def main():
             os.replace(tmp, args.headline_child)
         headline(args, sink=sink)
         return
-    if world > 1 or args.gpus > 1 or args.extras_in_process:
-        # N > 1: every rank is already a child of torch.distributed.run and creates no process of its own
+    if world > 1 or args.gpus > 1 or args.extras_in_process or being_profiled():
+        # N > 1: every rank is already a child of torch.distributed.run and creates no process of its own.  Under rocprofv3 the
+        # profiler's preloaded library has initialised the GPU in THIS process already: one process measures everything (and
+        # the trace then holds every kernel of the run)
         res = headline(args)
         if res is not None:
             print(json.dumps(finish_line(res)), flush=True)

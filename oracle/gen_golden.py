@@ -18,6 +18,7 @@ Fixture list:
   bbb.npz             GaussianParameter draw, KL, one BBBOptimizer trajectory
   bbb2.npz            BBBOptimizer with MixturePrior; with frozen parameters; over the reference's BBBConv2d CNN
   lrt.npz             the reference's BBBLinear layer: output and all five gradients at five sizes (bbb_layers.py:61-80)
+  lrt_tiled.npz       the same at batch 129 / 256 / 1000 (above the fused op's 128 rows per launch)
   ivon.npz            iVON trajectories with recorded noise (ivorn.py:41-115)
   ensemble.npz        DeepEnsemble.predict sample split     (ensemble.py:37-40)
   ref_*_checkpoint.pt state_dict()s written by the reference optimizers (wire compatibility); ref_svgd_checkpoint4*:
@@ -425,17 +426,22 @@ def gen_bbb2():
 
 
 # ------------------------------------------------------------------ iVON
-from lrt_cases import LRT_CASES, lrt_case_inputs   # oracle/lrt_cases.py: seeded inputs shared with the tests
+from lrt_cases import LRT_CASES, LRT_TILED_CASES, lrt_case_inputs   # oracle/lrt_cases.py: seeded inputs shared with the tests
 
 
-def gen_lrt():
+def gen_lrt_tiled():
+    """lrt_tiled.npz: the same record at batch sizes above 128 rows (129, 256, 1000)."""
+    gen_lrt(LRT_TILED_CASES, "lrt_tiled.npz")
+
+
+def gen_lrt(cases=LRT_CASES, fname="lrt.npz"):
     """lrt.npz: the REFERENCE's BBBLinear (bbb_layers.py:10-90, sampling="activations", training mode) on seeded inputs:
     the output and d(sum(out * g)) / d(input, weight mean / rho, bias mean / rho) from its autograd graph.  The [O, I]
     gradients are stored as row sums, column sums and one seeded projection (the inputs are regenerated by the tests
     from the seeds), which keeps the fixture small at the iWildCam-head size and at a wide layer."""
-    out = {"cases": np.array(LRT_CASES)}
+    out = {"cases": np.array(cases)}
     prior = ref_bbb.GaussianPrior(0, 1.0)
-    for seed, b, i, o in LRT_CASES:
+    for seed, b, i, o in cases:
         x, w_mu, w_rho, b_mu, b_rho, eps, g, probe = lrt_case_inputs(seed, b, i, o)
         layer = ref_bbb_layers.BBBLinear(i, o, prior, prior)
         layer.train()
@@ -461,7 +467,7 @@ def gen_lrt():
             out[t + name + "_colsum"] = gw.double().sum(0).numpy()
             out[t + name + "_proj"] = np.array((gw.double() * pr).sum().item())
             out[t + name + "_absmax"] = np.array(gw.abs().max().item())
-    np.savez_compressed(os.path.join(OUT, "lrt.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def gen_conv():
@@ -697,6 +703,7 @@ elif __name__ == "__main__":
     gen_bbb()
     gen_bbb2()
     gen_lrt()
+    gen_lrt_tiled()
     gen_conv()
     gen_ivon()
     gen_ensemble()

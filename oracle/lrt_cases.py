@@ -21,3 +21,6 @@ def lrt_case_inputs(seed, b, i, o):
 
 
 LRT_CASES = [(101, 40, 300, 70), (102, 16, 2048, 182), (103, 128, 96, 200), (104, 64, 1024, 1100), (105, 5, 13, 50)]
+# batches ABOVE the fused op's 128 rows per launch (tests/golden/lrt_tiled.npz): one row past a tile, two whole tiles, seven
+# tiles + a ragged eighth -- BBBLinear(fused_linear_max_rows=...) runs them as row tiles of the same kernels
+LRT_TILED_CASES = [(201, 129, 96, 70), (202, 256, 300, 50), (203, 1000, 48, 24)]

@@ -1876,18 +1876,31 @@ def check_native_nodes_equal_python_nodes(ops, dev, native):
         native.lrt_linear(torch.randn(200, 13, device=dev), leaves[0], leaves[1], None, None, True, None, 1, 2)   # B > 128
 
 
-def test_bbb_linear_layer_matches_reference_layer(golden, backend, monkeypatch):
+@pytest.mark.parametrize("rows", ["up_to_128", "row_tiles", "above_128_default"])
+def test_bbb_linear_layer_matches_reference_layer(golden, backend, monkeypatch, rows):
     """bde.BBBLinear forward + backward (fused ops: bde_lrt_linear_fwd / bde_lrt_linear_bwd on the GPU, their CPU
     restatement in the checker backend) against the REFERENCE's BBBLinear on the same seeded inputs (lrt.npz: output and
-    all five gradients from the reference's autograd graph, at the UCI size, the iWildCam head, a wide layer)."""
+    all five gradients from the reference's autograd graph, at the UCI size, the iWildCam head, a wide layer).
+    "row_tiles": lrt_tiled.npz, batches of 129 / 256 / 1000 rows with BBBLinear(fused_linear_max_rows=1024): ceil(rows / 128)
+    launches of the same kernels, weight and bias gradients accumulated over the tiles (bbb_layers.py:61-80 at any batch);
+    "above_128_default": the same batches through a default-constructed layer (two stock GEMMs + fused element-wise passes)."""
     ops, dev = backend
     import beyond_deep_ensembles_amd.bbb_layers as L
     from oracle.lrt_cases import lrt_case_inputs
-    g = golden("lrt.npz")
+    g = golden("lrt.npz" if rows == "up_to_128" else "lrt_tiled.npz")
     prior = bde.GaussianPrior(0, 1.0)
+    fused_rows = []
+    real_fwd = ops.lrt_linear_fwd
+    monkeypatch.setattr(ops, "lrt_linear_fwd", lambda x, *a, **k: (fused_rows.append(x.shape[0]), real_fwd(x, *a, **k))[1])
+    native = L._native_nodes(ops)
+    if native is not None:
+        real_node = native.lrt_linear
+        monkeypatch.setattr(native, "lrt_linear", lambda x, *a, **k: (fused_rows.append(x.shape[0]), real_node(x, *a, **k))[1])
     for seed, b, i, o in g["cases"].tolist():
         x, w_mu, w_rho, b_mu, b_rho, eps, gout, probe = [T(a).to(dev) for a in lrt_case_inputs(seed, b, i, o)]
-        layer = bde.BBBLinear(i, o, prior, prior, _ops=ops).to(dev).train()
+        kw = dict(fused_linear_max_rows=1024) if rows == "row_tiles" else {}
+        layer = bde.BBBLinear(i, o, prior, prior, _ops=ops, **kw).to(dev).train()
+        del fused_rows[:]
         with torch.no_grad():
             layer.weight.mean.copy_(w_mu)
             layer.weight.rho.copy_(w_rho)
@@ -1896,6 +1909,9 @@ def test_bbb_linear_layer_matches_reference_layer(golden, backend, monkeypatch):
         monkeypatch.setattr(L, "normal_like", lambda t: eps.to(t.device))
         xin = x.clone().requires_grad_(True)
         out = layer(xin)
+        # which path ran: one fused launch, ceil(b / 128) of them, or none (the stock GEMMs)
+        want_rows = {"up_to_128": [b], "above_128_default": []}.get(rows, [128] * (b // 128) + ([b % 128] if b % 128 else []))
+        assert fused_rows == want_rows, (rows, b, fused_rows)
         leaves = [xin, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho]
         gx, gwm, gwr, gbm, gbr = [t.detach().cpu().double() for t in torch.autograd.grad(out, leaves, grad_outputs=gout)]
         t = f"c{seed}_"
@@ -2305,3 +2321,48 @@ def test_svgd_many_particles_one_apply_launch_equals_the_optimizer_loop(backend,
         # (the fused paths keep ONE shared counter; the per-parameter step tensors are refreshed when the state is taken)
         assert int(base_a.state_dict()["state"][0]["step"]) == int(base_b.state_dict()["state"][0]["step"]) == 60
     assert "particle_19" in sd_a["state"][0]
+
+
+def test_r6_bbb_linear_row_tiles_with_in_kernel_noise(backend):
+    """BBBLinear(rng="philox", fused_linear_max_rows=...) above 128 rows: every row tile draws its activations' noise inside its
+    own launch from its own Philox stream, and its backward launch REGENERATES that noise (nothing is stored).  Checked without
+    knowing the streams: the noise is recovered from the output (eps = (out - mean) / sqrt(var), mean and var from the stock
+    composition of bbb_layers.py:70-80), must look like a standard normal, must differ between tiles, and feeding it back as
+    SUPPLIED noise must reproduce output and all five gradients."""
+    ops, dev = backend
+    import beyond_deep_ensembles_amd.bbb_layers as L
+    torch.manual_seed(8)
+    prior = bde.GaussianPrior(0, 1.0)
+    b, i, o = 300, 40, 24
+    layer = bde.BBBLinear(i, o, prior, prior, rng="philox", fused_linear_max_rows=512, _ops=ops).to(dev).train()
+    with torch.no_grad():
+        layer.weight.rho.add_(1.5)                                     # a variance large enough to recover the noise accurately
+    x = torch.randn(b, i, device=dev)
+    gout = torch.randn(b, o, device=dev)
+
+    def run(noise=None):
+        xin = x.clone().requires_grad_(True)
+        leaves = [xin, layer.weight.mean, layer.weight.rho, layer.bias.mean, layer.bias.rho]
+        real = L.normal_like
+        if noise is not None:
+            # supplied noise (the layer asks normal_like for it whenever the parameter does not draw inside the kernels)
+            layer.weight.noise_source = lambda t: torch.zeros_like(t)
+            L.normal_like = lambda t: noise.reshape(t.shape)
+        try:
+            out = layer(xin)
+            return out.detach(), [t.detach() for t in torch.autograd.grad(out, leaves, grad_outputs=gout)]
+        finally:
+            layer.weight.noise_source, L.normal_like = None, real
+    out, grads = run()
+    with torch.no_grad():
+        w, bb = layer.weight, layer.bias
+        mean = F.linear(x, w.mean, bb.mean)
+        var = F.linear((x ** 2).clamp(min=1e-4), (w.std ** 2).clamp(min=1e-4), (bb.std ** 2).clamp(min=1e-4))
+        eps = (out - mean) / var.sqrt()
+    assert abs(float(eps.mean())) < 0.05 and abs(float(eps.std()) - 1.0) < 0.05, (float(eps.mean()), float(eps.std()))
+    assert not torch.allclose(eps[:128], eps[128:256], atol=1e-2)       # tiles do not share a stream
+    assert not torch.allclose(eps[:44], eps[256:300], atol=1e-2)
+    out2, grads2 = run(eps)
+    torch.testing.assert_close(out2, out, rtol=1e-4, atol=1e-5)
+    for a, c in zip(grads, grads2):
+        torch.testing.assert_close(c, a, rtol=2e-3, atol=2e-4 * float(a.abs().max()))

@@ -5,7 +5,7 @@ R=${1:-r03}
 O=gpurun_out/prof_$R; mkdir -p $O
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 export PYTHONDONTWRITEBYTECODE=1
-# (a) exactly the driver's command
+# (a) exactly the driver's command (under rocprofv3 bench.py measures everything in ONE process: being_profiled())
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_full -o t -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-live-traffic > $O/bench_full_under_rocprof.json 2> $O/bench_full.err; echo "trace_full rc=$?"
 # (b) the timed loop alone: every launch of the three SVGD kernels in the CSV belongs to the headline
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_main -o t -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-live-traffic > $O/bench_main_under_rocprof.json 2> $O/bench_main.err; echo "trace_main rc=$?"
