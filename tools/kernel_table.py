@@ -21,7 +21,8 @@ BEGIN, END = "<!-- KERNEL-TABLE:BEGIN (tools/kernel_table.py --write) -->", "<!-
 # device status keys
 R3 = "yes -- green in the driver's r03 suite (GPUTEST_r03), source unchanged since"
 R4B = "yes -- green in builder calls r4b/r4c (profiles/r04_pytest_gpu_call_{b,c}.log) after its last change"
-NEVER = "**no** -- changed after the last GPU call (pool closed since round 4); runs on the CPU model only"
+NEVER = ("**no** -- changed after the last GPU call (pool closed since round 4); runs on the CPU model only; NOT a default path "
+         "until `device_verified.json` records a green device run of these sources (§0)")
 
 # kernel -> (replaces, algorithmic work per launch, last device measurement, device status, test)
 ROWS = {
@@ -51,12 +52,12 @@ ROWS = {
     "svgd_gram_finish_kernel": ("dimension-sharded exchange: slice Gram partials → fp64 block", "257 doubles / rank", "latency", R3,
                                 "`test_svgd_sharded_hip_two_ranks_one_device[alltoall*]`"),
     "svgd_kstats_gmat_kernel": ("the ranks' fp64 blocks summed in rank order → identical statistics on every rank", "latency", "—", R3, "same test"),
-    "sum_scalars_kernel": ("the returned loss (`svgd.py:66,72,105`): M−1 torch adds and the division by M → one launch (round 5)", "M scalars", "unmeasured",
-                           "**no** -- new in round 5; CPU model green", "`test_r5_sum_scalars_is_the_sequential_fp32_sum`"),
+    "sum_scalars_kernel": ("the returned loss (`svgd.py:66,72,105`): M−1 torch adds and the division by M → one launch (round 5; round 6: rounds like torch's GPU division, sum · fl(1/M))", "M scalars", "unmeasured",
+                           "**no** -- new in round 5; CPU model green; behind the `mean_scalars` gate (default: torch's adds)", "`test_r5_sum_scalars_is_the_sequential_fp32_sum`"),
     # ---- SVGD, small models (BASELINE configs[1])
     "svgd_step_small_kernel": ("the whole of `svgd.py:86-103` for M ≤ 8, D ≤ 524,288: two launches of one kernel", "`12·M·D` B (one pass over P)",
                                "14.6 µs fused SGD at D=273,610 (two launches), r4 bench line -- measured BEFORE the protocol deletion (−223 lines)", NEVER,
-                               "`test_svgd_small_model_kernel`, `test_svgd_small_model_fused_step`"),
+                               "`test_svgd_small_model_kernel`, `test_svgd_small_model_fused_step`, `test_svgd_every_particle_count_small_model_kernel`, `test_svgd_trajectory[hip-*-small*]`"),
     # ---- SWAG
     "swag_update_kernel": ("`swag.py:100-104` (mean, second moment, ring row)", "`24·D` B", "0.0865 ms = 6.62 TB/s (0.83); r4 bench line", R4B,
                            "`test_swag_update_bit_exact` (bit-exact)"),
