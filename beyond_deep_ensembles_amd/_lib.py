@@ -22,6 +22,7 @@ SIGNATURES = {
     "bde_version": (c_int, []),
     "bde_arch": (c_char_p, []),
     "bde_init": (c_int, []),
+    "bde_init_optional_failures": (c_int, []),
     "bde_svgd_ws_bytes": (c_size_t, [c_int]),
     "bde_svgd_kstat_floats": (c_size_t, [c_int]),
     "bde_svgd_gram": (c_int, [_P, c_int, c_int64, c_int64, _P, _P]),

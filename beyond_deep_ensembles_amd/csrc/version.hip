@@ -20,13 +20,30 @@ int bde_internal_load_swag_batched(void);
 // launch of one of its kernels; a process that is about to start communication threads (torch.distributed) or to share
 // the device with other processes calls this first, from one thread, so that no kernel's first launch coincides with
 // them (profiles/r03_first_launch_*.txt).  Idempotent, cheap after the first call; needs a visible device.
+//
+// The translation units whose kernels have been green on an MI355X must load: their failure is bde_init()'s return code.
+// The ones that have NOT (the small-model SVGD kernel, the fused convolution kernels -- no default call launches them,
+// device_verified.py / conv_profit.py) are uploaded as well, but a failure there is only RECORDED
+// (bde_init_optional_failures): one bad code object among the never-run kernels must not take every verified kernel, the
+// tests, smoke() and the bench down at construction.
+#include <atomic>
+static std::atomic<unsigned> g_optional_failures{0};
+
 extern "C" int bde_init(void) {
-  int (*const loaders[])(void) = {bde_internal_load_conv_lrt,   bde_internal_load_conv_lrt_bwd, bde_internal_load_gauss,      bde_internal_load_ivon,       bde_internal_load_lrt,
-                                  bde_internal_load_lrt_bwd,    bde_internal_load_svgd,       bde_internal_load_svgd_fused,
-                                  bde_internal_load_svgd_small, bde_internal_load_swag,       bde_internal_load_swag_batched};
-  for (auto load : loaders) {
+  int (*const required[])(void) = {bde_internal_load_gauss, bde_internal_load_ivon,       bde_internal_load_lrt,  bde_internal_load_lrt_bwd,
+                                   bde_internal_load_svgd,  bde_internal_load_svgd_fused, bde_internal_load_swag, bde_internal_load_swag_batched};
+  for (auto load : required) {
     const int rc = load();
     if (rc) return rc;
   }
+  int (*const optional[])(void) = {bde_internal_load_svgd_small, bde_internal_load_conv_lrt, bde_internal_load_conv_lrt_bwd};
+  unsigned failed = 0;
+  for (unsigned i = 0; i < 3; ++i)
+    if (optional[i]() != 0) failed |= 1u << i;
+  g_optional_failures.store(failed, std::memory_order_relaxed);
   return 0;
 }
+
+// Bit mask of the device-unverified translation units whose code object did not load in the last bde_init():
+// 1 svgd_small.hip, 2 conv_lrt.hip, 4 conv_lrt_bwd.hip; 0 = everything is resident.
+extern "C" int bde_init_optional_failures(void) { return static_cast<int>(g_optional_failures.load(std::memory_order_relaxed)); }

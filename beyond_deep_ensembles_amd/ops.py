@@ -177,6 +177,12 @@ class HipOps:
             return
         with torch.cuda.device(index):
             _check(self.lib.bde_init(), "bde_init")
+            failed = int(self.lib.bde_init_optional_failures())
+        if failed:
+            import warnings
+            names = [n for bit, n in enumerate(("svgd_small.hip", "conv_lrt.hip", "conv_lrt_bwd.hip")) if failed >> bit & 1]
+            warnings.warn(f"libbde_hip.so: the code object(s) of {', '.join(names)} did not load on device {index}; their kernels "
+                          "are opt-in (device_verified.py / conv_profit.py) and will fail when launched -- every default path is unaffected")
         HipOps._loaded_devices.add(index)
 
     # ------------------------------------------------------------ SVGD --

@@ -50,6 +50,10 @@ const char* bde_arch(void);
  * processes share the device, so that no first launch coincides with them.  Idempotent.  (No reference counterpart:
  * PyTorch loads its kernels the same lazy way.) */
 int bde_init(void);
+/* bde_init() fails only for the code objects whose kernels have been verified on a device.  The ones that have not (no default
+ * call launches them: the small-model SVGD kernel, the fused convolution kernels) are uploaded too, but a failure there is
+ * only recorded here -- bit 0 svgd_small, bit 1 conv_lrt, bit 2 conv_lrt_bwd of the LAST bde_init(); 0 = all resident. */
+int bde_init_optional_failures(void);
 
 /* ------------------------------------------------------------------ SVGD --
  * One SVGD posterior update over M flattened particles P [M, ld] with
