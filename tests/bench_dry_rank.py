@@ -3,7 +3,9 @@
 The same stand-ins as that file's `dry` fixture -- the product's HipOps over the STUB library (every C-ABI entry point returns at
 once), torch.cuda's events / synchronisation replaced by host clocks, `torch.device("cuda", i)` = the CPU, sizes scaled down --
 set with plain assignments (this is a process of its own), then bench.main() with the arguments given.  RANK / WORLD_SIZE /
-MASTER_* and BDE_BENCH_BACKEND=gloo come from the caller, exactly as torch.distributed.run would set them."""
+MASTER_* and BDE_BENCH_BACKEND=gloo come from the caller, exactly as torch.distributed.run would set them.  Without them this is
+`python bench.py` at N = 1: the GPU-free parent, whose headline / extras children are started through this same file
+(test_the_whole_process_tree_of_the_default_run)."""
 import contextlib
 import importlib.util
 import os
@@ -72,7 +74,15 @@ def main():
     bench.StreamProbes.__init__ = lambda self: setattr(self, "lib", None)
     bench.time_loop = lambda fn, iters, warm=3: (fn(), 1e-3)[1]
     bench.torch = _TorchOnCpu()
-    bench.D_RESNET50 = 200_004               # with `--dim 200004`: the "ResNet-50 size" branches (SWAG rates summed over the ranks) run too
+    # the flat-weight sizes scaled down (the code paths do not depend on them), also where they are default arguments
+    small = {bench.D_RESNET50: 200_004, bench.D_DENSENET: 120_002}
+    for fn in list(vars(bench).values()):
+        if callable(fn) and getattr(fn, "__defaults__", None) and getattr(fn, "__module__", None) == "bench":
+            fn.__defaults__ = tuple(small.get(v, v) if isinstance(v, int) else v for v in fn.__defaults__)
+    bench.D_RESNET50, bench.D_DENSENET = 200_004, 120_002
+    shapes = bench.resnet50_shapes
+    bench.resnet50_shapes = lambda *a, **k: [tuple(v // 8 if v >= 64 else v for v in sh) for sh in shapes(*a, **k)]
+    bench.__file__ = os.path.abspath(__file__)       # the parent's children re-enter through THIS file (same stand-ins)
     bench.main()
 
 

@@ -425,3 +425,32 @@ def test_two_ranks_print_one_line(tmp_path):
     for mode in ("allgather", "pipelined", "alltoall"):
         assert d["exchange"][mode]["step_ms"] > 0, mode
     assert d["swag"]["samples_per_s"] == 2000.0 and d["swag"]["samples_per_s_batched_S30"] == 60000.0    # 2 ranks x the stand-in's 1 ms: summed
+
+
+def test_the_whole_process_tree_of_the_default_run(tmp_path):
+    """`python bench.py` at N = 1 with REAL children: tests/bench_dry_rank.py is bench.main() over the CPU stand-ins, and the
+    parent it becomes starts its headline and extras children through the same file -- parent -> `--headline-child` (timed
+    region, roofline, SWAG, the reference's op sequence) -> CPU baseline in the parent -> `--extras-child` (every section) ->
+    ONE merged line.  The probe library is device code: its launch fails here (-2), which must show up as
+    roofline.probe_error beside an intact line -- the guard of the first optional section, exercised for real."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dry_rank.py"), "--steps", "2", "--warmup", "1", "--blocks", "2",
+                        "--no-live-traffic"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and "headline_child_error" not in d
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+    if os.path.exists(os.path.join(ROOT, "bench_probe", "libbde_bench_probe.so")):
+        assert "probe_error" in d["roofline"] and "frac_of_probe" not in d["roofline"]
+    assert d["swag"]["samples_per_s"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["gpu_torch_baseline"]["svgd_steps_per_s"] > 0
+    extra = d["extra"]
+    assert "error" not in extra, extra.get("error")
+    for key in ("svgd_combine_M8_resnet50", "swag_sample_batched_K20_S30_resnet50", "svgd_shell_step_ms", "svgd_shell_step_real_grads_ms",
+                "svgd_reference_constructor_step", "other_shell_steps_ms", "other_baseline_configs"):
+        assert key in extra, (key, sorted(extra))
+    assert not [k for k, v in extra.items() if isinstance(v, dict) and "error" in v]
