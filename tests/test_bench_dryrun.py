@@ -95,7 +95,8 @@ def test_config_extras_and_shell_steps_run_through(dry):
     for key in ("svgd_step_cifar_resnet20_shell_fused", "svgd_step_cifar_resnet20_shell_fused_small_kernel",
                 "svgd_step_cifar_resnet20_shell_unfused_small_kernel", "svgd_step_cifar_resnet20_shell_fused_graph_replay"):
         assert cfg[key]["ms"] > 0, key
-    assert cfg["svgd_step_cifar_resnet20_shell_fused"]["small_model_kernel"] is False      # the default: device-verified kernels only
+    from beyond_deep_ensembles_amd import device_verified             # the default: device-verified kernels only
+    assert cfg["svgd_step_cifar_resnet20_shell_fused"]["small_model_kernel"] is device_verified.enabled("svgd_small")
     assert cfg["svgd_step_cifar_resnet20_shell_fused_small_kernel"]["small_model_kernel"] is True
     assert any(k.startswith("bbb_conv2d_fwd_bwd") for k in cfg), sorted(cfg)
     assert all("fused_kernels" in v for k, v in cfg.items() if k.startswith("bbb_conv2d_fwd_bwd"))
