@@ -127,6 +127,15 @@ def main():
     reset = lambda: None
     measure("SVGD 8 particles, Adam, default ctor (fused)", lambda p: bde.SVGDOptimizer(
         p, reset, torch.optim.Adam(p, lr=3e-5), particle_count=8, dataset_size=50000, _ops=ops), profile=a.profile)
+    small = dict(single_launch="two", host_fast_paths=True)          # what the defaults become once device_verified.json holds records
+    measure("SVGD 8 particles, Adam, small-model kernel + native host paths", lambda p: bde.SVGDOptimizer(
+        p, reset, torch.optim.Adam(p, lr=3e-5), particle_count=8, dataset_size=50000, _ops=ops, **small))
+    measure("SVGD 8 particles, nesterov SGD, default ctor (fused)", lambda p: bde.SVGDOptimizer(
+        p, reset, torch.optim.SGD(p, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=3e-4), particle_count=8,
+        dataset_size=50000, _ops=ops))
+    measure("SVGD 8 particles, nesterov SGD, small-model kernel + native paths", lambda p: bde.SVGDOptimizer(
+        p, reset, torch.optim.SGD(p, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=3e-4), particle_count=8,
+        dataset_size=50000, _ops=ops, **small))
     measure("SVGD 8 particles, nesterov SGD, fused + reuse_gram", lambda p: bde.SVGDOptimizer(
         p, reset, torch.optim.SGD(p, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=3e-4), particle_count=8,
         dataset_size=50000, fuse_base_optimizer=True, reuse_gram=True, _ops=ops), profile=False)
