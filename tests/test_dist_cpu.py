@@ -136,6 +136,31 @@ def test_svgd_sharded_equals_single_process(tmp_path, m, fuse, kw):
     np.testing.assert_allclose(r0["losses"], np.array(losses), rtol=1e-6)
 
 
+@pytest.mark.parametrize("world,fuse,kw", [
+    (8, True, {}), (8, True, {"exchange_chunks": 3}), (8, True, {"exchange": "alltoall"}), (8, False, {}),
+    (4, True, {"exchange_chunks": 2, "overlap_backward": True}), (4, True, {"exchange": "alltoall", "base": "adam"}),
+], ids=["8_ranks_allgather_fused", "8_ranks_pipelined_fused", "8_ranks_alltoall", "8_ranks_allgather_torch_loop",
+        "4_ranks_overlap_fused", "4_ranks_alltoall_adam"])
+def test_svgd_eight_particles_sharded_over_four_and_eight_ranks(tmp_path, world, fuse, kw):
+    """BASELINE configs[3] / north_star: 8 particles sharded ONE per rank over 8 ranks (two per rank over 4), every exchange
+    mode -- the all-gather of the gradient rows, its chunk pipeline, the dimension-sharded all-to-all pair -- over gloo: every
+    rank runs forward / backward for its own particle(s) only, all ranks end every step with bit-identical particles and
+    losses, and the trajectory is the single-process one.  (What the driver's 8-GPU scaling run executes over RCCL.)"""
+    from tests.oracle_ops import OracleOps
+    m = 8
+    mp.spawn(_svgd_worker, args=(world, _free_port(), m, fuse, tuple(kw.items()), str(tmp_path)), nprocs=world, join=True)
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in ranks[1:]:
+        np.testing.assert_array_equal(ranks[0]["particles"], r["particles"])
+        np.testing.assert_array_equal(ranks[0]["losses"], r["losses"])
+    assert all(int(r["fwd"]) == 3 * m // world for r in ranks)
+    torch.set_num_threads(1)
+    model, opt = _make(100, m, OracleOps(), fuse=fuse, base=kw.get("base", "sgd"))
+    losses = _run_steps(model, opt)
+    np.testing.assert_allclose(ranks[0]["particles"], opt.particles.numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ranks[0]["losses"], np.array(losses), rtol=1e-6)
+
+
 def _forced_worker(rank, world, port, m, fuse, kw, out_dir):
     _svgd_worker(rank, world, port, m, fuse, kw, out_dir)
 
