@@ -397,8 +397,9 @@ def test_sections_behind_the_timed_region_are_guarded_and_checkpointed(dry, monk
     assert seen[-1] == json.loads(json.dumps(res))
 
 
-def test_two_ranks_print_one_line(tmp_path):
-    """`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as the driver's scaling run launches it, on the CPU: two
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_ranks_print_one_line(tmp_path, world):
+    """`torch.distributed.run --nproc-per-node N bench.py --gpus N` (N = 2, 8) as the driver's scaling run launches it, on the CPU: N
     processes (tests/bench_dry_rank.py: stub library, gloo), the product's multi-GPU update in all three exchange modes timed by
     each rank, barriers and the MAX reduction over ranks -- rank 0 prints the ONE line (n_gpus 2, scaling "strong", `exchange`
     with every mode), rank 1 prints nothing, both exit 0."""
@@ -409,23 +410,24 @@ def test_two_ranks_print_one_line(tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   BDE_BENCH_BACKEND="gloo", BDE_BENCH_DEVICE="0", OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_dry_rank.py"), "--gpus", "2", "--steps", "2",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BDE_BENCH_BACKEND="gloo", BDE_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_dry_rank.py"), "--gpus", str(world), "--steps", "2",
                                        "--warmup", "1", "--blocks", "2", "--dim", "200004"], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     outs = [p.communicate(timeout=600) for p in procs]
-    assert [p.returncode for p in procs] == [0, 0], (outs[0][1].decode()[-2000:], outs[1][1].decode()[-2000:])
+    assert [p.returncode for p in procs] == [0] * world, (outs[0][1].decode()[-2000:], outs[-1][1].decode()[-2000:])
     lines = [ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and not [ln for ln in outs[1][0].decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for o in outs[1:] for ln in o[0].decode().splitlines() if ln.startswith("{")]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["particles_per_rank"] == 4
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["particles_per_rank"] == 8 // world
     assert set(d["exchange"]) >= {"allgather", "pipelined", "alltoall", "headline", "best"} and d["exchange"]["headline"] == "allgather"
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
     for mode in ("allgather", "pipelined", "alltoall"):
         assert d["exchange"][mode]["step_ms"] > 0, mode
-    assert d["swag"]["samples_per_s"] == 2000.0 and d["swag"]["samples_per_s_batched_S30"] == 60000.0    # 2 ranks x the stand-in's 1 ms: summed
+    # every rank's stand-in rate (1 ms per call) summed over the ranks: the aggregate is the whole job's
+    assert d["swag"]["samples_per_s"] == 1000.0 * world and d["swag"]["samples_per_s_batched_S30"] == 30000.0 * world
 
 
 def test_the_whole_process_tree_of_the_default_run(tmp_path):
