@@ -769,6 +769,54 @@ def test_swag_prefetch_equals_one_by_one(backend):
     assert o2._prefetched is None and not o2.state["__params_dirty"]
 
 
+def test_r6_cifar_resnet20_swag_k20_thirty_samples_through_the_shell(backend):
+    """BASELINE configs[2] at its real size through the product shell: the 96 parameter tensors of the reference's CIFAR
+    ResNet-20 (273,610 elements), SwagOptimizer with K = 20 deviation columns (22 moment updates: the ring has wrapped),
+    then DeepEnsemble.predict with 30 posterior samples -- one batched sampling pass (rng="philox") served sample by sample.
+    Every sample is checked against the ORACLE's swag.py:57,107-114 restatement fed with the same Philox noise (drawn by the
+    checker's Philox, tests/oracle_ops.py), from the statistics the optimizer itself accumulated (which must equal the
+    oracle's moment recursion bit for bit, swag.py:98-104); the 30 samples are pairwise different and the training weights
+    come back afterwards."""
+    import oracle.bde_oracle as O
+    ops, dev = backend
+    torch.manual_seed(40)
+    shapes = _cifar_resnet20_shapes()
+    params = [nn.Parameter(torch.randn(sh, device=dev) * 0.05) for sh in shapes]
+    d, k, s_count = sum(p.numel() for p in params), 20, 30
+    assert d == 273_610
+    base = torch.optim.SGD(params, lr=0.05, momentum=0.9)
+    opt = bde.SwagOptimizer(params, base, update_interval=1, start_epoch=0, deviation_samples=k, rng="philox", seed=11, _ops=ops)
+    st = O.swag_init(flat(params).cpu(), k)
+    coef = [torch.randn(sh, device=dev) * 0.01 for sh in shapes]
+    for n in range(1, 23):
+        opt.step(lambda: sum((c * p).sum() + 0.05 * (p * p).sum() for c, p in zip(coef, params)), lambda l: l.backward())
+        st.updates = n
+        O.swag_moment_update(st, flat(params).cpu())
+    assert torch.equal(opt.mean_vector().cpu(), st.mean) and torch.equal(opt.sq_vector().cpu(), st.sq_weights)
+    assert torch.equal(opt.deviations_dk().cpu(), st.deviations)
+    trained = flat(params).cpu().clone()
+    model = nn.Module()
+    model.p = nn.ParameterList(params)
+    seen = bde.DeepEnsemble([(model, opt)]).predict(lambda m: flat(m.p).cpu().clone(), s_count)
+    assert seen.shape == (s_count, d)
+    from tests.oracle_ops import _philox
+    from oracle import philox as PH
+    for s in range(s_count):
+        # the noise of posterior sample s from the numpy Philox checker: one stream per sample (stream id = the optimizer's
+        # sample counter), eps_W from the low-rank domain, eps_D from the diagonal one -- swag.py:57's draw order
+        eps_w = _philox(opt.seed, s, k, PH.DOMAIN_LOWRANK, PH.SWAG_ROUNDS)         # (the samplers' own round count: 7)
+        eps_d = _philox(opt.seed, s, d, rounds=PH.SWAG_ROUNDS)
+        want = O.swag_sample(st.mean, st.sq_weights, st.deviations, eps_w, eps_d)
+        assert torch.allclose(seen[s], want, rtol=3e-5, atol=3e-6), (s, float((seen[s] - want).abs().max()))
+    # samples are draws around the SWAG mean with the posterior's spread, all different
+    spread = (seen - st.mean).std(dim=0).mean().item()
+    diag = (0.5 * (torch.relu(st.sq_weights - st.mean ** 2) + 1e-6)).sqrt().mean().item()
+    assert 0.5 * diag < spread < 4.0 * diag + st.deviations.abs().mean().item(), (spread, diag)
+    assert len({float(seen[s, 0]) for s in range(s_count)}) == s_count
+    opt.step(lambda: sum((p * p).sum() for p in params) * 0.0, lambda l: l.backward())      # the next step restores the weights
+    assert not opt.state["__params_dirty"]
+
+
 # ------------------------------------------------------------------- BBB --
 class LocalReparamLinear(nn.Module):
     """Test model layer: the local-reparameterisation forward of the reference's
