@@ -127,3 +127,8 @@ def status() -> dict:
         else:
             out[name] = "verified"
     return out
+
+
+if __name__ == "__main__":                       # python -m beyond_deep_ensembles_amd.device_verified
+    for _name, _state in status().items():
+        print(f"{_name:16s} {_state:48s} {FAMILIES[_name][1][:110]}")
