@@ -38,8 +38,10 @@ def main():
     probe = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_order_probe.py")], cwd=ROOT, stdout=subprocess.PIPE,
                            check=True, timeout=600)
     tests = json.loads(probe.stdout.decode())["tests"]
-    import torch
-    device = torch.cuda.get_device_name(0) if torch.cuda.is_available() else None
+    # this process never touches the GPU (it only starts children): the device's name comes from a child too
+    who = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.get_device_name(0) if torch.cuda.is_available() else '')"],
+                         cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    device = (who.stdout.decode().strip().splitlines() or [""])[-1] or None
     if device is None:
         raise SystemExit("tools/device_verify.py needs a GPU: a record is a statement about a device run")
     table = {"families": {}, "note": "written by tools/device_verify.py"}
