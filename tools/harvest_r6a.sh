@@ -11,6 +11,20 @@ for f in bench_plain.json bench_torchrun1.json; do
   [ -s "$O/$f" ] && { cp "$O/$f" "profiles/r06_$f"; echo "filed profiles/r06_$f"; }
 done
 [ -d "$O/verify" ] && for f in $O/verify/*.log; do tail -c 20000 "$f" > "profiles/r06_verify_$(basename ${f%.log}).txt"; done
+# the rocprofv3 kernel traces of the same bench command (tools/gpu_r6_first.sh): stats CSVs + the JSON lines of the traced runs
+P=gpurun_out/prof_r06/keep
+if [ -d "$P" ]; then
+  for f in $P/*; do cp "$f" "profiles/r06_$(basename $f)"; echo "filed profiles/r06_$(basename $f)"; done
+  python - <<'P2'
+import csv, glob
+for f in glob.glob("profiles/r06_trace_main_kernel_stats.csv"):
+    for row in csv.DictReader(open(f)):
+        if "svgd_combine_kernel<8, true>" in row["Name"]:
+            avg_ns = float(row["AverageNs"]); nb = 12 * 8 * 23_880_950
+            print(f"roofline from the trace: svgd_combine_kernel<8, true> calls {row['Calls']} avg {avg_ns/1e3:.2f} us -> "
+                  f"{nb/avg_ns:.1f} GB/s = {nb/avg_ns/8000:.3f} of 8 TB/s")
+P2
+fi
 if [ -s gpurun_out/device_verified.json ]; then
   python - <<'P'
 import json
