@@ -1,0 +1,209 @@
+"""The optimizers at the keyword values the reference's own experiment files use ("kwarg values actually
+exercised"), next to the IMPORTED reference on the same seeds, data and noise (build container only: skipped where
+/root/reference is absent, e.g. on the GPU box).
+
+Two backends behind our shells: "oracle" (the CPU checker) and "emu" -- the product's HipOps over the kernel SOURCES compiled
+for the CPU execution model of tests/hip_emu, so the comparison is reference -> C ABI -> kernels without the oracle in
+between.  What a default-constructed object launches (the streaming SVGD kernels, the SWAG / iVON kernels) is what runs.
+
+Operating points (reference file:line):
+  SVGD   particle_count 5, kernel_grad_scale 1.0, l2_reg 0.0 / dataset_size 129809 over Adam(lr 3e-5)  iwildcam.yaml:213-221
+         l2_reg 0.01 / dataset_size 269038 over Adam(lr 1e-3)                                          uci.yaml:234-242
+         SGD(lr .05, momentum .9, nesterov, wd 3e-4), dataset_size 50000                               cifar.yaml:218-223
+  SWAG   deviation_samples 30 (iwildcam.yaml:97, cifar.yaml:72) and 10 (civil.yaml), start_epoch > 0
+  iVON   lr 1e-4, prior_prec 50, damping 1e-3, augmentation 10, mc_samples 2, dataset_size 50000       cifar.yaml:163-168
+         lr 3e-5, prior_prec 100, damping 1e-3, augmentation 1, mc_samples 2, dataset_size 129809      iwildcam.yaml:199-204
+Tolerances are the ones of tests/test_against_reference_import.py: integer schedule and SWAG moments bit-exact, SVGD rtol
+1e-5 (fp32 reduction order of the Gram / kernel sums differs from ATen's).  iVON: the checker (ATen on this CPU) is
+bit-identical to the reference; the KERNEL is bit-identical to the IEEE-754 sequence of ivorn.py:108 (pinned against numpy
+below) and therefore up to one ulp of sqrt away from this container's reference run: torch's CPU `sqrt` is MKL's vmsSqrt in
+VML_HA mode (< 1 ulp, not correctly rounded; e.g. sqrt(fl32 0x1.58e2d4p+9) = 0x1.a43758p+4, correctly rounded
+0x1.a4375ap+4), which shows up in about one noise element in 400 and from there at the 1e-7 level in the trajectory."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "algos")), reason="reference checkout absent")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        import src.algos.svgd as svgd
+        import src.algos.swag as swag
+        import src.algos.ivorn as ivon
+        import src.algos.util as util
+    finally:
+        sys.path.remove(REF)
+    return {"svgd": svgd, "swag": swag, "ivon": ivon, "util": util}
+
+
+@pytest.fixture(params=["oracle", "emu"])
+def backend(request):
+    if request.param == "oracle":
+        from tests.oracle_ops import OracleOps
+        yield OracleOps()
+        return
+    from tests.hip_emu import build, emu_ops
+    if not build.available():
+        pytest.skip("no host clang / HIP headers to build the CPU model with")
+    with emu_ops.emulated(emu_ops.ALL) as ops:
+        yield ops
+
+
+def mlp(seed, hidden=9):
+    torch.manual_seed(seed)
+    return nn.Sequential(nn.Linear(6, hidden), nn.Tanh(), nn.Linear(hidden, 2))
+
+
+def flat(ps):
+    return torch.cat([p.detach().reshape(-1) for p in ps])
+
+
+def data(seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(24, 6, generator=g), torch.randn(24, 2, generator=g)
+
+
+SVGD_POINTS = {
+    "iwildcam": dict(l2_reg=0.0, dataset_size=129809, base=lambda ps: torch.optim.Adam(ps, lr=3e-5, weight_decay=0)),
+    "uci": dict(l2_reg=0.01, dataset_size=269038, base=lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=0)),
+    "cifar": dict(l2_reg=3e-4, dataset_size=50000,
+                  base=lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)),
+}
+
+
+@pytest.mark.parametrize("point", sorted(SVGD_POINTS))
+def test_svgd_at_the_reference_yaml_values(ref, backend, point):
+    """svgd.py:44-105 with particle_count 5 / kernel_grad_scale 1.0 and each experiment's l2_reg, dataset_size and base
+    optimizer: four steps, every particle row after the last one and every returned loss."""
+    import beyond_deep_ensembles_amd as bde
+    torch.set_num_threads(1)
+    cfg = SVGD_POINTS[point]
+    x, y = data(11)
+    results = []
+    for which in ("ref", "ours"):
+        model = mlp(3)
+        torch.manual_seed(103)             # the reset closure consumes the same RNG stream in both runs
+        kw = dict(particle_count=5, dataset_size=cfg["dataset_size"], l2_reg=cfg["l2_reg"], kernel_grad_scale=1.0)
+        if which == "ref":
+            opt = ref["svgd"].SVGDOptimizer(model.parameters(), lambda: ref["util"].reset_model_params(model),
+                                            cfg["base"](model.parameters()), **kw)
+        else:
+            opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model),
+                                    cfg["base"](model.parameters()), _ops=backend, **kw)
+        losses = []
+        for t in range(4):
+            xb, yb = x[(t % 3) * 8:(t % 3 + 1) * 8], y[(t % 3) * 8:(t % 3 + 1) * 8]
+            losses.append(float(opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())))
+        params = list(model.parameters())
+        parts = torch.stack([flat([opt.state[p][f"particle_{i}"] for p in params]) for i in range(5)])
+        results.append((parts, losses))
+    np.testing.assert_allclose(results[1][0].numpy(), results[0][0].numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(results[1][1], results[0][1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("k,start_epoch,interval", [(30, 1, 1), (10, 2, 2), (30, 0, 3.7)])
+def test_swag_at_the_reference_yaml_values(ref, backend, k, start_epoch, interval):
+    """swag.py:15-114 with deviation_samples 30 / 10: fewer updates than columns (the ring is partly zero, Q9: the factor stays
+    sqrt(2 (K - 1))) and, for K = 10, more updates than columns (the ring wraps).  Schedule and moments bit-exact; the sample
+    with the reference's random stream."""
+    import beyond_deep_ensembles_amd as bde
+    torch.set_num_threads(1)
+    x, y = data(21)
+    outs = []
+    for which in ("ref", "ours"):
+        model = mlp(5, hidden=5)
+        base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)
+        kw = dict(update_interval=interval, start_epoch=start_epoch, deviation_samples=k)
+        opt = ref["swag"].SwagOptimizer(model.parameters(), base, **kw) if which == "ref" else \
+            bde.SwagOptimizer(model.parameters(), base, _ops=backend, **kw)
+        for epoch in range(5):
+            for t in range(6):
+                xb, yb = x[(t % 3) * 8:(t % 3 + 1) * 8], y[(t % 3) * 8:(t % 3 + 1) * 8]
+                opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+            opt.complete_epoch()
+        torch.manual_seed(7)
+        opt.sample_parameters()
+        sample = flat(list(model.parameters()))
+        opt.step(lambda: F.mse_loss(model(x[:8]), y[:8]), lambda l: l.backward())      # restores, then steps
+        after = flat(list(model.parameters()))
+        if which == "ref":
+            stats = (opt.state["__mean"], opt.state["__sq_weights"], opt.state["__deviations"])
+        else:
+            stats = (opt.mean_vector(), opt.sq_vector(), opt.deviations_dk())
+        counters = (opt.state["__epoch"], opt.state["__steps_since_swag_start"], opt.state["__updates"])
+        outs.append(([s.cpu() for s in stats], counters, sample, after))
+    assert outs[0][1] == outs[1][1]
+    assert outs[0][1][2] > 0
+    for a, b in zip(outs[0][0], outs[1][0]):
+        np.testing.assert_array_equal(a.numpy(), b.numpy())
+    # the sample: mean + W eps_W + sqrt(diag) eps_D on the reference's noise.  The checker repeats ATen's order of operations;
+    # the kernel sums the K low-rank terms in its own order (tests/test_ops_gpu.py::test_swag_sample_golden_and_oracle: 1e-5)
+    np.testing.assert_allclose(outs[1][2].numpy(), outs[0][2].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(outs[0][3].numpy(), outs[1][3].numpy())
+
+
+@pytest.mark.parametrize("point,kw", [
+    ("cifar", dict(lr=1e-4, prior_prec=50, damping=1e-3, augmentation=10, mc_samples=2, dataset_size=50000)),
+    ("iwildcam", dict(lr=3e-5, prior_prec=100, damping=1e-3, augmentation=1, mc_samples=2, dataset_size=129809)),
+    ("uci", dict(lr=1e-3, prior_prec=1, damping=1e-3, augmentation=1, mc_samples=5, dataset_size=455))])
+def test_ivon_at_the_reference_yaml_values(ref, backend, point, kw):
+    """ivorn.py:15-127 at the experiments' values: four steps, mean / precision / live parameters bit-identical."""
+    import beyond_deep_ensembles_amd as bde
+    torch.set_num_threads(1)
+    x, y = data(31)
+    outs = []
+    for which in ("ref", "ours"):
+        model = mlp(7, hidden=5)
+        opt = ref["ivon"].iVONOptimizer(model.parameters(), **kw) if which == "ref" else \
+            bde.iVONOptimizer(model.parameters(), _ops=backend, **kw)
+        torch.manual_seed(55)            # rng="torch": one normal_like per tensor, in parameter order, as the reference
+        losses = []
+        for t in range(4):
+            xb, yb = x[(t % 3) * 8:(t % 3 + 1) * 8], y[(t % 3) * 8:(t % 3 + 1) * 8]
+            losses.append(float(opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())))
+        params = list(model.parameters())
+        outs.append((flat([opt.state[p]["mean"] for p in params]), flat([opt.state[p]["precision"] for p in params]),
+                     flat(params), losses))
+    if type(backend).__name__ == "OracleOps":
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            np.testing.assert_array_equal(a.numpy(), b.numpy())
+        assert outs[0][3] == outs[1][3]
+    else:           # the kernels: IEEE sqrt against MKL's VML_HA sqrt in the reference's sample (module docstring)
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(outs[1][3], outs[0][3], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n_eff", [129809.0, 500000.0])
+def test_ivon_sample_kernel_is_the_ieee_sequence_of_the_reference_line(n_eff):
+    """ivorn.py:108 `1 / (N * precision.clamp(min=1e-4)).sqrt() * noise`, then :111 `mean + delta`, evaluated in numpy fp32
+    (multiply, correctly rounded sqrt, divide, multiply, add -- one rounding each): the kernel source on the CPU model equals
+    it bit for bit on 100,003 elements (ragged tail included), first and accumulating call.  This is the pin that does not
+    depend on which sqrt a torch build links."""
+    from tests.hip_emu import build, emu_ops
+    if not build.available():
+        pytest.skip("no host clang / HIP headers to build the CPU model with")
+    rng = np.random.default_rng(int(n_eff))
+    n = 100003
+    mean = rng.standard_normal(n).astype(np.float32) * np.float32(0.3)
+    prec = np.exp(rng.uniform(np.log(2e-5), np.log(0.5), n)).astype(np.float32)       # both sides of the 1e-4 clamp
+    eps = rng.standard_normal(n).astype(np.float32)
+    f = np.float32
+    delta = (f(1) / np.sqrt(f(n_eff) * np.maximum(prec, f(1e-4)))) * eps
+    with emu_ops.emulated(["ivon.hip"]) as ops:
+        param, dsum = torch.empty(n), torch.empty(n)
+        ops.ivon_sample(torch.from_numpy(mean), torch.from_numpy(prec), param, dsum, n, n_eff, True, eps=torch.from_numpy(eps))
+        np.testing.assert_array_equal(param.numpy(), mean + delta)
+        np.testing.assert_array_equal(dsum.numpy(), delta)
+        ops.ivon_sample(torch.from_numpy(mean), torch.from_numpy(prec), param, dsum, n, n_eff, False, eps=torch.from_numpy(eps))
+        np.testing.assert_array_equal(dsum.numpy(), delta + delta)
