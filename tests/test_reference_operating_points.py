@@ -81,17 +81,26 @@ SVGD_POINTS = {
 }
 
 
+@pytest.mark.parametrize("path", ["default", pytest.param("small_model", marks=pytest.mark.device_unverified(
+    "svgd_small", "small_step_host", "mean_scalars", "fast_loop"))])
+@pytest.mark.parametrize("hidden", [9, 601])        # D = 83 / 5,411 in four tensors (ragged: 16-byte padding behind three of them)
 @pytest.mark.parametrize("point", sorted(SVGD_POINTS))
-def test_svgd_at_the_reference_yaml_values(ref, backend, point):
+def test_svgd_at_the_reference_yaml_values(ref, backend, point, hidden, path):
     """svgd.py:44-105 with particle_count 5 / kernel_grad_scale 1.0 and each experiment's l2_reg, dataset_size and base
-    optimizer: four steps, every particle row after the last one and every returned loss."""
+    optimizer: four steps, every particle row after the last one and every returned loss.  The wide case scales its loss by
+    0.1: with lr 0.05 and the raw MSE of 601 hidden units the steps are as large as the weights (0.5 - 1.0 per step) and the
+    training loop itself amplifies a first-step difference of 1.3e-7 to 6e-6 by step four -- in the reference against a
+    re-run of itself in another summation order just the same; scaled, every backend stays within one ulp of the reference.
+    path "small_model": the opt-in step of DESIGN section 0 (the two-launch small-model kernel, the native host paths, the
+    one-launch loss mean) instead of what a default-constructed optimizer runs -- never run on a device, on the CPU model here."""
     import beyond_deep_ensembles_amd as bde
     torch.set_num_threads(1)
     cfg = SVGD_POINTS[point]
     x, y = data(11)
+    ls = 1.0 if hidden == 9 else 0.1
     results = []
     for which in ("ref", "ours"):
-        model = mlp(3)
+        model = mlp(3, hidden)
         torch.manual_seed(103)             # the reset closure consumes the same RNG stream in both runs
         kw = dict(particle_count=5, dataset_size=cfg["dataset_size"], l2_reg=cfg["l2_reg"], kernel_grad_scale=1.0)
         if which == "ref":
@@ -99,11 +108,12 @@ def test_svgd_at_the_reference_yaml_values(ref, backend, point):
                                             cfg["base"](model.parameters()), **kw)
         else:
             opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model),
-                                    cfg["base"](model.parameters()), _ops=backend, **kw)
+                                    cfg["base"](model.parameters()), _ops=backend,
+                                    **(dict(single_launch="two", host_fast_paths=True) if path == "small_model" else {}), **kw)
         losses = []
         for t in range(4):
             xb, yb = x[(t % 3) * 8:(t % 3 + 1) * 8], y[(t % 3) * 8:(t % 3 + 1) * 8]
-            losses.append(float(opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())))
+            losses.append(float(opt.step(lambda: ls * F.mse_loss(model(xb), yb), lambda l: l.backward())))
         params = list(model.parameters())
         parts = torch.stack([flat([opt.state[p][f"particle_{i}"] for p in params]) for i in range(5)])
         results.append((parts, losses))
@@ -207,3 +217,83 @@ def test_ivon_sample_kernel_is_the_ieee_sequence_of_the_reference_line(n_eff):
         np.testing.assert_array_equal(dsum.numpy(), delta)
         ops.ivon_sample(torch.from_numpy(mean), torch.from_numpy(prec), param, dsum, n, n_eff, False, eps=torch.from_numpy(eps))
         np.testing.assert_array_equal(dsum.numpy(), delta + delta)
+
+
+BBB_POINTS = {
+    # prior_std 1.0, mc_samples 2, kl_rescaling 0.2, dataset_size 50000, SGD(momentum .9, nesterov, wd 0)   cifar.yaml:125-135
+    "cifar": dict(prior=1.0, mc=2, klr=0.2, n=50000,
+                  base=lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=0.0)),
+    # prior_std 1.0, mc_samples 2, kl_rescaling 1.0, dataset_size 129809, Adam(lr 3e-5... here 1e-3), wd 0   iwildcam.yaml:136-143
+    "iwildcam": dict(prior=1.0, mc=2, klr=1.0, n=129809, base=lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=0.0)),
+    # mc_samples 5, the script's dataset_size (the housing split: 455 rows), Adam                              uci.yaml:160-168
+    "uci": dict(prior=1.0, mc=5, klr=1.0, n=455, base=lambda ps: torch.optim.Adam(ps, lr=1e-3)),
+    # prior_std 0.1, kl_rescaling 1.0                                                                          cifar.yaml:236-246
+    "cifar_narrow_prior": dict(prior=0.1, mc=2, klr=1.0, n=50000,
+                               base=lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)),
+}
+
+
+@pytest.mark.parametrize("point", sorted(BBB_POINTS))
+def test_bbb_at_the_reference_yaml_values(ref, backend, point):
+    """bbb.py:47-89 over weight-sampling layers built on each side's GaussianParameter (util.py:151-186), the same noise tape
+    on both sides, blundell_init (util.py:161-163: mean ~ N(0, 0.1^2), rho = -3): four steps, every loss and every mean / rho."""
+    import beyond_deep_ensembles_amd as bde
+    sys.path.insert(0, REF)
+    try:
+        import src.algos.bbb as rbbb
+    finally:
+        sys.path.remove(REF)
+    torch.set_num_threads(1)
+    cfg = BBB_POINTS[point]
+    mc = cfg["mc"]
+    g = torch.Generator().manual_seed(77)
+    tape = [torch.randn(s, generator=g) for _ in range(4 * mc) for s in ((7, 6), (7,), (2, 7), (2,))]
+    x, y = data(41)
+
+    def build(side):
+        noise = [t.clone() for t in tape]
+        GP = ref["util"].GaussianParameter if side == "ref" else (lambda size: bde.GaussianParameter(size, _ops=backend))
+
+        class Lin(nn.Module):
+            def __init__(self, i, o):
+                super().__init__()
+                self.weight, self.bias = GP((o, i)), GP((o,))
+
+            def forward(self, inp):
+                return F.linear(inp, self.weight.sample(), self.bias.sample())
+        model = nn.Sequential(Lin(6, 7), nn.Tanh(), Lin(7, 2))
+        with torch.no_grad():
+            for p in model.parameters():
+                if getattr(p, "_is_gaussian_rho", False):
+                    p.fill_(-3.0)
+                else:
+                    p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(5 + p.numel())) * 0.1)
+        params = list(model.parameters())
+        if side == "ref":
+            ref["util"].normal_like = lambda t: noise.pop(0)
+            opt = rbbb.BBBOptimizer(params, cfg["base"](params), rbbb.GaussianPrior(0.0, cfg["prior"]), dataset_size=cfg["n"],
+                                    mc_samples=mc, kl_rescaling=cfg["klr"])
+        else:
+            for mod in model.modules():
+                if isinstance(mod, bde.GaussianParameter):
+                    mod.noise_source = lambda rho: noise.pop(0)
+            opt = bde.BBBOptimizer(params, cfg["base"](params), bde.GaussianPrior(0.0, cfg["prior"]), dataset_size=cfg["n"],
+                                   mc_samples=mc, kl_rescaling=cfg["klr"], _ops=backend)
+        return model, params, opt
+
+    old = ref["util"].normal_like
+    try:
+        m_r, p_r, o_r = build("ref")
+        losses_r, traj_r = [], []
+        for t in range(4):
+            xb, yb = x[(t % 3) * 8:(t % 3 + 1) * 8], y[(t % 3) * 8:(t % 3 + 1) * 8]
+            losses_r.append(float(o_r.step(lambda: F.mse_loss(m_r(xb), yb), lambda l: l.backward()).detach()))
+            traj_r.append(flat(p_r))
+    finally:
+        ref["util"].normal_like = old
+    m_o, p_o, o_o = build("ours")
+    for t in range(4):
+        xb, yb = x[(t % 3) * 8:(t % 3 + 1) * 8], y[(t % 3) * 8:(t % 3 + 1) * 8]
+        loss = float(o_o.step(lambda: F.mse_loss(m_o(xb), yb), lambda l: l.backward()).detach())
+        assert abs(loss - losses_r[t]) <= 2e-6 * abs(losses_r[t]), (t, loss, losses_r[t])
+        np.testing.assert_allclose(flat(p_o).numpy(), traj_r[t].numpy(), rtol=1e-5, atol=1e-6)
