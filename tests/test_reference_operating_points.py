@@ -297,3 +297,53 @@ def test_bbb_at_the_reference_yaml_values(ref, backend, point):
         loss = float(o_o.step(lambda: F.mse_loss(m_o(xb), yb), lambda l: l.backward()).detach())
         assert abs(loss - losses_r[t]) <= 2e-6 * abs(losses_r[t]), (t, loss, losses_r[t])
         np.testing.assert_allclose(flat(p_o).numpy(), traj_r[t].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_multiswag_five_modes_thirty_samples_against_the_reference_ensemble(ref, backend):
+    """BASELINE configs[4] in the small: the reference's DeepEnsemble (ensemble.py:28-44) of five SwagOptimizer members (K = 20,
+    trained separately as camelyon.py:98 does) making 30 predictions, next to ours on the same seeds -- the split
+    (6 per member, member 0 takes the remainder), the order of the units, every member's use of torch's random stream
+    (eps_W then eps_D per sample, Q11) and the callers' reduction logsumexp(out, 0) - log(S) (camelyon.py:29-30); then a
+    second call of 7 (2 + 4 x 1 ... the remainder rule again) from the state the first one left."""
+    import math
+    import beyond_deep_ensembles_amd as bde
+    sys.path.insert(0, REF)
+    try:
+        import src.algos.ensemble as rens
+    finally:
+        sys.path.remove(REF)
+    torch.set_num_threads(1)
+    x, y = data(51)
+
+    def members(side):
+        out = []
+        for m in range(5):
+            model = mlp(60 + m, hidden=5)
+            base = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)
+            kw = dict(update_interval=1, start_epoch=0, deviation_samples=20)
+            opt = ref["swag"].SwagOptimizer(model.parameters(), base, **kw) if side == "ref" else \
+                bde.SwagOptimizer(model.parameters(), base, _ops=backend, **kw)
+            for t in range(24):                                              # 24 updates: the ring of 20 columns wraps
+                xb, yb = x[(t % 3) * 8:(t % 3 + 1) * 8], y[(t % 3) * 8:(t % 3 + 1) * 8]
+                opt.step(lambda: F.mse_loss(model(xb), yb), lambda l: l.backward())
+            out.append((model, opt))
+        return out
+
+    def closure(model):
+        with torch.no_grad():
+            return F.log_softmax(model(x[:8]), dim=-1)
+    theirs, ours = rens.DeepEnsemble(members("ref")), bde.DeepEnsemble(members("ours"))
+    torch.manual_seed(99)
+    want = theirs.predict(closure, 30)
+    torch.manual_seed(99)
+    got = ours.predict(closure, 30)
+    assert got.shape == want.shape == (30, 8, 2)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose((torch.logsumexp(got.float(), 0) - math.log(30)).numpy(),
+                               (torch.logsumexp(want.float(), 0) - math.log(30)).numpy(), rtol=1e-5, atol=1e-6)
+    # a second call continues every member's sampler where the reference's second call does
+    torch.manual_seed(100)
+    want2 = theirs.predict(closure, 7)
+    torch.manual_seed(100)
+    got2 = ours.predict(closure, 7)
+    np.testing.assert_allclose(got2.numpy(), want2.numpy(), rtol=1e-5, atol=1e-6)
