@@ -347,3 +347,27 @@ def test_multiswag_five_modes_thirty_samples_against_the_reference_ensemble(ref,
     torch.manual_seed(100)
     got2 = ours.predict(closure, 7)
     np.testing.assert_allclose(got2.numpy(), want2.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("path", ["streaming", pytest.param("small_model", marks=pytest.mark.device_unverified("svgd_small"))])
+@pytest.mark.parametrize("m,d,h_override", [(5, 83, None), (5, 5411, None), (8, 4099, None), (5, 83, 0.75), (8, 4099, 3.0),
+                                            (2, 7, None), (1, 33, None), (16, 1000, None), (16, 1000, 11.5)])
+def test_rbf_function_against_the_reference_function(ref, backend, m, d, h_override, path):
+    """`rbf(particles, h_override=None)` (svgd.py:14-32), the function itself: kernel matrix and grad_kernel for particles like
+    the optimizer's (a shared start plus independent re-initialisations), median bandwidth and the override (no + 1e-8 on an
+    override, svgd.py:20), M = 1 (distances all zero: h = 1e-8, kernel = exp(-0 / 2e-16) = 1) and M = 16 (two Gram tiles).
+    Bars: |ours - fp64| <= max(2 |reference fp32 - fp64|, floor) per DESIGN section 3."""
+    from beyond_deep_ensembles_amd.svgd import rbf
+    if path == "small_model" and m > 8:
+        pytest.skip("the small-model kernel takes at most 8 particles")
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(1000 * m + d)
+    P = torch.randn(m, d, generator=g) * 0.05 + torch.randn(1, d, generator=g) * 0.3
+    k_ref, gk_ref = ref["svgd"].rbf(P, h_override)
+    k64, gk64 = ref["svgd"].rbf(P.double(), h_override)
+    k, gk = rbf(P, h_override, _ops=backend, _small=(path == "small_model"))
+    assert k.shape == k_ref.shape and gk.shape == gk_ref.shape
+    ek, ek_ref = (k.double() - k64).abs().max(), (k_ref.double() - k64).abs().max()
+    eg, eg_ref = (gk.double() - gk64).abs().max(), (gk_ref.double() - gk64).abs().max()
+    assert ek <= max(2 * ek_ref, 3e-6), (float(ek), float(ek_ref))
+    assert eg <= max(2 * eg_ref, 3e-6 * float(gk64.abs().max())), (float(eg), float(eg_ref), float(gk64.abs().max()))
