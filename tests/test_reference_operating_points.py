@@ -190,7 +190,7 @@ def test_ivon_at_the_reference_yaml_values(ref, backend, point, kw):
         assert outs[0][3] == outs[1][3]
     else:           # the kernels: IEEE sqrt against MKL's VML_HA sqrt in the reference's sample (module docstring)
         for a, b in zip(outs[0][:3], outs[1][:3]):
-            np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=2e-6, atol=1e-9)
+            np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=2e-6, atol=2e-7)    # atol: mean + delta cancels in some live parameters
         np.testing.assert_allclose(outs[1][3], outs[0][3], rtol=1e-6)
 
 
