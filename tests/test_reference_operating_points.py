@@ -371,3 +371,125 @@ def test_rbf_function_against_the_reference_function(ref, backend, m, d, h_overr
     eg, eg_ref = (gk.double() - gk64).abs().max(), (gk_ref.double() - gk64).abs().max()
     assert ek <= max(2 * ek_ref, 3e-6), (float(ek), float(ek_ref))
     assert eg <= max(2 * eg_ref, 3e-6 * float(gk64.abs().max())), (float(eg), float(eg_ref), float(gk64.abs().max()))
+
+
+# ------------------------------------------------- checkpoints, the other way round ("... and save back") --
+def _roundtrip(obj):
+    import io
+    b = io.BytesIO()
+    torch.save(obj, b)
+    b.seek(0)
+    return torch.load(b, weights_only=False)
+
+
+@pytest.mark.parametrize("base_kind", ["nesterov", "adam"])
+def test_the_reference_resumes_from_our_svgd_checkpoint(ref, backend, base_kind):
+    """tests/test_shells.py loads checkpoints the REFERENCE wrote; this is the way back: `torch.save(opt.state_dict())` of our
+    SVGDOptimizer after two steps, `load_state_dict` into the imported reference's SVGDOptimizer over a fresh model (the
+    per-tensor `particle_i` entries, the string keys of svgd.py:51-56; our extra `__fused` entry is carried along unread), the
+    base optimizer's state through its own state_dict -- and the reference's next two steps are our next two steps, and its
+    sample_parameters() cycles through our particles from our position (svgd.py:107-112)."""
+    import beyond_deep_ensembles_amd as bde
+    torch.set_num_threads(1)
+    x, y = data(61)
+    mk = (lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)) if base_kind == "nesterov" \
+        else (lambda ps: torch.optim.Adam(ps, lr=1e-3))
+    kw = dict(particle_count=5, dataset_size=50000, l2_reg=3e-4, kernel_grad_scale=1.0)
+    model = mlp(3)
+    torch.manual_seed(5)
+    base = mk(model.parameters())
+    opt = bde.SVGDOptimizer(model.parameters(), lambda: bde.reset_model_params(model), base, _ops=backend, **kw)
+    for t in range(2):
+        opt.step(lambda: 0.1 * F.mse_loss(model(x[:8]), y[:8]), lambda l: l.backward())
+    opt.sample_parameters()                                             # position 1 of the round robin goes into the file
+    ck = _roundtrip({"model": model.state_dict(), "optimizer": opt.state_dict(), "base": base.state_dict()})
+    model_r = mlp(99)
+    model_r.load_state_dict(ck["model"])
+    base_r = mk(model_r.parameters())
+    opt_r = ref["svgd"].SVGDOptimizer(model_r.parameters(), lambda: None, base_r, **kw)
+    sd = ck["optimizer"]
+    sd["state"]["__base_optimizer"] = base_r            # the pickled optimizer drives orphan tensors -- also in a file the reference wrote
+    opt_r.load_state_dict(sd)
+    base_r.load_state_dict(ck["base"])
+    assert opt_r.state["__current_particle"] == 1 and opt_r.state["__particle_count"] == 5
+
+    def rows(o, m):
+        return torch.stack([flat([o.state[p][f"particle_{i}"] for p in m.parameters()]) for i in range(5)])
+    np.testing.assert_array_equal(rows(opt_r, model_r).numpy(), rows(opt, model).numpy())
+    for t in range(2):
+        xb, yb = x[8 + 8 * t:16 + 8 * t], y[8 + 8 * t:16 + 8 * t]
+        loss_r = opt_r.step(lambda: 0.1 * F.mse_loss(model_r(xb), yb), lambda l: l.backward())
+        loss = opt.step(lambda: 0.1 * F.mse_loss(model(xb), yb), lambda l: l.backward())
+        np.testing.assert_allclose(float(loss), float(loss_r), rtol=1e-6)
+        np.testing.assert_allclose(rows(opt, model).numpy(), rows(opt_r, model_r).numpy(), rtol=1e-5, atol=1e-7)
+    for _ in range(6):
+        opt_r.sample_parameters()
+        opt.sample_parameters()
+        np.testing.assert_allclose(flat(model.parameters()).numpy(), flat(model_r.parameters()).numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_the_reference_resumes_from_our_swag_and_ivon_checkpoints(ref, backend):
+    """The same for SwagOptimizer (swag.py:28-35: `__mean`, `__sq_weights`, the rolled `[D, K]` `__deviations`, the three counters;
+    the ring has wrapped when the file is written) and iVONOptimizer (per-parameter mean / momentum / precision, ivorn.py:29-36):
+    the reference continues from our file bit for bit -- moments, deviation columns, counters, the next posterior sample on the
+    same random stream; iVON's mean / precision / live parameters on the checker, within the draw's one ulp on the kernels."""
+    import beyond_deep_ensembles_amd as bde
+    torch.set_num_threads(1)
+    x, y = data(62)
+    mk = lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4)      # noqa: E731
+    kw = dict(update_interval=1, start_epoch=0, deviation_samples=4)
+    model = mlp(3, hidden=5)
+    base = mk(model.parameters())
+    opt = bde.SwagOptimizer(model.parameters(), base, _ops=backend, **kw)
+    for t in range(6):
+        opt.step(lambda: F.mse_loss(model(x[:8]), y[:8]), lambda l: l.backward())
+    opt.complete_epoch()
+    ck = _roundtrip({"model": model.state_dict(), "optimizer": opt.state_dict(), "base": base.state_dict()})
+    model_r = mlp(9, hidden=5)
+    model_r.load_state_dict(ck["model"])
+    base_r = mk(model_r.parameters())
+    opt_r = ref["swag"].SwagOptimizer(model_r.parameters(), base_r, **kw)
+    sd = ck["optimizer"]
+    sd["state"]["__base_optimizer"] = base_r
+    opt_r.load_state_dict(sd)
+    base_r.load_state_dict(ck["base"])
+    for t in range(3):
+        opt_r.step(lambda: F.mse_loss(model_r(x[8:16]), y[8:16]), lambda l: l.backward())
+        opt.step(lambda: F.mse_loss(model(x[8:16]), y[8:16]), lambda l: l.backward())
+    assert (opt_r.state["__epoch"], opt_r.state["__steps_since_swag_start"], opt_r.state["__updates"]) == \
+        (opt.state["__epoch"], opt.state["__steps_since_swag_start"], opt.state["__updates"]) == (1, 9, 9)
+    np.testing.assert_array_equal(opt_r.state["__mean"].numpy(), opt.mean_vector().cpu().numpy())
+    np.testing.assert_array_equal(opt_r.state["__sq_weights"].numpy(), opt.sq_vector().cpu().numpy())
+    np.testing.assert_array_equal(opt_r.state["__deviations"].numpy(), opt.deviations_dk().cpu().numpy())
+    torch.manual_seed(1)
+    opt_r.sample_parameters()
+    torch.manual_seed(1)
+    opt.sample_parameters()
+    np.testing.assert_allclose(flat(model.parameters()).numpy(), flat(model_r.parameters()).numpy(), rtol=1e-5, atol=1e-6)
+
+    kw = dict(lr=1e-3, prior_prec=50, dataset_size=50000, damping=1e-3, augmentation=10, mc_samples=2)
+    model = mlp(3, hidden=5)
+    opt = bde.iVONOptimizer(model.parameters(), _ops=backend, **kw)
+    torch.manual_seed(4)
+    for t in range(2):
+        opt.step(lambda: F.mse_loss(model(x[:8]), y[:8]), lambda l: l.backward())
+    ck = _roundtrip({"model": model.state_dict(), "optimizer": opt.state_dict()})
+    model_r = mlp(9, hidden=5)
+    model_r.load_state_dict(ck["model"])
+    opt_r = ref["ivon"].iVONOptimizer(model_r.parameters(), **kw)
+    opt_r.load_state_dict(ck["optimizer"])
+    rng_state = torch.get_rng_state()
+    for t in range(2):
+        opt.step(lambda: F.mse_loss(model(x[8:16]), y[8:16]), lambda l: l.backward())
+    torch.set_rng_state(rng_state)
+    for t in range(2):
+        opt_r.step(lambda: F.mse_loss(model_r(x[8:16]), y[8:16]), lambda l: l.backward())
+    pr, po = list(model_r.parameters()), list(model.parameters())
+    exact = type(backend).__name__ == "OracleOps"
+    for key in ("mean", "momentum", "precision"):
+        a, b = flat([opt_r.state[p][key] for p in pr]).numpy(), flat([opt.state[p][key] for p in po]).numpy()
+        if exact:
+            np.testing.assert_array_equal(b, a)
+        else:
+            np.testing.assert_allclose(b, a, rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(flat(po).numpy(), flat(pr).numpy(), rtol=0 if exact else 2e-6, atol=0 if exact else 2e-7)
