@@ -493,3 +493,33 @@ def test_the_reference_resumes_from_our_swag_and_ivon_checkpoints(ref, backend):
         else:
             np.testing.assert_allclose(b, a, rtol=2e-6, atol=2e-7)
     np.testing.assert_allclose(flat(po).numpy(), flat(pr).numpy(), rtol=0 if exact else 2e-6, atol=0 if exact else 2e-7)
+
+
+def test_bayesian_layer_state_dicts_are_interchangeable_with_the_reference_layers():
+    """`model.state_dict()` of a network of our BBBConv2d / BBBLinear layers and of the reference's (bbb_layers.py:27-41,114-131:
+    `weight.mean`, `weight.rho`, `bias.mean`, `bias.rho` per layer) carry the same keys and shapes and load into each other with
+    strict=True -- what `torch.save(model.state_dict())` / `DeepEnsemble.state_dict()["models"]` (ensemble.py:17-21) put on disk."""
+    import beyond_deep_ensembles_amd as bde
+    from tests.oracle_ops import OracleOps
+    sys.path.insert(0, REF)
+    try:
+        import src.algos.bbb_layers as rl
+        import src.algos.bbb as rb
+    finally:
+        sys.path.remove(REF)
+    ops, rp, p = OracleOps(), rb.GaussianPrior(0, 1.0), bde.GaussianPrior(0, 1.0)
+    theirs = nn.Sequential(rl.BBBConv2d(3, 4, 3, rp, rp, padding=1), nn.Flatten(), rl.BBBLinear(4 * 8 * 8, 5, rp, rp),
+                           rl.BBBLinear(5, 2, rp, rp, bias=False))
+    ours = nn.Sequential(bde.BBBConv2d(3, 4, 3, p, p, padding=1, _ops=ops), nn.Flatten(), bde.BBBLinear(4 * 8 * 8, 5, p, p, _ops=ops),
+                         bde.BBBLinear(5, 2, p, p, bias=False, _ops=ops))
+    a, b = theirs.state_dict(), ours.state_dict()
+    assert list(a.keys()) == list(b.keys()) and all(a[k].shape == b[k].shape and a[k].dtype == b[k].dtype for k in a)
+    theirs.load_state_dict(_roundtrip(b), strict=True)
+    for k, v in theirs.state_dict().items():
+        assert torch.equal(v, b[k])
+    with torch.no_grad():
+        for v in theirs.parameters():
+            v.add_(0.25)
+    ours.load_state_dict(_roundtrip(theirs.state_dict()), strict=True)
+    for k, v in ours.state_dict().items():
+        assert torch.equal(v, theirs.state_dict()[k])
