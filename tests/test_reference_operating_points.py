@@ -351,7 +351,8 @@ def test_multiswag_five_modes_thirty_samples_against_the_reference_ensemble(ref,
 
 @pytest.mark.parametrize("path", ["streaming", pytest.param("small_model", marks=pytest.mark.device_unverified("svgd_small"))])
 @pytest.mark.parametrize("m,d,h_override", [(5, 83, None), (5, 5411, None), (8, 4099, None), (5, 83, 0.75), (8, 4099, 3.0),
-                                            (2, 7, None), (1, 33, None), (16, 1000, None), (16, 1000, 11.5)])
+                                            (2, 7, None), (1, 33, None), (16, 1000, None), (16, 1000, 11.5),
+                                            (8, 273_610, None), (5, 273_610, None)])     # BASELINE configs[1]: CIFAR ResNet-20
 def test_rbf_function_against_the_reference_function(ref, backend, m, d, h_override, path):
     """`rbf(particles, h_override=None)` (svgd.py:14-32), the function itself: kernel matrix and grad_kernel for particles like
     the optimizer's (a shared start plus independent re-initialisations), median bandwidth and the override (no + 1e-8 on an
