@@ -1,4 +1,4 @@
-"""Build-container tool (needs /root/reference; ~8 GB, ~3 min): the headline workload of bench.py -- 8 particles x 23,880,950
+"""Build-container tool (needs /root/reference; ~8 GB, ~3 min; `swag` as the only argument: the SWAG half instead): the headline workload of bench.py -- 8 particles x 23,880,950
 parameters (iWildCam ResNet-50 size), SURVEY 8d's synthetic inputs (a shared backbone, the last 372,918 entries re-initialised per
 particle, G ~ N(0, 0.01^2), l2_reg 0, kernel_grad_scale 1, dataset_size 129,809) -- through the kernel SOURCES on the CPU execution
 model (tests/hip_emu), next to the IMPORTED reference's `rbf` (svgd.py:14-32) and the two lines that follow it in `step`
@@ -14,7 +14,9 @@ sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 import src.algos.svgd as rsvgd                      # noqa: E402
+import src.algos.swag as rswag                      # noqa: E402
 sys.path.remove("/root/reference")
+import beyond_deep_ensembles_amd as bde             # noqa: E402
 from beyond_deep_ensembles_amd.svgd import rbf      # noqa: E402
 from tests.hip_emu import emu_ops                   # noqa: E402
 
@@ -25,8 +27,43 @@ def reference_phi(P, G, l2_reg, scale, n):
     return kernel, grad_kernel, torch.matmul(kernel, -grads) + scale * grad_kernel / n      # svgd.py:89 (no 1 / M)
 
 
+def swag(d=23_880_950, k=20, updates=25):
+    """SwagOptimizer (swag.py:15-114) on one parameter vector of ResNet-50 size: SURVEY 8d's random walk (25 updates, so the
+    ring of K = 20 columns has wrapped), then one posterior sample on the reference's random stream."""
+    g = torch.Generator().manual_seed(1234)
+    theta0 = torch.randn(d, generator=g) * 0.05
+    walk = [torch.randn(d, generator=g) * 1e-3 for _ in range(updates)]
+
+    def run(side, ops=None):
+        p = torch.nn.Parameter(theta0.clone())
+        base = torch.optim.SGD([p], lr=1.0)
+        kw = dict(update_interval=1, start_epoch=0, deviation_samples=k)
+        opt = rswag.SwagOptimizer([p], base, **kw) if side == "ref" else bde.SwagOptimizer([p], base, _ops=ops, **kw)
+        for w in walk:                             # SGD with lr 1 on the gradient -w: theta_t = theta_{t-1} + w_t
+            opt.step(lambda: -(p * w).sum(), lambda l: l.backward())
+        torch.manual_seed(7)
+        opt.sample_parameters()
+        sample = p.detach().clone()
+        if side == "ref":
+            return opt.state["__mean"], opt.state["__sq_weights"], opt.state["__deviations"], sample, opt.state["__updates"]
+        return opt.mean_vector().cpu(), opt.sq_vector().cpu(), opt.deviations_dk().cpu(), sample, opt.state["__updates"]
+    t0 = time.time()
+    r = run("ref")
+    t1 = time.time()
+    with emu_ops.emulated(emu_ops.ALL) as ops:
+        o = run("ours", ops)
+    print(f"SWAG, D = {d:,}, K = {k}, {updates} updates (reference {t1 - t0:.0f} s, CPU model {time.time() - t1:.0f} s): updates counter "
+          f"{r[4]} / {o[4]}")
+    print(f"  mean bit-exact {torch.equal(r[0], o[0])}, sq_weights bit-exact {torch.equal(r[1], o[1])}, deviations [D, K] bit-exact "
+          f"{torch.equal(r[2], o[2])}")
+    print(f"  posterior sample, the reference's random stream: max |ours - reference| {float((r[3] - o[3]).abs().max()):.2e} "
+          f"(max |sample| {float(r[3].abs().max()):.2e}, max |sample - mean| {float((r[3] - r[0]).abs().max()):.2e})")
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
+    if sys.argv[1:] == ["swag"]:
+        return swag()
     m, d, n = 8, 23_880_950, 129_809
     g = torch.Generator().manual_seed(1234)
     P = (torch.randn(1, d, generator=g) * 0.05).repeat(m, 1)
