@@ -1,4 +1,4 @@
-"""Build-container tool (needs /root/reference; ~8 GB, ~3 min; `swag` as the only argument: the SWAG half instead): the headline workload of bench.py -- 8 particles x 23,880,950
+"""Build-container tool (needs /root/reference; ~8 GB, ~3 min; `swag` / `ivon` / `bbb` as the only argument: that optimizer at the same size instead): the headline workload of bench.py -- 8 particles x 23,880,950
 parameters (iWildCam ResNet-50 size), SURVEY 8d's synthetic inputs (a shared backbone, the last 372,918 entries re-initialised per
 particle, G ~ N(0, 0.01^2), l2_reg 0, kernel_grad_scale 1, dataset_size 129,809) -- through the kernel SOURCES on the CPU execution
 model (tests/hip_emu), next to the IMPORTED reference's `rbf` (svgd.py:14-32) and the two lines that follow it in `step`
@@ -15,6 +15,9 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 import src.algos.svgd as rsvgd                      # noqa: E402
 import src.algos.swag as rswag                      # noqa: E402
+import src.algos.ivorn as rivon                     # noqa: E402
+import src.algos.bbb as rbbb                        # noqa: E402
+import src.algos.util as rutil                      # noqa: E402
 sys.path.remove("/root/reference")
 import beyond_deep_ensembles_amd as bde             # noqa: E402
 from beyond_deep_ensembles_amd.svgd import rbf      # noqa: E402
@@ -60,10 +63,83 @@ def swag(d=23_880_950, k=20, updates=25):
           f"(max |sample| {float(r[3].abs().max()):.2e}, max |sample - mean| {float((r[3] - r[0]).abs().max()):.2e})")
 
 
+def ivon(d=23_880_950):
+    """iVONOptimizer (ivorn.py:15-127) on one parameter vector of that size at iwildcam.yaml:199-204's values (prior_prec 100,
+    damping 1e-3, augmentation 1, mc_samples 2, N = 129,809), two steps on a quadratic loss."""
+    g = torch.Generator().manual_seed(99)
+    theta0, target = torch.randn(d, generator=g) * 0.05, torch.randn(d, generator=g) * 0.05
+    kw = dict(lr=3e-5, prior_prec=100, damping=1e-3, augmentation=1, mc_samples=2, dataset_size=129_809)
+
+    def run(side, ops=None):
+        p = torch.nn.Parameter(theta0.clone())
+        opt = rivon.iVONOptimizer([p], **kw) if side == "ref" else bde.iVONOptimizer([p], _ops=ops, **kw)
+        torch.manual_seed(3)
+        for _ in range(2):
+            opt.step(lambda: 0.5 * ((p - target) ** 2).sum(), lambda l: l.backward())
+        st = opt.state[p]
+        return st["mean"].detach().cpu().clone(), st["momentum"].detach().cpu().clone(), st["precision"].detach().cpu().clone(), \
+            p.detach().cpu().clone()
+    t0 = time.time()
+    r = run("ref")
+    t1 = time.time()
+    with emu_ops.emulated(emu_ops.ALL) as ops:
+        o = run("ours", ops)
+    print(f"iVON, D = {d:,}, 2 steps x 2 MC samples (reference {t1 - t0:.0f} s, CPU model {time.time() - t1:.0f} s)")
+    for name, a, b in zip(["mean", "momentum", "precision", "live parameters (mean + last draw)"], r, o):
+        diff = (a - b).abs()
+        print(f"  {name}: {int((a != b).sum()):,} of {d:,} entries differ, max |ours - reference| {float(diff.max()):.2e} "
+              f"(max |.| {float(a.abs().max()):.2e})")
+
+
+def bbb(d=23_880_950):
+    """One GaussianParameter of that size (util.py:151-186, blundell_init) under BBBOptimizer (bbb.py:47-89: prior N(0, 1),
+    mc_samples 2, kl_rescaling 1, N = 129,809: iwildcam.yaml:136-143) over SGD, two steps, the same noise tape on both sides: the
+    draw, its backward and the fused KL value + gradients."""
+    g = torch.Generator().manual_seed(5)
+    mean0, target = torch.randn(d, generator=g) * 0.1, torch.randn(d, generator=g) * 0.1
+    tape = [torch.randn(d, generator=g) for _ in range(4)]
+
+    def run(side, ops=None):
+        noise = list(tape)
+        gp = rutil.GaussianParameter((d,)) if side == "ref" else bde.GaussianParameter((d,), _ops=ops)
+        with torch.no_grad():
+            gp.mean.copy_(mean0)
+            gp.rho.fill_(-3.0)
+        params = list(gp.parameters())
+        base = torch.optim.SGD(params, lr=0.05, momentum=0.9)
+        old = rutil.normal_like
+        try:
+            if side == "ref":
+                rutil.normal_like = lambda t: noise.pop(0)
+                opt = rbbb.BBBOptimizer(params, base, rbbb.GaussianPrior(0.0, 1.0), dataset_size=129_809, mc_samples=2, kl_rescaling=1.0)
+            else:
+                gp.noise_source = lambda rho: noise.pop(0)
+                opt = bde.BBBOptimizer(params, base, bde.GaussianPrior(0.0, 1.0), dataset_size=129_809, mc_samples=2, kl_rescaling=1.0,
+                                       _ops=ops)
+            losses = [float(opt.step(lambda: 0.5 * ((gp.sample() - target) ** 2).sum(), lambda l: l.backward()).detach())
+                      for _ in range(2)]
+        finally:
+            rutil.normal_like = old
+        return gp.mean.detach().cpu().clone(), gp.rho.detach().cpu().clone(), losses
+    t0 = time.time()
+    r = run("ref")
+    t1 = time.time()
+    with emu_ops.emulated(emu_ops.ALL) as ops:
+        o = run("ours", ops)
+    print(f"BBB, one GaussianParameter of {d:,} entries, 2 steps x 2 MC samples (reference {t1 - t0:.0f} s, CPU model {time.time() - t1:.0f} s)")
+    print(f"  losses reference {r[2]}  ours {o[2]}")
+    for name, a, b in zip(["mean", "rho"], r[:2], o[:2]):
+        print(f"  {name}: max |ours - reference| {float((a - b).abs().max()):.2e} (max |step taken| {float((a - (mean0 if name == 'mean' else -3.0)).abs().max()):.2e})")
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     if sys.argv[1:] == ["swag"]:
         return swag()
+    if sys.argv[1:] == ["ivon"]:
+        return ivon()
+    if sys.argv[1:] == ["bbb"]:
+        return bbb()
     m, d, n = 8, 23_880_950, 129_809
     g = torch.Generator().manual_seed(1234)
     P = (torch.randn(1, d, generator=g) * 0.05).repeat(m, 1)
