@@ -1,4 +1,4 @@
-"""Build-container tool (needs /root/reference; ~8 GB, ~3 min; `swag` / `ivon` / `bbb` as the only argument: that optimizer at the same size instead): the headline workload of bench.py -- 8 particles x 23,880,950
+"""Build-container tool (needs /root/reference; ~8 GB, ~3 min; `swag` / `ivon` / `bbb` / `svgd_step nesterov|adam` as arguments: that optimizer's whole step at the same size instead): the headline workload of bench.py -- 8 particles x 23,880,950
 parameters (iWildCam ResNet-50 size), SURVEY 8d's synthetic inputs (a shared backbone, the last 372,918 entries re-initialised per
 particle, G ~ N(0, 0.01^2), l2_reg 0, kernel_grad_scale 1, dataset_size 129,809) -- through the kernel SOURCES on the CPU execution
 model (tests/hip_emu), next to the IMPORTED reference's `rbf` (svgd.py:14-32) and the two lines that follow it in `step`
@@ -132,8 +132,50 @@ def bbb(d=23_880_950):
         print(f"  {name}: max |ours - reference| {float((a - b).abs().max()):.2e} (max |step taken| {float((a - (mean0 if name == 'mean' else -3.0)).abs().max()):.2e})")
 
 
+def svgd_step(base_kind, d=23_880_950, m=8):
+    """The whole SVGDOptimizer.step (svgd.py:65-105) at BASELINE configs[3]'s size in ONE process: 8 particles of one parameter
+    vector of ResNet-50 size, particles 1..7 re-initialised in their last 372,918 entries only (iwildcam/models.py:118-119),
+    a quadratic loss per particle, two steps; base optimizer Adam(lr 3e-5) (iwildcam.yaml:213-216) or nesterov SGD
+    (cifar.yaml:218-223) -- ours on the default path (Gram -> statistics -> fused update with the shared optimizer state)."""
+    g = torch.Generator().manual_seed(11)
+    theta0, target = torch.randn(d, generator=g) * 0.05, torch.randn(d, generator=g) * 0.05
+    heads = [(torch.rand(372_918, generator=g) * 2 - 1) / 2048 ** 0.5 for _ in range(m - 1)]
+    mk = (lambda ps: torch.optim.Adam(ps, lr=3e-5, weight_decay=0)) if base_kind == "adam" else \
+        (lambda ps: torch.optim.SGD(ps, lr=0.05, momentum=0.9, nesterov=True, weight_decay=3e-4))
+    kw = dict(particle_count=m, dataset_size=129_809, l2_reg=0.0 if base_kind == "adam" else 3e-4, kernel_grad_scale=1.0)
+
+    def run(side, ops=None):
+        p = torch.nn.Parameter(theta0.clone())
+        todo = list(heads)
+
+        def reset():
+            with torch.no_grad():
+                p[-372_918:] = todo.pop(0)
+        base = mk([p])
+        opt = rsvgd.SVGDOptimizer([p], reset, base, **kw) if side == "ref" else bde.SVGDOptimizer([p], reset, base, _ops=ops, **kw)
+        losses = []
+        start = torch.stack([opt.state[p][f"particle_{i}"].detach().cpu() for i in range(m)]).clone()
+        for _ in range(2):
+            losses.append(float(opt.step(lambda: 0.5 * ((p - target) ** 2).sum() / 1000.0, lambda l: l.backward())))
+        return torch.stack([opt.state[p][f"particle_{i}"].detach().cpu() for i in range(m)]), losses, start
+    t0 = time.time()
+    r, lr_, start = run("ref")
+    t1 = time.time()
+    with emu_ops.emulated(emu_ops.ALL) as ops:
+        o, lo, start_o = run("ours", ops)
+    assert torch.equal(start, start_o)
+    diff = (r - o).abs()
+    moved = float((r - start).abs().max())
+    print(f"SVGDOptimizer.step, {m} particles x {d:,}, base {base_kind}, 2 steps (reference {t1 - t0:.0f} s, CPU model {time.time() - t1:.0f} s)")
+    print(f"  returned losses reference {lr_}  ours {lo}")
+    print(f"  particles: max |ours - reference| {float(diff.max()):.2e}; entries further than 1e-7 apart: {int((diff > 1e-7).sum()):,} of "
+          f"{m * d:,}; largest move of an entry over the two steps {moved:.2e}")
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
+    if sys.argv[1:2] == ["svgd_step"]:
+        return svgd_step(sys.argv[2] if len(sys.argv) > 2 else "nesterov")
     if sys.argv[1:] == ["swag"]:
         return swag()
     if sys.argv[1:] == ["ivon"]:
