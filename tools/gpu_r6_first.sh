@@ -8,7 +8,8 @@ left() { echo $(( BUDGET - ( $(date +%s) - T0 ) )); }
 O=gpurun_out/r6a; mkdir -p $O
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 export PYTHONDONTWRITEBYTECODE=1 HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 2400 python -m pytest tests -x -q -m gpu --durations=20 > $O/pytest_gpu_x.log 2>&1; echo "suite (-x) rc=$?"; tail -40 $O/pytest_gpu_x.log | cut -c1-220
+SUITE_T=$(( BUDGET > 2700 ? 2400 : BUDGET - 300 )); [ $SUITE_T -lt 240 ] && SUITE_T=240
+timeout $SUITE_T python -m pytest tests -x -q -m gpu --durations=20 > $O/pytest_gpu_x.log 2>&1; echo "suite (-x) rc=$?"; tail -40 $O/pytest_gpu_x.log | cut -c1-220
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $O/smoke.log
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_plain.json 2> $O/bench_plain.err; echo "bench plain rc=$?"; tail -c 1500 $O/bench_plain.err; head -c 2500 $O/bench_plain.json
 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29612 \
